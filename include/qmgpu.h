@@ -1,0 +1,215 @@
+/*
+ * qmgpu.h -- C ABI of the MI355X-native MPC + whole-body-control hot path for the AlienGo+Z1
+ *            quadruped manipulator (drop-in for the numeric path of danisotelo/qm_door).
+ *
+ * Nothing like this interface exists in the reference (it has no FFI); each entry point below
+ * names the reference interface it replaces (paths relative to the reference tree):
+ *
+ *   qmgpu_load_problem      <-> qm::QMInterface ctor + setupOptimalControlProblem
+ *                               (qm_interface/src/QMInterface.cpp:37-142) and
+ *                               WbcBase::loadTasksSetting (qm_wbc/src/WbcBase.cpp:597-627)
+ *   qmgpu_create/destroy    <-> QMController::setupMpc / setupWbc
+ *                               (qm_controllers/src/QMController.cpp:273-277, 287-307)
+ *   qmgpu_mpc_solve_batch   <-> ocs2::MPC_BASE::run -> SqpSolver::runImpl, one SQP iteration
+ *                               (object built at qm_controllers/src/QMController.cpp:288-289)
+ *   qmgpu_policy_eval_batch <-> MPC_MRT_Interface::evaluatePolicy (QMController.cpp:134-142)
+ *   qmgpu_wbc_solve_batch   <-> qm::WbcBase::update / HierarchicalWbc::update
+ *                               (qm_wbc/include/qm_wbc/WbcBase.h:31-34, qm_wbc/src/HierarchicalWbc.cpp:18-44)
+ *   qmgpu_cycle_batch       <-> one QMController::update tick fed by one advanceMpc
+ *                               (QMController.cpp:129-176, 316-327) for a batch of robots
+ *
+ * Conventions
+ *   - all floating point data is IEEE fp64, all matrices row-major unless stated otherwise
+ *   - "dev" pointers are HIP device pointers (HBM resident); the *_host variants take host
+ *     pointers and stage through pinned buffers
+ *   - the caller owns every buffer; the library owns device scratch behind the opaque handle
+ *   - no C++ exception crosses this boundary; every function returns a qmgpu_status
+ *   - one handle == one HIP stream; calls on one handle must be serialised by the caller
+ *
+ * Vector layouts (reference: SURVEY.md Appendix A)
+ *   state x[30]   = [ h_lin/m (3), h_ang/m (3) ; p_base (3), yaw, pitch, roll ; q_joint (18) ]
+ *   input u[30]   = [ f_LF, f_RF, f_LH, f_RH (12) ; v_joint (18) ]
+ *   joints (18)   = LF(HAA,HFE,KFE), LH, RF, RH, z1_joint_1..6          (Pinocchio order)
+ *   target[37]    = [ x_ref (30) ; p_ee (3) ; quat_ee (x,y,z,w) ]
+ *   rbd[55]       = [ zyx (3), p (3), q_j (18) ; w_world (3), v_lin (3), dq_j (18) ; p_ee (3), quat_ee (4) ]
+ *   wbc out[54]   = [ ddq (24), F (12) ; tau (18) ]
+ *   mode          = 8*LF + 4*RF + 2*LH + 1*RH   (1 = stance)
+ */
+#ifndef QMGPU_H
+#define QMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMGPU_NX 30
+#define QMGPU_NU 30
+#define QMGPU_NV 24
+#define QMGPU_NJ 18
+#define QMGPU_NB 19 /* moving bodies: floating base + 18 joint bodies */
+#define QMGPU_NC 4  /* 3-DoF contacts, order LF RF LH RH */
+#define QMGPU_NTARGET 37
+#define QMGPU_NRBD 55
+#define QMGPU_NWBC_DEC 36
+#define QMGPU_NWBC_OUT 54
+#define QMGPU_MAX_EVENTS 40 /* per-instance mode-schedule capacity */
+#define QMGPU_NSTATS 8
+
+typedef enum qmgpu_status {
+  QMGPU_OK = 0,
+  QMGPU_ERR_INVALID_ARGUMENT = 1,
+  QMGPU_ERR_FILE_NOT_FOUND = 2, /* reference: std::invalid_argument, QMInterface.cpp:45,53,61 */
+  QMGPU_ERR_PARSE = 3,
+  QMGPU_ERR_UNSUPPORTED_MODEL = 4,
+  QMGPU_ERR_NO_DEVICE = 5, /* no HIP device / kernels missing: the library never falls back to a CPU path */
+  QMGPU_ERR_HIP = 6,
+  QMGPU_ERR_CAPACITY = 7,
+  QMGPU_ERR_NUMERICAL = 8
+} qmgpu_status;
+
+/* Flat rigid-body model.  Every joint origin of the reference URDF has rpy = 0 and every axis is a
+ * positive unit coordinate axis; the loader rejects anything else. */
+typedef struct qmgpu_model {
+  int32_t parent[QMGPU_NB];          /* parent body, -1 for the base */
+  int32_t axis[QMGPU_NB];            /* joint axis 0/1/2 = x/y/z (unused for body 0) */
+  double joint_offset[QMGPU_NB][3];  /* joint origin in the parent body frame */
+  double mass[QMGPU_NB];             /* fixed children (feet, imu, z1_link_0, gripper) merged in */
+  double com[QMGPU_NB][3];           /* body frame */
+  double inertia[QMGPU_NB][6];       /* about com, body axes: xx xy xz yy yz zz */
+  int32_t foot_body[QMGPU_NC];
+  double foot_offset[QMGPU_NC][3];
+  int32_t ee_body;
+  double ee_offset[3];
+  double q_lower[QMGPU_NJ], q_upper[QMGPU_NJ], effort_limit[QMGPU_NJ], velocity_limit[QMGPU_NJ];
+  double total_mass;
+} qmgpu_model;
+
+typedef struct qmgpu_settings {
+  /* model_settings + swing_trajectory_config (task.info:8-31) */
+  double position_error_gain, phase_transition_stance_time;
+  double liftoff_velocity, touchdown_velocity, swing_height, touchdown_after_horizon, swing_time_scale;
+  /* sqp + mpc (task.info:76-93,139-149); alpha_decay/alpha_min/gamma_c/armijo are OCS2 defaults */
+  double dt, time_horizon, delta_tol, g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo_factor;
+  int32_t sqp_iterations, reserved0;
+  /* cost (task.info:193-288) */
+  double initial_state[QMGPU_NX];
+  double Q[QMGPU_NX * QMGPU_NX];
+  double R_task[QMGPU_NU * QMGPU_NU]; /* as loaded; the leg-velocity block is mapped by J^T R J at create time */
+  double ee_mu_position, ee_mu_orientation, ee_final_mu_position, ee_final_mu_orientation;
+  /* soft constraints (task.info:291-344); cone regularization / hessian shift are OCS2 defaults */
+  double friction_coefficient, friction_barrier_mu, friction_barrier_delta, friction_regularization, friction_hessian_shift;
+  double joint_pos_barrier_mu, joint_pos_barrier_delta;
+  double joint_vel_barrier_mu, joint_vel_barrier_delta;
+  double arm_vel_lower[6], arm_vel_upper[6];
+  /* reference.info */
+  double com_height, default_joint_state[QMGPU_NJ], target_displacement_velocity, target_rotation_velocity;
+  /* whole body control (task.info:347-350, qm_wbc/cfg/wbcWigeht.cfg:7-47) */
+  double wbc_friction_coefficient;
+  double kp_swing, kd_swing, kp_base_height, kd_base_height, kp_base_linear, kd_base_linear, kp_base_angular, kd_base_angular;
+  double kp_arm_joint[6], kd_arm_joint[6];
+  double kp_ee_linear[3], kd_ee_linear[3], kp_ee_angular[3], kd_ee_angular[3];
+  double gravity; /* 9.81 */
+} qmgpu_settings;
+
+typedef struct qmgpu_problem {
+  qmgpu_model model;
+  qmgpu_settings settings;
+} qmgpu_problem;
+
+/* A gait template (gait.info) */
+typedef struct qmgpu_gait {
+  int32_t num_modes;
+  int32_t modes[QMGPU_MAX_EVENTS];
+  double switching_times[QMGPU_MAX_EVENTS + 1];
+} qmgpu_gait;
+
+typedef struct qmgpu_context* qmgpu_handle;
+
+const char* qmgpu_strerror(int status);
+/* Last error detail (thread local, valid until the next failing call on this thread). */
+const char* qmgpu_last_error(void);
+
+/* ---- host-side configuration (no GPU needed) -------------------------------------------------- */
+int qmgpu_load_problem(const char* task_file, const char* urdf_file, const char* reference_file,
+                       const char* wbc_gains_file /* may be NULL: compiled-in defaults */, qmgpu_problem* out);
+int qmgpu_load_gait(const char* gait_file, const char* gait_name, qmgpu_gait* out);
+int qmgpu_mode_from_string(const char* name); /* "LF_RH" -> 9, unknown -> -1 */
+/* Tile a gait template over [t_begin, t_end] starting the first cycle at t_phase0, the way
+ * ocs2::legged_robot::GaitSchedule extends its template; writes a mode schedule
+ * (num_events event times, num_events + 1 modes). Returns QMGPU_ERR_CAPACITY if it does not fit. */
+int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, double t_end,
+                    int32_t* num_events, double* event_times /*[MAX_EVENTS]*/, int32_t* modes /*[MAX_EVENTS+1]*/);
+
+/* ---- device context ---------------------------------------------------------------------------- */
+int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, qmgpu_handle* out);
+int qmgpu_destroy(qmgpu_handle h);
+/* Use an externally owned HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
+int qmgpu_set_stream(qmgpu_handle h, void* hip_stream);
+int qmgpu_synchronize(qmgpu_handle h);
+/* Leg-velocity-mapped input weight R' (30x30, row major) computed at create time (QMInterface.cpp:274-299). */
+int qmgpu_get_input_weight(qmgpu_handle h, double* R_host);
+
+/* Per-batch problem data, all device pointers. */
+typedef struct qmgpu_mpc_args {
+  int32_t batch, num_nodes;            /* N shooting intervals -> N+1 nodes */
+  int32_t num_target_knots;            /* K >= 1 */
+  int32_t line_search;                 /* 0: take the full step, 1: OCS2 filter line search */
+  const double* t0;                    /* [batch] */
+  const double* x0;                    /* [batch][30] */
+  const double* time_grid;             /* [batch][N+1] or NULL -> t0 + k*dt */
+  const double* target_times;          /* [batch][K] */
+  const double* target_states;         /* [batch][K][37] */
+  const int32_t* sched_num_events;     /* [batch] */
+  const double* sched_event_times;     /* [batch][MAX_EVENTS] */
+  const int32_t* sched_modes;          /* [batch][MAX_EVENTS+1] */
+  const double* warm_x;                /* [batch][N+1][30] or NULL -> initializer (QMInitializer.cpp:33-41) */
+  const double* warm_u;                /* [batch][N][30]   or NULL */
+  double* out_t;                       /* [batch][N+1] */
+  double* out_x;                       /* [batch][N+1][30] */
+  double* out_u;                       /* [batch][N][30] */
+  int32_t* out_mode;                   /* [batch][N+1] */
+  double* out_stats;                   /* [batch][NSTATS]: merit0, violation0, merit1, violation1, alpha, step_type, armijo, status */
+} qmgpu_mpc_args;
+
+int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args);
+
+/* Linear interpolation of a solved trajectory at t_eval (MRT evaluatePolicy). All device pointers. */
+int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const double* t_grid, const double* X,
+                            const double* U, const int32_t* modes, const double* t_eval, double* x_out /*[batch][30]*/,
+                            double* u_out /*[batch][30]*/, int32_t* mode_out /*[batch]*/);
+
+typedef struct qmgpu_wbc_args {
+  int32_t batch;
+  int32_t variant;                     /* 0: HierarchicalWbc, 1: HierarchicalMpcWbc */
+  const double* state_desired;         /* [batch][30] */
+  const double* input_desired;         /* [batch][30] */
+  const double* rbd_measured;          /* [batch][55] */
+  const int32_t* mode;                 /* [batch] */
+  const double* period;                /* [batch] */
+  const double* time;                  /* [batch]  (t < 10 s selects the start-up task set, HierarchicalWbc.cpp:32-37) */
+  double* input_last;                  /* [batch][30] in/out: WbcBase::inputLast_ (WbcBase.cpp:224-225) */
+  double* out;                         /* [batch][54] */
+  int32_t* out_status;                 /* [batch] 0 = all three QPs converged; bit l set = level l hit the iteration cap */
+} qmgpu_wbc_args;
+
+int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args);
+
+/* One control cycle per robot: MPC solve, policy evaluation at t_eval, WBC.  */
+int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t_eval /*[batch]*/, qmgpu_wbc_args* wbc);
+
+/* Diagnostics used by the parity tests: per-node LQ blocks of the last qmgpu_mpc_solve_batch
+ * (before projection: A B b | Q R q r | C D e ; nc rows valid).  Host pointers, any may be NULL. */
+int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double* B, double* b, double* Q, double* R,
+                       double* q, double* r, double* C, double* D, double* e, int32_t* nc);
+
+/* Average device time (ms) of each kernel of the last call, measured with HIP events on the handle's stream:
+ * [0] lq_node  [1] riccati  [2] line search + update  [3] wbc  [4] whole call */
+int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms5);
+int qmgpu_enable_timing(qmgpu_handle h, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMGPU_H */

@@ -1,0 +1,174 @@
+// qmo_api.cpp -- TEST INFRASTRUCTURE ONLY.  extern "C" entry points of the CPU oracle for ctypes (tests/, smoke(),
+// bench.py cpu_baseline).  PARITY UNPINNED: see qmo_core.h.  The product (qm_door_amd/) never links or loads this.
+#include <chrono>
+#include <cstdio>
+#include <memory>
+
+#include "qmo_mpc.h"
+#include "qmo_wbc.h"
+
+using namespace qmo;
+
+extern "C" {
+
+void qmo_flow_map(const qmgpu_problem* P, const double* x, const double* u, double* f) { flowMap<double>(P->model, P->settings.gravity, x, u, f); }
+
+void qmo_flow_map_lin(const qmgpu_problem* P, const double* x, const double* u, double* f, double* A, double* B) {
+  Mat Am, Bm;
+  flowMapLinearization(*P, x, u, f, Am, Bm);
+  Am.to(A); Bm.to(B);
+}
+
+void qmo_kinematics(const qmgpu_problem* P, const double* x, const double* u, double* footPos, double* footVel, double* eePos, double* eeQuat, double* com) {
+  double f[30];
+  FlowAux<double> aux;
+  flowMap<double>(P->model, P->settings.gravity, x, u, f, &aux);
+  for (int c = 0; c < 4; ++c) for (int a = 0; a < 3; ++a) { footPos[3 * c + a] = aux.footPos[c][a]; footVel[3 * c + a] = aux.footVel[c][a]; }
+  for (int a = 0; a < 3; ++a) eePos[a] = aux.eePos[a];
+  matrixToQuaternion(aux.eeRot, eeQuat);
+  if (com) { Kin<double> k; forwardKinematics<double>(P->model, x + 6, k); for (int a = 0; a < 3; ++a) com[a] = k.comTotal[a]; }
+}
+
+void qmo_centroidal_matrix(const qmgpu_problem* P, const double* q, double* A /*6x24*/) {
+  Kin<double> k; forwardKinematics<double>(P->model, q, k);
+  double Am[6][NV]; centroidalMomentumMatrix(P->model, k, Am);
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < NV; ++j) A[i * NV + j] = Am[i][j];
+}
+
+void qmo_input_weight(const qmgpu_problem* P, double* R) { inputWeight(*P).to(R); }
+
+int qmo_mode_at(int nEv, const double* ev, const int32_t* modes, double t) { ModeSchedule ms{nEv, ev, modes}; return ms.modeAt(t); }
+
+void qmo_swing_reference(const qmgpu_problem* P, int nEv, const double* ev, const int32_t* modes, double t, double* zpos4, double* zvel4) {
+  ModeSchedule ms{nEv, ev, modes};
+  for (int c = 0; c < 4; ++c) swingReference(P->settings, ms, c, t, &zpos4[c], &zvel4[c]);
+}
+
+void qmo_reference_at(int K, const double* times, const double* states, double t, double* xref, double* eePos, double* eeQuat) {
+  Target tg{K, times, states};
+  referenceAt(tg, t, xref, eePos, eeQuat);
+}
+
+// LQ approximation of one node before projection; matrices row-major 30x30, C/D nc x 30 packed (capacity 16 rows).
+void qmo_lq_node(const qmgpu_problem* P, double t, double dt, const double* x, const double* u, const double* xnext, int terminal, int nEv, const double* ev,
+                 const int32_t* modes, int K, const double* ttimes, const double* tstates, double* A, double* B, double* b, double* Q, double* R, double* q,
+                 double* r, double* C, double* D, double* e, int32_t* nc, double* cost) {
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+  NodeLQ o;
+  nodeLQ(pr, t, dt, x, u, xnext, terminal != 0, o);
+  o.Q.to(Q);
+  for (int i = 0; i < 30; ++i) q[i] = o.q[i];
+  *cost = o.cost;
+  *nc = o.nc;
+  if (terminal) return;
+  o.A.to(A); o.B.to(B); o.R.to(R);
+  for (int i = 0; i < 30; ++i) { b[i] = o.b[i]; r[i] = o.r[i]; }
+  if (o.nc > 0) { o.C.to(C); o.D.to(D); for (int i = 0; i < o.nc; ++i) e[i] = o.e[i]; }
+}
+
+// One SQP iteration. warmX/warmU may be NULL (initializer: x_k = x0, u_k = weight compensation; QMInitializer.cpp:33-41).
+int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, const double* timeGrid, int K, const double* ttimes, const double* tstates,
+                  int nEv, const double* ev, const int32_t* modes, const double* warmX, const double* warmU, int lineSearch, double* outT, double* outX,
+                  double* outU, int32_t* outMode, double* stats) {
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+  std::vector<double> tg(N + 1);
+  for (int k = 0; k <= N; ++k) tg[k] = timeGrid ? timeGrid[k] : t0 + k * P->settings.dt;
+  std::vector<double> X((N + 1) * 30), U(N * 30);
+  for (int k = 0; k <= N; ++k) for (int i = 0; i < 30; ++i) X[k * 30 + i] = warmX ? warmX[k * 30 + i] : x0[i];
+  for (int i = 0; i < 30; ++i) X[i] = x0[i];
+  for (int k = 0; k < N; ++k) {
+    if (warmU) for (int i = 0; i < 30; ++i) U[k * 30 + i] = warmU[k * 30 + i];
+    else weightCompensatingInput(*P, pr.ms.modeAt(tg[k]), &U[k * 30]);
+  }
+  const SqpResult r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
+  for (int k = 0; k <= N; ++k) { outT[k] = tg[k]; outMode[k] = pr.ms.modeAt(tg[k]); }
+  std::copy(r.X.begin(), r.X.end(), outX);
+  std::copy(r.U.begin(), r.U.end(), outU);
+  if (stats) { stats[0] = r.merit0; stats[1] = r.viol0; stats[2] = r.merit1; stats[3] = r.viol1; stats[4] = r.alpha; stats[5] = r.stepType; stats[6] = r.armijo; stats[7] = r.status; }
+  return r.status;
+}
+
+// performance index of a trajectory (merit, constraint violation)
+void qmo_performance(const qmgpu_problem* P, int N, const double* tgrid, const double* x0, const double* X, const double* U, int K, const double* ttimes,
+                     const double* tstates, int nEv, const double* ev, const int32_t* modes, double* merit, double* viol) {
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+  double cost = 0, dyn = 0, eq = 0;
+  for (int i = 0; i < 30; ++i) dyn += (x0[i] - X[i]) * (x0[i] - X[i]);
+  for (int k = 0; k < N; ++k) { const NodeMetrics m = nodeMetrics(pr, tgrid[k], tgrid[k + 1] - tgrid[k], X + k * 30, U + k * 30, X + (k + 1) * 30, false); cost += m.cost; dyn += m.dynViolationSSE; eq += m.eqViolationSSE; }
+  cost += nodeMetrics(pr, tgrid[N], 0.0, X + N * 30, nullptr, nullptr, true).cost;
+  *merit = cost; *viol = std::sqrt(dyn + eq);
+}
+
+// WBC model quantities for parity of the model-update kernel
+void qmo_wbc_model(const qmgpu_problem* P, const double* xDes, const double* uDes, const double* rbd, double period, double* inputLast, double* M, double* nle,
+                   double* J, double* dJ, double* baseJ, double* baseDJ, double* armJ, double* armDJ, double* qvMD /*4x24: qM vM qD vD*/, double* baseAcc,
+                   double* feet /*4 x [posM velM posD velD] x3 = 48*/, double* ee /* posM velM posD velD angVelM (15) + RM(9) + RD(9) */) {
+  WbcModel w;
+  wbcUpdateMeasured(*P, rbd, w);
+  wbcUpdateDesired(*P, xDes, uDes, inputLast, period, w);
+  w.M.to(M); w.J.to(J); w.dJ.to(dJ); w.baseJ.to(baseJ); w.baseDJ.to(baseDJ); w.armJ.to(armJ); w.armDJ.to(armDJ);
+  for (int i = 0; i < NV; ++i) { nle[i] = w.nle[i]; qvMD[i] = w.qM[i]; qvMD[NV + i] = w.vM[i]; qvMD[2 * NV + i] = w.qD[i]; qvMD[3 * NV + i] = w.vD[i]; }
+  for (int i = 0; i < 6; ++i) baseAcc[i] = w.baseAccDesired[i];
+  for (int c = 0; c < 4; ++c) for (int a = 0; a < 3; ++a) { feet[12 * c + a] = w.footPosM[c][a]; feet[12 * c + 3 + a] = w.footVelM[c][a]; feet[12 * c + 6 + a] = w.footPosD[c][a]; feet[12 * c + 9 + a] = w.footVelD[c][a]; }
+  for (int a = 0; a < 3; ++a) { ee[a] = w.eePosM[a]; ee[3 + a] = w.eeVelM[a]; ee[6 + a] = w.eePosD[a]; ee[9 + a] = w.eeVelD[a]; ee[12 + a] = w.eeAngVelM[a]; }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { ee[15 + 3 * i + j] = w.eeRotM.m[i][j]; ee[24 + 3 * i + j] = w.eeRotD.m[i][j]; }
+}
+
+int qmo_wbc_update(const qmgpu_problem* P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
+                   double* inputLast, double* out54) {
+  return wbcUpdate(*P, variant, xDes, uDes, rbd, mode, period, time, inputLast, out54);
+}
+
+// generic QP (row-major H n x n, D m x n) for KKT tests
+int qmo_qp_solve(int n, int m, const double* H, const double* c, const double* D, const double* f, double* z, double* kktRes) {
+  Mat Hm = Mat::from(H, n, n), Dm = m > 0 ? Mat::from(D, m, n) : Mat(0, n);
+  Vec cv(c, c + n), fv(f, f + m), zv;
+  const int it = solveQpIpm(Hm, cv, Dm, fv, zv, 60, kktRes);
+  for (int i = 0; i < n; ++i) z[i] = zv[i];
+  return it;
+}
+
+// The three QPs of one WBC update (H c D f per level), for checking the GPU's structured solve against the dense data.
+int qmo_wbc_levels(const qmgpu_problem* P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
+                   const double* inputLastIn, int level, int32_t* dims /*nz, rows, numDec*/, double* H, double* c, double* D, double* f, double* sol, double* xLevel) {
+  double il[30]; for (int i = 0; i < 30; ++i) il[i] = inputLastIn[i];
+  WbcModel w;
+  wbcUpdateMeasured(*P, rbd, w);
+  wbcUpdateDesired(*P, xDes, uDes, il, period, w);
+  WbcTasks tk(*P, w, mode);
+  const Task task0 = tk.floatingBaseEom() + tk.torqueLimits() + tk.noContactMotion() + tk.frictionCone();
+  Task task1, task2;
+  if (variant == 0) { task1 = (time < 10.0) ? tk.armJointNominalTracking() : (tk.baseHeight() + tk.baseAngular() + tk.eeLinear() + tk.eeAngular() + tk.swingLeg() * 100.0); task2 = tk.contactForce(uDes) + tk.baseLinear(); }
+  else { task1 = tk.baseHeight() + tk.baseAngular() + tk.baseLinear() + tk.swingLeg() * 100.0; task2 = tk.contactForce(uDes); }
+  HoQp h0(task0, nullptr);
+  const HoQp* h = &h0;
+  HoQp h1(task1, &h0);
+  if (level >= 1) h = &h1;
+  std::unique_ptr<HoQp> h2;
+  if (level >= 2) { if (h1.Z.c == 0) return -1; h2.reset(new HoQp(task2, &h1)); h = h2.get(); }
+  dims[0] = h->Hm.r; dims[1] = h->Dm.r; dims[2] = h->numDec;
+  h->Hm.to(H); h->Dm.to(D);
+  for (size_t i = 0; i < h->cv.size(); ++i) c[i] = h->cv[i];
+  for (size_t i = 0; i < h->fv.size(); ++i) f[i] = h->fv[i];
+  for (int i = 0; i < h->numDec; ++i) sol[i] = h->decSol[i];
+  for (size_t i = 0; i < h->slackSol.size(); ++i) sol[h->numDec + i] = h->slackSol[i];
+  const Vec x = h->solution();
+  for (int i = 0; i < 36; ++i) xLevel[i] = x[i];
+  return h->qpIters;
+}
+
+// CPU baseline: time `count` full MPC(+WBC) cycles, returns seconds.
+double qmo_time_cycles(const qmgpu_problem* P, int count, int N, const double* x0s /*count x 30*/, int K, const double* ttimes, const double* tstates, int nEv,
+                       const double* ev, const int32_t* modes, const double* rbds /*count x 55*/, int lineSearch) {
+  std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(8);
+  std::vector<int32_t> md(N + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < count; ++i) {
+    qmo_mpc_solve(P, N, 0.0, x0s + i * 30, nullptr, K, ttimes, tstates, nEv, ev, modes, nullptr, nullptr, lineSearch, T.data(), X.data(), U.data(), md.data(), st.data());
+    double il[30] = {0}, out[54];
+    wbcUpdate(*P, 0, X.data(), U.data(), rbds + i * 55, md[0], 0.002, 20.0, il, out);
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // extern "C"
