@@ -208,6 +208,8 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
  * [0] lq_node  [1] riccati  [2] line search + update  [3] wbc  [4] whole call */
 int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms5);
 int qmgpu_enable_timing(qmgpu_handle h, int enable);
+/* Allocate / enable the per-node dump read by qmgpu_debug_get_lq (off by default: 37 KiB per node). */
+int qmgpu_enable_debug(qmgpu_handle h, int enable);
 
 #ifdef __cplusplus
 }

@@ -84,10 +84,26 @@ SYMBOLS = [
     "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait",
     "qmgpu_create", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
     "qmgpu_policy_eval_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
-    "qmgpu_enable_timing",
+    "qmgpu_enable_timing", "qmgpu_enable_debug",
 ]
 
 _lib = None
+
+
+def _preload_hip_runtime():
+    """Bind to the HIP runtime PyTorch-ROCm ships (if present) before libqmgpu.so is mapped.
+
+    torch/lib/libamdhip64.so carries SONAME libamdhip64.so.7 but no file of that name, so the dynamic loader would
+    otherwise satisfy libqmgpu.so's NEEDED entry from /opt/rocm and the process would end up with two HIP/HSA runtimes,
+    of which only the first one initialised sees the GPU.  Loading torch's copy first makes both users share it.
+    """
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def load_library(path=None):
@@ -99,6 +115,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                            "qm_door_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(p)
     lib.qmgpu_strerror.restype = C.c_char_p
     lib.qmgpu_strerror.argtypes = [C.c_int]
@@ -119,6 +136,7 @@ def load_library(path=None):
     lib.qmgpu_debug_get_lq.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.POINTER(i32)]
     lib.qmgpu_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(d)]
     lib.qmgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.qmgpu_enable_debug.argtypes = [C.c_void_p, C.c_int]
     if path is None:
         _lib = lib
     return lib

@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference's interfaces for the hot path, over the C ABI (include/qmgpu.h).
+
+  QMInterface      <-> qm::QMInterface               (qm_interface/include/qm_interface/QMInterface.h:37-54): loads task/urdf/reference
+  GaitSchedule     <-> gait.info templates + upstream GaitSchedule tiling (QMInterface.cpp:455-480)
+  GpuSolver.mpc()  <-> ocs2::MPC_BASE::run            (QMController.cpp:288-289, 316-327), batched
+  GpuSolver.wbc()  <-> qm::WbcBase::update            (qm_wbc/include/qm_wbc/WbcBase.h:31-34), batched
+  GpuSolver.cycle()<-> one QMController::update tick  (QMController.cpp:129-176), batched
+
+Arrays are whatever owns the memory the library can dereference: torch CUDA tensors on the GPU (``.data_ptr()``).
+This module is plumbing: it never computes anything itself and has no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return C.c_void_p(a.data_ptr())
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    raise TypeError(f"unsupported buffer type {type(a)}")
+
+
+class QMInterface:
+    """Problem definition loaded from the reference's own config files (or the distilled fixtures in qm_door_amd/data)."""
+
+    def __init__(self, task_file=None, urdf_file=None, reference_file=None, wbc_gains_file=None, lib=None):
+        self.lib = lib or abi.load_library()
+        d = abi.DATA_DIR
+        self.task_file = task_file or os.path.join(d, "task.info")
+        self.urdf_file = urdf_file or os.path.join(d, "aliengo_z1.urdf")
+        self.reference_file = reference_file or os.path.join(d, "reference.info")
+        gains = wbc_gains_file if wbc_gains_file is not None else os.path.join(d, "wbc_gains.info")
+        self.problem = abi.Problem()
+        abi.check(self.lib, self.lib.qmgpu_load_problem(self.task_file.encode(), self.urdf_file.encode(), self.reference_file.encode(),
+                                                        gains.encode() if gains else None, C.byref(self.problem)))
+
+    @property
+    def initial_state(self):
+        return np.array(self.problem.settings.initial_state[:])
+
+    @property
+    def robot_mass(self):
+        return self.problem.model.total_mass
+
+
+class GaitSchedule:
+    def __init__(self, gait_file=None, lib=None):
+        self.lib = lib or abi.load_library()
+        self.gait_file = gait_file or os.path.join(abi.DATA_DIR, "gait.info")
+
+    def template(self, name):
+        g = abi.Gait()
+        abi.check(self.lib, self.lib.qmgpu_load_gait(self.gait_file.encode(), name.encode(), C.byref(g)))
+        return g
+
+    def mode_schedule(self, name, t_phase0, t_begin, t_end):
+        """(num_events, event_times[MAX_EVENTS], modes[MAX_EVENTS+1]) covering [t_begin, t_end]."""
+        g = self.template(name)
+        n = abi.i32(0)
+        ev = (abi.d * abi.MAX_EVENTS)()
+        md = (abi.i32 * (abi.MAX_EVENTS + 1))()
+        abi.check(self.lib, self.lib.qmgpu_tile_gait(C.byref(g), t_phase0, t_begin, t_end, C.byref(n), ev, md))
+        return n.value, np.array(ev[:]), np.array(md[:], dtype=np.int32)
+
+
+class GpuSolver:
+    """Owns a qmgpu handle (device scratch + stream)."""
+
+    def __init__(self, interface, max_batch, max_nodes, device=0):
+        self.lib = interface.lib
+        self.interface = interface
+        self.handle = C.c_void_p()
+        abi.check(self.lib, self.lib.qmgpu_create(C.byref(interface.problem), device, max_batch, max_nodes, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.qmgpu_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        abi.check(self.lib, self.lib.qmgpu_set_stream(self.handle, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        abi.check(self.lib, self.lib.qmgpu_synchronize(self.handle))
+
+    def enable_timing(self, on=True):
+        abi.check(self.lib, self.lib.qmgpu_enable_timing(self.handle, int(on)))
+
+    def enable_debug(self, on=True):
+        abi.check(self.lib, self.lib.qmgpu_enable_debug(self.handle, int(on)))
+
+    def input_weight(self):
+        R = np.zeros((30, 30))
+        abi.check(self.lib, self.lib.qmgpu_get_input_weight(self.handle, R.ctypes.data_as(C.POINTER(abi.d))))
+        return R
+
+    def last_kernel_ms(self):
+        ms = (abi.d * 5)()
+        abi.check(self.lib, self.lib.qmgpu_last_kernel_ms(self.handle, ms))
+        return list(ms)
+
+    @staticmethod
+    def mpc_args(batch, num_nodes, x0, target_times, target_states, sched_num, sched_times, sched_modes, out_t, out_x, out_u, out_mode, out_stats=None,
+                 t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True):
+        K = target_times.shape[-1] if target_times.ndim > 1 else 1
+        a = abi.MpcArgs()
+        a.batch, a.num_nodes, a.num_target_knots, a.line_search = batch, num_nodes, K, int(line_search)
+        for name, val in (("t0", t0), ("x0", x0), ("time_grid", time_grid), ("target_times", target_times), ("target_states", target_states),
+                          ("sched_num_events", sched_num), ("sched_event_times", sched_times), ("sched_modes", sched_modes), ("warm_x", warm_x),
+                          ("warm_u", warm_u), ("out_t", out_t), ("out_x", out_x), ("out_u", out_u), ("out_mode", out_mode), ("out_stats", out_stats)):
+            setattr(a, name, _ptr(val))
+        a._keep = (t0, x0, time_grid, target_times, target_states, sched_num, sched_times, sched_modes, warm_x, warm_u, out_t, out_x, out_u, out_mode, out_stats)
+        return a
+
+    @staticmethod
+    def wbc_args(batch, rbd, period, time, input_last, out, out_status=None, state_desired=None, input_desired=None, mode=None, variant=0):
+        a = abi.WbcArgs()
+        a.batch, a.variant = batch, variant
+        for name, val in (("state_desired", state_desired), ("input_desired", input_desired), ("rbd_measured", rbd), ("mode", mode), ("period", period),
+                          ("time", time), ("input_last", input_last), ("out", out), ("out_status", out_status)):
+            setattr(a, name, _ptr(val))
+        a._keep = (state_desired, input_desired, rbd, mode, period, time, input_last, out, out_status)
+        return a
+
+    def mpc(self, args):
+        abi.check(self.lib, self.lib.qmgpu_mpc_solve_batch(self.handle, C.byref(args)))
+
+    def wbc(self, args):
+        abi.check(self.lib, self.lib.qmgpu_wbc_solve_batch(self.handle, C.byref(args)))
+
+    def cycle(self, mpc_args, t_eval, wbc_args):
+        abi.check(self.lib, self.lib.qmgpu_cycle_batch(self.handle, C.byref(mpc_args), _ptr(t_eval), C.byref(wbc_args)))
+
+    def policy_eval(self, batch, num_nodes, t_grid, X, U, modes, t_eval, x_out, u_out, mode_out):
+        abi.check(self.lib, self.lib.qmgpu_policy_eval_batch(self.handle, batch, num_nodes, _ptr(t_grid), _ptr(X), _ptr(U), _ptr(modes), _ptr(t_eval),
+                                                            _ptr(x_out), _ptr(u_out), _ptr(mode_out)))
+
+    def debug_lq(self, instance, node):
+        A, B, Q, R = (np.zeros((30, 30)) for _ in range(4))
+        b, q, r = (np.zeros(30) for _ in range(3))
+        Cm, Dm, e = np.zeros((16, 30)), np.zeros((16, 30)), np.zeros(16)
+        nc = abi.i32(0)
+        abi.check(self.lib, self.lib.qmgpu_debug_get_lq(self.handle, instance, node, _ptr(A), _ptr(B), _ptr(b), _ptr(Q), _ptr(R), _ptr(q), _ptr(r), _ptr(Cm),
+                                                       _ptr(Dm), _ptr(e), C.byref(nc)))
+        n = nc.value
+        return dict(A=A, B=B, b=b, Q=Q, R=R, q=q, r=r, C=Cm[:n], D=Dm[:n], e=e[:n], nc=n)

@@ -1,0 +1,62 @@
+"""Builds qm_door_amd/libqmgpu.so in-tree: hipcc (gfx950) for the kernels + C ABI, g++ for the host loaders.
+
+The HIP runtime the library binds to is the one the host process already uses: under the Python harness that is the
+libamdhip64 bundled with PyTorch-ROCm (two HIP/HSA runtimes in one process cannot both see the GPU); a C++ host such as
+the qm_controllers plugin links the same objects against the system ROCm instead.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OUT = os.path.join(PKG, "libqmgpu.so")
+OBJ = os.path.join(PKG, "build")
+ARCH = "gfx950"
+
+
+def _torch_lib_dir():
+    try:
+        import torch
+        d = os.path.join(os.path.dirname(torch.__file__), "lib")
+        if os.path.exists(os.path.join(d, "libamdhip64.so")):
+            return d
+    except Exception:
+        pass
+    return None
+
+
+def _sources():
+    deps = [os.path.join(PKG, "..", "include", "qmgpu.h")]
+    for root, _, files in os.walk(CSRC):
+        deps += [os.path.join(root, f) for f in files]
+    return deps
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    deps = _sources() + [os.path.abspath(__file__)]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    api_o, host_o = os.path.join(OBJ, "qmgpu_api.o"), os.path.join(OBJ, "host_config.o")
+    cmds = [
+        [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *extra_flags, "-c", os.path.join(CSRC, "qmgpu_api.hip"), "-o", api_o],
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, "host", "host_config.cpp"), "-o", host_o],
+    ]
+    tl = _torch_lib_dir()
+    libdirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
+    link = ["g++", "-shared", "-o", OUT, api_o, host_o]
+    for d in libdirs:
+        link += [f"-L{d}", f"-Wl,-rpath,{d}"]
+    link += ["-lamdhip64", "-lstdc++", "-lm"]
+    cmds.append(link)
+    for c in cmds:
+        if verbose:
+            print(" ".join(c), file=sys.stderr)
+        subprocess.check_call(c)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,106 @@
+// Small set-up kernels: input-weight mapping, initial trajectories, policy evaluation.
+#pragma once
+#include "layout.h"
+#include "lq_kernel.h"
+
+namespace qmk {
+
+// R' = R_task with the 12x12 leg-velocity block replaced by J^T R_task J, J = feet Jacobian w.r.t. the leg joints at the
+// initial state (QMInterface::initializeInputCostWeight, QMInterface.cpp:274-299).  One wavefront; the Jacobian columns come
+// from the same lane-tangent sweep the LQ kernel uses (lane 42+j carries d/d(v_joint j)).
+__global__ void __launch_bounds__(64) input_weight_kernel(const qmgpu_problem* P, const double* zeros, double* Rw) {
+  __shared__ double J[12 * 12];
+  __shared__ double RJ[12 * 12];
+  const int lane = threadIdx.x;
+  const qmgpu_model& md = P->model;
+  Du k1[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) k1[i] = Du(0.0);
+  const DuIn in{P->settings.initial_state, zeros, lane, 0.0, k1};
+  Feet<Du> feet;
+  Du f[12];
+  BaseMotion<Du> bm;
+  centroidalSweep<Du>(md, P->settings.gravity, in, [&](int c, Vec3<Du> r, Vec3<Du> v) { feet.set(c, r, v); }, [&](Vec3<Du>, const Mat3<Du>&) {}, f, bm);
+  if (lane >= 42 && lane < 54) {
+    const int j = lane - 42;
+    for (int c = 0; c < 4; ++c) { const Vec3<Du> v = feet.v(c); J[(3 * c + 0) * 12 + j] = v.x.d; J[(3 * c + 1) * 12 + j] = v.y.d; J[(3 * c + 2) * 12 + j] = v.z.d; }
+  }
+  __syncthreads();
+  const double* Rt = P->settings.R_task;
+  for (int e = lane; e < 144; e += 64) {
+    const int i = e / 12, j = e % 12;
+    double s = 0.0;
+    for (int k = 0; k < 12; ++k) s += Rt[(12 + i) * 30 + 12 + k] * J[k * 12 + j];
+    RJ[e] = s;
+  }
+  __syncthreads();
+  for (int e = lane; e < 900; e += 64) {
+    const int i = e / 30, j = e % 30;
+    double v = Rt[e];
+    if (i >= 12 && i < 24 && j >= 12 && j < 24) {
+      v = 0.0;
+      for (int k = 0; k < 12; ++k) v += J[k * 12 + (i - 12)] * RJ[k * 12 + (j - 12)];
+    }
+    Rw[e] = v;
+  }
+}
+
+struct InitArgs {
+  const qmgpu_problem* P;
+  int batch, N;
+  const double* t0; const double* x0; const double* timeGrid; const double* warmX; const double* warmU;
+  const int* schedNum; const double* schedTimes; const int* schedModes;
+  double* tgrid; double* X; double* U;
+};
+
+// Time grid + initial trajectories: previous solution when given, else QMInitializer::compute (QMInitializer.cpp:33-41):
+// u = weight-compensating input for the contact flags at t_k, x_{k+1} = x_k.  x[0] is always the measured state.
+__global__ void mpc_init_kernel(InitArgs a) {
+  const int inst = blockIdx.x;
+  const qmgpu_settings& st = a.P->settings;
+  const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
+  for (int k = threadIdx.x; k <= a.N; k += blockDim.x) {
+    const double t = a.timeGrid ? a.timeGrid[size_t(inst) * (a.N + 1) + k] : a.t0[inst] + k * st.dt;
+    a.tgrid[size_t(inst) * (a.N + 1) + k] = t;
+    double* x = a.X + (size_t(inst) * (a.N + 1) + k) * 30;
+    const double* src = (a.warmX && k > 0) ? a.warmX + (size_t(inst) * (a.N + 1) + k) * 30 : a.x0 + size_t(inst) * 30;
+    for (int i = 0; i < 30; ++i) x[i] = src[i];
+    if (k < a.N) {
+      double* u = a.U + (size_t(inst) * a.N + k) * 30;
+      if (a.warmU) {
+        const double* su = a.warmU + (size_t(inst) * a.N + k) * 30;
+        for (int i = 0; i < 30; ++i) u[i] = su[i];
+      } else {
+        const int mode = sched.modes[phaseAt(sched, t)];
+        int n = 0;
+        for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
+        for (int i = 0; i < 30; ++i) u[i] = 0.0;
+        if (n > 0) for (int c = 0; c < 4; ++c) if (contactOf(mode, c)) u[3 * c + 2] = a.P->model.total_mass * st.gravity / n;
+      }
+    }
+  }
+}
+
+// MPC_MRT_Interface::evaluatePolicy (call site QMController.cpp:134-142): linear interpolation of (X, U) at t_eval, planned mode
+// of the interval.  One thread per instance.
+__global__ void policy_eval_kernel(int batch, int N, const double* tgrid, const double* X, const double* U, const int* modes, const double* tEval, double* xOut,
+                                   double* uOut, int* modeOut) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= batch) return;
+  const double* tg = tgrid + size_t(inst) * (N + 1);
+  const double t = tEval[inst];
+  int idx; double alpha;
+  timeSegment(tg, N + 1, t, idx, alpha);
+  const double* xl = X + (size_t(inst) * (N + 1) + idx) * 30;
+  for (int i = 0; i < 30; ++i) xOut[size_t(inst) * 30 + i] = alpha * xl[i] + (1.0 - alpha) * xl[30 + i];
+  // the input trajectory has N entries; upstream pads it by repeating the last input at the final time
+  const int iu0 = min(idx, N - 1), iu1 = min(idx + 1, N - 1);
+  const double* ul = U + (size_t(inst) * N + iu0) * 30; const double* ur = U + (size_t(inst) * N + iu1) * 30;
+  for (int i = 0; i < 30; ++i) uOut[size_t(inst) * 30 + i] = alpha * ul[i] + (1.0 - alpha) * ur[i];
+  // mode of the node interval containing t (lower_bound convention of the grid)
+  int k = 0;
+  while (k < N && tg[k + 1] < t) ++k;
+  modeOut[inst] = modes[size_t(inst) * (N + 1) + k];
+}
+
+}  // namespace qmk

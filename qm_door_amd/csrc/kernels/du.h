@@ -1,0 +1,78 @@
+// Lane-tangent dual numbers for CDNA4 wavefronts.
+//
+// A wave evaluates a function ONCE in its primal part (`v`, identical in all 64 lanes, so branches on it
+// stay wave-uniform) while every lane carries the directional derivative `d` along its own seed direction:
+// lane l < 30 differentiates w.r.t. x[l], lane 30 <= l < 60 w.r.t. u[l-30].  After one pass lane l holds
+// column l of the Jacobian [df/dx | df/du] -- the 60 Jacobian columns the reference obtains from CppAD
+// (qm_interface/src/dynamics/QMDynamicsAD.cpp:30-33) come out of a single SIMD sweep, 60/64 lanes busy.
+//
+// The same templated device code runs with T = double (one shooting node per lane, value only) in the
+// line-search kernel.
+#pragma once
+#include "gpu_rt.h"
+
+namespace qmk {
+
+struct Du {
+  double v, d;
+  __device__ __forceinline__ Du() : v(0.0), d(0.0) {}
+  __device__ __forceinline__ Du(double a) : v(a), d(0.0) {}  // NOLINT implicit
+  __device__ __forceinline__ Du(double a, double b) : v(a), d(b) {}
+};
+__device__ __forceinline__ Du operator+(Du a, Du b) { return Du(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Du operator-(Du a, Du b) { return Du(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Du operator-(Du a) { return Du(-a.v, -a.d); }
+__device__ __forceinline__ Du operator*(Du a, Du b) { return Du(a.v * b.v, fma(a.v, b.d, a.d * b.v)); }
+__device__ __forceinline__ Du operator*(double a, Du b) { return Du(a * b.v, a * b.d); }
+__device__ __forceinline__ Du operator*(Du b, double a) { return Du(a * b.v, a * b.d); }
+__device__ __forceinline__ Du operator+(Du a, double b) { return Du(a.v + b, a.d); }
+__device__ __forceinline__ Du operator+(double b, Du a) { return Du(a.v + b, a.d); }
+__device__ __forceinline__ Du operator-(Du a, double b) { return Du(a.v - b, a.d); }
+__device__ __forceinline__ Du operator-(double b, Du a) { return Du(b - a.v, -a.d); }
+__device__ __forceinline__ Du operator/(Du a, Du b) { const double q = a.v / b.v; return Du(q, (a.d - q * b.d) / b.v); }
+__device__ __forceinline__ Du operator/(Du a, double b) { const double r = 1.0 / b; return Du(a.v * r, a.d * r); }
+__device__ __forceinline__ Du operator/(double a, Du b) { const double q = a / b.v; return Du(q, -q * b.d / b.v); }
+__device__ __forceinline__ Du& operator+=(Du& a, Du b) { a.v += b.v; a.d += b.d; return a; }
+__device__ __forceinline__ Du& operator-=(Du& a, Du b) { a.v -= b.v; a.d -= b.d; return a; }
+
+__device__ __forceinline__ void sincosT(double a, double& s, double& c) { sincos(a, &s, &c); }
+__device__ __forceinline__ void sincosT(Du a, Du& s, Du& c) { double sv, cv; sincos(a.v, &sv, &cv); s = Du(sv, cv * a.d); c = Du(cv, -sv * a.d); }
+__device__ __forceinline__ double sqrtT(double a) { return sqrt(a); }
+__device__ __forceinline__ Du sqrtT(Du a) { const double r = sqrt(a.v); return Du(r, 0.5 * a.d / r); }
+__device__ __forceinline__ double val(double a) { return a; }
+__device__ __forceinline__ double val(Du a) { return a.v; }
+// fused multiply-add helpers: r = a*b + c
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ Du fmaT(Du a, Du b, Du c) { return Du(fma(a.v, b.v, c.v), fma(a.v, b.d, fma(a.d, b.v, c.d))); }
+__device__ __forceinline__ Du fmaT(double a, Du b, Du c) { return Du(fma(a, b.v, c.v), fma(a, b.d, c.d)); }
+
+template <class T> struct Vec3 {
+  T x, y, z;
+  __device__ __forceinline__ Vec3() : x(0.0), y(0.0), z(0.0) {}
+  __device__ __forceinline__ Vec3(T a, T b, T c) : x(a), y(b), z(c) {}
+};
+template <class T> __device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return Vec3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> __device__ __forceinline__ Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return Vec3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> __device__ __forceinline__ Vec3<T> operator*(T s, Vec3<T> a) { return Vec3<T>(s * a.x, s * a.y, s * a.z); }
+template <class T> __device__ __forceinline__ Vec3<T> scale(double s, Vec3<T> a) { return Vec3<T>(s * a.x, s * a.y, s * a.z); }
+template <class T> __device__ __forceinline__ Vec3<T> cross(Vec3<T> a, Vec3<T> b) { return Vec3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <class T> __device__ __forceinline__ T dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// 3x3 matrix stored by columns (a joint rotation about a body axis only mixes two columns)
+template <class T> struct Mat3 {
+  Vec3<T> c0, c1, c2;
+};
+template <class T> __device__ __forceinline__ Vec3<T> mul(const Mat3<T>& R, double x, double y, double z) { return scale(x, R.c0) + scale(y, R.c1) + scale(z, R.c2); }
+template <class T> __device__ __forceinline__ Vec3<T> mul(const Mat3<T>& R, Vec3<T> v) { return v.x * R.c0 + v.y * R.c1 + v.z * R.c2; }
+template <class T> __device__ __forceinline__ Vec3<T> mulT(const Mat3<T>& R, Vec3<T> v) { return Vec3<T>(dot(R.c0, v), dot(R.c1, v), dot(R.c2, v)); }
+
+// symmetric 3x3: xx xy xz yy yz zz
+template <class T> struct Sym3 {
+  T xx, xy, xz, yy, yz, zz;
+  __device__ __forceinline__ Sym3() : xx(0.0), xy(0.0), xz(0.0), yy(0.0), yz(0.0), zz(0.0) {}
+};
+template <class T> __device__ __forceinline__ Vec3<T> mul(const Sym3<T>& S, Vec3<T> v) {
+  return Vec3<T>(S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z);
+}
+
+}  // namespace qmk

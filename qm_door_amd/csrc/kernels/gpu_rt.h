@@ -1,0 +1,10 @@
+// Single include point for the GPU runtime.  The product is built by hipcc for gfx950 only; the
+// QMGPU_HOST_EMULATION branch exists solely so tests/emu can run the same kernel sources on host
+// threads in the GPU-less build container (see tests/emu/simt_emu.h) -- it is never part of libqmgpu.so.
+#pragma once
+#ifdef QMGPU_HOST_EMULATION
+#include "simt_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif

@@ -1,0 +1,279 @@
+// Device context and kernel orchestration behind the C ABI (include/qmgpu.h).
+//
+// One handle owns one HIP stream and all scratch in HBM, sized for (max_batch, max_nodes) at create time and laid out
+// horizon-stacked (layout.h).  A call enqueues, on that stream:
+//     mpc_init -> lq_node (batch*(N+1) wavefronts) -> riccati (batch wavefronts) -> linesearch (batch workgroups)
+//     -> policy_eval -> wbc (batch workgroups)
+// with no host synchronisation in between; the caller synchronises when it needs the results.
+// There is no CPU fallback: without a HIP device qmgpu_create returns QMGPU_ERR_NO_DEVICE.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qmgpu.h"
+#include "host/host_error.h"
+#include "kernels/aux_kernels.h"
+#include "kernels/gpu_rt.h"
+#include "kernels/layout.h"
+#include "kernels/linesearch_kernel.h"
+#include "kernels/lq_kernel.h"
+#include "kernels/riccati_kernel.h"
+#include "kernels/wbc_kernel.h"
+
+using namespace qmhost;
+using namespace qmk;
+
+#define HIP_CHECK(expr)                                                                                       \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) throw HipFailure(std::string(#expr) + " failed: " + hipGetErrorString(e_));         \
+  } while (0)
+
+struct qmgpu_context {
+  int device = 0, maxBatch = 0, maxNodes = 0;
+  hipStream_t ownStream = nullptr, stream = nullptr;
+  qmgpu_problem hostProblem;
+  // device buffers
+  qmgpu_problem* dP = nullptr;
+  double *dRw = nullptr, *dZeros = nullptr;
+  double *dTgrid = nullptr, *dX = nullptr, *dU = nullptr, *dStages = nullptr, *dMetrics = nullptr, *dGains = nullptr, *ddX = nullptr, *ddU = nullptr;
+  double *dXt = nullptr, *dUt = nullptr, *dInstStats = nullptr, *dDebug = nullptr;
+  int *dStageNc = nullptr, *dNodeMode = nullptr;
+  // policy evaluation outputs feeding the WBC inside qmgpu_cycle_batch
+  double *dPolX = nullptr, *dPolU = nullptr;
+  int* dPolMode = nullptr;
+  double* dWbcScratch = nullptr;
+  std::vector<void*> allocations;
+  bool timing = false, debugLq = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double lastMs[5] = {0, 0, 0, 0, 0};
+  int lastBatch = 0, lastN = 0;
+
+  template <class T> T* alloc(size_t count) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
+    allocations.push_back(p);
+    return static_cast<T*>(p);
+  }
+};
+
+static void checkTopology(const qmgpu_model& m) {
+  bool ok = m.parent[0] == -1;
+  for (int l = 0; l < 4; ++l) ok = ok && m.parent[1 + 3 * l] == 0 && m.parent[2 + 3 * l] == 1 + 3 * l && m.parent[3 + 3 * l] == 2 + 3 * l;
+  ok = ok && m.parent[13] == 0;
+  for (int a = 1; a < 6; ++a) ok = ok && m.parent[13 + a] == 12 + a;
+  bool seen[4] = {false, false, false, false};
+  for (int c = 0; c < 4; ++c) { const int b = m.foot_body[c]; ok = ok && (b == 3 || b == 6 || b == 9 || b == 12); if (ok) seen[b / 3 - 1] = true; }
+  ok = ok && seen[0] && seen[1] && seen[2] && seen[3] && m.ee_body == 18;
+  if (!ok) throw UnsupportedModel("kernels are specialised to the AlienGo+Z1 topology (4 x 3-joint legs + 6-joint arm)");
+}
+
+extern "C" {
+
+int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, qmgpu_handle* out) {
+  if (!problem || !out || max_batch < 1 || max_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments to qmgpu_create");
+  *out = nullptr;
+  qmgpu_context* ctx = nullptr;
+  const int st = guarded([&]() {
+    checkTopology(problem->model);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw NoDevice("no HIP device visible; qm_door_amd has no CPU execution path");
+    if (device < 0 || device >= count) throw NoDevice("HIP device index out of range");
+    HIP_CHECK(hipSetDevice(device));
+    ctx = new qmgpu_context();
+    ctx->device = device; ctx->maxBatch = max_batch; ctx->maxNodes = max_nodes; ctx->hostProblem = *problem;
+    HIP_CHECK(hipStreamCreate(&ctx->ownStream));
+    ctx->stream = ctx->ownStream;
+    const size_t B = size_t(max_batch), N1 = size_t(max_nodes) + 1, N = size_t(max_nodes);
+    ctx->dP = ctx->alloc<qmgpu_problem>(1);
+    ctx->dRw = ctx->alloc<double>(900);
+    ctx->dZeros = ctx->alloc<double>(64);
+    ctx->dTgrid = ctx->alloc<double>(B * N1);
+    ctx->dX = ctx->alloc<double>(B * N1 * 30);
+    ctx->dU = ctx->alloc<double>(B * N * 30);
+    ctx->dStages = ctx->alloc<double>(B * N1 * STAGE_DOUBLES);
+    ctx->dMetrics = ctx->alloc<double>(B * N1 * NODE_METRICS);
+    ctx->dGains = ctx->alloc<double>(B * N * GAIN_DOUBLES);
+    ctx->ddX = ctx->alloc<double>(B * N1 * 30);
+    ctx->ddU = ctx->alloc<double>(B * N * 30);
+    ctx->dXt = ctx->alloc<double>(B * N1 * 30);
+    ctx->dUt = ctx->alloc<double>(B * N * 30);
+    ctx->dInstStats = ctx->alloc<double>(B * 4);
+    ctx->dStageNc = ctx->alloc<int>(B * N1);
+    ctx->dNodeMode = ctx->alloc<int>(B * N1);
+    ctx->dPolX = ctx->alloc<double>(B * 30);
+    ctx->dPolU = ctx->alloc<double>(B * 30);
+    ctx->dPolMode = ctx->alloc<int>(B);
+    ctx->dWbcScratch = ctx->alloc<double>(B * WBC_SCRATCH_DOUBLES);
+    HIP_CHECK(hipMemcpy(ctx->dP, problem, sizeof(qmgpu_problem), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemsetAsync(ctx->dZeros, 0, 64 * sizeof(double), ctx->stream));
+    for (auto& e : ctx->ev) HIP_CHECK(hipEventCreate(&e));
+    QM_LAUNCH(input_weight_kernel, 1, 64, ctx->stream, ctx->dP, ctx->dZeros, ctx->dRw);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+  if (st != QMGPU_OK) {
+    if (ctx) { for (void* p : ctx->allocations) hipFree(p); delete ctx; }
+    return st;
+  }
+  *out = ctx;
+  return QMGPU_OK;
+}
+
+int qmgpu_destroy(qmgpu_handle h) {
+  if (!h) return QMGPU_OK;
+  hipStreamSynchronize(h->stream);
+  for (void* p : h->allocations) hipFree(p);
+  for (auto& e : h->ev) if (e) hipEventDestroy(e);
+  if (h->ownStream) hipStreamDestroy(h->ownStream);
+  delete h;
+  return QMGPU_OK;
+}
+
+int qmgpu_set_stream(qmgpu_handle h, void* hip_stream) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->ownStream;
+  return QMGPU_OK;
+}
+
+int qmgpu_synchronize(qmgpu_handle h) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() { HIP_CHECK(hipStreamSynchronize(h->stream)); });
+}
+
+int qmgpu_get_input_weight(qmgpu_handle h, double* R_host) {
+  if (!h || !R_host) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&]() { HIP_CHECK(hipStreamSynchronize(h->stream)); HIP_CHECK(hipMemcpy(R_host, h->dRw, 900 * sizeof(double), hipMemcpyDeviceToHost)); });
+}
+
+int qmgpu_enable_timing(qmgpu_handle h, int enable) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  h->timing = enable != 0;
+  return QMGPU_OK;
+}
+
+int qmgpu_enable_debug(qmgpu_handle h, int enable) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() {
+    if (enable && !h->dDebug) h->dDebug = h->alloc<double>(size_t(h->maxBatch) * (h->maxNodes + 1) * DBG_DOUBLES);
+    h->debugLq = enable != 0;
+  });
+}
+
+static void checkMpcArgs(qmgpu_handle h, const qmgpu_mpc_args* a) {
+  if (!h || !a) throw std::invalid_argument("null argument");
+  if (a->batch < 1 || a->num_nodes < 1 || a->num_target_knots < 1) throw std::invalid_argument("batch, num_nodes and num_target_knots must be positive");
+  if (a->batch > h->maxBatch || a->num_nodes > h->maxNodes) throw CapacityError("batch / num_nodes exceed the capacity given to qmgpu_create");
+  if (!a->x0 || !a->target_times || !a->target_states || !a->sched_num_events || !a->sched_event_times || !a->sched_modes) throw std::invalid_argument("missing MPC input pointer");
+  if (!a->time_grid && !a->t0) throw std::invalid_argument("either t0 or time_grid is required");
+  if (!a->out_t || !a->out_x || !a->out_u || !a->out_mode) throw std::invalid_argument("missing MPC output pointer");
+}
+
+static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
+  const int B = a->batch, N = a->num_nodes;
+  hipStream_t s = h->stream;
+  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[0], s));
+  InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, a->warm_x, a->warm_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU};
+  QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
+  LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
+            a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr};
+  QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
+  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
+  RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
+  QM_LAUNCH(riccati_kernel, B, 64, s, ra);
+  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
+  LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
+            a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
+  QM_LAUNCH(linesearch_kernel, B, (N + 1 <= 128 ? 128 : 256), s, ls);
+  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[3], s));
+  HIP_CHECK(hipGetLastError());
+  h->lastBatch = B; h->lastN = N;
+}
+
+static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
+  if (!w || w->batch < 1) throw std::invalid_argument("bad WBC arguments");
+  if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
+  if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
+  WbcArgs wa{h->dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, h->dWbcScratch};
+  QM_LAUNCH(wbc_kernel, w->batch, 64, h->stream, wa);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void finishTiming(qmgpu_handle h, bool mpc, bool wbc) {
+  if (!h->timing) return;
+  HIP_CHECK(hipEventSynchronize(h->ev[mpc ? (wbc ? 5 : 3) : 5]));
+  float ms = 0.f;
+  for (double& v : h->lastMs) v = 0.0;
+  if (mpc) for (int i = 0; i < 3; ++i) { HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1])); h->lastMs[i] = ms; }
+  if (wbc) { HIP_CHECK(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); h->lastMs[3] = ms; }
+  HIP_CHECK(hipEventElapsedTime(&ms, h->ev[mpc ? 0 : 4], h->ev[wbc ? 5 : 3]));
+  h->lastMs[4] = ms;
+}
+
+int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args) {
+  return guarded([&]() { checkMpcArgs(h, args); enqueueMpc(h, args); finishTiming(h, true, false); });
+}
+
+int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const double* t_grid, const double* X, const double* U, const int32_t* modes, const double* t_eval,
+                            double* x_out, double* u_out, int32_t* mode_out) {
+  if (!h || !t_grid || !X || !U || !modes || !t_eval || !x_out || !u_out || !mode_out || batch < 1 || num_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments");
+  return guarded([&]() {
+    QM_LAUNCH(policy_eval_kernel, (batch + 63) / 64, 64, h->stream, batch, num_nodes, t_grid, X, U, modes, t_eval, x_out, u_out, mode_out);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() {
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
+    enqueueWbc(h, args);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[5], h->stream));
+    finishTiming(h, false, true);
+  });
+}
+
+int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t_eval, qmgpu_wbc_args* wbc) {
+  if (!h || !t_eval || !wbc) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&]() {
+    checkMpcArgs(h, mpc);
+    if (wbc->batch != mpc->batch) throw std::invalid_argument("MPC and WBC batch sizes differ");
+    enqueueMpc(h, mpc);
+    QM_LAUNCH(policy_eval_kernel, (mpc->batch + 63) / 64, 64, h->stream, mpc->batch, mpc->num_nodes, mpc->out_t, mpc->out_x, mpc->out_u, mpc->out_mode, t_eval, h->dPolX, h->dPolU,
+              h->dPolMode);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
+    qmgpu_wbc_args w = *wbc;
+    w.state_desired = h->dPolX; w.input_desired = h->dPolU; w.mode = h->dPolMode;
+    enqueueWbc(h, &w);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[5], h->stream));
+    finishTiming(h, true, true);
+  });
+}
+
+int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double* B, double* b, double* Q, double* R, double* q, double* r, double* C, double* D, double* e,
+                       int32_t* nc) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() {
+    if (!h->debugLq || !h->dDebug) throw std::invalid_argument("call qmgpu_enable_debug(h, 1) before the solve");
+    if (instance < 0 || instance >= h->lastBatch || node < 0 || node > h->lastN) throw std::invalid_argument("instance / node out of range");
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<double> rec(DBG_DOUBLES);
+    const size_t idx = size_t(instance) * (h->lastN + 1) + node;
+    HIP_CHECK(hipMemcpy(rec.data(), h->dDebug + idx * DBG_DOUBLES, DBG_DOUBLES * sizeof(double), hipMemcpyDeviceToHost));
+    int ncv = 0;
+    HIP_CHECK(hipMemcpy(&ncv, h->dStageNc + idx, sizeof(int), hipMemcpyDeviceToHost));
+    auto cp = [&](double* dst, int off, int n) { if (dst) std::memcpy(dst, rec.data() + off, n * sizeof(double)); };
+    cp(A, DBG_A, 900); cp(B, DBG_B, 900); cp(b, DBG_b, 30); cp(Q, DBG_Q, 900); cp(R, DBG_R, 900); cp(q, DBG_q, 30); cp(r, DBG_r, 30);
+    cp(C, DBG_C, 16 * 30); cp(D, DBG_D, 16 * 30); cp(e, DBG_e, 16);
+    if (nc) *nc = ncv;
+  });
+}
+
+int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms5) {
+  if (!h || !ms5) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
+  for (int i = 0; i < 5; ++i) ms5[i] = h->lastMs[i];
+  return QMGPU_OK;
+}
+
+}  // extern "C"

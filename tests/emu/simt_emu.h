@@ -1,0 +1,82 @@
+// simt_emu.h -- TEST-ONLY host emulation of the tiny subset of the HIP programming model our kernels use.
+//
+// Purpose: this build container has no GPU, and a gpurun round trip takes minutes.  Compiling the *same* kernel
+// sources with -DQMGPU_HOST_EMULATION (g++ -std=c++20) runs every workgroup as blockDim.x host threads joined by a
+// barrier at __syncthreads(), one workgroup at a time, so the kernel logic (LDS hand-offs, lane roles, index math)
+// can be debugged against the oracle in seconds.  It is NOT a product path: nothing in qm_door_amd/ loads the
+// emulation library, libqmgpu.so is built by hipcc only and refuses to run without a HIP device.
+#pragma once
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x = 1, y = 1, z = 1;
+  dim3() = default;
+  dim3(unsigned a, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+inline std::barrier<>* g_emuBarrier = nullptr;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+inline void __syncthreads() { g_emuBarrier->arrive_and_wait(); }
+inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
+using std::acos; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::sqrt; using std::sin; using std::cos;
+using std::max; using std::min;
+
+template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
+  const unsigned nt = block.x * block.y * block.z;
+  std::barrier<> bar(nt);
+  g_emuBarrier = &bar;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t]() {
+      blockDim = block; gridDim = grid;
+      threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+      for (unsigned b = 0; b < grid.x * grid.y * grid.z; ++b) {
+        blockIdx = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
+        body();
+        bar.arrive_and_wait();  // all lanes leave the workgroup before the (static) LDS is reused
+      }
+    });
+  for (auto& t : th) t.join();
+  g_emuBarrier = nullptr;
+}
+
+// ---- runtime API subset -------------------------------------------------------------------------------------------------
+using hipError_t = int;
+using hipStream_t = void*;
+using hipEvent_t = double*;
+constexpr int hipSuccess = 0;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? 0 : 1; }
+inline hipError_t hipFree(void* p) { std::free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0); return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
+#define QM_LAUNCH(kernel, grid, block, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))

@@ -1,0 +1,191 @@
+"""Shared test plumbing: oracle (ctypes), emulated kernel library, seeded scenario generators.
+
+The oracle (oracle/libqm_oracle.so) is TEST INFRASTRUCTURE: it is only ever loaded from here, from
+__graft_entry__.smoke() and from bench.py's cpu_baseline leg.  PARITY UNPINNED (see oracle/qmo_core.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from qm_door_amd import abi  # noqa: E402
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libqm_oracle.so")
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "build", "libqmgpu_emu.so")
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    return ORACLE_LIB
+
+
+def build_emu():
+    """g++ build of the kernel sources against tests/emu/simt_emu.h (host threads instead of lanes)."""
+    srcs = [os.path.join(ROOT, "qm_door_amd", "csrc", "qmgpu_api.hip"), os.path.join(ROOT, "qm_door_amd", "csrc", "host", "host_config.cpp")]
+    deps = srcs + [os.path.join(ROOT, "qm_door_amd", "csrc", "kernels", f) for f in os.listdir(os.path.join(ROOT, "qm_door_amd", "csrc", "kernels"))]
+    deps += [os.path.join(EMU_DIR, "simt_emu.h"), os.path.join(ROOT, "include", "qmgpu.h")]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
+        return EMU_LIB
+    os.makedirs(os.path.dirname(EMU_LIB), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-DQMGPU_HOST_EMULATION", "-I", EMU_DIR, "-x", "c++", *srcs, "-o", EMU_LIB, "-lpthread"])
+    return EMU_LIB
+
+
+def p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, problem):
+        build_oracle()
+        self.lib = C.CDLL(ORACLE_LIB)
+        self.P = problem
+        self.lib.qmo_time_cycles.restype = C.c_double
+
+    def flow_map(self, x, u):
+        f = np.zeros(30)
+        self.lib.qmo_flow_map(C.byref(self.P), p(x), p(u), p(f))
+        return f
+
+    def flow_map_lin(self, x, u):
+        f, A, B = np.zeros(30), np.zeros((30, 30)), np.zeros((30, 30))
+        self.lib.qmo_flow_map_lin(C.byref(self.P), p(x), p(u), p(f), p(A), p(B))
+        return f, A, B
+
+    def kinematics(self, x, u):
+        fp, fv, ee, eq, com = np.zeros(12), np.zeros(12), np.zeros(3), np.zeros(4), np.zeros(3)
+        self.lib.qmo_kinematics(C.byref(self.P), p(x), p(u), p(fp), p(fv), p(ee), p(eq), p(com))
+        return fp.reshape(4, 3), fv.reshape(4, 3), ee, eq, com
+
+    def centroidal_matrix(self, q):
+        A = np.zeros((6, 24))
+        self.lib.qmo_centroidal_matrix(C.byref(self.P), p(q), p(A))
+        return A
+
+    def input_weight(self):
+        R = np.zeros((30, 30))
+        self.lib.qmo_input_weight(C.byref(self.P), p(R))
+        return R
+
+    def mode_at(self, ev, modes, t):
+        ev = np.ascontiguousarray(ev, dtype=np.float64); modes = np.ascontiguousarray(modes, dtype=np.int32)
+        self.lib.qmo_mode_at.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
+        return self.lib.qmo_mode_at(len(ev), p(ev), p(modes), t)
+
+    def swing_reference(self, nev, ev, modes, t):
+        zp, zv = np.zeros(4), np.zeros(4)
+        self.lib.qmo_swing_reference.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        self.lib.qmo_swing_reference(C.byref(self.P), nev, p(ev), p(modes), t, p(zp), p(zv))
+        return zp, zv
+
+    def lq_node(self, t, dt, x, u, xnext, terminal, nev, ev, modes, ttimes, tstates):
+        A, B, Q, R = (np.zeros((30, 30)) for _ in range(4))
+        b, q, r = (np.zeros(30) for _ in range(3))
+        Cm, Dm, e = np.zeros((16, 30)), np.zeros((16, 30)), np.zeros(16)
+        nc = C.c_int32(0); cost = C.c_double(0)
+        self.lib.qmo_lq_node.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p] + [C.c_void_p] * 10 + [C.c_void_p, C.c_void_p]
+        u_ = u if u is not None else np.zeros(30)
+        xn = xnext if xnext is not None else x
+        self.lib.qmo_lq_node(C.byref(self.P), t, dt, p(x), p(u_), p(xn), int(terminal), nev, p(ev), p(modes), len(ttimes), p(ttimes), p(tstates), p(A), p(B), p(b), p(Q),
+                             p(R), p(q), p(r), p(Cm), p(Dm), p(e), C.byref(nc), C.byref(cost))
+        n = nc.value
+        return dict(A=A, B=B, b=b, Q=Q, R=R, q=q, r=r, C=Cm[:n], D=Dm[:n], e=e[:n], nc=n, cost=cost.value)
+
+    def mpc_solve(self, N, t0, x0, ttimes, tstates, nev, ev, modes, warm=None, line_search=True, time_grid=None):
+        T, X, U, M, st = np.zeros(N + 1), np.zeros((N + 1, 30)), np.zeros((N, 30)), np.zeros(N + 1, dtype=np.int32), np.zeros(8)
+        self.lib.qmo_mpc_solve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        wx = p(np.ascontiguousarray(warm[0])) if warm else None
+        wu = p(np.ascontiguousarray(warm[1])) if warm else None
+        rc = self.lib.qmo_mpc_solve(C.byref(self.P), N, t0, p(x0), p(time_grid), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), wx, wu, int(line_search), p(T),
+                                    p(X), p(U), p(M), p(st))
+        return dict(status=rc, T=T, X=X, U=U, mode=M, stats=st)
+
+    def wbc_update(self, x_des, u_des, rbd, mode, period, time, input_last, variant=0):
+        out = np.zeros(54)
+        il = np.array(input_last, dtype=np.float64)
+        self.lib.qmo_wbc_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        st = self.lib.qmo_wbc_update(C.byref(self.P), variant, p(x_des), p(u_des), p(rbd), int(mode), period, time, p(il), p(out))
+        return st, out, il
+
+    def wbc_model(self, x_des, u_des, rbd, period, input_last):
+        il = np.array(input_last, dtype=np.float64)
+        o = dict(M=np.zeros((24, 24)), nle=np.zeros(24), J=np.zeros((12, 24)), dJ=np.zeros((12, 24)), baseJ=np.zeros((6, 24)), baseDJ=np.zeros((6, 24)),
+                 armJ=np.zeros((6, 24)), armDJ=np.zeros((6, 24)), qv=np.zeros((4, 24)), baseAcc=np.zeros(6), feet=np.zeros((4, 4, 3)), ee=np.zeros(33))
+        self.lib.qmo_wbc_model.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 13
+        self.lib.qmo_wbc_model(C.byref(self.P), p(x_des), p(u_des), p(rbd), period, p(il), p(o["M"]), p(o["nle"]), p(o["J"]), p(o["dJ"]), p(o["baseJ"]), p(o["baseDJ"]),
+                               p(o["armJ"]), p(o["armDJ"]), p(o["qv"]), p(o["baseAcc"]), p(o["feet"]), p(o["ee"]))
+        return o
+
+    def qp_solve(self, H, c, D, f):
+        n, m = H.shape[0], D.shape[0]
+        z = np.zeros(n); res = C.c_double(0)
+        self.lib.qmo_qp_solve.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
+        it = self.lib.qmo_qp_solve(n, m, p(np.ascontiguousarray(H)), p(np.ascontiguousarray(c)), p(np.ascontiguousarray(D)), p(np.ascontiguousarray(f)), p(z), C.byref(res))
+        return it, z, res.value
+
+    def wbc_level(self, level, x_des, u_des, rbd, mode, period, time, input_last, variant=0):
+        dims = np.zeros(3, dtype=np.int32)
+        H, c, D, f, sol, xl = np.zeros(128 * 128), np.zeros(128), np.zeros(160 * 128), np.zeros(160), np.zeros(128), np.zeros(36)
+        self.lib.qmo_wbc_levels.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        it = self.lib.qmo_wbc_levels(C.byref(self.P), variant, p(x_des), p(u_des), p(rbd), int(mode), period, time, p(np.array(input_last, dtype=np.float64)), level,
+                                     p(dims), p(H), p(c), p(D), p(f), p(sol), p(xl))
+        nz, rows, nd = (int(v) for v in dims)
+        return dict(iters=it, H=H[:nz * nz].reshape(nz, nz), c=c[:nz], D=D[:rows * nz].reshape(rows, nz), f=f[:rows], sol=sol[:nz], x=xl, num_dec=nd)
+
+    def time_cycles(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, line_search=True):
+        self.lib.qmo_time_cycles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        return self.lib.qmo_time_cycles(C.byref(self.P), count, N, p(x0s), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), p(rbds), int(line_search))
+
+
+def load_problem(lib):
+    P = abi.Problem()
+    d = abi.DATA_DIR.encode()
+    st = lib.qmgpu_load_problem(d + b"/task.info", d + b"/aliengo_z1.urdf", d + b"/reference.info", d + b"/wbc_gains.info", C.byref(P))
+    assert st == 0, lib.qmgpu_last_error()
+    return P
+
+
+# ------------------------------------------------------------------------------------------------ scenarios
+def trot_schedule(t_end, period=0.70, phase0=0.0):
+    """STANCE until phase0, then LF_RH / RF_LH (gait.info trot) tiled past t_end, then the default final STANCE."""
+    ev, md = [phase0], [15]
+    t = phase0
+    while t < t_end:
+        for mode in (9, 6):
+            md.append(mode); t += period / 2; ev.append(t)
+    md.append(15)
+    evp = np.full(abi.MAX_EVENTS, 1e300); evp[:len(ev)] = ev
+    mdp = np.full(abi.MAX_EVENTS + 1, 15, dtype=np.int32); mdp[:len(md)] = md
+    return len(ev), evp, mdp
+
+
+def nominal_target(oracle, x_nom):
+    _, _, ee, eq, _ = oracle.kinematics(x_nom, np.zeros(30))
+    return np.r_[x_nom, ee, eq]
+
+
+def perturbed_states(x_nom, batch, seed=0):
+    """Config 2 of SURVEY.md section 8(d): x0 = x_nom + U(-1,1) * s per component."""
+    rng = np.random.default_rng(seed)
+    s = np.r_[np.full(6, 0.1), np.full(3, 0.05), np.full(3, 0.05), np.full(18, 0.1)]
+    return x_nom[None, :] + rng.uniform(-1, 1, (batch, 30)) * s[None, :]
+
+
+def rbd_from_state(oracle, x, v=None):
+    r = np.zeros(55)
+    r[0:3] = x[9:12]; r[3:6] = x[6:9]; r[6:24] = x[12:30]
+    if v is not None:
+        r[24:48] = v
+    _, _, ee, eq, _ = oracle.kinematics(x, np.zeros(30))
+    r[48:51] = ee; r[51:55] = eq
+    return r

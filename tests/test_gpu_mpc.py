@@ -1,0 +1,61 @@
+"""-m gpu: HIP MPC path (lq_node -> riccati -> linesearch) against the CPU oracle on identical seeded inputs, through the C ABI."""
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenario(interface, oracle, B, N, seed=0, phase0=0.03):
+    x_nom = interface.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=seed)
+    tgt = S.nominal_target(oracle, x_nom)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(N * interface.problem.settings.dt + 1.0, phase0=phase0)
+    return x0, tt, ts, nev, ev, md
+
+
+def test_lq_blocks_match_oracle(interface, oracle):
+    import gpu_harness as G
+    B, N = 2, 6
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, B, N)
+    sol = G.make_solver(interface, B, N)
+    sol.enable_debug(True)
+    assert np.abs(sol.input_weight() - oracle.input_weight()).max() < 1e-13
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.mpc(mb.args)
+    mb.results()
+    dt = interface.problem.settings.dt
+    for inst in range(B):
+        for k in (0, 2, 3, N):
+            g = sol.debug_lq(inst, k)
+            mode = oracle.mode_at(ev[:nev], md[:nev + 1], k * dt)
+            flags = [(mode >> (3 - c)) & 1 for c in range(4)]
+            u = np.zeros(30)
+            for c in range(4):
+                if flags[c]:
+                    u[3 * c + 2] = interface.robot_mass * 9.81 / sum(flags)
+            o = oracle.lq_node(k * dt, dt if k < N else 0.0, x0[inst], u if k < N else None, x0[inst], k == N, nev, ev, md, tt[inst], ts[inst])
+            assert g["nc"] == o["nc"]
+            for key in (["Q", "q"] if k == N else ["A", "B", "b", "Q", "R", "q", "r", "C", "D", "e"]):
+                scale = max(1.0, np.abs(o[key]).max())
+                assert np.abs(g[key] - o[key]).max() <= 1e-10 * scale, (inst, k, key)
+
+
+@pytest.mark.parametrize("N,B", [(20, 3), (100, 2)])
+def test_sqp_iteration_matches_oracle(interface, oracle, N, B):
+    """Trajectories within 1e-6 rel-inf of the CPU restatement (BASELINE.json north_star tolerance); modes bit-exact."""
+    import gpu_harness as G
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, B, N, seed=1)
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.mpc(mb.args)
+    r = mb.results()
+    for i in range(B):
+        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert np.array_equal(r["mode"][i], ref["mode"])
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        assert r["stats"][i][4] == ref["stats"][4] and r["stats"][i][5] == ref["stats"][5]
+        assert np.allclose(r["stats"][i][:4], ref["stats"][:4], rtol=1e-8, atol=1e-10)
