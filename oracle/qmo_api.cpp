@@ -157,6 +157,26 @@ int qmo_wbc_levels(const qmgpu_problem* P, int variant, const double* xDes, cons
   return h->qpIters;
 }
 
+// Stacked task data (A b | D f) of one priority level, for debugging the task-assembly of the HIP kernel.
+int qmo_wbc_task(const qmgpu_problem* P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
+                 const double* inputLastIn, int level, int32_t* dims /*ra, rd*/, double* A, double* b, double* D, double* f) {
+  double il[30]; for (int i = 0; i < 30; ++i) il[i] = inputLastIn[i];
+  WbcModel w;
+  wbcUpdateMeasured(*P, rbd, w);
+  wbcUpdateDesired(*P, xDes, uDes, il, period, w);
+  WbcTasks tk(*P, w, mode);
+  Task t;
+  if (level == 0) t = tk.floatingBaseEom() + tk.torqueLimits() + tk.noContactMotion() + tk.frictionCone();
+  else if (level == 1) {
+    if (variant == 0) t = (time < 10.0) ? tk.armJointNominalTracking() : (tk.baseHeight() + tk.baseAngular() + tk.eeLinear() + tk.eeAngular() + tk.swingLeg() * 100.0);
+    else t = tk.baseHeight() + tk.baseAngular() + tk.baseLinear() + tk.swingLeg() * 100.0;
+  } else t = variant == 0 ? tk.contactForce(uDes) + tk.baseLinear() : tk.contactForce(uDes);
+  dims[0] = t.a.r; dims[1] = t.d.r;
+  if (t.a.r > 0) { t.a.to(A); for (int i = 0; i < t.a.r; ++i) b[i] = t.b[i]; }
+  if (t.d.r > 0) { t.d.to(D); for (int i = 0; i < t.d.r; ++i) f[i] = t.f[i]; }
+  return 0;
+}
+
 // CPU baseline: time `count` full MPC(+WBC) cycles, returns seconds.
 double qmo_time_cycles(const qmgpu_problem* P, int count, int N, const double* x0s /*count x 30*/, int K, const double* ttimes, const double* tstates, int nEv,
                        const double* ev, const int32_t* modes, const double* rbds /*count x 55*/, int lineSearch) {

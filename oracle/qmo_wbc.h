@@ -300,6 +300,23 @@ struct WbcTasks {
   }
 };
 
+// Cholesky with a pivot floor (1e-13 x the largest diagonal entry of the cost Hessian, NOT of the barrier-weighted matrix): directions no task and no inequality row touches have (numerically) zero curvature;
+// flooring the pivot leaves them where they are (their right-hand side is zero) instead of dividing by roundoff.
+inline bool choleskyFloored(Mat& A, double floorv) {
+  const int n = A.r;
+  for (int j = 0; j < n; ++j) {
+    double d = A(j, j);
+    for (int k = 0; k < j; ++k) d -= A(j, k) * A(j, k);
+    if (!(d > floorv)) d = floorv;
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A(j, j) = d;
+    for (int i = j + 1; i < n; ++i) { double t = A(i, j); for (int k = 0; k < j; ++k) t -= A(i, k) * A(j, k); A(i, j) = t / d; }
+    for (int i = 0; i < j; ++i) A(i, j) = 0.0;
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ dense convex QP: min 1/2 z'Hz + c'z  s.t.  D z <= f
 // Mehrotra predictor-corrector primal-dual interior point.  Returns iterations used, negative on failure.
 inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 60, double* kktRes = nullptr) {
@@ -315,6 +332,8 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     Mat L = H; if (!cholesky(L)) return -1;
     z = -1.0 * c; cholSolve(L, z); return 0;
   }
+  double pivotFloor = 0.0;
+  for (int i = 0; i < n; ++i) pivotFloor = std::max(pivotFloor, 1e-13 * H(i, i));
   Vec s(m), lam(m, 1.0);
   { const Vec Dz = D * z; for (int i = 0; i < m; ++i) s[i] = std::max(1.0, f[i] - Dz[i]); }
   double scale = 1.0; for (double v : c) scale = std::max(scale, std::fabs(v)); for (double v : f) scale = std::max(scale, std::fabs(v));
@@ -325,10 +344,13 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     double mu = dot(s, lam) / m;
     double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
-    if (nrd <= 1e-9 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
+    // primal feasibility and complementarity tight; the dual residual tolerance is looser because rows that are active with a
+    // zero multiplier (s -> 0 and lambda -> 0 together) drive the barrier weights to 1e18 and the Newton accuracy with them
+    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
+    if (!(mu == mu) || mu < 1e-20 * scale) return -3;  // numerical breakdown
     Mat K = H;
     for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
-    if (!cholesky(K)) return -2;
+    if (!choleskyFloored(K, pivotFloor)) return -2;
     auto solve = [&](const Vec& rc, Vec& dz, Vec& ds, Vec& dl) {
       Vec t(m); for (int i = 0; i < m; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
       dz = -1.0 * (rd + tmul(D, t));
@@ -398,6 +420,14 @@ struct HoQp {
     Vec sol;
     if (nz > 0) qpIters = solveQpIpm(Hm, cv, Dm, fv, sol); else sol.clear();
     decSol = Vec(sol.begin(), sol.begin() + numDec); slackSol = Vec(sol.begin() + numDec, sol.end());
+    // An interior point method leaves the slacks of inactive rows at O(sqrt(mu)) (v = 0 and its multiplier = 0 is a degenerate
+    // complementarity pair).  The exact minimiser, which an active-set solver like qpOASES returns, has v = max(0, D z - f):
+    // restore it from the decision variables, which are not affected.
+    if (hasIneq) {
+      const Vec dz = (task.d * Zprev) * decSol;
+      const Vec dx = task.d * xPrev;
+      for (int i = 0; i < numSlack; ++i) slackSol[i] = std::max(0.0, dz[i] + dx[i] - task.f[i]);
+    }
     // buildZMatrix
     if (hasEq) Z = Zprev * kernelFullPivLU(aZ); else Z = Zprev;
     // stackSlackSolutions
@@ -426,8 +456,15 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
   HoQp h1(task1, &h0);
   Vec x;
   int status = (h0.qpIters < 0 || h0.qpIters >= 60 ? 1 : 0) | (h1.qpIters < 0 || h1.qpIters >= 60 ? 2 : 0);
-  if (h1.Z.c > 0) { HoQp h2(task2, &h1); x = h2.solution(); status |= (h2.qpIters < 0 || h2.qpIters >= 60 ? 4 : 0); }
-  else x = h1.solution();  // FLY: level 2 has no decision variables left -> skip
+  if (h1.Z.c > 0) {
+    HoQp h2(task2, &h1); x = h2.solution(); status |= (h2.qpIters < 0 || h2.qpIters >= 60 ? 4 : 0);
+    if (h2.Z.c > 0) {
+      // Directions no task sees (the arm accelerations of HierarchicalMpcWbc) are fixed in the reference only by HoQp's 1e-12
+      // regulariser and qpOASES' internal regularisation, i.e. "small".  Defined here as the minimum-norm completion: one more
+      // level with the task x = 0.
+      HoQp h3(Task(Mat::identity(36), Vec(36, 0.0), Mat(), Vec()), &h2); x = h3.solution(); status |= (h3.qpIters < 0 || h3.qpIters >= 60 ? 8 : 0);
+    }
+  } else x = h1.solution();  // FLY: level 2 has no decision variables left -> skip
   // updateCmd (WbcBase.cpp:580-595)
   for (int i = 0; i < 36; ++i) out[i] = x[i];
   for (int i = 0; i < NJ; ++i) {

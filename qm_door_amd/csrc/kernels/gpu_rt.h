@@ -7,4 +7,8 @@
 #else
 #include <hip/hip_runtime.h>
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
+// dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)
+#define QM_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) double name[]
+#define QM_ALLOW_DYNAMIC_LDS(kernel, bytes) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
 #endif

@@ -122,7 +122,7 @@ __device__ inline void nodePerformance(const qmgpu_problem& P, const double* Rw,
   cost = dt * c; dyn *= dt; eq *= dt;
 }
 
-__global__ void linesearch_kernel(LsArgs a) {
+__global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __shared__ double red[3 * 256];
   __shared__ double ctl[8];
   const int inst = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;

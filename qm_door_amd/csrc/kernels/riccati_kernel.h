@@ -33,19 +33,21 @@ struct RiccatiArgs {
 constexpr int R_STG = 0;                         // staged record (first OFF_PX doubles used backward, all of it forward)
 constexpr int R_S = R_STG + STAGE_DOUBLES;       // S [30][30]
 constexpr int R_SV = R_S + 900;                  // s [30] (+2 pad)
-constexpr int R_G = R_SV + 32;                   // G [MT][30]
-constexpr int R_H = R_G + MT * 30;               // H / L [MT][MT+1]
-constexpr int R_T = R_H + MT * (MT + 1);         // scratch matrix [30][32]
+constexpr int R_Y = R_SV + 32;                   // y columns, lane private [30][64]
+constexpr int R_GH = R_Y + 30 * 64;              // [G | g | H] columns, lane private [MT][64]; G[j][i] = GH[j*64 + i]
+constexpr int R_H = R_GH + MT * 64;              // H / L [MT][MT+1]
+constexpr int R_T = R_H + MT * (MT + 1);         // new value function [30][32]
 constexpr int R_GAIN = R_T + 960;                // staged gains (forward)
 constexpr int R_VEC = R_GAIN + GAIN_DOUBLES;     // dx[30] dut[18] ...
-constexpr int RICCATI_LDS_DOUBLES = R_VEC + 64;  // 8158 doubles = 63.7 KiB
+constexpr int RICCATI_LDS_DOUBLES = R_VEC + 64;
+constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~86 KiB (dynamic LDS)
 
 __global__ void __launch_bounds__(64) riccati_kernel(RiccatiArgs a) {
-  __shared__ double lds[RICCATI_LDS_DOUBLES];
+  QM_DYNAMIC_LDS(lds);
   const int lane = threadIdx.x;
   const int inst = blockIdx.x;
   const int N = a.N;
-  double* stg = lds + R_STG; double* S = lds + R_S; double* sv = lds + R_SV; double* GL = lds + R_G; double* HL = lds + R_H; double* Tm = lds + R_T;
+  double* stg = lds + R_STG; double* S = lds + R_S; double* sv = lds + R_SV; double* YL = lds + R_Y; double* GH = lds + R_GH; double* HL = lds + R_H; double* Tm = lds + R_T;
   double* gn = lds + R_GAIN; double* dxv = lds + R_VEC; double* dut = dxv + 32;
   const double* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const int* ncI = a.stageNc + size_t(inst) * (N + 1);
@@ -66,35 +68,30 @@ __global__ void __launch_bounds__(64) riccati_kernel(RiccatiArgs a) {
     for (int e = lane; e < OFF_PX; e += 64) stg[e] = rec[e];
     __syncthreads();
     const bool isA = lane < 30, isb = lane == 30, isB = lane > 30 && lane < 31 + nt;
-    const bool active = lane < 31 + nt;
-    // my column of [A~ | b~ | B~]
-    double col[30];
+    // ---- y = S col (+ s for the b~ lane); outer loop rolled, my column of [A~ | b~ | B~] in registers
+    {
+      double col[30];
 #pragma unroll
-    for (int i = 0; i < 30; ++i) col[i] = isA ? stg[OFF_AT + i * 30 + lane] : (isb ? stg[OFF_bt + i] : (isB ? stg[OFF_BT + i * MT + (lane - 31)] : 0.0));
-    // y = S col  (+ s for the b~ lane)
+      for (int i = 0; i < 30; ++i) col[i] = isA ? stg[OFF_AT + i * 30 + lane] : (isb ? stg[OFF_bt + i] : (isB ? stg[OFF_BT + i * MT + (lane - 31)] : 0.0));
+#pragma unroll 1
+      for (int i = 0; i < 30; ++i) {
+        double s = isb ? sv[i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 30; ++q) s += S[i * 30 + q] * col[q];
+        YL[i * 64 + lane] = s;
+      }
+    }
     double y[30];
 #pragma unroll
-    for (int i = 0; i < 30; ++i) {
-      double s = isb ? sv[i] : 0.0;
-#pragma unroll
-      for (int q = 0; q < 30; ++q) s += S[i * 30 + q] * col[q];
-      y[i] = s;
-    }
-    // gh = B~^T y + [P~ | r~ | R~] column
-    double gh[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      double s = 0.0;
+    for (int i = 0; i < 30; ++i) y[i] = YL[i * 64 + lane];
+    // ---- gh = B~^T y + [P~ | r~ | R~] column
+#pragma unroll 1
+    for (int j = 0; j < nt; ++j) {
+      double s = isA ? stg[OFF_PT + j * 30 + lane] : (isb ? stg[OFF_rt + j] : (isB ? stg[OFF_RT + j * MT + (lane - 31)] : 0.0));
 #pragma unroll
       for (int i = 0; i < 30; ++i) s += stg[OFF_BT + i * MT + j] * y[i];
-      const double base = isA ? stg[OFF_PT + j * 30 + lane] : (isb ? stg[OFF_rt + j] : (isB ? stg[OFF_RT + j * MT + (lane - 31)] : 0.0));
-      gh[j] = (j < nt) ? s + base : 0.0;
-    }
-    // publish G (lanes < 30) and H (lanes 31+)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      if (isA) GL[j * 30 + lane] = gh[j];
-      else if (isB) HL[j * (MT + 1) + (lane - 31)] = gh[j];
+      GH[j * 64 + lane] = s;
+      if (isB) HL[j * (MT + 1) + (lane - 31)] = s;
     }
     __syncthreads();
     // ---- Cholesky H = L L^T in LDS (lane r owns row r)
@@ -117,7 +114,7 @@ __global__ void __launch_bounds__(64) riccati_kernel(RiccatiArgs a) {
     double kx[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-      double s = gh[j];
+      double s = (j < nt) ? GH[j * 64 + lane] : 0.0;
 #pragma unroll
       for (int q = 0; q < MT; ++q) if (q < j) s -= HL[j * (MT + 1) + q] * kx[q];
       kx[j] = (j < nt) ? s / HL[j * (MT + 1) + j] : 0.0;
@@ -136,26 +133,25 @@ __global__ void __launch_bounds__(64) riccati_kernel(RiccatiArgs a) {
       if (isA) gain[OFF_KFB + j * 30 + lane] = kx[j];
       else if (isb) gain[OFF_kff + j] = kx[j];
     }
-    // ---- new value function column: base + A~^T y + G^T kx
+    // ---- new value function column: base + A~^T y + G^T kx   (lanes <= 30; rolled over the output row)
     if (lane <= 30) {
-#pragma unroll
+#pragma unroll 1
       for (int i = 0; i < 30; ++i) {
         double s = isA ? stg[OFF_QT + i * 30 + lane] : stg[OFF_qt + i];
 #pragma unroll
         for (int q = 0; q < 30; ++q) s += stg[OFF_AT + q * 30 + i] * y[q];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) if (j < nt) s += GL[j * 30 + i] * kx[j];
+        for (int j = 0; j < MT; ++j) if (j < nt) s += GH[j * 64 + i] * kx[j];
         Tm[i * 32 + lane] = s;
       }
     }
     __syncthreads();
     if (isA) {
-#pragma unroll
+#pragma unroll 1
       for (int i = 0; i < 30; ++i) S[i * 30 + lane] = 0.5 * (Tm[i * 32 + lane] + Tm[lane * 32 + i]);
       sv[lane] = Tm[lane * 32 + 30];
     }
     __syncthreads();
-    (void)active;
   }
 
   // ================================================================== forward substitution

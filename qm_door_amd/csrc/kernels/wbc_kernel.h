@@ -1,9 +1,766 @@
-// placeholder (real kernel follows)
+// wbc_kernel -- whole-body controller: rigid-body model update, task assembly and the three-level hierarchical QP.
+// One wavefront per robot instance; every matrix lives in (dynamic) LDS.
+//
+// Replaces qm::WbcBase::update / updateMeasured / updateDesired (qm_wbc/src/WbcBase.cpp:123-238), the task builders
+// (WbcBase.cpp:240-578), Task stacking (qm_wbc/include/qm_wbc/Task.h:28-65), the HoQp cascade (qm_wbc/src/HoQp.cpp:12-158)
+// including its qpOASES solve (HoQp.cpp:135-150) and null-space update (HoQp.cpp:126-133), the task grouping of
+// HierarchicalWbc::update / HierarchicalMpcWbc::update and WbcBase::updateCmd (WbcBase.cpp:580-595).
+//
+// Model update: one recursive velocity/bias-acceleration pass over the tree (RNEA forward sweep with zero generalized
+// acceleration) gives every body's twist and classical bias acceleration, from which
+//   nle_k  = sum_b  J_k,b^T [ m (a_c + g) ; I alpha + w x I w ]          (lane k = generalized velocity k)
+//   M_ik   = sum_b  J_i,b^T diag(m, I_b) J_k,b                           (lane k owns column k)
+//   dJ v   = bias acceleration of the frame point                        (no dJ matrix is ever formed)
+// QP: Mehrotra predictor-corrector interior point on the reference's (H, c, D, f) of HoQp::formulateProblem with the slack
+// block eliminated analytically (it is diagonal), so the factorised system is n x n (n <= 36) instead of (n + 56)^2.
+// Only the highest-priority task may carry inequality rows (true for both reference controllers).
 #pragma once
-#include "gpu_rt.h"
 #include "../../../include/qmgpu.h"
+#include "gpu_rt.h"
+#include "linesearch_kernel.h"  // DblIn
+#include "sweep_dev.h"
+
 namespace qmk {
-constexpr int WBC_SCRATCH_DOUBLES = 8;
-struct WbcArgs { const qmgpu_problem* P; int batch, variant; const double* xDes; const double* uDes; const double* rbd; const int* mode; const double* period; const double* time; double* inputLast; double* out; int* status; double* scratch; };
-__global__ void wbc_kernel(WbcArgs a) {}
+
+struct WbcArgs {
+  const qmgpu_problem* P;
+  int batch, variant;
+  const double* xDes; const double* uDes; const double* rbd; const int* mode; const double* period; const double* time;
+  double* inputLast; double* out; int* status;
+};
+
+constexpr int WBC_SCRATCH_DOUBLES = 8;  // (unused, kept for the context layout)
+constexpr int ND = 36, NVV = 24, MAXR = 22, MAXM = 56;
+constexpr int LDZ = 37, LDK = 37;
+// ---- LDS carve (doubles)
+constexpr int W_IN = 0;                          // rbd[55] xDes[30] uDes[30] inputLast[30] -> 160
+constexpr int W_Q = W_IN + 160;                  // qM vM qD vD [4][24]
+constexpr int W_BODY = W_Q + 96;                 // per body: R9 p3 c3 I6 w3 al3 vo3 ao3 = 33  -> 19*33 = 627 (+pad)
+constexpr int W_DOF = W_BODY + 640;              // dof axis[24][3], origin[24][3]
+constexpr int W_WR = W_DOF + 144;                // body wrench force[19][3] torque[19][3]
+constexpr int W_M = W_WR + 120;                  // M [24][24]
+constexpr int W_NLE = W_M + 576;                 // nle[24]
+constexpr int W_JF = W_NLE + 24;                 // feet J [12][24]
+constexpr int W_JA = W_JF + 288;                 // arm J [6][24]
+constexpr int W_MISC = W_JA + 144;               // see offsets below (144)
+constexpr int W_A = W_MISC + 144;                // task A [MAXR][36], b[MAXR]
+constexpr int W_B = W_A + MAXR * ND;
+constexpr int W_D0 = W_B + 24;                   // D0 [MAXM][36]
+constexpr int W_F0 = W_D0 + MAXM * ND;           // f0[56], slack solution v0[56]
+constexpr int W_Z = W_F0 + 2 * MAXM;             // Z [36][LDZ]
+constexpr int W_ZN = W_Z + ND * LDZ;             // Znew
+constexpr int W_AZ = W_ZN + ND * LDZ;            // A Z [MAXR][LDZ]
+constexpr int W_DZ = W_AZ + MAXR * LDZ;          // D0 Z [MAXM][LDZ]
+constexpr int W_K = W_DZ + MAXM * LDZ;           // K / Cholesky [36][LDK]
+constexpr int W_G = W_K + ND * LDK;              // G = AZ^T AZ + eps [36][LDK]
+constexpr int W_VH = W_G + ND * LDK;             // Householder vectors [MAXR][40]
+constexpr int W_VEC = W_VH + MAXR * 40;          // vectors: x[36] z[36] g[36] rd[36] rhs[36] dz[36] fhat[56] lam[56] wt[56] tz[56] red[64]
+constexpr int WBC_LDS_DOUBLES = W_VEC + 6 * 36 + 4 * 56 + 64 + 8;
+constexpr int WBC_LDS_BYTES = WBC_LDS_DOUBLES * 8;
+// misc block
+constexpr int MI_FOOTPM = 0, MI_FOOTVM = 12, MI_FOOTDJV = 24, MI_FOOTPD = 36, MI_FOOTVD = 48, MI_EEPM = 60, MI_EEVM = 63, MI_EEWM = 66, MI_EEDJL = 69, MI_EEDJA = 72,
+              MI_EERM = 75, MI_EEPD = 84, MI_EEVD = 87, MI_EERD = 90, MI_AL0 = 99, MI_BACC = 102, MI_JACC = 108 /*18*/, MI_BAX = 126 /*measured base Euler axes, 9*/;
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// Recursive pass: placements, twists and bias accelerations (generalized accelerations: 0 for the base, qddj for joints).
+// All lanes execute it identically (wave-uniform); lane 0 publishes to LDS.
+__device__ inline void bodyPass(const qmgpu_model& md, const double* q, const double* v, const double* qddj, double* body, double* dof, int lane) {
+  double sz, cz, sy, cy, sx, cx;
+  sincos(q[3], &sz, &cz); sincos(q[4], &sy, &cy); sincos(q[5], &sx, &cx);
+  double R0[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx, sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx, -sy, cy * sx, cy * cx};  // row major
+  const double a3[3] = {0, 0, 1}, a4[3] = {-sz, cz, 0}, a5[3] = {cz * cy, sz * cy, -sy};
+  double w0[3], al0[3], t1[3], t2[3], t3[3];
+  for (int i = 0; i < 3; ++i) { t1[i] = a3[i] * v[3]; t2[i] = a4[i] * v[4]; t3[i] = a5[i] * v[5]; w0[i] = t1[i] + t2[i] + t3[i]; }
+  { double c1[3], s12[3], c2[3]; cross3(t1, t2, c1); for (int i = 0; i < 3; ++i) s12[i] = t1[i] + t2[i]; cross3(s12, t3, c2); for (int i = 0; i < 3; ++i) al0[i] = c1[i] + c2[i]; }
+  const double p0[3] = {q[0], q[1], q[2]}, vo0[3] = {v[0], v[1], v[2]}, ao0[3] = {0, 0, 0};
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) { dof[k * 3 + i] = (i == k) ? 1.0 : 0.0; dof[72 + k * 3 + i] = 0.0; }
+    for (int i = 0; i < 3; ++i) { dof[9 + i] = a3[i]; dof[12 + i] = a4[i]; dof[15 + i] = a5[i]; dof[72 + 9 + i] = p0[i]; dof[72 + 12 + i] = p0[i]; dof[72 + 15 + i] = p0[i]; }
+  }
+  auto publish = [&](int b, const double* R, const double* p, const double* w, const double* al, const double* vo, const double* ao) {
+    double c[3], RI[9], Iw[6];
+    const double* cm = md.com[b];
+    for (int i = 0; i < 3; ++i) c[i] = p[i] + R[i * 3] * cm[0] + R[i * 3 + 1] * cm[1] + R[i * 3 + 2] * cm[2];
+    const double* in = md.inertia[b];
+    const double I[9] = {in[0], in[1], in[2], in[1], in[3], in[4], in[2], in[4], in[5]};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RI[i * 3 + j] = R[i * 3] * I[j] + R[i * 3 + 1] * I[3 + j] + R[i * 3 + 2] * I[6 + j];
+    int e = 0;
+    for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) Iw[e++] = RI[i * 3] * R[j * 3] + RI[i * 3 + 1] * R[j * 3 + 1] + RI[i * 3 + 2] * R[j * 3 + 2];
+    if (lane == 0) {
+      double* o = body + b * 33;
+      for (int i = 0; i < 9; ++i) o[i] = R[i];
+      for (int i = 0; i < 3; ++i) { o[9 + i] = p[i]; o[12 + i] = c[i]; o[21 + i] = w[i]; o[24 + i] = al[i]; o[27 + i] = vo[i]; o[30 + i] = ao[i]; }
+      for (int i = 0; i < 6; ++i) o[15 + i] = Iw[i];
+    }
+  };
+  publish(0, R0, p0, w0, al0, vo0, ao0);
+  double R[9], p[3], w[3], al[3], vo[3], ao[3];
+#pragma unroll 1
+  for (int b = 1; b < QMGPU_NB; ++b) {
+    if (md.parent[b] == 0) { for (int i = 0; i < 9; ++i) R[i] = R0[i]; for (int i = 0; i < 3; ++i) { p[i] = p0[i]; w[i] = w0[i]; al[i] = al0[i]; vo[i] = vo0[i]; ao[i] = ao0[i]; } }
+    const double* off = md.joint_offset[b];
+    double ow[3], tmp[3], tmp2[3];
+    for (int i = 0; i < 3; ++i) ow[i] = R[i * 3] * off[0] + R[i * 3 + 1] * off[1] + R[i * 3 + 2] * off[2];
+    // origin velocity / bias acceleration use the PARENT twist
+    cross3(w, ow, tmp);
+    for (int i = 0; i < 3; ++i) vo[i] += tmp[i];
+    cross3(w, tmp, tmp2);
+    cross3(al, ow, tmp);
+    for (int i = 0; i < 3; ++i) { ao[i] += tmp[i] + tmp2[i]; p[i] += ow[i]; }
+    const int ax = md.axis[b];
+    double aw[3] = {R[ax], R[3 + ax], R[6 + ax]};
+    const double qd = v[5 + b], qdd = qddj ? qddj[b - 1] : 0.0;
+    double wj[3] = {aw[0] * qd, aw[1] * qd, aw[2] * qd};
+    cross3(w, wj, tmp);
+    for (int i = 0; i < 3; ++i) { al[i] += tmp[i] + aw[i] * qdd; w[i] += wj[i]; }
+    if (lane == 0) for (int i = 0; i < 3; ++i) { dof[(5 + b) * 3 + i] = aw[i]; dof[72 + (5 + b) * 3 + i] = p[i]; }
+    double sn, cs;
+    sincos(q[5 + b], &sn, &cs);
+    const int bb = (ax + 1) % 3, cc = (ax + 2) % 3;
+    for (int i = 0; i < 3; ++i) { const double rb = R[i * 3 + bb], rc = R[i * 3 + cc]; R[i * 3 + bb] = cs * rb + sn * rc; R[i * 3 + cc] = cs * rc - sn * rb; }
+    publish(b, R, p, w, al, vo, ao);
+  }
 }
+
+// point kinematics on a body: position, velocity, classical bias acceleration
+__device__ __forceinline__ void pointKin(const qmgpu_model& md, const double* body, int b, const double* off, double* pos, double* vel, double* acc) {
+  const double* o = body + b * 33;
+  double d[3], t[3], t2[3];
+  for (int i = 0; i < 3; ++i) d[i] = o[i * 3] * off[0] + o[i * 3 + 1] * off[1] + o[i * 3 + 2] * off[2];
+  for (int i = 0; i < 3; ++i) pos[i] = o[9 + i] + d[i];
+  cross3(o + 21, d, t);
+  for (int i = 0; i < 3; ++i) vel[i] = o[27 + i] + t[i];
+  cross3(o + 21, t, t2);
+  cross3(o + 24, d, t);
+  for (int i = 0; i < 3; ++i) acc[i] = o[30 + i] + t[i] + t2[i];
+}
+__device__ __forceinline__ bool dofMoves(int k, int b) {
+  if (k < 6) return true;
+  const int jb = k - 5;
+  const int hi = jb <= 12 ? 3 * ((jb + 2) / 3) : 18;
+  return b >= jb && b <= hi;
+}
+// Jacobian column k of a point r on body b (world axes): lin, ang
+__device__ __forceinline__ void jacCol(const double* dof, int k, int b, const double* r, double* lin, double* ang) {
+  lin[0] = lin[1] = lin[2] = 0.0; ang[0] = ang[1] = ang[2] = 0.0;
+  if (!dofMoves(k, b)) return;
+  const double* a = dof + k * 3;
+  if (k < 3) { lin[0] = a[0]; lin[1] = a[1]; lin[2] = a[2]; return; }
+  const double* o = dof + 72 + k * 3;
+  const double d[3] = {r[0] - o[0], r[1] - o[1], r[2] - o[2]};
+  cross3(a, d, lin);
+  ang[0] = a[0]; ang[1] = a[1]; ang[2] = a[2];
+}
+__device__ __forceinline__ void symMul(const double* I6, const double* v, double* o) {
+  o[0] = I6[0] * v[0] + I6[1] * v[1] + I6[2] * v[2]; o[1] = I6[1] * v[0] + I6[3] * v[1] + I6[4] * v[2]; o[2] = I6[2] * v[0] + I6[4] * v[1] + I6[5] * v[2];
+}
+
+__device__ __forceinline__ double wbcSum(double* red, int lane, double v) { red[lane] = v; __syncthreads(); double s = 0; for (int i = 0; i < 64; ++i) s += red[i]; __syncthreads(); return s; }
+__device__ __forceinline__ double wbcMax(double* red, int lane, double v) { red[lane] = v; __syncthreads(); double s = red[0]; for (int i = 1; i < 64; ++i) s = fmax(s, red[i]); __syncthreads(); return s; }
+__device__ __forceinline__ double wbcMin(double* red, int lane, double v) { red[lane] = v; __syncthreads(); double s = red[0]; for (int i = 1; i < 64; ++i) s = fmin(s, red[i]); __syncthreads(); return s; }
+
+// In-place Cholesky of the n x n matrix K (row stride LDK) in LDS, lane = row; pivots are floored at floorv
+// (1e-13 x the largest diagonal entry of the level's cost Hessian G, as in the oracle's choleskyFloored).
+__device__ inline void ldsCholesky(double* K, int n, int lane, double floorv) {
+#pragma unroll 1
+  for (int j = 0; j < n; ++j) {
+    const double d = K[j * LDK + j];
+    const double dj = sqrt(d > floorv ? d : floorv);
+    __syncthreads();
+    if (lane == j) K[j * LDK + j] = dj;
+    else if (lane > j && lane < n) K[lane * LDK + j] = K[lane * LDK + j] / dj;
+    __syncthreads();
+    if (lane > j && lane < n) {
+      const double lij = K[lane * LDK + j];
+      for (int q = j + 1; q <= lane; ++q) K[lane * LDK + q] -= lij * K[q * LDK + j];
+    }
+    __syncthreads();
+  }
+}
+// Solve L L^T x = y in place (y in LDS), lane = row.
+__device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane) {
+#pragma unroll 1
+  for (int j = 0; j < n; ++j) {
+    const double xj = y[j] / L[j * LDK + j];
+    __syncthreads();
+    if (lane == j) y[j] = xj;
+    else if (lane > j && lane < n) y[lane] -= L[lane * LDK + j] * xj;
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int j = n - 1; j >= 0; --j) {
+    const double xj = y[j] / L[j * LDK + j];
+    __syncthreads();
+    if (lane == j) y[j] = xj;
+    else if (lane < j) y[lane] -= L[j * LDK + lane] * xj;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
+  QM_DYNAMIC_LDS(lds);
+  const int lane = threadIdx.x, inst = blockIdx.x;
+  const qmgpu_model& md = a.P->model;
+  const qmgpu_settings& st = a.P->settings;
+  double* in = lds + W_IN; double* rbd = in; double* xDes = in + 55; double* uDes = in + 85; double* il = in + 115;
+  double* qM = lds + W_Q; double* vM = qM + 24; double* qD = qM + 48; double* vD = qM + 72;
+  double* body = lds + W_BODY; double* dof = lds + W_DOF; double* wr = lds + W_WR; double* M = lds + W_M; double* nle = lds + W_NLE;
+  double* Jf = lds + W_JF; double* Ja = lds + W_JA; double* mi = lds + W_MISC;
+  double* A = lds + W_A; double* bvec = lds + W_B; double* D0 = lds + W_D0; double* f0 = lds + W_F0; double* v0 = f0 + MAXM;
+  double* Z = lds + W_Z; double* Zn = lds + W_ZN; double* AZ = lds + W_AZ; double* DZ = lds + W_DZ; double* K = lds + W_K; double* G = lds + W_G; double* Vh = lds + W_VH;
+  double* xs = lds + W_VEC; double* zs = xs + 36; double* gs = zs + 36; double* rds = gs + 36; double* rhs = rds + 36; double* dzs = rhs + 36;
+  double* fhat = dzs + 36; double* lam = fhat + 56; double* wt = lam + 56; double* tzv = wt + 56; double* red = tzv + 56; double* ctl = red + 64;
+
+  const int mode = a.mode[inst];
+  const double period = a.period[inst], time = a.time[inst];
+  bool contact[4]; int nst = 0;
+  for (int c = 0; c < 4; ++c) { contact[c] = contactOf(mode, c); nst += contact[c] ? 1 : 0; }
+  const int nsw = 4 - nst;
+
+  // ---- S1: inputs
+  if (lane < 55) rbd[lane] = a.rbd[size_t(inst) * 55 + lane];
+  if (lane < 30) { xDes[lane] = a.xDes[size_t(inst) * 30 + lane]; uDes[lane] = a.uDes[size_t(inst) * 30 + lane]; il[lane] = a.inputLast[size_t(inst) * 30 + lane]; }
+  __syncthreads();
+  // ---- S2: Pinocchio coordinates of the measured state (WbcBase.cpp:150-156)
+  if (lane == 0) {
+    for (int i = 0; i < 3; ++i) { qM[i] = rbd[3 + i]; qM[3 + i] = rbd[i]; vM[i] = rbd[24 + 3 + i]; }
+    for (int j = 0; j < 18; ++j) { qM[6 + j] = rbd[6 + j]; vM[6 + j] = rbd[24 + 6 + j]; }
+    double sz, cz, sy, cy;
+    sincos(qM[3], &sz, &cz); sincos(qM[4], &sy, &cy);
+    const double wx = rbd[24], wy = rbd[25], wz = rbd[26];
+    const double tmp = cz * wx / cy + sz * wy / cy;
+    vM[3] = sy * tmp + wz; vM[4] = -sz * wx + cz * wy; vM[5] = tmp;
+    for (int j = 0; j < 18; ++j) { qD[6 + j] = xDes[12 + j]; vD[6 + j] = uDes[12 + j]; mi[MI_JACC + j] = (uDes[12 + j] - il[12 + j]) / period; }
+    for (int i = 0; i < 6; ++i) qD[i] = xDes[6 + i];
+  }
+  if (lane < 30) a.inputLast[size_t(inst) * 30 + lane] = uDes[lane];  // WbcBase.cpp:225
+  __syncthreads();
+
+  // ---- S3: measured pass (zero generalized acceleration -> bias terms)
+  bodyPass(md, qM, vM, nullptr, body, dof, lane);
+  __syncthreads();
+  // body wrenches for the nonlinear effects: f = m (a_c + g), n = I alpha + w x I w
+  if (lane < QMGPU_NB) {
+    const double* o = body + lane * 33;
+    double pos[3], vel[3], acc[3], Iw_w[3], Iw_al[3], t[3];
+    pointKin(md, body, lane, md.com[lane], pos, vel, acc);
+    symMul(o + 15, o + 21, Iw_w); symMul(o + 15, o + 24, Iw_al); cross3(o + 21, Iw_w, t);
+    for (int i = 0; i < 3; ++i) { wr[lane * 3 + i] = md.mass[lane] * (acc[i] + (i == 2 ? st.gravity : 0.0)); wr[57 + lane * 3 + i] = Iw_al[i] + t[i]; }
+  }
+  __syncthreads();
+  // ---- S4: lane k = generalized velocity k: nle_k, column k of M, Jacobian columns
+  if (lane < NVV) {
+    const int k = lane;
+    double macc[NVV];
+#pragma unroll
+    for (int i = 0; i < NVV; ++i) macc[i] = 0.0;
+    double h = 0.0;
+#pragma unroll 1
+    for (int b = 0; b < QMGPU_NB; ++b) {
+      if (!dofMoves(k, b)) continue;
+      const double* o = body + b * 33;
+      double lk[3], ak[3], Fk[3], Nk[3];
+      jacCol(dof, k, b, o + 12, lk, ak);
+      h += dot3(lk, wr + b * 3) + dot3(ak, wr + 57 + b * 3);
+      for (int i = 0; i < 3; ++i) Fk[i] = md.mass[b] * lk[i];
+      symMul(o + 15, ak, Nk);
+#pragma unroll
+      for (int i = 0; i < NVV; ++i) {
+        double li[3], ai[3];
+        jacCol(dof, i, b, o + 12, li, ai);
+        macc[i] += dot3(li, Fk) + dot3(ai, Nk);
+      }
+    }
+    nle[k] = h;
+#pragma unroll
+    for (int i = 0; i < NVV; ++i) M[i * NVV + k] = macc[i];
+    for (int c = 0; c < 4; ++c) {
+      const int b = md.foot_body[c];
+      double pos[3], vel[3], acc[3], lin[3], ang[3];
+      pointKin(md, body, b, md.foot_offset[c], pos, vel, acc);
+      jacCol(dof, k, b, pos, lin, ang);
+      for (int r = 0; r < 3; ++r) Jf[(3 * c + r) * NVV + k] = lin[r];
+    }
+    {
+      double pos[3], vel[3], acc[3], lin[3], ang[3];
+      pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
+      jacCol(dof, k, md.ee_body, pos, lin, ang);
+      for (int r = 0; r < 3; ++r) { Ja[r * NVV + k] = lin[r]; Ja[(3 + r) * NVV + k] = ang[r]; }
+    }
+  }
+  if (lane >= 32 && lane < 36) {  // feet: position, velocity, dJ v
+    const int c = lane - 32;
+    double pos[3], vel[3], acc[3];
+    pointKin(md, body, md.foot_body[c], md.foot_offset[c], pos, vel, acc);
+    for (int r = 0; r < 3; ++r) { mi[MI_FOOTPM + 3 * c + r] = pos[r]; mi[MI_FOOTVM + 3 * c + r] = vel[r]; mi[MI_FOOTDJV + 3 * c + r] = acc[r]; }
+  }
+  if (lane == 40) {  // arm end-effector + base angular bias
+    double pos[3], vel[3], acc[3];
+    pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
+    const double* o = body + md.ee_body * 33;
+    for (int r = 0; r < 3; ++r) {
+      mi[MI_EEPM + r] = pos[r]; mi[MI_EEVM + r] = vel[r]; mi[MI_EEDJL + r] = acc[r]; mi[MI_EEWM + r] = o[21 + r];
+      mi[MI_AL0 + r] = body[24 + r];
+      for (int j = 0; j < 3; ++j) mi[MI_BAX + 3 * j + r] = dof[(3 + j) * 3 + r];
+      mi[MI_EEDJA + r] = o[24 + r] - body[24 + r];  // (dJ_ang with columns 3..5 zeroed) v  (WbcBase.cpp:550-553)
+    }
+    for (int i = 0; i < 9; ++i) mi[MI_EERM + i] = o[i];
+  }
+  __syncthreads();
+
+  // ---- S5: desired pass.  v_des base from the centroidal map (WbcBase.cpp:217-219) with the MPC's own sweep.
+  {
+    double k1z[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) k1z[i] = 0.0;
+    const DblIn din{xDes, uDes, 0.0, k1z};
+    double f[12];
+    BaseMotion<double> bm;
+    centroidalSweep<double>(md, st.gravity, din, [&](int, Vec3<double>, Vec3<double>) {}, [&](Vec3<double>, const Mat3<double>&) {}, f, bm);
+    if (lane == 0) for (int i = 0; i < 6; ++i) vD[i] = f[6 + i];
+  }
+  __syncthreads();
+  bodyPass(md, qD, vD, mi + MI_JACC, body, dof, lane);
+  __syncthreads();
+  if (lane == 0) {
+    // momentum rate produced by (v_des, joint accelerations, zero base acceleration): Adot v + Aj qdd_j (WbcBase.cpp:231-234)
+    double ct[3] = {0, 0, 0};
+    for (int b = 0; b < QMGPU_NB; ++b) for (int i = 0; i < 3; ++i) ct[i] += md.mass[b] * body[b * 33 + 12 + i];
+    for (int i = 0; i < 3; ++i) ct[i] /= md.total_mass;
+    double hl[3] = {0, 0, 0}, ha[3] = {0, 0, 0}, Ic[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < QMGPU_NB; ++b) {
+      const double* o = body + b * 33;
+      double pos[3], vel[3], acc[3], Iw_w[3], Iw_al[3], t[3], r[3], t2[3];
+      pointKin(md, body, b, md.com[b], pos, vel, acc);
+      symMul(o + 15, o + 21, Iw_w); symMul(o + 15, o + 24, Iw_al); cross3(o + 21, Iw_w, t);
+      for (int i = 0; i < 3; ++i) r[i] = pos[i] - ct[i];
+      double ma[3] = {md.mass[b] * acc[0], md.mass[b] * acc[1], md.mass[b] * acc[2]};
+      cross3(r, ma, t2);
+      const double rr = dot3(r, r), m = md.mass[b];
+      for (int i = 0; i < 3; ++i) { hl[i] += ma[i]; ha[i] += Iw_al[i] + t[i] + t2[i]; }
+      Ic[0] += o[15] + m * (rr - r[0] * r[0]); Ic[1] += o[16] - m * r[0] * r[1]; Ic[2] += o[17] - m * r[0] * r[2];
+      Ic[3] += o[18] + m * (rr - r[1] * r[1]); Ic[4] += o[19] - m * r[1] * r[2]; Ic[5] += o[20] + m * (rr - r[2] * r[2]);
+    }
+    double rl[3] = {-hl[0], -hl[1], -md.total_mass * st.gravity - hl[2]}, ra[3] = {-ha[0], -ha[1], -ha[2]};
+    for (int c = 0; c < 4; ++c) {
+      double pos[3], vel[3], acc[3], t[3], r[3];
+      pointKin(md, body, md.foot_body[c], md.foot_offset[c], pos, vel, acc);
+      for (int i = 0; i < 3; ++i) { mi[MI_FOOTPD + 3 * c + i] = pos[i]; mi[MI_FOOTVD + 3 * c + i] = vel[i]; r[i] = pos[i] - ct[i]; rl[i] += uDes[3 * c + i]; }
+      cross3(r, uDes + 3 * c, t);
+      for (int i = 0; i < 3; ++i) ra[i] += t[i];
+    }
+    // wdot = Ic^-1 ra ; euler acceleration = T^-1 wdot ; linear = rl/m - wdot x (c - p0)
+    Sym3<double> S; S.xx = Ic[0]; S.xy = Ic[1]; S.xz = Ic[2]; S.yy = Ic[3]; S.yz = Ic[4]; S.zz = Ic[5];
+    const Vec3<double> wd = solveSym3(S, Vec3<double>(ra[0], ra[1], ra[2]));
+    const double wdv[3] = {wd.x, wd.y, wd.z}, rc[3] = {ct[0] - qD[0], ct[1] - qD[1], ct[2] - qD[2]};
+    double t[3];
+    cross3(wdv, rc, t);
+    double sz, cz, sy, cy;
+    sincos(qD[3], &sz, &cz); sincos(qD[4], &sy, &cy);
+    const double tmp = (cz * wd.x + sz * wd.y) / cy;
+    for (int i = 0; i < 3; ++i) mi[MI_BACC + i] = rl[i] / md.total_mass - t[i];
+    mi[MI_BACC + 3] = sy * tmp + wd.z; mi[MI_BACC + 4] = cz * wd.y - sz * wd.x; mi[MI_BACC + 5] = tmp;
+    double pos[3], vel[3], acc[3];
+    pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
+    for (int i = 0; i < 3; ++i) { mi[MI_EEPD + i] = pos[i]; mi[MI_EEVD + i] = vel[i]; }
+    for (int i = 0; i < 9; ++i) mi[MI_EERD + i] = body[md.ee_body * 33 + i];
+  }
+  __syncthreads();
+
+  // ================================================================== hierarchical QP
+  int status = 0;
+  // x = 0, Z = I
+  for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e / LDZ) == (e % LDZ)) ? 1.0 : 0.0;
+  if (lane < ND) xs[lane] = 0.0;
+  // ---- task 0 inequality rows (kept hard, with their slacks, by the lower levels): torque limits + friction pyramid (+ zero rows)
+  const int m0 = 36 + 5 * nst + 3 * nsw;
+  for (int e = lane; e < MAXM * ND; e += 64) D0[e] = 0.0;
+  __syncthreads();
+  if (lane < 18) {  // WbcBase.cpp:392-415; the LF leg limits are reused for every leg (WbcBase.cpp:599-600)
+    const int i = lane;
+    for (int j = 0; j < NVV; ++j) { D0[i * ND + j] = M[(6 + i) * NVV + j]; D0[(18 + i) * ND + j] = -M[(6 + i) * NVV + j]; }
+    for (int j = 0; j < 12; ++j) { D0[i * ND + 24 + j] = -Jf[j * NVV + 6 + i]; D0[(18 + i) * ND + 24 + j] = Jf[j * NVV + 6 + i]; }
+    const double lim = i < 12 ? md.effort_limit[i % 3] : md.effort_limit[i];
+    f0[i] = lim - nle[6 + i]; f0[18 + i] = lim + nle[6 + i];
+  }
+  if (lane == 32) {  // WbcBase.cpp:439-469
+    const double mu = st.wbc_friction_coefficient;
+    int j = 0;
+    for (int c = 0; c < 4; ++c) if (contact[c]) {
+      double* r = D0 + (36 + 5 * j) * ND + 24 + 3 * c;
+      r[2] = -1.0; r[ND] = 1.0; r[ND + 2] = -mu; r[2 * ND] = -1.0; r[2 * ND + 2] = -mu; r[3 * ND + 1] = 1.0; r[3 * ND + 2] = -mu; r[4 * ND + 1] = -1.0; r[4 * ND + 2] = -mu;
+      ++j;
+    }
+    for (int r = 36; r < m0; ++r) f0[r] = 0.0;
+  }
+  __syncthreads();
+
+  const int numLevels = 4;  // level 3 = minimum-norm completion (task x = 0) of whatever no task pinned
+  int n = ND;  // current null-space dimension
+#pragma unroll 1
+  for (int level = 0; level < numLevels; ++level) {
+    if (n == 0) break;  // FLY: nothing left to decide
+    // ---- assemble this level's equality task A x = b  (rows r)
+    for (int e = lane; e < MAXR * ND; e += 64) A[e] = 0.0;
+    __syncthreads();
+    int r = 0;
+    if (level == 0) {
+      r = 18;
+      if (lane < 6) {  // floating-base equations of motion (WbcBase.cpp:370-388)
+        for (int j = 0; j < NVV; ++j) A[lane * ND + j] = M[lane * NVV + j];
+        for (int j = 0; j < 12; ++j) A[lane * ND + 24 + j] = -Jf[j * NVV + lane];
+        bvec[lane] = -nle[lane];
+      }
+      if (lane == 32) {
+        int row = 6;
+        for (int c = 0; c < 4; ++c) if (contact[c]) {  // no contact motion (WbcBase.cpp:418-433)
+          for (int q = 0; q < 3; ++q) { for (int j = 0; j < NVV; ++j) A[(row + q) * ND + j] = Jf[(3 * c + q) * NVV + j]; bvec[row + q] = -mi[MI_FOOTDJV + 3 * c + q]; }
+          row += 3;
+        }
+        for (int c = 0; c < 4; ++c) if (!contact[c]) {  // swing feet carry no force (WbcBase.cpp:440-449)
+          for (int q = 0; q < 3; ++q) { A[(row + q) * ND + 24 + 3 * c + q] = 1.0; bvec[row + q] = 0.0; }
+          row += 3;
+        }
+      }
+    } else if (level == 1) {
+      const bool startup = a.variant == 0 && time < 10.0;  // HierarchicalWbc.cpp:32-37
+      if (startup) {
+        r = 6;
+        if (lane < 6) {  // arm joint tracking (WbcBase.cpp:471-497)
+          A[lane * ND + 18 + lane] = 1.0;
+          bvec[lane] = st.kp_arm_joint[lane] * (qD[18 + lane] - qM[18 + lane]) + st.kd_arm_joint[lane] * (vD[18 + lane] - vM[18 + lane]);
+        }
+      } else {
+        const int extra = a.variant == 0 ? 6 : 2;
+        r = 4 + extra + 3 * nsw;
+        if (lane == 0) {
+          // base height (WbcBase.cpp:308-320)
+          A[2] = 1.0;
+          bvec[0] = mi[MI_BACC + 2] + st.kp_base_height * (qD[2] - qM[2]) + st.kd_base_height * (vD[2] - vM[2]);
+          // base angular (WbcBase.cpp:270-305): Euler maps at the MEASURED angles
+          for (int q = 0; q < 3; ++q) for (int j = 3; j < 6; ++j) A[(1 + q) * ND + j] = mi[MI_BAX + 3 * (j - 3) + q];
+          double sz, cz, sy, cy;
+          sincos(qM[3], &sz, &cz); sincos(qM[4], &sy, &cy);
+          auto omegaOf = [&](const double* de, double* w) { w[0] = -sz * de[1] + cy * cz * de[2]; w[1] = cz * de[1] + cy * sz * de[2]; w[2] = de[0] - sy * de[2]; };
+          double wM[3], wD[3], acc[3];
+          omegaOf(vM + 3, wM); omegaOf(vD + 3, wD);
+          {
+            const double* de = vD + 3; const double* dde = mi + MI_BACC + 3;
+            const double szt = cz * de[0], czt = -sz * de[0], syt = cy * de[1], cyt = -sy * de[1];
+            acc[0] = -sz * dde[1] + cy * cz * dde[2] - szt * de[1] + (cyt * cz + cy * czt) * de[2];
+            acc[1] = cz * dde[1] + cy * sz * dde[2] + czt * de[1] + (cyt * sz + cy * szt) * de[2];
+            acc[2] = dde[0] - sy * dde[2] - syt * de[2];
+          }
+          // rotation error log(R_des R_meas^T)
+          double Rd[9], Rm[9];
+          {
+            double s3, c3, s4, c4, s5, c5;
+            sincos(qD[3], &s3, &c3); sincos(qD[4], &s4, &c4); sincos(qD[5], &s5, &c5);
+            const double t[9] = {c3 * c4, c3 * s4 * s5 - s3 * c5, c3 * s4 * c5 + s3 * s5, s3 * c4, s3 * s4 * s5 + c3 * c5, s3 * s4 * c5 - c3 * s5, -s4, c4 * s5, c4 * c5};
+            for (int i = 0; i < 9; ++i) Rd[i] = t[i];
+            sincos(qM[5], &s5, &c5);
+            const double u[9] = {cz * cy, cz * sy * s5 - sz * c5, cz * sy * c5 + sz * s5, sz * cy, sz * sy * s5 + cz * c5, sz * sy * c5 - cz * s5, -sy, cy * s5, cy * c5};
+            for (int i = 0; i < 9; ++i) Rm[i] = u[i];
+          }
+          auto rotErr = [&](const double* L, const double* Rr, double* e) {
+            double E[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E[i * 3 + j] = L[i * 3] * Rr[j * 3] + L[i * 3 + 1] * Rr[j * 3 + 1] + L[i * 3 + 2] * Rr[j * 3 + 2];
+            const double tr = E[0] + E[4] + E[8];
+            const double cth = fmax(-1.0, fmin(1.0, 0.5 * (tr - 1.0)));
+            const double th = acos(cth);
+            const double kk = th < 1e-4 ? 0.5 + th * th / 12.0 : 0.5 * th / sin(th);
+            e[0] = kk * (E[7] - E[5]); e[1] = kk * (E[2] - E[6]); e[2] = kk * (E[3] - E[1]);
+          };
+          double err[3];
+          rotErr(Rd, Rm, err);
+          for (int q = 0; q < 3; ++q) bvec[1 + q] = acc[q] + st.kp_base_angular * err[q] + st.kd_base_angular * (wD[q] - wM[q]) - mi[MI_AL0 + q];
+          int row = 4;
+          if (a.variant == 0) {
+            // end-effector linear (WbcBase.cpp:499-524) and angular (WbcBase.cpp:526-563: columns 3..5 zeroed, desired angular velocity unused)
+            double eerr[3];
+            rotErr(mi + MI_EERD, mi + MI_EERM, eerr);
+            for (int q = 0; q < 3; ++q) {
+              for (int j = 0; j < NVV; ++j) { A[(row + q) * ND + j] = Ja[q * NVV + j]; A[(row + 3 + q) * ND + j] = (j >= 3 && j < 6) ? 0.0 : Ja[(3 + q) * NVV + j]; }
+              bvec[row + q] = st.kp_ee_linear[q] * (mi[MI_EEPD + q] - mi[MI_EEPM + q]) + st.kd_ee_linear[q] * (mi[MI_EEVD + q] - mi[MI_EEVM + q]) - mi[MI_EEDJL + q];
+              bvec[row + 3 + q] = st.kp_ee_angular[q] * eerr[q] + st.kd_ee_angular[q] * (-mi[MI_EEWM + q]) - mi[MI_EEDJA + q];
+            }
+            row += 6;
+          } else {
+            for (int q = 0; q < 2; ++q) {  // base linear (WbcBase.cpp:240-252)
+              A[(row + q) * ND + q] = 1.0;
+              bvec[row + q] = mi[MI_BACC + q] + st.kp_base_linear * (qD[q] - qM[q]) + st.kd_base_linear * (vD[q] - vM[q]);
+            }
+            row += 2;
+          }
+          for (int c = 0; c < 4; ++c) if (!contact[c]) {  // swing legs, weight 100 (WbcBase.cpp:323-346, HierarchicalWbc.cpp:29)
+            for (int q = 0; q < 3; ++q) {
+              const double acc2 = st.kp_swing * (mi[MI_FOOTPD + 3 * c + q] - mi[MI_FOOTPM + 3 * c + q]) + st.kd_swing * (mi[MI_FOOTVD + 3 * c + q] - mi[MI_FOOTVM + 3 * c + q]);
+              for (int j = 0; j < NVV; ++j) A[(row + q) * ND + j] = 100.0 * Jf[(3 * c + q) * NVV + j];
+              bvec[row + q] = 100.0 * (acc2 - mi[MI_FOOTDJV + 3 * c + q]);
+            }
+            row += 3;
+          }
+        }
+      }
+    } else if (level == 3) {
+      r = ND;  // A = I, b = 0: handled without materialising A (see below)
+    } else {
+      r = a.variant == 0 ? 14 : 12;
+      if (lane < 12) { A[lane * ND + 24 + lane] = 1.0; bvec[lane] = uDes[lane]; }  // contact forces (WbcBase.cpp:566-578)
+      if (a.variant == 0 && lane >= 12 && lane < 14) {  // base linear (WbcBase.cpp:240-252)
+        const int q = lane - 12;
+        A[lane * ND + q] = 1.0;
+        bvec[lane] = mi[MI_BACC + q] + st.kp_base_linear * (qD[q] - qM[q]) + st.kd_base_linear * (vD[q] - vM[q]);
+      }
+    }
+    __syncthreads();
+
+#ifdef QMGPU_EMU_DEBUG
+    if (lane == 0 && inst == 0) { printf("EMU level %d r %d n %d b:", level, r, n); for (int i = 0; i < r; ++i) printf(" %.10g", bvec[i]); printf("\n"); }
+#endif
+    // ---- reduced data: AZ = A Z (r x n), rhat = A x - b, DZ = D0 Z, fhat
+    const int mOwn = (level == 0) ? m0 : 0, mPrev = (level == 0) ? 0 : m0;
+    const int mRows = mOwn + mPrev;  // <= 56, one row per lane
+    const double* AZp = AZ;
+    if (level == 3) AZp = Z;  // A = I  =>  A Z = Z
+    else
+      for (int e = lane; e < r * n; e += 64) {
+        const int i = e / n, j = e % n;
+        double s = 0.0;
+        for (int q = 0; q < ND; ++q) s += A[i * ND + q] * Z[q * LDZ + j];
+        AZ[i * LDZ + j] = s;
+      }
+    for (int e = lane; e < m0 * n; e += 64) {
+      const int i = e / n, j = e % n;
+      double s = 0.0;
+      for (int q = 0; q < ND; ++q) s += D0[i * ND + q] * Z[q * LDZ + j];
+      DZ[i * LDZ + j] = s;
+    }
+    if (lane < r) {  // A x_prev - b (temporarily in tzv)
+      double s;
+      if (level == 3) s = xs[lane];
+      else { s = -bvec[lane]; for (int q = 0; q < ND; ++q) s += A[lane * ND + q] * xs[q]; }
+      tzv[lane] = s;
+    }
+    bool rowActive = lane < mRows;
+    if (lane < m0) {
+      double s = f0[lane];
+      if (level > 0) { for (int q = 0; q < ND; ++q) s -= D0[lane * ND + q] * xs[q]; s += v0[lane]; }
+      fhat[lane] = s;
+    }
+    __syncthreads();
+    // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e % n;
+      double s = (i == j) ? 1e-12 : 0.0;
+      for (int q = 0; q < r; ++q) s += AZp[q * LDZ + i] * AZp[q * LDZ + j];
+      G[i * LDK + j] = s;
+    }
+    if (lane < n) { double s = 0.0; for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
+    // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
+    if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
+    __syncthreads();
+
+    // ---- interior point iterations
+    const double pivotFloor = 1e-13 * wbcMax(red, lane, lane < n ? G[lane * LDK + lane] : 0.0);
+    const double fl = rowActive ? fhat[lane] : 0.0;
+    double scale = wbcMax(red, lane, fmax(rowActive ? fabs(fl) : 0.0, lane < n ? fabs(gs[lane]) : 0.0));
+    scale = fmax(1.0, scale);
+    const double nRowsTot = wbcSum(red, lane, rowActive ? (mOwn > 0 ? 2.0 : 1.0) : 0.0);
+    double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
+    const bool own = mOwn > 0;
+    int it = 0;
+    if (nRowsTot > 0.0) {
+#pragma unroll 1
+      for (; it < 60; ++it) {
+        // residuals
+        double Dz = 0.0;
+        if (rowActive) for (int j = 0; j < n; ++j) Dz += DZ[lane * LDZ + j] * zs[j];
+        const double rp1 = rowActive ? (Dz - (own ? v : 0.0) + s1 - fl) : 0.0;
+        const double rp2 = (rowActive && own) ? (-v + s2) : 0.0;
+        const double rdv = (rowActive && own) ? (v - l1 - l2) : 0.0;
+        if (lane < 56) lam[lane] = rowActive ? l1 : 0.0;
+        __syncthreads();
+        if (lane < n) {
+          double s = gs[lane];
+          for (int j = 0; j < n; ++j) s += G[lane * LDK + j] * zs[j];
+          for (int i = 0; i < m0; ++i) s += lam[i] * DZ[i * LDZ + lane];
+          rds[lane] = s;
+        }
+        __syncthreads();
+        const double mu = wbcSum(red, lane, rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
+        const double nrd = wbcMax(red, lane, fmax(lane < n ? fabs(rds[lane]) : 0.0, fabs(rdv)));
+        const double nrp = wbcMax(red, lane, fmax(fabs(rp1), fabs(rp2)));
+#ifdef QMGPU_EMU_DEBUG
+        if (lane == 0 && level == 2) printf("EMU inst %d it %d mu %.3e nrd %.3e nrp %.3e\n", inst, it, mu, nrd, nrp);
+#endif
+        if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;  // same tolerances as the oracle's solveQpIpm
+        if (!(mu == mu) || mu < 1e-20 * scale) { it = 60; break; }                       // numerical breakdown -> flagged in out_status
+        // weights and the reduced normal matrix K = G + DZ^T diag(wt) DZ
+        const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
+        if (lane < 56) wt[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
+        __syncthreads();
+        for (int e = lane; e < n * n; e += 64) {
+          const int i = e / n, j = e % n;
+          if (j > i) continue;
+          double s = G[i * LDK + j];
+          for (int q = 0; q < m0; ++q) s += wt[q] * DZ[q * LDZ + i] * DZ[q * LDZ + j];
+          K[i * LDK + j] = s;
+        }
+        __syncthreads();
+        ldsCholesky(K, n, lane, pivotFloor);
+        double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0;
+        double alphaAff = 1.0, sigma = 0.0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+          const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + ds1 * dl1 - sigma * mu;
+          const double rc2 = pass == 0 ? s2 * l2 : s2 * l2 + ds2 * dl2 - sigma * mu;
+          const double t1 = rowActive ? (l1 * rp1 - rc1) / s1 : 0.0;
+          const double t2 = (rowActive && own) ? (l2 * rp2 - rc2) / s2 : 0.0;
+          const double rhsv = -rdv + t1 + t2;
+          if (lane < 56) tzv[lane] = rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0;
+          __syncthreads();
+          if (lane < n) {
+            double s = -rds[lane];
+            for (int i = 0; i < m0; ++i) s -= DZ[i * LDZ + lane] * tzv[i];
+            dzs[lane] = s;
+          }
+          __syncthreads();
+          ldsCholSolve(K, n, dzs, lane);
+          double Ddz = 0.0;
+          if (rowActive) for (int j = 0; j < n; ++j) Ddz += DZ[lane * LDZ + j] * dzs[j];
+          if (rowActive) {
+            if (own) {
+              dv = (rhsv + w1 * Ddz) / kvv;
+              ds1 = -rp1 - (Ddz - dv); ds2 = -rp2 + dv;
+              dl1 = (-rc1 - l1 * ds1) / s1; dl2 = (-rc2 - l2 * ds2) / s2;
+            } else { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
+          }
+          double amax = 1.0;
+          if (rowActive) {
+            if (ds1 < 0) amax = fmin(amax, -s1 / ds1);
+            if (dl1 < 0) amax = fmin(amax, -l1 / dl1);
+            if (own) { if (ds2 < 0) amax = fmin(amax, -s2 / ds2); if (dl2 < 0) amax = fmin(amax, -l2 / dl2); }
+          }
+          amax = wbcMin(red, lane, amax);
+          if (pass == 0) {
+            alphaAff = amax;
+            const double muAff = wbcSum(red, lane, rowActive ? ((s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) + (own ? (s2 + alphaAff * ds2) * (l2 + alphaAff * dl2) : 0.0)) : 0.0) / nRowsTot;
+            const double ratio = muAff / mu;
+            sigma = ratio * ratio * ratio;
+          } else {
+            const double tau = fmax(0.995, 1.0 - mu);
+            const double al = fmin(1.0, tau * amax);
+            if (lane < n) zs[lane] += al * dzs[lane];
+            if (rowActive) { s1 += al * ds1; l1 += al * dl1; if (own) { v += al * dv; s2 += al * ds2; l2 += al * dl2; } }
+          }
+          __syncthreads();
+        }
+      }
+    } else {
+      // no inequality rows at all: z = -G^-1 g
+      for (int e = lane; e < n * n; e += 64) K[(e / n) * LDK + (e % n)] = G[(e / n) * LDK + (e % n)];
+      if (lane < n) dzs[lane] = -gs[lane];
+      __syncthreads();
+      ldsCholesky(K, n, lane, pivotFloor);
+      ldsCholSolve(K, n, dzs, lane);
+      if (lane < n) zs[lane] = dzs[lane];
+      __syncthreads();
+    }
+    if (it >= 60) status |= (1 << level);
+    // ---- x = x_prev + Z z (HoQp.h:31-34); keep the slack solution of task 0 (HoQp.cpp:152-158)
+    double xn = 0.0;
+    if (lane < ND) { xn = xs[lane]; for (int j = 0; j < n; ++j) xn += Z[lane * LDZ + j] * zs[j]; }
+    // slack solution of task 0 = max(0, D x - f): the interior point leaves inactive slacks at O(sqrt(mu)) (degenerate
+    // complementarity); the exact minimiser -- what qpOASES hands to the next level -- is restored from z.
+    if (level == 0 && lane < m0) { double dzv = 0.0; for (int j = 0; j < n; ++j) dzv += DZ[lane * LDZ + j] * zs[j]; v0[lane] = fmax(0.0, dzv - fhat[lane]); }
+    __syncthreads();
+    if (lane < ND) xs[lane] = xn;
+#ifdef QMGPU_EMU_DEBUG
+    __syncthreads();
+    if (lane == 0 && inst == 0) { printf("EMU level %d it %d x:", level, it); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
+#endif
+    if (level == numLevels - 1) break;
+
+    // ---- Z <- Z null(A Z) (HoQp.cpp:126-133): Householder QR of (A Z)^T with dependent columns skipped
+    {
+      double dcol[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) dcol[i] = (lane < r && i < n) ? AZ[lane * LDZ + i] : 0.0;
+      double n2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) n2 += dcol[i] * dcol[i];
+      const double tol2 = 1e-20 * wbcMax(red, lane, lane < r ? n2 : 0.0);
+      int kk = 0;
+#pragma unroll 1
+      for (int j = 0; j < r && kk < n; ++j) {
+        if (lane == j) {
+          double m2 = 0.0, dk = 0.0;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { if (i >= kk) m2 += dcol[i] * dcol[i]; if (i == kk) dk = dcol[i]; }
+          ctl[0] = m2;
+          if (m2 > tol2) {
+            const double nrm = sqrt(m2), alpha = dk > 0.0 ? -nrm : nrm;
+            double vn = 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) { const double vv = (i > kk) ? dcol[i] : ((i == kk) ? dk - alpha : 0.0); Vh[kk * 40 + i] = vv; vn += vv * vv; }
+            Vh[kk * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
+          }
+        }
+        __syncthreads();
+        const bool indep = ctl[0] > tol2;
+        if (indep && lane > j && lane < r) {
+          double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) s += Vh[kk * 40 + i] * dcol[i];
+          s *= Vh[kk * 40 + 36];
+#pragma unroll
+          for (int i = 0; i < ND; ++i) dcol[i] -= s * Vh[kk * 40 + i];
+        }
+        __syncthreads();
+        if (indep) ++kk;
+      }
+      const int rank = kk, nNew = n - rank;
+      // null vectors: Q e_{rank + lane}
+      double nv[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) nv[i] = (i == rank + lane && lane < nNew) ? 1.0 : 0.0;
+#pragma unroll 1
+      for (int k = rank - 1; k >= 0; --k) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) s += Vh[k * 40 + i] * nv[i];
+        s *= Vh[k * 40 + 36];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) nv[i] -= s * Vh[k * 40 + i];
+      }
+      if (lane < nNew) {
+#pragma unroll 1
+        for (int i = 0; i < ND; ++i) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < ND; ++q) s += Z[i * LDZ + q] * nv[q];
+          Zn[i * LDZ + lane] = s;
+        }
+      }
+      __syncthreads();
+      for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
+      n = nNew;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // ---- updateCmd (WbcBase.cpp:580-595): tau = [M_j, -J_j^T] x + h_j
+  if (lane < ND) a.out[size_t(inst) * 54 + lane] = xs[lane];
+  if (lane < 18) {
+    double s = nle[6 + lane];
+    for (int j = 0; j < NVV; ++j) s += M[(6 + lane) * NVV + j] * xs[j];
+    for (int j = 0; j < 12; ++j) s -= Jf[j * NVV + 6 + lane] * xs[24 + j];
+    a.out[size_t(inst) * 54 + 36 + lane] = s;
+  }
+  if (lane == 0 && a.status) a.status[inst] = status;
+}
+
+}  // namespace qmk

@@ -109,6 +109,8 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     HIP_CHECK(hipMemcpy(ctx->dP, problem, sizeof(qmgpu_problem), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemsetAsync(ctx->dZeros, 0, 64 * sizeof(double), ctx->stream));
     for (auto& e : ctx->ev) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(wbc_kernel, WBC_LDS_BYTES));
+    HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(riccati_kernel, RICCATI_LDS_BYTES));
     QM_LAUNCH(input_weight_kernel, 1, 64, ctx->stream, ctx->dP, ctx->dZeros, ctx->dRw);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -181,7 +183,7 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
   RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
-  QM_LAUNCH(riccati_kernel, B, 64, s, ra);
+  QM_LAUNCH_DYN(riccati_kernel, B, 64, RICCATI_LDS_BYTES, s, ra);
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
   LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
             a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
@@ -195,8 +197,8 @@ static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
   if (!w || w->batch < 1) throw std::invalid_argument("bad WBC arguments");
   if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
   if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
-  WbcArgs wa{h->dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, h->dWbcScratch};
-  QM_LAUNCH(wbc_kernel, w->batch, 64, h->stream, wa);
+  WbcArgs wa{h->dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status};
+  QM_LAUNCH_DYN(wbc_kernel, w->batch, 64, WBC_LDS_BYTES, h->stream, wa);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -80,3 +80,6 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define QM_LAUNCH(kernel, grid, block, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
+#define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
+#define QM_DYNAMIC_LDS(name) static double name[20480]  /* 160 KiB, the CU's whole LDS */
+#define QM_ALLOW_DYNAMIC_LDS(kernel, bytes) 0

@@ -142,6 +142,15 @@ class Oracle:
         nz, rows, nd = (int(v) for v in dims)
         return dict(iters=it, H=H[:nz * nz].reshape(nz, nz), c=c[:nz], D=D[:rows * nz].reshape(rows, nz), f=f[:rows], sol=sol[:nz], x=xl, num_dec=nd)
 
+    def wbc_task(self, level, x_des, u_des, rbd, mode, period, time, input_last, variant=0):
+        dims = np.zeros(2, dtype=np.int32)
+        A, b, D, f = np.zeros((64, 36)), np.zeros(64), np.zeros((64, 36)), np.zeros(64)
+        self.lib.qmo_wbc_task.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        self.lib.qmo_wbc_task(C.byref(self.P), variant, p(x_des), p(u_des), p(rbd), int(mode), period, time, p(np.array(input_last, dtype=np.float64)), level, p(dims),
+                              p(A), p(b), p(D), p(f))
+        ra, rd = int(dims[0]), int(dims[1])
+        return dict(A=A[:ra], b=b[:ra], D=D[:rd], f=f[:rd])
+
     def time_cycles(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, line_search=True):
         self.lib.qmo_time_cycles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         return self.lib.qmo_time_cycles(C.byref(self.P), count, N, p(x0s), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), p(rbds), int(line_search))
