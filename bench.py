@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPC+WBC hot path (BASELINE.json metric) on N GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (qmgpu_cycle_batch: one SQP-iteration MPC solve over N=100 shooting nodes, policy
+evaluation, three-level WBC) over a batch of 256 independent AlienGo+Z1 instances per GPU (BASELINE.json configs[1]; weak
+scaling: every rank owns its own 256 instances).  With N > 1 the solved trajectories + torques are all-gathered over RCCL
+inside the timed region -- the only exchange the path has.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (HIP events on the kernels' own stream, recorded during
+the timed steps); `cpu_baseline` times the CPU oracle (a restatement, NOT the reference OCS2 path, which cannot be built here)
+on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BATCH_PER_GPU = 256
+HORIZON_N = 100
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public spec, v_mfma_f64_16x16x4_f64 (not listed in MI355X_MICROARCH.md)
+
+
+def node_flops(nc):
+    """Algorithmic dense-contraction FLOPs of one shooting node, split by kernel."""
+    n, m = 30, 30
+    mt = m - nc
+    discretise = 2 * n**3 + 2 * n * n * m
+    project = (2 * m * nc * nc + 2 * m * n * nc + (2 * n * n * m + 2 * n * mt * m) + (2 * m * m * mt + 2 * mt * mt * m + 2 * m * m * n + 2 * mt * n * m)
+               + 3 * 2 * n * n * m)
+    riccati = 2 * 2 * n**3 + 2 * n * n * mt + 2 * mt * mt * n + 2 * mt * n * n + mt**3 / 3.0 + 2 * mt * mt * n + 2 * n * n * mt
+    forward = 2 * (2 * mt * n + n * n) + 2 * m * mt + 2 * m * n
+    return {"lq_node_kernel": discretise + project, "riccati_kernel": riccati + forward}
+
+
+def build_scenario(itf, batch, seed):
+    """Config 2 of SURVEY.md 8(d): x0 = nominal + U(-1,1)*s, trot, hold-pose target (QMController.cpp:107-113 construction)."""
+    from qm_door_amd import abi
+    rng = np.random.default_rng(seed)
+    x_nom = itf.initial_state
+    s = np.r_[np.full(6, 0.1), np.full(3, 0.05), np.full(3, 0.05), np.full(18, 0.1)]
+    x0 = x_nom[None, :] + rng.uniform(-1, 1, (batch, 30)) * s[None, :]
+    ee = np.array([x_nom[6] + 0.6, x_nom[7], x_nom[8] + 0.036, 0.0, 0.0, 0.0, 1.0])  # StartingPosition.h:13-15, yaw 0
+    target = np.r_[x_nom, ee]
+    tt = np.zeros((batch, 1)); ts = np.tile(target, (batch, 1, 1)).copy()
+    from qm_door_amd import api
+    nev, ev, md = api.GaitSchedule(lib=itf.lib).mode_schedule("trot", 0.0, 0.0, HORIZON_N * itf.problem.settings.dt + 0.5)
+    rbd = np.zeros((batch, 55))
+    rbd[:, 0:3] = x0[:, 9:12]; rbd[:, 3:6] = x0[:, 6:9]; rbd[:, 6:24] = x0[:, 12:30]
+    return dict(x0=x0, tt=tt, ts=ts, nev=nev, ev=ev, md=md, rbd=rbd)
+
+
+def cpu_baseline(itf, sc, budget_s=15.0):
+    """Oracle ("port": our own fp64 CPU restatement, 1 thread) on a bounded sample of the same workload."""
+    import support as S
+    orc = S.Oracle(itf.problem)
+    probe = orc.time_cycles(1, HORIZON_N, sc["x0"][:1].copy(), sc["tt"][0], sc["ts"][0], sc["nev"], sc["ev"], sc["md"], sc["rbd"][:1].copy())
+    count = int(max(2, min(BATCH_PER_GPU, budget_s / max(probe, 1e-3))))
+    sec = orc.time_cycles(count, HORIZON_N, sc["x0"][:count].copy(), sc["tt"][0], sc["ts"][0], sc["nev"], sc["ev"], sc["md"], sc["rbd"][:count].copy())
+    return {"value": count / sec, "unit": "cycles/s", "cores": 1, "kind": "port",
+            "sample": f"{count} of the {BATCH_PER_GPU} instances (same x0/target/gait, N={HORIZON_N}), {sec:.1f} s; own CPU restatement, not OCS2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gpu_harness as G
+    from qm_door_amd import api
+    itf = api.QMInterface()
+    B, N = BATCH_PER_GPU, HORIZON_N
+    sc = build_scenario(itf, B, seed=1000 * rank)
+    sol = G.make_solver(itf, B, N)
+    mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int32), np.tile(sc["ev"], (B, 1)), np.tile(sc["md"], (B, 1)), N)
+    il0 = np.zeros((B, 30))
+    wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), il0)
+    t_eval = G.dev(np.zeros(B), torch.float64)
+    # packed result gathered across ranks: X, U, tau (+ modes as doubles)
+    pack_len = (N + 1) * 30 + N * 30 + 54 + (N + 1)
+    packed = torch.zeros((B, pack_len), dtype=torch.float64, device="cuda")
+    gathered = torch.zeros((world * B, pack_len), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        sol.cycle(mb.args, t_eval, wb.args)
+        if world > 1:
+            packed[:, :(N + 1) * 30] = mb.oX.view(B, -1)
+            packed[:, (N + 1) * 30:(N + 1) * 30 + N * 30] = mb.oU.view(B, -1)
+            packed[:, (N + 1) * 30 + N * 30:(N + 1) * 30 + N * 30 + 54] = wb.out
+            packed[:, -(N + 1):] = mb.oM.to(torch.float64)
+            dist.all_gather_into_tensor(gathered, packed)
+
+    for _ in range(args.warmup):
+        step()
+    sol.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = sol.kernel_ms_mean(args.steps)  # [lq, riccati, linesearch, wbc, whole]
+    sol.enable_timing(False)
+
+    res = mb.results(); wres = wb.results()
+    ok = bool(np.isfinite(res["X"]).all() and np.isfinite(wres["out"]).all() and (res["stats"][:, 7] == 0).all())
+
+    if rank == 0:
+        names = ["lq_node_kernel", "riccati_kernel", "linesearch_kernel", "wbc_kernel"]
+        modes = res["mode"][:, :N]
+        nc = 3 * np.array([[bin(int(m)).count("1") for m in row] for row in modes]) + 4 * (4 - np.array([[bin(int(m)).count("1") for m in row] for row in modes]))
+        flops = {k: 0.0 for k in ("lq_node_kernel", "riccati_kernel")}
+        for v in np.unique(nc):
+            cnt = int((nc == v).sum())
+            for k, f in node_flops(int(v)).items():
+                flops[k] += cnt * f
+        dom = int(np.argmax(kernel_ms[:4]))
+        dom_name = names[dom]
+        path_flops = flops["lq_node_kernel"] + flops["riccati_kernel"]
+        roof_kernel = dom_name if dom_name in flops else "riccati_kernel"
+        kms = kernel_ms[names.index(roof_kernel)]
+        achieved = flops[roof_kernel] / (kms * 1e-3) / 1e12
+        out = {
+            "metric": "MPC+WBC cycles/sec (AlienGo+Z1, N=100)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=256 MPC instances per GPU, horizon N=100, dt=0.015, trot, 1 SQP iteration + filter line search + 3-level WBC",
+                       "batch_per_gpu": B, "horizon_nodes": N, "gait": "trot", "seed": 0, "results_finite_and_converged": ok,
+                       "collective": "all_gather(X,U,tau,mode) over RCCL" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None,
+                         "note": "algorithmic dense-contraction FLOPs of SURVEY.md 8(d) per launch / HIP-event kernel time; fp64 matrix peak is the public spec; "
+                                 "the path is latency bound, not MFMA bound (DESIGN.md)",
+                         "kernel_ms": dict(zip(names + ["whole_call"], kernel_ms)),
+                         "path_achieved": path_flops / (kernel_ms[4] * 1e-3) / 1e12, "path_frac": path_flops / (kernel_ms[4] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(itf, sc)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ SYMBOLS = [
     "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait",
     "qmgpu_create", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
     "qmgpu_policy_eval_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
-    "qmgpu_enable_timing", "qmgpu_enable_debug",
+    "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_kernel_ms_mean",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def load_library(path=None):
     lib.qmgpu_debug_get_lq.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.POINTER(i32)]
     lib.qmgpu_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(d)]
     lib.qmgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.qmgpu_kernel_ms_mean.argtypes = [C.c_void_p, C.c_int, C.POINTER(d)]
     lib.qmgpu_enable_debug.argtypes = [C.c_void_p, C.c_int]
     if path is None:
         _lib = lib

@@ -112,6 +112,11 @@ class GpuSolver:
         abi.check(self.lib, self.lib.qmgpu_last_kernel_ms(self.handle, ms))
         return list(ms)
 
+    def kernel_ms_mean(self, last_calls):
+        ms = (abi.d * 5)()
+        abi.check(self.lib, self.lib.qmgpu_kernel_ms_mean(self.handle, int(last_calls), ms))
+        return list(ms)
+
     @staticmethod
     def mpc_args(batch, num_nodes, x0, target_times, target_states, sched_num, sched_times, sched_modes, out_t, out_x, out_u, out_mode, out_stats=None,
                  t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True):

@@ -6,6 +6,7 @@
 //     -> policy_eval -> wbc (batch workgroups)
 // with no host synchronisation in between; the caller synchronises when it needs the results.
 // There is no CPU fallback: without a HIP device qmgpu_create returns QMGPU_ERR_NO_DEVICE.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -46,7 +47,12 @@ struct qmgpu_context {
   double* dWbcScratch = nullptr;
   std::vector<void*> allocations;
   bool timing = false, debugLq = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // HIP-event ring: one set of 6 events per call while timing is enabled, read back without a per-call sync
+  static constexpr int kRing = 256;
+  hipEvent_t ring[kRing][6];
+  int ringKind[kRing];  // bit0: mpc recorded, bit1: wbc recorded
+  long callCount = 0;   // calls recorded since timing was enabled
+  hipEvent_t* ev = nullptr;
   double lastMs[5] = {0, 0, 0, 0, 0};
   int lastBatch = 0, lastN = 0;
 
@@ -108,7 +114,8 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     ctx->dWbcScratch = ctx->alloc<double>(B * WBC_SCRATCH_DOUBLES);
     HIP_CHECK(hipMemcpy(ctx->dP, problem, sizeof(qmgpu_problem), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemsetAsync(ctx->dZeros, 0, 64 * sizeof(double), ctx->stream));
-    for (auto& e : ctx->ev) HIP_CHECK(hipEventCreate(&e));
+    for (auto& set : ctx->ring) for (auto& e : set) HIP_CHECK(hipEventCreate(&e));
+    ctx->ev = ctx->ring[0];
     HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(wbc_kernel, WBC_LDS_BYTES));
     HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(riccati_kernel, RICCATI_LDS_BYTES));
     QM_LAUNCH(input_weight_kernel, 1, 64, ctx->stream, ctx->dP, ctx->dZeros, ctx->dRw);
@@ -127,7 +134,7 @@ int qmgpu_destroy(qmgpu_handle h) {
   if (!h) return QMGPU_OK;
   hipStreamSynchronize(h->stream);
   for (void* p : h->allocations) hipFree(p);
-  for (auto& e : h->ev) if (e) hipEventDestroy(e);
+  for (auto& set : h->ring) for (auto& e : set) if (e) hipEventDestroy(e);
   if (h->ownStream) hipStreamDestroy(h->ownStream);
   delete h;
   return QMGPU_OK;
@@ -152,6 +159,7 @@ int qmgpu_get_input_weight(qmgpu_handle h, double* R_host) {
 int qmgpu_enable_timing(qmgpu_handle h, int enable) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   h->timing = enable != 0;
+  h->callCount = 0;
   return QMGPU_OK;
 }
 
@@ -202,19 +210,30 @@ static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
   HIP_CHECK(hipGetLastError());
 }
 
+static void beginTiming(qmgpu_handle h) {
+  if (h->timing) h->ev = h->ring[h->callCount % qmgpu_context::kRing];
+}
 static void finishTiming(qmgpu_handle h, bool mpc, bool wbc) {
   if (!h->timing) return;
-  HIP_CHECK(hipEventSynchronize(h->ev[mpc ? (wbc ? 5 : 3) : 5]));
+  h->ringKind[h->callCount % qmgpu_context::kRing] = (mpc ? 1 : 0) | (wbc ? 2 : 0);
+  ++h->callCount;
+}
+// elapsed times of one recorded call: [lq, riccati, linesearch, wbc, whole]
+static void readTiming(qmgpu_handle h, long call, double* ms5) {
+  hipEvent_t* ev = h->ring[call % qmgpu_context::kRing];
+  const int kind = h->ringKind[call % qmgpu_context::kRing];
+  const bool mpc = kind & 1, wbc = kind & 2;
+  HIP_CHECK(hipEventSynchronize(ev[wbc ? 5 : 3]));
   float ms = 0.f;
-  for (double& v : h->lastMs) v = 0.0;
-  if (mpc) for (int i = 0; i < 3; ++i) { HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1])); h->lastMs[i] = ms; }
-  if (wbc) { HIP_CHECK(hipEventElapsedTime(&ms, h->ev[4], h->ev[5])); h->lastMs[3] = ms; }
-  HIP_CHECK(hipEventElapsedTime(&ms, h->ev[mpc ? 0 : 4], h->ev[wbc ? 5 : 3]));
-  h->lastMs[4] = ms;
+  for (int i = 0; i < 5; ++i) ms5[i] = 0.0;
+  if (mpc) for (int i = 0; i < 3; ++i) { HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); ms5[i] = ms; }
+  if (wbc) { HIP_CHECK(hipEventElapsedTime(&ms, ev[4], ev[5])); ms5[3] = ms; }
+  HIP_CHECK(hipEventElapsedTime(&ms, ev[mpc ? 0 : 4], ev[wbc ? 5 : 3]));
+  ms5[4] = ms;
 }
 
 int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args) {
-  return guarded([&]() { checkMpcArgs(h, args); enqueueMpc(h, args); finishTiming(h, true, false); });
+  return guarded([&]() { checkMpcArgs(h, args); beginTiming(h); enqueueMpc(h, args); finishTiming(h, true, false); });
 }
 
 int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const double* t_grid, const double* X, const double* U, const int32_t* modes, const double* t_eval,
@@ -229,6 +248,7 @@ int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const doub
 int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() {
+    beginTiming(h);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
     enqueueWbc(h, args);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[5], h->stream));
@@ -241,6 +261,7 @@ int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t
   return guarded([&]() {
     checkMpcArgs(h, mpc);
     if (wbc->batch != mpc->batch) throw std::invalid_argument("MPC and WBC batch sizes differ");
+    beginTiming(h);
     enqueueMpc(h, mpc);
     QM_LAUNCH(policy_eval_kernel, (mpc->batch + 63) / 64, 64, h->stream, mpc->batch, mpc->num_nodes, mpc->out_t, mpc->out_x, mpc->out_u, mpc->out_mode, t_eval, h->dPolX, h->dPolU,
               h->dPolMode);
@@ -274,8 +295,21 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
 
 int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms5) {
   if (!h || !ms5) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
-  for (int i = 0; i < 5; ++i) ms5[i] = h->lastMs[i];
-  return QMGPU_OK;
+  return guarded([&]() {
+    if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
+    readTiming(h, h->callCount - 1, ms5);
+  });
+}
+
+int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms5) {
+  if (!h || !ms5 || last_calls < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad argument");
+  return guarded([&]() {
+    if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
+    const long n = std::min<long>(std::min<long>(last_calls, h->callCount), qmgpu_context::kRing);
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (long c = h->callCount - n; c < h->callCount; ++c) { double m[5]; readTiming(h, c, m); for (int i = 0; i < 5; ++i) acc[i] += m[i]; }
+    for (int i = 0; i < 5; ++i) ms5[i] = acc[i] / double(n);
+  });
 }
 
 }  // extern "C"
