@@ -338,16 +338,25 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   { const Vec Dz = D * z; for (int i = 0; i < m; ++i) s[i] = std::max(1.0, f[i] - Dz[i]); }
   double scale = 1.0; for (double v : c) scale = std::max(scale, std::fabs(v)); for (double v : f) scale = std::max(scale, std::fabs(v));
   int it = 0;
+  Vec zPrev = z, sPrev = s, lamPrev = lam;
+  double nrdPrev = 0.0, muPrev = 0.0;
   for (; it < maxIter; ++it) {
     const Vec rd = H * z + c + tmul(D, lam);
     Vec rp = D * z + s - f;
     double mu = dot(s, lam) / m;
     double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
+    // Late iterations of degenerate problems (rows active with a zero multiplier) push the barrier weights to ~1e18 and the
+    // Newton step can lose all accuracy.  A step that blows the dual residual up (or produces NaN) is rejected: the previous
+    // iterate is returned, as converged if its complementarity was already <= 1e-8 * scale, flagged otherwise.
+    if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) {
+      z = zPrev; s = sPrev; lam = lamPrev;
+      if (kktRes) *kktRes = std::max(nrdPrev, muPrev);
+      return muPrev <= 1e-8 * scale ? it : -3;
+    }
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
-    // primal feasibility and complementarity tight; the dual residual tolerance is looser because rows that are active with a
-    // zero multiplier (s -> 0 and lambda -> 0 together) drive the barrier weights to 1e18 and the Newton accuracy with them
+    // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
     if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
-    if (!(mu == mu) || mu < 1e-20 * scale) return -3;  // numerical breakdown
+    zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = H;
     for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
     if (!choleskyFloored(K, pivotFloor)) return -2;

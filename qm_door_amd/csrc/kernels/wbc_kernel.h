@@ -17,6 +17,9 @@
 #pragma once
 #include "../../../include/qmgpu.h"
 #include "gpu_rt.h"
+#ifndef QMGPU_DEBUG_INST
+#define QMGPU_DEBUG_INST 0
+#endif
 #include "linesearch_kernel.h"  // DblIn
 #include "sweep_dev.h"
 
@@ -518,7 +521,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     __syncthreads();
 
 #ifdef QMGPU_EMU_DEBUG
-    if (lane == 0 && inst == 0) { printf("EMU level %d r %d n %d b:", level, r, n); for (int i = 0; i < r; ++i) printf(" %.10g", bvec[i]); printf("\n"); }
+    if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d r %d n %d b:", level, r, n); for (int i = 0; i < r; ++i) printf(" %.10g", bvec[i]); printf("\n"); }
 #endif
     // ---- reduced data: AZ = A Z (r x n), rhat = A x - b, DZ = D0 Z, fhat
     const int mOwn = (level == 0) ? m0 : 0, mPrev = (level == 0) ? 0 : m0;
@@ -571,6 +574,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     const double nRowsTot = wbcSum(red, lane, rowActive ? (mOwn > 0 ? 2.0 : 1.0) : 0.0);
     double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
     const bool own = mOwn > 0;
+    double s1p = s1, l1p = l1, s2p = s2, l2p = l2, vp = v, nrdPrev = 0.0, muPrev = 0.0;
     int it = 0;
     if (nRowsTot > 0.0) {
 #pragma unroll 1
@@ -593,11 +597,23 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
         const double mu = wbcSum(red, lane, rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
         const double nrd = wbcMax(red, lane, fmax(lane < n ? fabs(rds[lane]) : 0.0, fabs(rdv)));
         const double nrp = wbcMax(red, lane, fmax(fabs(rp1), fabs(rp2)));
+        const double nanProbe = wbcSum(red, lane, (lane < n ? rds[lane] : 0.0) + rdv + rp1 + rp2);  // NaN anywhere -> NaN here (fmax drops NaNs)
 #ifdef QMGPU_EMU_DEBUG
-        if (lane == 0 && level == 2) printf("EMU inst %d it %d mu %.3e nrd %.3e nrp %.3e\n", inst, it, mu, nrd, nrp);
+        if (lane == 0 && level >= 1 && inst == QMGPU_DEBUG_INST) printf("DBG inst %d level %d it %d mu %.3e nrd %.3e nrp %.3e scale %.3e floor %.3e\n", inst, level, it, mu, nrd, nrp, scale, pivotFloor);
 #endif
+        // A late Newton step of a degenerate problem can lose all accuracy (barrier weights ~1e18).  As in the oracle's
+        // solveQpIpm: a step that blows the dual residual up or yields NaN is rejected and the previous iterate returned --
+        // as converged if its complementarity was already <= 1e-8 * scale, flagged in out_status otherwise.
+        if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
+          if (lane < n) zs[lane] = rhs[lane];
+          s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
+          if (!(muPrev <= 1e-8 * scale)) it = 60;
+          __syncthreads();
+          break;
+        }
         if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;  // same tolerances as the oracle's solveQpIpm
-        if (!(mu == mu) || mu < 1e-20 * scale) { it = 60; break; }                       // numerical breakdown -> flagged in out_status
+        if (lane < n) rhs[lane] = zs[lane];
+        s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
         // weights and the reduced normal matrix K = G + DZ^T diag(wt) DZ
         const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
         if (lane < 56) wt[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
@@ -680,7 +696,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     if (lane < ND) xs[lane] = xn;
 #ifdef QMGPU_EMU_DEBUG
     __syncthreads();
-    if (lane == 0 && inst == 0) { printf("EMU level %d it %d x:", level, it); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
+    if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d it %d x:", level, it); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
 #endif
     if (level == numLevels - 1) break;
 
