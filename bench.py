@@ -100,19 +100,14 @@ def main():
     il0 = np.zeros((B, 30))
     wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), il0)
     t_eval = G.dev(np.zeros(B), torch.float64)
-    # packed result gathered across ranks: X, U, tau (+ modes as doubles)
-    pack_len = (N + 1) * 30 + N * 30 + 54 + (N + 1)
-    packed = torch.zeros((B, pack_len), dtype=torch.float64, device="cuda")
-    gathered = torch.zeros((world * B, pack_len), dtype=torch.float64, device="cuda") if world > 1 else None
+    # packed result gathered across ranks: X | U | wbc out | modes (qm_door_amd/sharding.py)
+    from qm_door_amd import sharding
+    gathered = torch.zeros((world * B, sharding.pack_len(N)), dtype=torch.float64, device="cuda") if world > 1 else None
 
     def step():
         sol.cycle(mb.args, t_eval, wb.args)
         if world > 1:
-            packed[:, :(N + 1) * 30] = mb.oX.view(B, -1)
-            packed[:, (N + 1) * 30:(N + 1) * 30 + N * 30] = mb.oU.view(B, -1)
-            packed[:, (N + 1) * 30 + N * 30:(N + 1) * 30 + N * 30 + 54] = wb.out
-            packed[:, -(N + 1):] = mb.oM.to(torch.float64)
-            dist.all_gather_into_tensor(gathered, packed)
+            dist.all_gather_into_tensor(gathered, sharding.pack(mb.oX, mb.oU, wb.out, mb.oM))
 
     for _ in range(args.warmup):
         step()

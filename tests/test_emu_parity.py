@@ -1,0 +1,82 @@
+"""CPU tier: the SAME kernel sources compiled against tests/emu/simt_emu.h (workgroups as host threads) are checked against the
+oracle.  This validates the kernels' lane roles, LDS hand-offs and index math without a GPU; the -m gpu tests repeat the
+comparison on the real hipcc build.  The emulation library is test infrastructure and is never loaded by qm_door_amd."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import support as S
+from qm_door_amd import abi, api
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    return itf, S.Oracle(itf.problem)
+
+
+def test_emu_lq_and_sqp_iteration(emu):
+    itf, orc = emu
+    B, N = 2, 6
+    x_nom = itf.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=0)
+    tgt = S.nominal_target(orc, x_nom)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.03)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+    assert np.abs(sol.input_weight() - orc.input_weight()).max() < 1e-13
+    sol.enable_debug(True)
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, 8))
+    a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B))
+    sol.mpc(a)
+    dt = itf.problem.settings.dt
+    for inst in range(B):
+        for k in (0, 3, N):
+            g = sol.debug_lq(inst, k)
+            mode = orc.mode_at(ev[:nev], md[:nev + 1], k * dt)
+            flags = [(mode >> (3 - c)) & 1 for c in range(4)]
+            u = np.zeros(30)
+            for c in range(4):
+                if flags[c]:
+                    u[3 * c + 2] = itf.robot_mass * 9.81 / sum(flags)
+            o = orc.lq_node(k * dt, dt if k < N else 0.0, x0[inst], u if k < N else None, x0[inst], k == N, nev, ev, md, tt[inst], ts[inst])
+            assert g["nc"] == o["nc"]
+            for key in (["Q", "q"] if k == N else ["A", "B", "b", "Q", "R", "q", "r", "C", "D", "e"]):
+                assert np.abs(g[key] - o[key]).max() <= 1e-10 * max(1.0, np.abs(o[key]).max()), (inst, k, key)
+        ref = orc.mpc_solve(N, 0.0, x0[inst], tt[inst], ts[inst], nev, ev, md)
+        assert np.array_equal(oM[inst], ref["mode"])
+        assert np.abs(oX[inst] - ref["X"]).max() <= 1e-8 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(oU[inst] - ref["U"]).max() <= 1e-8 * max(1.0, np.abs(ref["U"]).max())
+        assert np.allclose(oS[inst][:7], ref["stats"][:7], rtol=1e-8, atol=1e-10)
+
+
+def test_emu_wbc(emu):
+    itf, orc = emu
+    rng = np.random.default_rng(3)
+    x_nom, m = itf.initial_state, itf.robot_mass
+    cases = []
+    for mode, t in ((9, 20.0), (15, 5.0)):
+        flags = [(mode >> (3 - c)) & 1 for c in range(4)]
+        u = np.zeros(30)
+        for c in range(4):
+            if flags[c]:
+                u[3 * c + 2] = m * 9.81 / sum(flags)
+        u[12:] = rng.uniform(-1, 1, 18) * 0.05
+        xd = x_nom + rng.uniform(-1, 1, 30) * 0.02
+        rbd = S.rbd_from_state(orc, x_nom + rng.uniform(-1, 1, 30) * 0.01, rng.uniform(-1, 1, 24) * 0.05)
+        cases.append((xd, u, rbd, mode, t, u + rng.uniform(-1, 1, 30) * 0.001))
+    B = len(cases)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=4)
+    out, st = np.zeros((B, 54)), np.zeros(B, dtype=np.int32)
+    il = np.array([c[5] for c in cases])
+    a = sol.wbc_args(B, np.array([c[2] for c in cases]), np.full(B, 0.002), np.array([c[4] for c in cases]), il, out, st, np.array([c[0] for c in cases]),
+                     np.array([c[1] for c in cases]), np.array([c[3] for c in cases], dtype=np.int32), 0)
+    sol.wbc(a)
+    assert (st == 0).all()
+    for i, (xd, u, rbd, mode, t, il0) in enumerate(cases):
+        s, ref, il_ref = orc.wbc_update(xd, u, rbd, mode, 0.002, t, il0)
+        assert s == 0
+        assert np.abs(out[i] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+        assert np.array_equal(il[i], il_ref)

@@ -1,0 +1,111 @@
+"""Host logic: URDF/INFO loaders (known-answer values of SURVEY.md Appendix C/D), gait tables, mode schedule tiling, errors."""
+import ctypes as C
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from qm_door_amd import abi, api
+
+JOINTS = ["LF_HAA", "LF_HFE", "LF_KFE", "LH_HAA", "LH_HFE", "LH_KFE", "RF_HAA", "RF_HFE", "RF_KFE", "RH_HAA", "RH_HFE", "RH_KFE",
+          "z1_joint_1", "z1_joint_2", "z1_joint_3", "z1_joint_4", "z1_joint_5", "z1_joint_6"]
+
+
+def test_model_known_answers(interface):
+    m = interface.problem.model
+    assert abs(m.total_mass - 27.86796983) < 1e-8          # sum of URDF inertials
+    assert list(m.parent) == [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14, 15, 16, 17]
+    assert list(m.axis)[1:] == [0, 1, 1] * 4 + [2, 1, 1, 1, 2, 0]                      # HAA x, HFE/KFE y; arm z y y y z x
+    assert list(m.foot_body) == [3, 9, 6, 12]                                        # contact order LF RF LH RH on joint order LF LH RF RH
+    assert [list(o) for o in m.foot_offset] == [[0.0, 0.0, -0.25]] * 4
+    assert m.ee_body == 18 and np.allclose(list(m.ee_offset), [0.051 + 0.135, 0, 0])
+    assert np.allclose(list(m.effort_limit), [35.278, 35.278, 44.4] * 4 + [30, 60, 30, 30, 30, 30])
+    assert np.allclose(list(m.joint_offset[1]), [0.2407, 0.051, 0]) and np.allclose(list(m.joint_offset[13]), [0.2535, 0, 0.056 + 0.0585])
+
+
+def test_model_against_independent_urdf_parse(interface):
+    """Independent Python parse of the URDF: masses per moving body (fixed children merged), limits, joint order."""
+    root = ET.parse(interface.urdf_file).getroot()
+    joints = {j.get("name"): j for j in root.findall("joint")}
+    links = {l.get("name"): l for l in root.findall("link")}
+    mass = lambda n: float(links[n].find("inertial").find("mass").get("value")) if links[n].find("inertial") is not None else 0.0
+    children = {}
+    for j in joints.values():
+        children.setdefault(j.find("parent").get("link"), []).append(j)
+    def body_mass(link):
+        tot = mass(link)
+        for j in children.get(link, []):
+            if j.get("name") not in JOINTS:
+                tot += body_mass(j.find("child").get("link"))
+        return tot
+    m = interface.problem.model
+    assert abs(m.mass[0] - body_mass("base")) < 1e-12
+    for b, name in enumerate(JOINTS, start=1):
+        j = joints[name]
+        assert abs(m.mass[b] - body_mass(j.find("child").get("link"))) < 1e-12
+        lim = j.find("limit")
+        assert m.q_lower[b - 1] == float(lim.get("lower")) and m.q_upper[b - 1] == float(lim.get("upper")) and m.effort_limit[b - 1] == float(lim.get("effort"))
+
+
+def test_settings_known_answers(interface):
+    s = interface.problem.settings
+    Q = np.array(s.Q[:]).reshape(30, 30)
+    assert np.allclose(np.diag(Q), [50, 50, 300, 10, 30, 30, 1000, 1000, 3000, 1000, 2000, 2000] + [5, 5, 2.5] * 4 + [0, 0, 5, 0, 0, 0])
+    assert np.count_nonzero(Q - np.diag(np.diag(Q))) == 0
+    R = np.array(s.R_task[:]).reshape(30, 30)
+    assert np.allclose(np.diag(R), [5e-3] * 12 + [5.0] * 12 + [1.0] * 6)
+    assert (s.dt, s.sqp_iterations, s.g_max, s.g_min, s.delta_tol) == (0.015, 1, 1e-2, 1e-6, 1e-4)
+    assert (s.ee_mu_position, s.ee_mu_orientation, s.friction_coefficient, s.friction_barrier_mu, s.friction_barrier_delta) == (2000.0, 1000.0, 0.7, 0.1, 5.0)
+    assert (s.joint_pos_barrier_mu, s.joint_pos_barrier_delta, s.wbc_friction_coefficient) == (0.1, 1e-3, 0.3)
+    assert np.allclose(list(s.arm_vel_upper), [0.628] * 3 + [0.837] * 3) and np.allclose(list(s.arm_vel_lower), [-0.628] * 3 + [-0.837] * 3)
+    assert (s.liftoff_velocity, s.touchdown_velocity, s.swing_height, s.swing_time_scale) == (0.05, -0.1, 0.15, 0.15)
+    assert (s.position_error_gain, s.phase_transition_stance_time, s.com_height) == (0.0, 0.1, 0.4)
+    assert np.allclose(list(s.default_joint_state), [0, 0.8, -1.5] * 4 + [0, 1.11, -0.69, -0.4, 0, 0])
+    assert (s.kp_swing, s.kd_swing, s.kp_base_height, s.kd_base_height, s.kp_base_linear, s.kd_base_linear) == (350, 37, 400, 140, 400, 100)
+    assert list(s.kp_arm_joint) == [4000, 4200, 4000, 4000, 4200, 6000] and list(s.kd_ee_angular) == [75, 75, 75]
+
+
+def test_missing_files_and_bad_model(hip_lib, tmp_path):
+    P = abi.Problem()
+    d = abi.DATA_DIR.encode()
+    st = hip_lib.qmgpu_load_problem(b"/nonexistent/task.info", d + b"/aliengo_z1.urdf", d + b"/reference.info", None, C.byref(P))
+    assert st == abi.ERR_FILE_NOT_FOUND and b"task.info" in hip_lib.qmgpu_last_error()      # QMInterface.cpp:45
+    urdf = open(os.path.join(abi.DATA_DIR, "aliengo_z1.urdf")).read().replace('<axis xyz="1 0 0" />', '<axis xyz="0.7 0.7 0" />', 1)
+    bad = tmp_path / "bad.urdf"
+    bad.write_text(urdf)
+    st = hip_lib.qmgpu_load_problem(d + b"/task.info", str(bad).encode(), d + b"/reference.info", None, C.byref(P))
+    assert st == abi.ERR_UNSUPPORTED_MODEL
+    assert hip_lib.qmgpu_load_problem(None, None, None, None, None) == abi.ERR_INVALID_ARGUMENT
+
+
+def test_gait_tables(hip_lib):
+    """Every template of gait.info:17-255 loads; mode numbers follow 8*LF + 4*RF + 2*LH + RH (bit exact)."""
+    gs = api.GaitSchedule(lib=hip_lib)
+    expect = {"stance": ([15], [0.0, 0.5]), "trot": ([9, 6], [0.0, 0.35, 0.70]), "standing_trot": ([9, 15, 6, 15], [0, 0.4, 0.5, 0.9, 1.0]),
+              "flying_trot": ([9, 0, 6, 0], [0, 0.25, 0.30, 0.55, 0.60]), "pace": ([10, 0, 5, 0], [0, 0.28, 0.30, 0.58, 0.60]),
+              "standing_pace": ([10, 15, 5, 15], [0, 0.30, 0.35, 0.65, 0.70]), "dynamic_walk": ([13, 5, 7, 14, 10, 11], [0, 0.2, 0.3, 0.5, 0.7, 0.8, 1.0]),
+              "static_walk": ([13, 7, 14, 11], [0, 0.3, 0.6, 0.9, 1.2]), "amble": ([6, 10, 9, 5], [0, 0.15, 0.40, 0.55, 0.80])}
+    for name, (modes, times) in expect.items():
+        g = gs.template(name)
+        assert g.num_modes == len(modes) and list(g.modes[:g.num_modes]) == modes and np.allclose(list(g.switching_times[:g.num_modes + 1]), times), name
+    for name in ("lindyhop", "skipping", "pawup"):
+        assert gs.template(name).num_modes > 0
+    for name, val in abi.MODE_NAMES.items():
+        assert hip_lib.qmgpu_mode_from_string(name.encode()) == val
+    assert hip_lib.qmgpu_mode_from_string(b"NOPE") == -1
+    with pytest.raises(abi.QmGpuError):
+        gs.template("moonwalk")
+
+
+def test_tile_gait(hip_lib):
+    gs = api.GaitSchedule(lib=hip_lib)
+    n, ev, md = gs.mode_schedule("trot", 0.2, 0.0, 1.5)
+    assert md[0] == 15 and md[n] == 15                      # initial STANCE, default final STANCE
+    assert np.allclose(ev[:n], 0.2 + 0.35 * np.arange(n)) and ev[n - 1] >= 1.5
+    assert list(md[1:n]) == [9, 6] * ((n - 1) // 2)
+    n2, ev2, md2 = gs.mode_schedule("stance", 0.0, 0.0, 2.0)  # equal neighbours merge: a single STANCE phase
+    assert n2 == 0 and md2[0] == 15
+    g = gs.template("trot")
+    nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
+    assert hip_lib.qmgpu_tile_gait(C.byref(g), 0.0, 0.0, 100.0, C.byref(nn), e, m) == abi.ERR_CAPACITY

@@ -1,0 +1,247 @@
+"""Pins the CPU oracle (PARITY UNPINNED: the reference ships no golden vectors) by the invariant suite of SURVEY.md 8(c):
+model identities, finite-difference checks of every derivative, rigid-body dynamics identities, QP optimality (KKT),
+hierarchy properties of the HoQP cascade, bit-exact mode tables, swing-spline boundary conditions, SQP convergence."""
+import itertools
+
+import numpy as np
+import pytest
+
+import support as S
+
+
+@pytest.fixture(scope="module")
+def rng():
+    return np.random.default_rng(11)
+
+
+def _state(interface, rng, scale=1.0):
+    x = interface.initial_state + rng.uniform(-1, 1, 30) * 0.1 * scale
+    u = np.zeros(30)
+    u[[2, 5, 8, 11]] = interface.robot_mass * 9.81 / 4
+    u += rng.uniform(-1, 1, 30) * np.r_[np.full(12, 10.0), np.full(18, 0.5)] * scale
+    return x, u
+
+
+# ------------------------------------------------------------------------------------------------ model / dynamics
+def test_nominal_flow_map(interface, oracle):
+    x = interface.initial_state
+    u = np.zeros(30); u[[2, 5, 8, 11]] = interface.robot_mass * 9.81 / 4
+    f = oracle.flow_map(x, u)
+    assert np.abs(f[:3]).max() < 1e-13            # weight compensation: no linear momentum rate
+    assert np.abs(f[6:]).max() < 1e-13            # zero momentum, zero joint velocity: nothing moves
+    fp, _, _, _, com = oracle.kinematics(x, u)
+    assert np.allclose(f[3:6], sum(np.cross(fp[c] - com, u[3 * c:3 * c + 3]) for c in range(4)) / interface.robot_mass, atol=1e-13)
+
+
+def test_centroidal_matrix_identities(interface, oracle, rng):
+    x, u = _state(interface, rng)
+    A = oracle.centroidal_matrix(x[6:])
+    m = interface.robot_mass
+    assert np.allclose(A[:3, :3], m * np.eye(3), atol=1e-12)      # A_G[0:3,0:3] = m I
+    assert np.allclose(A[3:, :3], 0, atol=1e-12)                  # translation carries no angular momentum about the com
+    # flow map base velocity is consistent with A_G: A_G [v_b; v_j] = m h
+    f = oracle.flow_map(x, u)
+    v = np.r_[f[6:12], u[12:]]
+    assert np.allclose(A @ v, m * x[:6], atol=1e-10)
+    # linear momentum = m * com velocity (finite difference of the com along v)
+    eps = 1e-6
+    com = lambda q: oracle.kinematics(np.r_[x[:6], q], u)[4]
+    dcom = (com(x[6:] + eps * v) - com(x[6:] - eps * v)) / (2 * eps)
+    assert np.allclose(A[:3] @ v, m * dcom, atol=1e-7)
+
+
+def test_flow_map_derivatives_vs_finite_differences(interface, oracle, rng):
+    x, u = _state(interface, rng)
+    f, A, B = oracle.flow_map_lin(x, u)
+    eps = 1e-6
+    for j in range(30):
+        d = np.zeros(30); d[j] = eps
+        assert np.allclose(A[:, j], (oracle.flow_map(x + d, u) - oracle.flow_map(x - d, u)) / (2 * eps), rtol=1e-6, atol=1e-7)
+        assert np.allclose(B[:, j], (oracle.flow_map(x, u + d) - oracle.flow_map(x, u - d)) / (2 * eps), rtol=1e-6, atol=1e-7)
+
+
+def test_lq_node_against_finite_differences(interface, oracle, rng):
+    """Constraint Jacobians, cost gradient/Hessian structure and the RK2 sensitivities of one trot node."""
+    x, u = _state(interface, rng, 0.5)
+    nev, ev, md = S.trot_schedule(2.0)
+    tgt = S.nominal_target(oracle, interface.initial_state)
+    tt, ts = np.zeros(1), tgt[None, :].copy()
+    t, dt = 0.1, 0.015
+    xn = x + 0.01
+    o = oracle.lq_node(t, dt, x, u, xn, False, nev, ev, md, tt, ts)
+    assert o["nc"] == 14                                           # trot: 2 stance (3 rows) + 2 swing (3 + 1 rows)
+    eps = 1e-6
+    def pert(j, s):
+        d = np.zeros(60); d[j] = s
+        return oracle.lq_node(t, dt, x + d[:30], u + d[30:], xn, False, nev, ev, md, tt, ts)
+    for j in range(60):
+        p, q = pert(j, eps), pert(j, -eps)
+        col = (p["e"] - q["e"]) / (2 * eps)
+        ref = o["C"][:, j] if j < 30 else o["D"][:, j - 30]
+        assert np.allclose(col, ref, rtol=1e-6, atol=1e-7)
+        colb = (p["b"] - q["b"]) / (2 * eps)
+        refb = o["A"][:, j] if j < 30 else o["B"][:, j - 30]
+        assert np.allclose(colb, refb, rtol=1e-6, atol=1e-7)
+        g = (p["cost"] - q["cost"]) / (2 * eps)
+        refg = o["q"][j] if j < 30 else o["r"][j - 30]
+        assert abs(g - refg) <= 1e-5 * max(1.0, abs(refg))
+    assert np.allclose(o["Q"], o["Q"].T) and np.allclose(o["R"], o["R"].T)
+    assert np.linalg.eigvalsh(o["R"]).min() > 0 and np.linalg.eigvalsh(o["Q"]).min() > -1e-9
+
+
+def test_rigid_body_dynamics_identities(interface, oracle, rng):
+    x, _ = _state(interface, rng)
+    v = rng.uniform(-1, 1, 24) * 0.5
+    rbd = S.rbd_from_state(oracle, x)
+    # measured velocities: world angular velocity from Euler rates
+    e = x[9:12]
+    sz, cz, sy, cy = np.sin(e[0]), np.cos(e[0]), np.sin(e[1]), np.cos(e[1])
+    w = np.array([-sz * v[4] + cy * cz * v[5], cz * v[4] + cy * sz * v[5], v[3] - sy * v[5]])
+    rbd[24:27] = w; rbd[27:30] = v[:3]; rbd[30:48] = v[6:]
+    u = np.zeros(30)
+    mdl = oracle.wbc_model(x, u, rbd, 0.002, np.zeros(30))
+    M, nle = mdl["M"], mdl["nle"]
+    assert np.allclose(mdl["qv"][1], v, atol=1e-12)
+    assert np.allclose(M, M.T, atol=1e-12) and np.linalg.eigvalsh(M).min() > 0
+    assert np.allclose(M[:3] @ v, oracle.centroidal_matrix(x[6:])[:3] @ v, atol=1e-10)      # base rows of M v = linear momentum
+    # gravity part: nle(q, 0) = dV/dq by finite differences of the potential energy
+    rbd0 = rbd.copy(); rbd0[24:48] = 0
+    g = oracle.wbc_model(x, u, rbd0, 0.002, np.zeros(30))["nle"]
+    m_tot, eps = interface.robot_mass, 1e-6
+    V = lambda q: m_tot * 9.81 * oracle.kinematics(np.r_[x[:6], q], u)[4][2]
+    dV = np.array([(V(x[6:] + eps * np.eye(24)[k]) - V(x[6:] - eps * np.eye(24)[k])) / (2 * eps) for k in range(24)])
+    assert np.allclose(g, dV, atol=1e-6)
+    # Coriolis part: v^T C(q,v) v = 1/2 v^T dM/dt v   (M_dot - 2C skew symmetric)
+    def Mat(q):
+        r2 = rbd0.copy(); r2[3:6] = q[:3]; r2[0:3] = q[3:6]; r2[6:24] = q[6:]
+        return oracle.wbc_model(np.r_[x[:6], q], u, r2, 0.002, np.zeros(30))["M"]
+    dM = (Mat(x[6:] + eps * v) - Mat(x[6:] - eps * v)) / (2 * eps)
+    assert abs(v @ (nle - g) - 0.5 * v @ dM @ v) < 1e-6
+    # dJ v = d/dt (J v) with v constant
+    def Jv(q):
+        r2 = rbd.copy(); r2[3:6] = q[:3]; r2[0:3] = q[3:6]; r2[6:24] = q[6:]
+        # keep the generalized velocity v fixed: rebuild the world angular velocity for the perturbed Euler angles
+        s0, c0, s1, c1 = np.sin(q[3]), np.cos(q[3]), np.sin(q[4]), np.cos(q[4])
+        r2[24:27] = [-s0 * v[4] + c1 * c0 * v[5], c0 * v[4] + c1 * s0 * v[5], v[3] - s1 * v[5]]
+        mm = oracle.wbc_model(np.r_[x[:6], q], u, r2, 0.002, np.zeros(30))
+        return np.r_[mm["J"] @ v, mm["armJ"] @ v, mm["baseJ"] @ v]
+    fd = (Jv(x[6:] + eps * v) - Jv(x[6:] - eps * v)) / (2 * eps)
+    an = np.r_[mdl["dJ"] @ v, mdl["armDJ"] @ v, mdl["baseDJ"] @ v]
+    assert np.allclose(fd, an, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ schedule
+def test_mode_numbers_and_lookup(oracle):
+    ev = np.array([0.35, 0.70]); md = np.array([9, 6, 15], dtype=np.int32)
+    assert oracle.mode_at(ev, md, 0.0) == 9 and oracle.mode_at(ev, md, 0.35) == 9      # an event time still belongs to the phase before it
+    assert oracle.mode_at(ev, md, 0.35 + 1e-12) == 6 and oracle.mode_at(ev, md, 0.70) == 6 and oracle.mode_at(ev, md, 5.0) == 15
+
+
+def test_swing_spline_boundary_conditions(interface, oracle):
+    st = interface.problem.settings
+    nev, ev, md = S.trot_schedule(3.0)          # events 0, .35, .70, ...; RF/LH swing on [0, .35], LF/RH on [.35, .70]
+    eps = 1e-9
+    zp, zv = oracle.swing_reference(nev, ev, md, 0.0 + eps)
+    assert abs(zp[1]) < 1e-8 and abs(zv[1] - st.liftoff_velocity) < 1e-6 and zp[0] == 0 and zv[0] == 0     # lift-off of RF, LF in stance
+    zp, zv = oracle.swing_reference(nev, ev, md, 0.175)
+    assert abs(zp[1] - st.swing_height) < 1e-12 and abs(zv[1]) < 1e-12                                    # apex at mid swing
+    zp, zv = oracle.swing_reference(nev, ev, md, 0.35 - eps)
+    assert abs(zp[2]) < 1e-8 and abs(zv[2] - st.touchdown_velocity) < 1e-6                                # touch-down
+
+
+# ------------------------------------------------------------------------------------------------ QP
+def _kkt_residual(H, c, D, f, z, act_tol=1e-6):
+    """max violation of the KKT conditions; multipliers of the (near-)active rows by non-negative least squares."""
+    from scipy.optimize import nnls
+    r = D @ z - f
+    act = r > -act_tol * max(1.0, np.abs(f).max())
+    g = H @ z + c
+    stat = np.abs(g).max()
+    if act.any():
+        lam, _ = nnls(D[act].T, -g)
+        stat = np.abs(g + D[act].T @ lam).max()
+    return max(stat, max(r.max(), 0))
+
+
+def test_qp_solver_kkt_and_enumeration(oracle, rng):
+    for trial in range(5):
+        n, m = 6, 8
+        L = rng.normal(size=(n, n)); H = L @ L.T + 0.1 * np.eye(n)
+        c = rng.normal(size=n); D = rng.normal(size=(m, n)); f = rng.uniform(0.1, 1.0, m)
+        it, z, res = oracle.qp_solve(H, c, D, f)
+        assert it >= 0
+        scale = max(1, np.abs(c).max())
+        assert _kkt_residual(H, c, D, f, z) < 1e-6 * scale
+        # brute force over active sets
+        best, bestz = np.inf, None
+        for k in range(0, n + 1):
+            for act in itertools.combinations(range(m), k):
+                Da = D[list(act)]
+                K = np.block([[H, Da.T], [Da, np.zeros((k, k))]])
+                try:
+                    sol = np.linalg.solve(K, np.r_[-c, f[list(act)]])
+                except np.linalg.LinAlgError:
+                    continue
+                zz, lam = sol[:n], sol[n:]
+                if (D @ zz - f).max() < 1e-9 and (lam > -1e-9).all():
+                    val = 0.5 * zz @ H @ zz + c @ zz
+                    if val < best:
+                        best, bestz = val, zz
+        assert bestz is not None and np.allclose(z, bestz, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ HoQP
+def test_hoqp_hierarchy_properties(interface, oracle, rng):
+    x_nom, m = interface.initial_state, interface.robot_mass
+    u = np.zeros(30); u[[2, 11]] = m * 9.81 / 2; u[12:] = rng.uniform(-1, 1, 18) * 0.05
+    xd = x_nom + rng.uniform(-1, 1, 30) * 0.01
+    rbd = S.rbd_from_state(oracle, x_nom + rng.uniform(-1, 1, 30) * 0.005, rng.uniform(-1, 1, 24) * 0.02)
+    il = u.copy()
+    st, out, il2 = oracle.wbc_update(xd, u, rbd, 9, 0.002, 20.0, il)
+    assert st == 0 and np.array_equal(il2, u)
+    x, tau = out[:36], out[36:]
+    t0 = oracle.wbc_task(0, xd, u, rbd, 9, 0.002, 20.0, il)
+    assert t0["A"].shape == (18, 36) and t0["D"].shape == (36 + 10 + 6, 36)                 # trot: (88,104) QP of SURVEY.md 8a
+    assert np.abs(t0["A"] @ x - t0["b"]).max() < 1e-7                                    # highest priority equalities hold
+    assert (t0["D"] @ x - t0["f"]).max() < 1e-7                                          # and its inequalities (feasible case)
+    assert np.abs(x[24 + 3:24 + 9]).max() < 1e-7                                         # swing feet carry no force
+    assert (np.abs(tau) <= np.r_[np.tile([35.278, 35.278, 44.4], 4), [30, 60, 30, 30, 30, 30]] + 1e-6).all()
+    # level solutions: each lower level keeps the residual of the levels above
+    l0, l1, l2 = (oracle.wbc_level(k, xd, u, rbd, 9, 0.002, 20.0, il) for k in range(3))
+    assert (l0["H"].shape[0], l0["D"].shape[0]) == (88, 104) and (l1["H"].shape[0], l1["D"].shape[0]) == (18, 52) and (l2["H"].shape[0], l2["D"].shape[0]) == (2, 52)
+    t1 = oracle.wbc_task(1, xd, u, rbd, 9, 0.002, 20.0, il)
+    r1 = lambda xx: np.linalg.norm(t1["A"] @ xx - t1["b"])
+    assert abs(r1(l2["x"]) - r1(l1["x"])) < 1e-6 * max(1.0, r1(l1["x"]))
+    for lv in (l0, l1, l2):
+        assert _kkt_residual(lv["H"], lv["c"], lv["D"], lv["f"], lv["sol"]) < 1e-5 * max(1.0, np.abs(lv["c"]).max())
+
+
+def test_wbc_standing_is_physically_consistent(interface, oracle):
+    x = interface.initial_state
+    u = np.zeros(30); u[[2, 5, 8, 11]] = interface.robot_mass * 9.81 / 4
+    rbd = S.rbd_from_state(oracle, x)
+    st, out, _ = oracle.wbc_update(x, u, rbd, 15, 0.002, 20.0, u)
+    assert st == 0
+    F = out[24:36].reshape(4, 3)
+    mu = interface.problem.settings.wbc_friction_coefficient
+    assert (F[:, 2] > 0).all() and (np.abs(F[:, 0]) <= mu * F[:, 2] + 1e-9).all() and (np.abs(F[:, 1]) <= mu * F[:, 2] + 1e-9).all()
+    # Newton for the whole robot: sum F = m (a_com + g); a_com from the linear rows of the centroidal map (zero velocity: no bias)
+    A = oracle.centroidal_matrix(x[6:])
+    assert np.allclose(F.sum(0), A[:3] @ out[:24] + np.array([0, 0, interface.robot_mass * 9.81]), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ SQP
+def test_sqp_iterations_converge(interface, oracle):
+    x0 = S.perturbed_states(interface.initial_state, 1, seed=4)[0]
+    tgt = S.nominal_target(oracle, interface.initial_state)
+    tt, ts = np.zeros(1), tgt[None, :].copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.05)
+    r = oracle.mpc_solve(20, 0.0, x0, tt, ts, nev, ev, md)
+    v = [r["stats"][1], r["stats"][3]]
+    for _ in range(4):
+        r = oracle.mpc_solve(20, 0.0, x0, tt, ts, nev, ev, md, warm=(r["X"], r["U"]))
+        v.append(r["stats"][3])
+        assert r["stats"][4] > 0
+    assert v[-1] < 1e-3 * v[0]                          # constraint violation collapses
+    assert np.allclose(r["X"][0], x0)
+    assert list(r["mode"][:5]) == [15, 15, 15, 15, 9]   # nodes at t <= 0.05 are STANCE, then LF_RH
