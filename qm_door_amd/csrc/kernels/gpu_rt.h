@@ -6,6 +6,9 @@
 #include "simt_emu.h"
 #else
 #include <hip/hip_runtime.h>
+// Lanes of a wavefront execute in lockstep and LDS operations of one wavefront complete in issue order, so an intra-wave LDS
+// hand-off needs no hardware barrier -- only a compiler scheduling fence.
+#define QM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
 // dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)

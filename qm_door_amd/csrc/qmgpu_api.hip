@@ -117,7 +117,7 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     for (auto& set : ctx->ring) for (auto& e : set) HIP_CHECK(hipEventCreate(&e));
     ctx->ev = ctx->ring[0];
     HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(wbc_kernel, WBC_LDS_BYTES));
-    HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(riccati_kernel, RICCATI_LDS_BYTES));
+    HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(riccati_kernel<RICCATI_WAVES>, RICCATI_LDS_BYTES));
     QM_LAUNCH(input_weight_kernel, 1, 64, ctx->stream, ctx->dP, ctx->dZeros, ctx->dRw);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -191,7 +191,7 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
   RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
-  QM_LAUNCH_DYN(riccati_kernel, B, 64, RICCATI_LDS_BYTES, s, ra);
+  QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
   LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
             a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};

@@ -21,8 +21,10 @@ struct dim3 {
   dim3() = default;
   dim3(unsigned a, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
 };
+struct alignas(16) double2 { double x, y; };
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 inline std::barrier<>* g_emuBarrier = nullptr;
+inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one per 64-lane wavefront of the running workgroup
 
 #define __global__
 #define __device__
@@ -32,6 +34,8 @@ inline std::barrier<>* g_emuBarrier = nullptr;
 #define __launch_bounds__(...)
 #define __restrict__
 inline void __syncthreads() { g_emuBarrier->arrive_and_wait(); }
+// lanes of one wavefront run in lockstep on the GPU; the emulation needs a real rendezvous wherever a kernel relies on that
+#define QM_WAVE_SYNC() g_emuWaveBarriers[(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) / 64]->arrive_and_wait()
 inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
 using std::acos; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::sqrt; using std::sin; using std::cos;
 using std::max; using std::min;
@@ -40,6 +44,8 @@ template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
   const unsigned nt = block.x * block.y * block.z;
   std::barrier<> bar(nt);
   g_emuBarrier = &bar;
+  g_emuWaveBarriers.clear();
+  for (unsigned w = 0; w < (nt + 63) / 64; ++w) g_emuWaveBarriers.emplace_back(std::make_unique<std::barrier<>>(std::min(64u, nt - 64 * w)));
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; ++t)
     th.emplace_back([&, t]() {
