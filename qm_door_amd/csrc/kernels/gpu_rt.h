@@ -9,6 +9,8 @@
 // Lanes of a wavefront execute in lockstep and LDS operations of one wavefront complete in issue order, so an intra-wave LDS
 // hand-off needs no hardware barrier -- only a compiler scheduling fence.
 #define QM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// butterfly exchange inside one wavefront (DPP / ds_swizzle); `scratch` (64 doubles of LDS) is only used by the host emulation
+__device__ __forceinline__ double qmShflXor(double v, int mask, double* scratch) { (void)scratch; return __shfl_xor(v, mask, 64); }
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
 // dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)

@@ -54,7 +54,7 @@ struct DuIn {
   __device__ __forceinline__ Vec3<Du> force(int c) const { return Vec3<Du>(su(3 * c), su(3 * c + 1), su(3 * c + 2)); }
 };
 
-constexpr int PAW = 50;                      // row stride of [Px | Pe | Pu] in LDS (49 used)
+constexpr int PAW = 52;                      // row stride of [Px | Pe | Pu] in LDS (49 used, read in groups of four)
 constexpr int CDW = 62;                      // row stride of [C | D | e] (61 used), aliases the same region
 constexpr int L_B = 0;                       // B      [30][30]
 constexpr int L_R = L_B + 900;               // R      [30][30]   (dt-scaled)
@@ -66,6 +66,15 @@ constexpr int L_VEC = L_EEJ + 192;           // small vectors: b[30] r[30] e[16]
 constexpr int L_RED = L_VEC + 96;            // reduction scratch [64]
 constexpr int LQ_LDS_DOUBLES = L_RED + 64;   // 4420 doubles = 34.5 KiB
 static_assert(16 * CDW <= 30 * PAW, "CD must fit in the Pall region");
+
+// dot product of a broadcast LDS row with a register vector, three independent FMA chains (one wavefront per SIMD: the fp64 FMA
+// latency is hidden by instruction-level parallelism only)
+__device__ __forceinline__ double dot30(const double* row, const double (&z)[30]) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 30; i += 3) { s0 += row[i] * z[i]; s1 += row[i + 1] * z[i + 1]; s2 += row[i + 2] * z[i + 2]; }
+  return s0 + s1 + s2;
+}
 
 __device__ __forceinline__ double waveSum(double* red, int lane, double v) {
   red[lane] = v;
@@ -343,10 +352,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       }
       __syncthreads();
       if (lane > k && lane < nc) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 30; ++i) s += Vh[k * 32 + i] * dcol[i];
-        s *= Vh[k * 32 + 30];
+        double s = dot30(Vh + k * 32, dcol) * Vh[k * 32 + 30];
 #pragma unroll
         for (int i = 0; i < 30; ++i) dcol[i] -= s * Vh[k * 32 + i];
       }
@@ -377,10 +383,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const int nt = 30 - nc;  // projected input dimension m~
 #pragma unroll 1
   for (int k = nc - 1; k >= 0; --k) {
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 30; ++i) s += Vh[k * 32 + i] * z[i];
-    s *= Vh[k * 32 + 30];
+    const double s = dot30(Vh + k * 32, z) * Vh[k * 32 + 30];
 #pragma unroll
     for (int i = 0; i < 30; ++i) z[i] -= s * Vh[k * 32 + i];
   }
@@ -404,28 +407,44 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     for (int i = 0; i < 30; ++i) rec[OFF_PU + i * MT + (lane - 31)] = z[i];
   }
 #pragma unroll 1
-  for (int i = 0; i < 30; ++i) {
-    double sb = 0.0, sr = 0.0;
+  for (int i0 = 0; i0 < 30; i0 += 3) {  // three rows per trip: six independent FMA chains
+    double sb[3] = {0.0, 0.0, 0.0}, sr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < 30; ++k) { sb += Bm[i * 30 + k] * z[k]; sr += Rm[i * 30 + k] * z[k]; }
-    if (isX) rec[OFF_AT + i * 30 + lane] += sb;
-    else if (isE) rec[OFF_bt + i] = bv[i] + sb;
-    else if (isU) rec[OFF_BT + i * MT + (lane - 31)] = sb;
-    if (active) WL[i * PAW + lane] = sr;
+    for (int k = 0; k < 30; ++k) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { sb[r] += Bm[(i0 + r) * 30 + k] * z[k]; sr[r] += Rm[(i0 + r) * 30 + k] * z[k]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int i = i0 + r;
+      if (isX) rec[OFF_AT + i * 30 + lane] += sb[r];
+      else if (isE) rec[OFF_bt + i] = bv[i] + sb[r];
+      else if (isU) rec[OFF_BT + i * MT + (lane - 31)] = sb[r];
+      if (active) WL[i * PAW + lane] = sr[r];
+    }
   }
   __syncthreads();
   // G[a][lane] = sum_k W[k][a] z[k]   (= Pall_a^T R Pall_lane)
   double g30 = 0.0;
 #pragma unroll 1
-  for (int aa = 0; aa < 31 + nt; ++aa) {
-    double s = 0.0;
+  for (int a0 = 0; a0 < 31 + nt; a0 += 4) {  // four columns of W per trip: four independent FMA chains
+    double sg[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < 30; ++k) s += WL[k * PAW + aa] * z[k];
-    if (aa == 30) g30 = s;
-    if (isX) {
-      if (aa < 30) rec[OFF_QT + aa * 30 + lane] += s;
-      else if (aa > 30) rec[OFF_PT + (aa - 31) * 30 + lane] = s;
-    } else if (isU && aa > 30) rec[OFF_RT + (aa - 31) * MT + (lane - 31)] = s;
+    for (int k = 0; k < 30; ++k) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sg[r] += WL[k * PAW + a0 + r] * z[k];  // columns beyond 30 + nt are padding (PAW = 50 >= 49 + 3)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int aa = a0 + r;
+      if (aa >= 31 + nt) continue;
+      const double sv = sg[r];
+      if (aa == 30) g30 = sv;
+      if (isX) {
+        if (aa < 30) rec[OFF_QT + aa * 30 + lane] += sv;
+        else if (aa > 30) rec[OFF_PT + (aa - 31) * 30 + lane] = sv;
+      } else if (isU && aa > 30) rec[OFF_RT + (aa - 31) * MT + (lane - 31)] = sv;
+    }
   }
   if (isX) rec[OFF_qt + lane] = qc + tz + g30;
   else if (isU) rec[OFF_rt + (lane - 31)] = tz + g30;

@@ -535,10 +535,10 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
         for (int q = 0; q < ND; ++q) s += A[i * ND + q] * Z[q * LDZ + j];
         AZ[i * LDZ + j] = s;
       }
-    for (int e = lane; e < m0 * n; e += 64) {
-      const int i = e / n, j = e % n;
+    for (int e = lane; e < m0 * ND; e += 64) {  // columns >= n are zero padding: the register code below always spans 36 columns
+      const int i = e / ND, j = e % ND;
       double s = 0.0;
-      for (int q = 0; q < ND; ++q) s += D0[i * ND + q] * Z[q * LDZ + j];
+      if (j < n) for (int q = 0; q < ND; ++q) s += D0[i * ND + q] * Z[q * LDZ + j];
       DZ[i * LDZ + j] = s;
     }
     if (lane < r) {  // A x_prev - b (temporarily in tzv)
@@ -555,49 +555,64 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     }
     __syncthreads();
     // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e % n;
-      double s = (i == j) ? 1e-12 : 0.0;
-      for (int q = 0; q < r; ++q) s += AZp[q * LDZ + i] * AZp[q * LDZ + j];
+    for (int e = lane; e < ND * ND; e += 64) {
+      const int i = e / ND, j = e % ND;
+      double s = 0.0;
+      if (i < n && j < n) { s = (i == j) ? 1e-12 : 0.0; for (int q = 0; q < r; ++q) s += AZp[q * LDZ + i] * AZp[q * LDZ + j]; }
       G[i * LDK + j] = s;
     }
-    if (lane < n) { double s = 0.0; for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
+    if (lane < ND) { double s = 0.0; if (lane < n) for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
     // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
     __syncthreads();
 
-    // ---- interior point iterations
-    const double pivotFloor = 1e-13 * wbcMax(red, lane, lane < n ? G[lane * LDK + lane] : 0.0);
+    // ---- interior point iterations.  Per iteration: lane b builds row b of K = G + DZ^T diag(wt) DZ in registers, the Cholesky
+    //      runs on those register rows (pivot / column exchange through LDS, wavefront-synchronous), L^-1 is formed column per lane
+    //      and both Newton solves (predictor, corrector) are two small products with it.
+    double* Lm = K;            // L, row major [36][LDK]
+    double* Li = Zn;           // L^-1, row major [36][LDK]   (Znew is free until the null-space update)
+    double* LCp = Vh;          // pivots [36]                 (the Householder block is free as well)
+    double* LCc = Vh + 40;     // two column buffers [2][64]
+    double* invD = Vh + 40 + 128;  // 1 / L_jj [36]
+    auto allSum = [&](double v) { for (int m = 32; m >= 1; m >>= 1) v += qmShflXor(v, m, red); return v; };
+    auto allMax = [&](double v) { for (int m = 32; m >= 1; m >>= 1) v = fmax(v, qmShflXor(v, m, red)); return v; };
+    auto allMin = [&](double v) { for (int m = 32; m >= 1; m >>= 1) v = fmin(v, qmShflXor(v, m, red)); return v; };
+    const double pivotFloor = 1e-13 * allMax(lane < n ? G[lane * LDK + lane] : 0.0);
     const double fl = rowActive ? fhat[lane] : 0.0;
-    double scale = wbcMax(red, lane, fmax(rowActive ? fabs(fl) : 0.0, lane < n ? fabs(gs[lane]) : 0.0));
-    scale = fmax(1.0, scale);
-    const double nRowsTot = wbcSum(red, lane, rowActive ? (mOwn > 0 ? 2.0 : 1.0) : 0.0);
-    double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
+    const double scale = fmax(1.0, allMax(fmax(rowActive ? fabs(fl) : 0.0, lane < n ? fabs(gs[lane]) : 0.0)));
     const bool own = mOwn > 0;
+    const double nRowsTot = allSum(rowActive ? (own ? 2.0 : 1.0) : 0.0);
+    double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
     double s1p = s1, l1p = l1, s2p = s2, l2p = l2, vp = v, nrdPrev = 0.0, muPrev = 0.0;
+    const int rowL = lane < MAXM ? lane : 0;   // idle lanes alias row 0 (results unused)
+    const int colL = lane < ND ? lane : 0;
     int it = 0;
     if (nRowsTot > 0.0) {
 #pragma unroll 1
       for (; it < 60; ++it) {
-        // residuals
-        double Dz = 0.0;
-        if (rowActive) for (int j = 0; j < n; ++j) Dz += DZ[lane * LDZ + j] * zs[j];
+        // ---- residuals
+        double Dz0 = 0.0, Dz1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < ND; j += 2) { Dz0 += DZ[rowL * LDZ + j] * zs[j]; Dz1 += DZ[rowL * LDZ + j + 1] * zs[j + 1]; }
+        const double Dz = Dz0 + Dz1;
         const double rp1 = rowActive ? (Dz - (own ? v : 0.0) + s1 - fl) : 0.0;
         const double rp2 = (rowActive && own) ? (-v + s2) : 0.0;
         const double rdv = (rowActive && own) ? (v - l1 - l2) : 0.0;
-        if (lane < 56) lam[lane] = rowActive ? l1 : 0.0;
+        if (lane < MAXM) lam[lane] = rowActive ? l1 : 0.0;
         __syncthreads();
-        if (lane < n) {
-          double s = gs[lane];
-          for (int j = 0; j < n; ++j) s += G[lane * LDK + j] * zs[j];
-          for (int i = 0; i < m0; ++i) s += lam[i] * DZ[i * LDZ + lane];
-          rds[lane] = s;
+        double rdz;
+        {
+          double a0 = gs[colL], a1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < ND; j += 2) { a0 += G[colL * LDK + j] * zs[j]; a1 += G[colL * LDK + j + 1] * zs[j + 1]; }
+#pragma unroll 4
+          for (int i = 0; i < m0; ++i) a0 += lam[i] * DZ[i * LDZ + colL];
+          rdz = (lane < n) ? a0 + a1 : 0.0;
         }
-        __syncthreads();
-        const double mu = wbcSum(red, lane, rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
-        const double nrd = wbcMax(red, lane, fmax(lane < n ? fabs(rds[lane]) : 0.0, fabs(rdv)));
-        const double nrp = wbcMax(red, lane, fmax(fabs(rp1), fabs(rp2)));
-        const double nanProbe = wbcSum(red, lane, (lane < n ? rds[lane] : 0.0) + rdv + rp1 + rp2);  // NaN anywhere -> NaN here (fmax drops NaNs)
+        const double mu = allSum(rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
+        const double nrd = allMax(fmax(fabs(rdz), fabs(rdv)));
+        const double nrp = allMax(fmax(fabs(rp1), fabs(rp2)));
+        const double nanProbe = allSum(rdz + rdv + rp1 + rp2);  // NaN anywhere -> NaN here (fmax drops NaNs)
 #ifdef QMGPU_EMU_DEBUG
         if (lane == 0 && level >= 1 && inst == QMGPU_DEBUG_INST) printf("DBG inst %d level %d it %d mu %.3e nrd %.3e nrp %.3e scale %.3e floor %.3e\n", inst, level, it, mu, nrd, nrp, scale, pivotFloor);
 #endif
@@ -605,28 +620,66 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
         // solveQpIpm: a step that blows the dual residual up or yields NaN is rejected and the previous iterate returned --
         // as converged if its complementarity was already <= 1e-8 * scale, flagged in out_status otherwise.
         if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
-          if (lane < n) zs[lane] = rhs[lane];
+          if (lane < ND) zs[lane] = rhs[lane];
           s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
           if (!(muPrev <= 1e-8 * scale)) it = 60;
           __syncthreads();
           break;
         }
         if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;  // same tolerances as the oracle's solveQpIpm
-        if (lane < n) rhs[lane] = zs[lane];
+        if (lane < ND) rhs[lane] = zs[lane];
         s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
-        // weights and the reduced normal matrix K = G + DZ^T diag(wt) DZ
+        // ---- weights; row colL of K in registers
         const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
-        if (lane < 56) wt[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
+        if (lane < MAXM) wt[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
         __syncthreads();
-        for (int e = lane; e < n * n; e += 64) {
-          const int i = e / n, j = e % n;
-          if (j > i) continue;
-          double s = G[i * LDK + j];
-          for (int q = 0; q < m0; ++q) s += wt[q] * DZ[q * LDZ + i] * DZ[q * LDZ + j];
-          K[i * LDK + j] = s;
+        double krow[ND];
+#pragma unroll
+        for (int a2 = 0; a2 < ND; ++a2) krow[a2] = G[colL * LDK + a2];
+#pragma unroll 2
+        for (int q = 0; q < m0; ++q) {
+          const double coef = wt[q] * DZ[q * LDZ + colL];
+#pragma unroll
+          for (int a2 = 0; a2 < ND; ++a2) krow[a2] += coef * DZ[q * LDZ + a2];
+        }
+        // ---- Cholesky on the register rows (pivots floored at pivotFloor as in the oracle's choleskyFloored)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+          if (j < n) {
+            if (lane == j) LCp[j] = krow[j];
+            QM_WAVE_SYNC();
+            const double d = LCp[j];
+            const double dj = sqrt(d > pivotFloor ? d : pivotFloor), idj = 1.0 / dj;
+            if (lane == j) invD[j] = idj;
+            const double l = (lane == j) ? dj : krow[j] * idj;
+            krow[j] = l;
+            LCc[(j & 1) * 64 + lane] = l;
+            QM_WAVE_SYNC();
+#pragma unroll
+            for (int q = j + 1; q < ND; ++q) krow[q] -= l * LCc[(j & 1) * 64 + q];
+          }
+        }
+        if (lane < ND) {
+#pragma unroll
+          for (int q = 0; q < ND; ++q) Lm[lane * LDK + q] = krow[q];
         }
         __syncthreads();
-        ldsCholesky(K, n, lane, pivotFloor);
+        // ---- L^-1, column colL per lane (forward substitution on e_c), then published row major
+        {
+          double x[ND];
+#pragma unroll
+          for (int i = 0; i < ND; ++i) {
+            double sacc = (i == colL) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k2 = 0; k2 < ND; ++k2) if (k2 < i) sacc -= Lm[i * LDK + k2] * x[k2];
+            x[i] = (i < n) ? sacc * invD[i < n ? i : 0] : 0.0;
+          }
+          if (lane < ND) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) Li[i * LDK + lane] = x[i];
+          }
+        }
+        __syncthreads();
         double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0;
         double alphaAff = 1.0, sigma = 0.0;
 #pragma unroll 1
@@ -636,17 +689,35 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
           const double t1 = rowActive ? (l1 * rp1 - rc1) / s1 : 0.0;
           const double t2 = (rowActive && own) ? (l2 * rp2 - rc2) / s2 : 0.0;
           const double rhsv = -rdv + t1 + t2;
-          if (lane < 56) tzv[lane] = rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0;
+          if (lane < MAXM) tzv[lane] = rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0;
           __syncthreads();
-          if (lane < n) {
-            double s = -rds[lane];
-            for (int i = 0; i < m0; ++i) s -= DZ[i * LDZ + lane] * tzv[i];
-            dzs[lane] = s;
+          {  // right-hand side of the reduced system, then t = L^-1 rhs (row colL of L^-1 from LDS)
+            double a0 = -rdz;
+#pragma unroll 4
+            for (int i = 0; i < m0; ++i) a0 -= DZ[i * LDZ + colL] * tzv[i];
+            if (lane < ND) dzs[lane] = (lane < n) ? a0 : 0.0;
           }
           __syncthreads();
-          ldsCholSolve(K, n, dzs, lane);
-          double Ddz = 0.0;
-          if (rowActive) for (int j = 0; j < n; ++j) Ddz += DZ[lane * LDZ + j] * dzs[j];
+          {
+            double t0 = 0.0, t1b = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < ND; c2 += 2) { t0 += Li[colL * LDK + c2] * dzs[c2]; t1b += Li[colL * LDK + c2 + 1] * dzs[c2 + 1]; }
+            __syncthreads();
+            if (lane < ND) dzs[lane] = t0 + t1b;
+          }
+          __syncthreads();
+          {  // dz = L^-T t : column colL of L^-1 dotted with t
+            double t0 = 0.0, t1b = 0.0;
+#pragma unroll
+            for (int i = 0; i < ND; i += 2) { t0 += Li[i * LDK + colL] * dzs[i]; t1b += Li[(i + 1) * LDK + colL] * dzs[i + 1]; }
+            __syncthreads();
+            if (lane < ND) dzs[lane] = t0 + t1b;
+          }
+          __syncthreads();
+          double Dd0 = 0.0, Dd1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < ND; j += 2) { Dd0 += DZ[rowL * LDZ + j] * dzs[j]; Dd1 += DZ[rowL * LDZ + j + 1] * dzs[j + 1]; }
+          const double Ddz = Dd0 + Dd1;
           if (rowActive) {
             if (own) {
               dv = (rhsv + w1 * Ddz) / kvv;
@@ -660,23 +731,23 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
             if (dl1 < 0) amax = fmin(amax, -l1 / dl1);
             if (own) { if (ds2 < 0) amax = fmin(amax, -s2 / ds2); if (dl2 < 0) amax = fmin(amax, -l2 / dl2); }
           }
-          amax = wbcMin(red, lane, amax);
+          amax = allMin(amax);
           if (pass == 0) {
             alphaAff = amax;
-            const double muAff = wbcSum(red, lane, rowActive ? ((s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) + (own ? (s2 + alphaAff * ds2) * (l2 + alphaAff * dl2) : 0.0)) : 0.0) / nRowsTot;
+            const double muAff = allSum(rowActive ? ((s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) + (own ? (s2 + alphaAff * ds2) * (l2 + alphaAff * dl2) : 0.0)) : 0.0) / nRowsTot;
             const double ratio = muAff / mu;
             sigma = ratio * ratio * ratio;
           } else {
             const double tau = fmax(0.995, 1.0 - mu);
             const double al = fmin(1.0, tau * amax);
-            if (lane < n) zs[lane] += al * dzs[lane];
+            if (lane < ND) zs[lane] += al * dzs[lane];
             if (rowActive) { s1 += al * ds1; l1 += al * dl1; if (own) { v += al * dv; s2 += al * ds2; l2 += al * dl2; } }
           }
           __syncthreads();
         }
       }
     } else {
-      // no inequality rows at all: z = -G^-1 g
+      // no inequality rows at all: z = -G^-1 g  (LDS Cholesky; never on the hot path of the reference's task sets)
       for (int e = lane; e < n * n; e += 64) K[(e / n) * LDK + (e % n)] = G[(e / n) * LDK + (e % n)];
       if (lane < n) dzs[lane] = -gs[lane];
       __syncthreads();

@@ -40,6 +40,15 @@ inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std:
 using std::acos; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::sqrt; using std::sin; using std::cos;
 using std::max; using std::min;
 
+inline double qmShflXor(double v, int mask, double* scratch) {
+  const unsigned lane = threadIdx.x & 63u;
+  scratch[lane] = v;
+  QM_WAVE_SYNC();
+  const double o = scratch[lane ^ unsigned(mask)];
+  QM_WAVE_SYNC();
+  return o;
+}
+
 template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
   const unsigned nt = block.x * block.y * block.z;
   std::barrier<> bar(nt);
