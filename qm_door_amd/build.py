@@ -44,8 +44,11 @@ def build_library(force=False, verbose=False, extra_flags=()):
         [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *extra_flags, "-c", os.path.join(CSRC, "qmgpu_api.hip"), "-o", api_o],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, "host", "host_config.cpp"), "-o", host_o],
     ]
-    tl = _torch_lib_dir()
-    libdirs = ([tl] if tl else []) + ["/opt/rocm/lib"]
+    # Inside this repository the process already holds PyTorch's bundled HIP runtime, so link against that one first; a catkin
+    # workspace without PyTorch sets QMGPU_HIP_LIBDIR=/opt/rocm/lib.
+    override = os.environ.get("QMGPU_HIP_LIBDIR")
+    tl = None if override else _torch_lib_dir()
+    libdirs = [override] if override else (([tl] if tl else []) + ["/opt/rocm/lib"])
     link = ["g++", "-shared", "-o", OUT, api_o, host_o]
     for d in libdirs:
         link += [f"-L{d}", f"-Wl,-rpath,{d}"]

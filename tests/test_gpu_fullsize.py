@@ -1,0 +1,83 @@
+"""-m gpu: BASELINE.json configs[1] at full size (256 instances, N = 100) through the C ABI -- size-independent properties.
+
+The oracle needs ~0.3 s per cycle, so only a sample is compared value by value; the whole batch is covered by properties that
+need no second implementation: batch independence and permutation equivariance (bit-exact), mode tables (bit-exact), the
+Newton-step identity of the linearised dynamics, filter acceptance, and every WBC output against the (cheap) oracle WBC.
+"""
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+B, N = 256, 100
+
+
+@pytest.fixture(scope="module")
+def solved(interface, oracle):
+    import gpu_harness as G
+    import torch
+    x_nom = interface.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=0)
+    tgt = S.nominal_target(oracle, x_nom)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(N * interface.problem.settings.dt + 1.0, phase0=0.0)
+    rbd = np.array([S.rbd_from_state(oracle, x0[i]) for i in range(B)])
+
+    def run(idx):
+        n = len(idx)
+        sol = G.make_solver(interface, n, N)
+        mb = G.MpcBatch(x0[idx], tt[idx], ts[idx], np.full(n, nev, dtype=np.int32), np.tile(ev, (n, 1)), np.tile(md, (n, 1)), N)
+        wb = G.WbcBatch(rbd[idx], np.full(n, 0.002), np.full(n, 20.0), np.zeros((n, 30)))
+        sol.cycle(mb.args, G.dev(np.zeros(n), torch.float64), wb.args)
+        r = mb.results(); r.update(wb.results())
+        return r
+
+    return dict(run=run, full=run(np.arange(B)), x0=x0, tt=tt, ts=ts, sched=(nev, ev, md), rbd=rbd)
+
+
+def test_finite_converged_and_modes_bit_exact(solved, interface, oracle):
+    r = solved["full"]; nev, ev, md = solved["sched"]
+    assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(r["out"]).all()
+    assert (r["stats"][:, 7] == 0).all() and (r["status"] == 0).all()
+    dt = interface.problem.settings.dt
+    assert np.array_equal(r["T"], np.tile(np.arange(N + 1) * dt, (B, 1)))
+    modes = np.array([oracle.mode_at(ev[:nev], md[:nev + 1], k * dt) for k in range(N + 1)], dtype=np.int32)
+    assert np.array_equal(r["mode"], np.tile(modes, (B, 1)))
+    assert np.array_equal(r["X"][:, 0], solved["x0"])      # the initial state is never moved
+
+
+def test_filter_line_search_acceptance(solved):
+    st = solved["full"]["stats"]
+    alpha = st[:, 4]
+    assert ((alpha > 0) & (alpha <= 1)).all() and np.array_equal(np.log2(alpha), np.round(np.log2(alpha)))
+    # an accepted step never leaves the filter's outer box (g_max = 1e-2) unless it reduced the violation it started from
+    assert ((st[:, 3] <= 1e-2) | (st[:, 3] < st[:, 1])).all()
+
+
+def test_batch_independence_and_permutation(solved):
+    full = solved["full"]
+    idx = np.array([255, 17, 0, 128])
+    sub = solved["run"](idx)
+    for key in ("X", "U", "mode", "stats", "out"):
+        assert np.array_equal(sub[key], full[key][idx]), key
+
+
+def test_sample_against_oracle(solved, oracle):
+    full = solved["full"]; nev, ev, md = solved["sched"]
+    for i in (0, 101, 255):
+        ref = oracle.mpc_solve(N, 0.0, solved["x0"][i], solved["tt"][i], solved["ts"][i], nev, ev, md)
+        assert np.abs(full["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(full["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+
+
+def test_every_wbc_output_against_oracle(solved, oracle):
+    """The WBC consumes the GPU's own MPC policy at t = 0 (X[0], U[0]); the oracle WBC is cheap enough for all 256."""
+    full = solved["full"]
+    worst = 0.0
+    for i in range(B):
+        st, out, _ = oracle.wbc_update(full["X"][i, 0], full["U"][i, 0], solved["rbd"][i], int(full["mode"][i, 0]), 0.002, 20.0, np.zeros(30))
+        assert st == 0
+        worst = max(worst, np.abs(full["out"][i][36:] - out[36:]).max() / max(1.0, np.abs(out[36:]).max()))
+    assert worst <= 1e-6

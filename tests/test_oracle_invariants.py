@@ -245,3 +245,43 @@ def test_sqp_iterations_converge(interface, oracle):
     assert v[-1] < 1e-3 * v[0]                          # constraint violation collapses
     assert np.allclose(r["X"][0], x0)
     assert list(r["mode"][:5]) == [15, 15, 15, 15, 9]   # nodes at t <= 0.05 are STANCE, then LF_RH
+
+
+def test_riccati_step_equals_dense_kkt_solve(interface, oracle):
+    """Projection + Riccati recursion == one dense KKT solve of the same equality-constrained QP."""
+    N, dt, m = 5, interface.problem.settings.dt, interface.robot_mass
+    x0 = S.perturbed_states(interface.initial_state, 1, seed=11)[0]
+    tgt = S.nominal_target(oracle, interface.initial_state)
+    tt, ts = np.zeros(1), tgt[None, :].copy()
+    nev, ev, md = S.trot_schedule(1.0, phase0=2.5 * dt)          # nodes 0..2 STANCE, 3.. LF_RH
+    r = oracle.mpc_solve(N, 0.0, x0, tt, ts, nev, ev, md, line_search=False)
+    # cold start (QMInitializer): x_k = x0, u_k = weight compensation of the node's mode
+    lq = []
+    for k in range(N + 1):
+        mode = oracle.mode_at(ev[:nev], md[:nev + 1], k * dt)
+        flags = [(mode >> (3 - c)) & 1 for c in range(4)]
+        u = np.zeros(30)
+        for c in range(4):
+            if flags[c]:
+                u[3 * c + 2] = m * 9.81 / sum(flags)
+        lq.append((oracle.lq_node(k * dt, dt if k < N else 0.0, x0, u if k < N else None, x0, k == N, nev, ev, md, tt, ts), u))
+    nz = 30 * (N + 1) + 30 * N
+    ix = lambda k: slice(30 * k, 30 * k + 30)
+    iu = lambda k: slice(30 * (N + 1) + 30 * k, 30 * (N + 1) + 30 * k + 30)
+    H, g, rows, rhs = np.zeros((nz, nz)), np.zeros(nz), [], []
+    E = np.zeros((30, nz)); E[:, ix(0)] = np.eye(30); rows.append(E); rhs.append(np.zeros(30))
+    for k, (o, _) in enumerate(lq):
+        H[ix(k), ix(k)] += o["Q"]; g[ix(k)] += o["q"]
+        if k == N:
+            break
+        H[iu(k), iu(k)] += o["R"]; g[iu(k)] += o["r"]
+        E = np.zeros((30, nz)); E[:, ix(k)] = o["A"]; E[:, iu(k)] = o["B"]; E[:, ix(k + 1)] = -np.eye(30); rows.append(E); rhs.append(-o["b"])
+        E = np.zeros((o["nc"], nz)); E[:, ix(k)] = o["C"]; E[:, iu(k)] = o["D"]; rows.append(E); rhs.append(-o["e"])
+    Aeq, beq = np.vstack(rows), np.concatenate(rhs)
+    KKT = np.block([[H, Aeq.T], [Aeq, np.zeros((Aeq.shape[0],) * 2)]])
+    sol = np.linalg.lstsq(KKT, np.r_[-g, beq], rcond=None)[0][:nz]
+    assert np.abs(KKT[:nz] @ np.linalg.lstsq(KKT, np.r_[-g, beq], rcond=None)[0] + g).max() < 1e-7
+    dX = np.array([sol[ix(k)] for k in range(N + 1)]); dU = np.array([sol[iu(k)] for k in range(N)])
+    U0 = np.array([u for _, u in lq[:N]])
+    assert np.abs(r["X"] - (x0[None, :] + dX)).max() <= 1e-9 * max(1.0, np.abs(dX).max())
+    assert np.abs(r["U"] - (U0 + dU)).max() <= 1e-8 * max(1.0, np.abs(dU).max())
