@@ -11,6 +11,17 @@
 #define QM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // butterfly exchange inside one wavefront (DPP / ds_swizzle); `scratch` (64 doubles of LDS) is only used by the host emulation
 __device__ __forceinline__ double qmShflXor(double v, int mask, double* scratch) { (void)scratch; return __shfl_xor(v, mask, 64); }
+// value of lane `src` (wave-uniform, compile-time constant after unrolling) broadcast through an SGPR pair: v_readlane_b32 x 2
+__device__ __forceinline__ double qmReadLane(double v, int src, double* scratch) {
+  (void)scratch;
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// One v_mfma_f64_16x16x4_f64: C[16x16] += A[16x4] B[4x16].  Operand / result layout measured on gfx950 (tools/probe_mfma.hip):
+//   lane l supplies a = A[l % 16][l / 16] and b = B[l / 16][l % 16]; accumulator register r of lane l is C[l / 16 + 4 r][l % 16].
+typedef double QmAcc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void qmMfma(QmAcc& c, double a, double b, double* scratch) { (void)scratch; c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ double qmRsqrt(double x) { return rsqrt(x); }
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
 // dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)

@@ -1,18 +1,24 @@
 // riccati_kernel -- backward Riccati factorisation + forward substitution of the projected, equality-free OCP-QP.
-// One WORKGROUP of NW wavefronts per MPC instance (one wavefront per SIMD of the CU that owns the instance), sequential over
-// the horizon, stage blocks streamed HBM -> registers -> LDS one stage ahead of their use.
+// One WORKGROUP of 4 wavefronts per MPC instance (one wavefront per SIMD of the CU that owns the instance), sequential over the
+// horizon, stage blocks streamed HBM -> registers -> LDS one stage ahead of their use.
 //
 // Replaces upstream HPIPM's OCP-QP solve as called by ocs2_sqp::SqpSolver (the object built at
 // qm_controllers/src/QMController.cpp:288-289, settings task.info:76-93): with the state-input equalities projected out
 // (projectStateInputEqualityConstraints true) and all inequalities handled as soft costs the QP has no inequality rows, so
 // HPIPM's interior point reduces to one Riccati factorisation and solve.
 //
-// Work split per stage (n = 30 states, m~ = 30 - nc <= 18 projected inputs):
-//   lane c (same in every wavefront):  c < 30 column c of A~ | c == 30 the vector b~ | c = 31 + j column j of B~
-//   wavefront w:                       the output ROWS [w*RPW, (w+1)*RPW) of every "matrix in LDS x my column in registers" product
-// so a product costs each wavefront 1/NW of the FMAs and of the (broadcast) LDS reads.  The m~ x m~ Cholesky runs in wavefront 0
-// with one row per lane in registers; the column solves are repeated by every wavefront (cheaper than exchanging K).
-// Idle lanes alias lane 0's data through per-lane (offset, stride) pairs -- no exec-mask branching in the hot loops.
+// Backward stage (n = 30 states, m~ = 30 - nc <= 18 projected inputs), every product on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64, 16x16 output tiles, operands read from LDS in the lane layout of gpu_rt.h: qmMfma):
+//   M  = [A~ | b~ | 0 | B~ | 0]           30 x 64 view of the staged record (columns 0..29, 30, 32..32+m~-1)
+//   P1 Y  = S M  (+ s in column 30)        so Y = [S A~ | S b~ + s | . | S B~]
+//   P2 T  = B~^T Y + [P~ | r~ | . | R~]    so T = [G | g | . | H]
+//   P3 H  = L L^T and L^-1                 wavefront 0, one column of [H | I] per lane in registers, row operations with the
+//                                          multipliers broadcast by v_readlane (no LDS round trip on the dependent chain)
+//   P4 W  = L^-1 [G | g]
+//   P5 [K | k] = -L^-T W                   -> gains (HBM)
+//   P6 [S' | s'] = [Q~ | q~] + A~^T [S A~ | y] - W^T W
+// Column 30 carries the affine terms (b~, y, g, k, s') through the same tiles as the matrices.  Zero padding: rows/columns
+// 30,31 of S, rows >= m~ of T / W / L^-1 are kept at exactly zero so that partial tiles need no predication on the k loops.
 #pragma once
 #include "layout.h"
 #include "gpu_rt.h"
@@ -32,19 +38,22 @@ struct RiccatiArgs {
 };
 
 constexpr int RICCATI_WAVES = 4;
-constexpr int R_STG = 0;                         // staged record (first OFF_PX doubles used backward, all of it forward)
-constexpr int R_GAIN = R_STG + STAGE_DOUBLES;    // staged gains (forward)
-constexpr int R_S = R_GAIN + GAIN_DOUBLES;       // S [30][30]
-constexpr int R_SV = R_S + 900;                  // s [30] (+2 pad)
-constexpr int R_Y = R_SV + 32;                   // y columns, lane private [30][64]
-constexpr int R_GH = R_Y + 30 * 64;              // [G | g | H] columns, lane private [MT][64]; G[j][i] = GH[j*64 + i]
-constexpr int R_H = R_GH + MT * 64;              // H / L [MT][MT+1]
-constexpr int R_T = R_H + MT * (MT + 1);         // new value function [30][32]
-constexpr int R_LC = R_T + 960;                  // Cholesky exchange: pivots [MT] (+2) + two column buffers [2][64]
-constexpr int R_VEC = R_LC + MT + 2 + 128 + MT + 2; // dx[32] dut[32]   (R_LC also holds the reciprocal diagonal of L)
-constexpr int R_ZERO = R_VEC + 64;               // 32 zeros
-constexpr int RICCATI_LDS_DOUBLES = R_ZERO + 32;
-constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~88 KiB (dynamic LDS)
+// LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
+constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48;
+constexpr int R_STG = 0;                          // staged record: OFF_PX doubles backward; the whole record forward (over Y)
+constexpr int R_Y = R_STG + OFF_PX + 4;           // Y [32][LDS_Y]
+constexpr int R_T = R_Y + 32 * LDS_Y;             // T [32][LDS_Y]
+constexpr int R_GAIN = R_STG + STAGE_DOUBLES;     // staged gains (forward only; aliases Y / T)
+constexpr int R_S = R_T + 32 * LDS_Y;             // S [32][LDS_S]
+constexpr int R_SV = R_S + 32 * LDS_S;            // s [32]
+constexpr int R_W = R_SV + 32;                    // W [20][LDS_W]
+constexpr int R_LI = R_W + 20 * LDS_W;            // L^-1 row major [20][LDS_W]
+constexpr int R_LIT = R_LI + 20 * LDS_W;          // L^-T row major [20][LDS_W]
+constexpr int R_VEC = R_LIT + 20 * LDS_W;         // dx[32] dut[32]
+constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][128]; armijo reduction
+constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 128;
+constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~105 KiB (dynamic LDS)
+static_assert(R_GAIN + GAIN_DOUBLES <= R_S, "forward-sweep staging must not reach the live value function");
 
 // Register-staged HBM -> LDS copy for a whole workgroup: issue() puts PF 16-byte loads per thread in flight, commit() drains
 // them into LDS.  Between the two the workgroup computes on the *current* stage, so the memory latency of the next stage is
@@ -66,30 +75,31 @@ template <int PF, int NTHR> struct StagePrefetch {
 };
 
 template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(RiccatiArgs a) {
+  static_assert(NW == 4, "tile ownership below is written for four wavefronts");
   QM_DYNAMIC_LDS(lds);
   constexpr int NTHR = NW * 64;
-  constexpr int RPW = (30 + NW - 1) / NW;   // output rows per wavefront
-  constexpr int JPW = (MT + NW - 1) / NW;   // projected-input rows per wavefront
   constexpr int PFB = (OFF_PX / 2 + NTHR - 1) / NTHR;
   constexpr int PFR = (STAGE_DOUBLES / 2 + NTHR - 1) / NTHR;
   constexpr int PFG = (GAIN_DOUBLES / 2 + NTHR - 1) / NTHR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, h = lane >> 4;   // MFMA operand coordinates of this lane
   const int inst = blockIdx.x;
   const int N = a.N;
-  double* stg = lds + R_STG; double* gn = lds + R_GAIN; double* S = lds + R_S; double* sv = lds + R_SV; double* YL = lds + R_Y; double* GH = lds + R_GH;
-  double* HL = lds + R_H; double* Tm = lds + R_T; double* LCp = lds + R_LC; double* LCc = LCp + MT + 2; double* dxv = lds + R_VEC; double* dut = dxv + 32; const double* invD = LCp + MT + 2 + 128;
-  double* zero32 = lds + R_ZERO;
+  double* stg = lds + R_STG; double* gn = lds + R_GAIN; double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
+  double* W = lds + R_W; double* LI = lds + R_LI; double* LIT = lds + R_LIT; double* dxv = lds + R_VEC; double* dut = dxv + 32;
+  double* scr = lds + R_SCR + wave * 128; double* red = lds + R_SCR;
   const double* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const double* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
   const int* ncI = a.stageNc + size_t(inst) * (N + 1);
   int status = 0;
-  if (tid < 32) zero32[tid] = 0.0;
 
-  // ---- terminal value function S_N = Q_N, s_N = q_N, and the first stage to process
+  // ---- terminal value function S_N = Q_N, s_N = q_N (zero padded), and the first stage to process
   {
     const double* rec = stagesI + size_t(N) * STAGE_DOUBLES;
-    for (int e = tid; e < 900; e += NTHR) S[e] = rec[OFF_QT + e];
-    if (tid < 30) sv[tid] = rec[OFF_qt + tid];
+    for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0; }
+    if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0;
+    for (int e = tid; e < 3 * 20 * LDS_W; e += NTHR) W[e] = 0.0;        // W, L^-1, L^-T (contiguous)
+    for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
     pf.commit(stg, OFF_PX, tid);
@@ -99,151 +109,154 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
     const int nt = 30 - ncI[k];
+    const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
+    const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
+    const int kSteps = (nt + 3) >> 2;        // k steps of 4 over the m~ dimension
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid);  // next stage's blocks, in flight during this stage
-    const bool isA = lane < 30, isb = lane == 30, isB = lane > 30 && lane < 31 + nt;
-    const int colOff = isA ? OFF_AT + lane : (isb ? OFF_bt : (isB ? OFF_BT + (lane - 31) : OFF_AT));
-    const int colStr = isA ? 30 : (isb ? 1 : (isB ? MT : 30));
-    const int ghOff = isA ? OFF_PT + lane : (isb ? OFF_rt : (isB ? OFF_RT + (lane - 31) : OFF_PT));
-    const int ghStr = isA ? 30 : (isb ? 1 : (isB ? MT : 30));
-    const double* accInit = isb ? sv : zero32;  // s enters only the b~ lane's product
-    // ---- y = S col (+ s): my column of [A~ | b~ | B~] in registers, this wavefront's RPW output rows as independent FMA chains
-    {
-      double col[30];
+    // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T
+    const int jc = wave * 16 + l16;          // my column of M / Y / T
+    const bool jA = jc < 30, jb = jc == 30, jB = jc >= 32 && jc < 32 + nt;
+    if (wave < nTiles) {
+      const int mOff = jA ? OFF_AT + jc : (jb ? OFF_bt : (jB ? OFF_BT + (jc - 32) : 0));
+      const int mStr = jA ? 30 : (jb ? 1 : (jB ? MT : 0));
+      const bool mValid = jA || jb || jB;
+      QmAcc c0, c1;
 #pragma unroll
-      for (int i = 0; i < 30; ++i) col[i] = stg[colOff + i * colStr];
-#pragma unroll 1
-      for (int rr = 0; rr < RPW; rr += 4) {  // four independent FMA chains per trip
-        const int i0 = wave * RPW + rr;
-        int row[4];
+      for (int r = 0; r < 4; ++r) { c0[r] = jb ? sv[h + 4 * r] : 0.0; c1[r] = jb ? sv[16 + h + 4 * r] : 0.0; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) row[r] = (i0 + r < 30 && rr + r < RPW) ? i0 + r : 29;
-        double acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = accInit[row[r]];
-#pragma unroll
-        for (int q = 0; q < 30; ++q) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] += S[row[r] * 30 + q] * col[q];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (i0 + r < 30 && rr + r < RPW) YL[(i0 + r) * 64 + lane] = acc[r];
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of S^T are zero: the clamped b operand is multiplied by 0
+        const double a0 = S[kk * LDS_S + l16], a1 = S[kk * LDS_S + 16 + l16];  // S is symmetric: S[i][k] read as S[k][i]
+        const double bv = mValid ? stg[mOff + kc * mStr] : 0.0;
+        qmMfma(c0, a0, bv, scr);
+        qmMfma(c1, a1, bv, scr);
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
     __syncthreads();
-    // ---- gh = B~^T y + [P~ | r~ | R~] column; this wavefront's JPW rows (rows >= m~ are padding: computed, never used)
-    {
-      double y[30];
+    if (wave < nTiles) {
+      QmAcc c0, c1;
 #pragma unroll
-      for (int i = 0; i < 30; ++i) y[i] = YL[i * 64 + lane];
-      const int j0 = wave * JPW;
-      double acc[JPW];
+      for (int r = 0; r < 4; ++r) {
+        const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
+        const int i0c = i0 < MT ? i0 : 0, i1c = i1 < MT ? i1 : 0;
+        const double v0 = jA ? stg[OFF_PT + i0c * 30 + jc] : (jb ? stg[OFF_rt + i0c] : (jB ? stg[OFF_RT + i0c * MT + (jc - 32)] : 0.0));
+        const double v1 = jA ? stg[OFF_PT + i1c * 30 + jc] : (jb ? stg[OFF_rt + i1c] : (jB ? stg[OFF_RT + i1c * MT + (jc - 32)] : 0.0));
+        c0[r] = i0 < nt ? v0 : 0.0;
+        c1[r] = i1 < nt ? v1 : 0.0;
+      }
+      const bool a0ok = l16 < nt, a1ok = 16 + l16 < nt;
+      const int a1c = 16 + l16 < MT ? 16 + l16 : 0;
 #pragma unroll
-      for (int r = 0; r < JPW; ++r) acc[r] = stg[ghOff + (j0 + r < MT ? j0 + r : MT - 1) * ghStr];
-#pragma unroll
-      for (int i = 0; i < 30; ++i) {
-#pragma unroll
-        for (int r = 0; r < JPW; ++r) acc[r] += stg[OFF_BT + i * MT + (j0 + r < MT ? j0 + r : MT - 1)] * y[i];
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of Y are zero
+        const double bv = Y[kk * LDS_Y + jc];
+        const double a0 = a0ok ? stg[OFF_BT + kc * MT + l16] : 0.0;   // B~^T[i][k] = B~[k][i]
+        qmMfma(c0, a0, bv, scr);
+        if (mtTiles == 2) { const double a1 = a1ok ? stg[OFF_BT + kc * MT + a1c] : 0.0; qmMfma(c1, a1, bv, scr); }
       }
 #pragma unroll
-      for (int r = 0; r < JPW; ++r) {
-        const int j = j0 + r;
-        if (j < MT) { GH[j * 64 + lane] = acc[r]; if (isB) HL[j * (MT + 1) + (lane - 31)] = acc[r]; }
-      }
+      for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r]; if (mtTiles == 2) T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
     __syncthreads();
-    // ---- Cholesky H = L L^T: wavefront 0, lane r holds row r in registers; pivots and columns pass through LDS
+    // ---- P3: H = L L^T and L^-1 by row operations on [H | I]; lane c < 32 holds column c of H, lane 32 + c column c of I
     if (wave == 0) {
-      double hrow[MT];
+      const bool isH = lane < 32;
+      const int c = isH ? lane : lane - 32;
+      double col[MT];
 #pragma unroll
-      for (int q = 0; q < MT; ++q) hrow[q] = HL[(lane < MT ? lane : 0) * (MT + 1) + q];
+      for (int r = 0; r < MT; ++r) {
+        const double e = (r == c) ? 1.0 : 0.0;
+        col[r] = (isH && lane < nt && r < nt) ? T[r * LDS_Y + 32 + (lane < nt ? lane : 0)] : e;
+      }
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         if (j < nt) {
-          if (lane == j) LCp[j] = hrow[j];
-          QM_WAVE_SYNC();
-          const double d = LCp[j];
-          if (!(d > 0.0)) status = 1;
-          const double dj = sqrt(d > 0.0 ? d : 1.0), idj = 1.0 / dj;
-          if (lane == j) LCp[MT + 2 + 128 + j] = idj;  // reciprocal diagonal, read by the column solves
-          const double l = (lane == j) ? dj : hrow[j] * idj;
-          hrow[j] = l;
-          LCc[(j & 1) * 64 + lane] = l;
-          QM_WAVE_SYNC();
+          const double piv = qmReadLane(col[j], j, scr);
+          if (!(piv > 0.0)) status = 1;
+          const double inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+          col[j] *= inv;                                     // row j of [L^T | .] / sqrt(pivot)
 #pragma unroll
-          for (int q = j + 1; q < MT; ++q) hrow[q] -= l * LCc[(j & 1) * 64 + q];
-        }
-      }
-      if (lane < MT) {
-#pragma unroll
-        for (int q = 0; q < MT; ++q) HL[lane * (MT + 1) + q] = hrow[q];
-      }
-    }
-    __syncthreads();
-    // ---- solve L L^T x = gh for the G columns and g (every wavefront, for all of its lanes): K = -x
-    double kx[MT];
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      double s = (j < nt) ? GH[j * 64 + lane] : 0.0;
-#pragma unroll
-      for (int q = 0; q < MT; ++q) if (q < j) s -= HL[j * (MT + 1) + q] * kx[q];
-      kx[j] = (j < nt) ? s * invD[j] : 0.0;
-    }
-#pragma unroll
-    for (int j = MT - 1; j >= 0; --j) {
-      double s = kx[j];
-#pragma unroll
-      for (int q = 0; q < MT; ++q) if (q > j && q < nt) s -= HL[q * (MT + 1) + j] * kx[q];
-      kx[j] = (j < nt) ? s * invD[j] : 0.0;
-    }
-    double* gain = a.gains + (size_t(inst) * N + k) * GAIN_DOUBLES;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      kx[j] = -kx[j];
-      if ((j % NW) == wave) {  // the K rows are written once, spread over the wavefronts
-        if (isA) gain[OFF_KFB + j * 30 + lane] = kx[j];
-        else if (isb) gain[OFF_kff + j] = kx[j];
-      }
-    }
-    // ---- new value function column: base + A~^T y + G^T kx   (lanes <= 30 matter; this wavefront's RPW rows)
-    {
-      const int qOff = isA ? OFF_QT + lane : (isb ? OFF_qt : OFF_QT), qStr = isb ? 1 : 30;
-      const int tLane = lane <= 30 ? lane : 31;  // idle lanes dump into the spare column 31 of Tm
-      double y[30];
-#pragma unroll
-      for (int i = 0; i < 30; ++i) y[i] = YL[i * 64 + lane];
-#pragma unroll 1
-      for (int rr = 0; rr < RPW; rr += 4) {
-        const int i0 = wave * RPW + rr;
-        int row[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) row[r] = (i0 + r < 30 && rr + r < RPW) ? i0 + r : 29;
-        double acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = stg[qOff + row[r] * qStr];
-#pragma unroll
-        for (int q = 0; q < 30; ++q) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] += stg[OFF_AT + q * 30 + row[r]] * y[q];
-        }
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-          if (j < nt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += GH[j * 64 + row[r]] * kx[j];
+          for (int r = j + 1; r < MT; ++r) {
+            const double f = qmReadLane(col[j], r, scr);     // L[r][j] (zero for r >= m~: those lanes hold identity columns)
+            col[r] -= f * col[j];
           }
         }
+      }
+      if (!isH && c < 20) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (i0 + r < 30 && rr + r < RPW) Tm[(i0 + r) * 32 + tLane] = acc[r];
+        for (int r = 0; r < MT; ++r) { const double v = (c < nt && r < nt) ? col[r] : 0.0; LI[r * LDS_W + c] = v; LIT[c * LDS_W + r] = v; }
       }
     }
     __syncthreads();
-    // symmetrise into S (rows of this wavefront), new s, and drain the prefetched next stage into the (now free) staging buffer
-    if (isA) {
+    // ---- P4: W = L^-1 [G | g]: wavefront w owns tile (w >> 1, w & 1)
+    const int tm = wave >> 1, tn = wave & 1;
+    if (tm < mtTiles) {
+      QmAcc c;
 #pragma unroll
-      for (int r = 0; r < RPW; ++r) { const int i = wave * RPW + r; if (i < 30) S[i * 30 + lane] = 0.5 * (Tm[i * 32 + lane] + Tm[lane * 32 + i]); }
-      if (wave == 0) sv[lane] = Tm[lane * 32 + 30];
+      for (int r = 0; r < 4; ++r) c[r] = 0.0;
+#pragma unroll 1
+      for (int ks = 0; ks < kSteps; ++ks) {
+        const int kk = 4 * ks + h;
+        qmMfma(c, LIT[kk * LDS_W + tm * 16 + l16], T[kk * LDS_Y + tn * 16 + l16], scr);   // L^-1[i][k] = L^-T[k][i]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int i = tm * 16 + h + 4 * r; if (i < 20) W[i * LDS_W + tn * 16 + l16] = c[r]; }
     }
+    __syncthreads();
+    // ---- P5: [K | k] = -L^-T W -> gains
+    if (tm < mtTiles) {
+      QmAcc c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = 0.0;
+#pragma unroll 1
+      for (int ks = 0; ks < kSteps; ++ks) {
+        const int kk = 4 * ks + h;
+        qmMfma(c, -LI[kk * LDS_W + tm * 16 + l16], W[kk * LDS_W + tn * 16 + l16], scr);   // L^-T[i][k] = L^-1[k][i]
+      }
+      double* gain = a.gains + (size_t(inst) * N + k) * GAIN_DOUBLES;
+      const int j = tn * 16 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tm * 16 + h + 4 * r;
+        if (i < MT) {
+          const double v = i < nt ? c[r] : 0.0;
+          if (j < 30) gain[OFF_KFB + i * 30 + j] = v;
+          else if (j == 30) gain[OFF_kff + i] = v;
+        }
+      }
+    }
+    // ---- P6: [S' | s'] = [Q~ | q~] + A~^T [S A~ | y] - W^T W: wavefront w owns tile (w >> 1, w & 1) of the 32 x 32 result
+    {
+      const int j = tn * 16 + l16;
+      QmAcc c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tm * 16 + h + 4 * r, ic = i < 30 ? i : 0;
+        const double v = j < 30 ? stg[OFF_QT + ic * 30 + j] : (j == 30 ? stg[OFF_qt + ic] : 0.0);
+        c[r] = i < 30 ? v : 0.0;
+      }
+      const int ai = tm * 16 + l16 < 30 ? tm * 16 + l16 : 29;   // rows 30,31 of the result are discarded
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
+        qmMfma(c, stg[OFF_AT + kc * 30 + ai], Y[kk * LDS_Y + j], scr);                    // A~^T[i][k] = A~[k][i]
+      }
+#pragma unroll 1
+      for (int ks = 0; ks < kSteps; ++ks) {
+        const int kk = 4 * ks + h;
+        qmMfma(c, -W[kk * LDS_W + tm * 16 + l16], W[kk * LDS_W + j], scr);
+      }
+      // nobody reads S or s between P1 and the end of the stage: store in place
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tm * 16 + h + 4 * r;
+        if (i < 30) { if (j < 30) S[i * LDS_S + j] = c[r]; else if (j == 30) sv[i] = c[r]; }
+      }
+    }
+    __syncthreads();
     pf.commit(stg, OFF_PX, tid);
     __syncthreads();
   }
@@ -306,11 +319,12 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
     armijo += stagesI[size_t(N) * STAGE_DOUBLES + OFF_qt + lane] * dxv[lane];
   }
   // reduce armijo over the lanes of wavefront WX through LDS
-  if (wave == WX) Tm[lane] = armijo;
+  __syncthreads();
+  if (wave == WX) red[lane] = armijo;
   __syncthreads();
   if (tid == 0) {
     double s = 0.0;
-    for (int i = 0; i < 64; ++i) s += Tm[i];
+    for (int i = 0; i < 64; ++i) s += red[i];
     a.instStats[size_t(inst) * 4 + 0] = s;
     a.instStats[size_t(inst) * 4 + 1] = double(status);
   }

@@ -49,6 +49,32 @@ inline double qmShflXor(double v, int mask, double* scratch) {
   return o;
 }
 
+inline double qmReadLane(double v, int src, double* scratch) {
+  const unsigned lane = threadIdx.x & 63u;
+  scratch[lane] = v;
+  QM_WAVE_SYNC();
+  const double o = scratch[unsigned(src) & 63u];
+  QM_WAVE_SYNC();
+  return o;
+}
+
+// v_mfma_f64_16x16x4_f64 on host threads: the operands of the 64 lanes are exchanged through 128 doubles of `scratch`
+struct QmAcc { double v[4]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
+inline void qmMfma(QmAcc& c, double a, double b, double* scratch) {
+  const unsigned lane = threadIdx.x & 63u;
+  scratch[lane] = a; scratch[64 + lane] = b;
+  QM_WAVE_SYNC();
+  const unsigned j = lane & 15u, h = lane >> 4;
+  for (unsigned r = 0; r < 4; ++r) {
+    const unsigned i = h + 4 * r;
+    double acc = c.v[r];
+    for (unsigned k = 0; k < 4; ++k) acc += scratch[k * 16 + i] * scratch[64 + k * 16 + j];
+    c.v[r] = acc;
+  }
+  QM_WAVE_SYNC();
+}
+inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
+
 template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
   const unsigned nt = block.x * block.y * block.z;
   std::barrier<> bar(nt);
