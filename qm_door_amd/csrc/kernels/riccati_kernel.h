@@ -111,7 +111,6 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
     const int nt = 30 - ncI[k];
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
-    const int kSteps = (nt + 3) >> 2;        // k steps of 4 over the m~ dimension
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid);  // next stage's blocks, in flight during this stage
     // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T
@@ -123,15 +122,17 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
       const bool mValid = jA || jb || jB;
       QmAcc c0, c1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { c0[r] = jb ? sv[h + 4 * r] : 0.0; c1[r] = jb ? sv[16 + h + 4 * r] : 0.0; }
+      for (int r = 0; r < 4; ++r) { const double s0 = sv[h + 4 * r], s1 = sv[16 + h + 4 * r]; c0[r] = jb ? s0 : 0.0; c1[r] = jb ? s1 : 0.0; }
+      double a0[8], a1[8], bv[8];   // all operands first (unconditional loads, selects afterwards): the LDS latency is paid once
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of S^T are zero: the clamped b operand is multiplied by 0
-        const double a0 = S[kk * LDS_S + l16], a1 = S[kk * LDS_S + 16 + l16];  // S is symmetric: S[i][k] read as S[k][i]
-        const double bv = mValid ? stg[mOff + kc * mStr] : 0.0;
-        qmMfma(c0, a0, bv, scr);
-        qmMfma(c1, a1, bv, scr);
+        a0[ks] = S[kk * LDS_S + l16]; a1[ks] = S[kk * LDS_S + 16 + l16];  // S is symmetric: S[i][k] read as S[k][i]
+        const double raw = stg[mOff + kc * mStr];
+        bv[ks] = mValid ? raw : 0.0;
       }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
@@ -142,21 +143,26 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
       for (int r = 0; r < 4; ++r) {
         const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
         const int i0c = i0 < MT ? i0 : 0, i1c = i1 < MT ? i1 : 0;
-        const double v0 = jA ? stg[OFF_PT + i0c * 30 + jc] : (jb ? stg[OFF_rt + i0c] : (jB ? stg[OFF_RT + i0c * MT + (jc - 32)] : 0.0));
-        const double v1 = jA ? stg[OFF_PT + i1c * 30 + jc] : (jb ? stg[OFF_rt + i1c] : (jB ? stg[OFF_RT + i1c * MT + (jc - 32)] : 0.0));
+        const int jcA = jA ? jc : 0, jcB = jB ? jc - 32 : 0;
+        const double p0 = stg[OFF_PT + i0c * 30 + jcA], q0 = stg[OFF_rt + i0c], w0 = stg[OFF_RT + i0c * MT + jcB];
+        const double p1 = stg[OFF_PT + i1c * 30 + jcA], q1 = stg[OFF_rt + i1c], w1 = stg[OFF_RT + i1c * MT + jcB];
+        const double v0 = jA ? p0 : (jb ? q0 : (jB ? w0 : 0.0));
+        const double v1 = jA ? p1 : (jb ? q1 : (jB ? w1 : 0.0));
         c0[r] = i0 < nt ? v0 : 0.0;
         c1[r] = i1 < nt ? v1 : 0.0;
       }
       const bool a0ok = l16 < nt, a1ok = 16 + l16 < nt;
       const int a1c = 16 + l16 < MT ? 16 + l16 : 0;
+      double a0[8], a1[8], bv[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of Y are zero
-        const double bv = Y[kk * LDS_Y + jc];
-        const double a0 = a0ok ? stg[OFF_BT + kc * MT + l16] : 0.0;   // B~^T[i][k] = B~[k][i]
-        qmMfma(c0, a0, bv, scr);
-        if (mtTiles == 2) { const double a1 = a1ok ? stg[OFF_BT + kc * MT + a1c] : 0.0; qmMfma(c1, a1, bv, scr); }
+        bv[ks] = Y[kk * LDS_Y + jc];
+        const double r0 = stg[OFF_BT + kc * MT + l16], r1 = stg[OFF_BT + kc * MT + a1c];   // B~^T[i][k] = B~[k][i]
+        a0[ks] = a0ok ? r0 : 0.0; a1[ks] = a1ok ? r1 : 0.0;
       }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); if (mtTiles == 2) qmMfma(c1, a1[ks], bv[ks], scr); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r]; if (mtTiles == 2) T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
@@ -169,20 +175,19 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
 #pragma unroll
       for (int r = 0; r < MT; ++r) {
         const double e = (r == c) ? 1.0 : 0.0;
-        col[r] = (isH && lane < nt && r < nt) ? T[r * LDS_Y + 32 + (lane < nt ? lane : 0)] : e;
+        const double hv = T[r * LDS_Y + 32 + (lane < MT ? lane : 0)];
+        col[r] = (isH && lane < nt && r < nt) ? hv : e;
       }
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        if (j < nt) {
-          const double piv = qmReadLane(col[j], j, scr);
-          if (!(piv > 0.0)) status = 1;
-          const double inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
-          col[j] *= inv;                                     // row j of [L^T | .] / sqrt(pivot)
+      for (int j = 0; j < MT; ++j) {   // steps j >= m~ meet identity columns (pivot 1, multipliers 0): no branch, one basic block
+        const double piv = qmReadLane(col[j], j, scr);
+        if (!(piv > 0.0)) status = 1;
+        const double inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+        col[j] *= inv;                                     // row j of [L^T | .] / sqrt(pivot)
 #pragma unroll
-          for (int r = j + 1; r < MT; ++r) {
-            const double f = qmReadLane(col[j], r, scr);     // L[r][j] (zero for r >= m~: those lanes hold identity columns)
-            col[r] -= f * col[j];
-          }
+        for (int r = j + 1; r < MT; ++r) {
+          const double f = qmReadLane(col[j], r, scr);     // L[r][j] (zero for r >= m~: those lanes hold identity columns)
+          col[r] -= f * col[j];
         }
       }
       if (!isH && c < 20) {
@@ -193,29 +198,29 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
     __syncthreads();
     // ---- P4: W = L^-1 [G | g]: wavefront w owns tile (w >> 1, w & 1)
     const int tm = wave >> 1, tn = wave & 1;
-    if (tm < mtTiles) {
+    {
       QmAcc c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[r] = 0.0;
-#pragma unroll 1
-      for (int ks = 0; ks < kSteps; ++ks) {
-        const int kk = 4 * ks + h;
-        qmMfma(c, LIT[kk * LDS_W + tm * 16 + l16], T[kk * LDS_Y + tn * 16 + l16], scr);   // L^-1[i][k] = L^-T[k][i]
-      }
+      double av[5], bw[5];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = LIT[kk * LDS_W + tm * 16 + l16]; bw[ks] = T[kk * LDS_Y + tn * 16 + l16]; }   // L^-1[i][k] = L^-T[k][i]
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int i = tm * 16 + h + 4 * r; if (i < 20) W[i * LDS_W + tn * 16 + l16] = c[r]; }
     }
     __syncthreads();
     // ---- P5: [K | k] = -L^-T W -> gains
-    if (tm < mtTiles) {
+    {
       QmAcc c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) c[r] = 0.0;
-#pragma unroll 1
-      for (int ks = 0; ks < kSteps; ++ks) {
-        const int kk = 4 * ks + h;
-        qmMfma(c, -LI[kk * LDS_W + tm * 16 + l16], W[kk * LDS_W + tn * 16 + l16], scr);   // L^-T[i][k] = L^-1[k][i]
-      }
+      double av[5], bw[5];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -LI[kk * LDS_W + tm * 16 + l16]; bw[ks] = W[kk * LDS_W + tn * 16 + l16]; }   // L^-T[i][k] = L^-1[k][i]
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
       double* gain = a.gains + (size_t(inst) * N + k) * GAIN_DOUBLES;
       const int j = tn * 16 + l16;
 #pragma unroll
@@ -239,16 +244,16 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
         c[r] = i < 30 ? v : 0.0;
       }
       const int ai = tm * 16 + l16 < 30 ? tm * 16 + l16 : 29;   // rows 30,31 of the result are discarded
+      double av[13], bw[13];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
-        qmMfma(c, stg[OFF_AT + kc * 30 + ai], Y[kk * LDS_Y + j], scr);                    // A~^T[i][k] = A~[k][i]
+        av[ks] = stg[OFF_AT + kc * 30 + ai]; bw[ks] = Y[kk * LDS_Y + j];   // A~^T[i][k] = A~[k][i]
       }
-#pragma unroll 1
-      for (int ks = 0; ks < kSteps; ++ks) {
-        const int kk = 4 * ks + h;
-        qmMfma(c, -W[kk * LDS_W + tm * 16 + l16], W[kk * LDS_W + j], scr);
-      }
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[8 + ks] = -W[kk * LDS_W + tm * 16 + l16]; bw[8 + ks] = W[kk * LDS_W + j]; }
+#pragma unroll
+      for (int ks = 0; ks < 13; ++ks) qmMfma(c, av[ks], bw[ks], scr);
       // nobody reads S or s between P1 and the end of the stage: store in place
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
