@@ -22,6 +22,24 @@ __device__ __forceinline__ double qmReadLane(double v, int src, double* scratch)
 typedef double QmAcc __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void qmMfma(QmAcc& c, double a, double b, double* scratch) { (void)scratch; c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ double qmRsqrt(double x) { return rsqrt(x); }
+// upper-triangle tile set of a symmetric product: acc[(ti,tj), ti <= tj] += A_ti B_tj for one k step of 4
+template <int TP> __device__ __forceinline__ void qmMfmaUpper(QmAcc* acc, const double* a, const double* b, double* scratch) {
+  int t = 0;
+#pragma unroll
+  for (int ti = 0; ti < TP; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < TP; ++tj, ++t) qmMfma(acc[t], a[ti], b[tj], scratch);
+}
+// "every lane's value, addressable by (compile-time) lane index": v_readlane at the point of use
+struct QmGather {
+  double v;
+  __device__ __forceinline__ double get(int src) const { return qmReadLane(v, src, nullptr); }
+};
+__device__ __forceinline__ QmGather qmGather(double v, double* scratch) { (void)scratch; return QmGather{v}; }
+// wavefront all-reduces (xor butterfly: every lane ends with the same value)
+__device__ __forceinline__ double qmAllSum(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64); return v; }
+__device__ __forceinline__ double qmAllMax(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64)); return v; }
+__device__ __forceinline__ double qmAllMin(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64)); return v; }
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
 // dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)

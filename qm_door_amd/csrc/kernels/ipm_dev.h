@@ -1,0 +1,234 @@
+// ipm_dev.h -- one wavefront solves   min 1/2 z'Gz + g'z (+ 1/2 |v|^2)   s.t.  DZ z (- v) <= fhat, (v >= 0)
+// by Mehrotra's predictor-corrector interior point: the QP of one HoQp level (qm_wbc/src/HoQp.cpp:60-134) with the slack block
+// eliminated analytically.  Replaces the qpOASES call of HoQp.cpp:136-149; same iteration and tolerances as the oracle's
+// solveQpIpm (oracle/qmo_wbc.h).
+//
+// NP = n padded (8 / 20 / 36) sizes every register array and loop.  Lane roles: lane i < m0 owns inequality ROW i
+// (slack, multiplier, residuals); lane c < NP owns COLUMN c (z_c, column c of K and of the identity during the factorisation).
+//   K = G + DZ' diag(w) DZ    on the fp64 matrix cores (16x16 tiles, upper triangle, mirrored into LDS)
+//   K = L L', L^-1            row operations on [K | I], one column per lane in registers, multipliers broadcast by v_readlane
+//   dz = L^-T (L^-1 rhs)      forward substitution + one dot product per lane, operands broadcast by v_readlane
+// Nothing on the dependent chain of an iteration goes through LDS except the K tiles and the DZ rows/columns themselves.
+#pragma once
+#include "gpu_rt.h"
+
+namespace qmk {
+
+struct IpmIo {
+  const double* G;      // [36][ldk], zero outside n x n
+  const double* g;      // [36]
+  const double* DZ;     // [56][ldz]; columns >= n zero; rows >= m0 finite
+  const double* fhat;   // [56]
+  double* Kt;           // [36][ldk] scratch for the K tiles
+  double* wtL;          // [64] scratch: row weights
+  double* zs;           // [36] out: solution (lanes >= n write 0)
+  double* red;          // wavefront exchange scratch of the host emulation (>= 1024 doubles)
+};
+
+// returns the iteration count; 60 = not converged
+template <int NP, int LDZ_, int LDK_>
+__device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool rowActive, int lane, double* vOut) {
+  constexpr int TP = (NP + 15) / 16;           // 16-wide tiles per dimension
+  constexpr int KS = 14;                       // k steps of 4 rows: 56 inequality rows
+  const int l16 = lane & 15, h = lane >> 4;
+  const double* G = io.G; const double* DZ = io.DZ; double* red = io.red;
+  auto allSum = [&](double v) { return qmAllSum(v, red); };
+  auto allMax = [&](double v) { return qmAllMax(v, red); };
+  auto allMin = [&](double v) { return qmAllMin(v, red); };
+  const int colL = lane < NP ? lane : 0;       // idle lanes alias column 0 / row 0 (results unused)
+  const int rowL = lane < 56 ? lane : 0;
+  const bool colOn = lane < n;
+  const double gC = io.g[colL];
+  const double pivotFloor = 1e-13 * allMax(colOn ? G[colL * LDK_ + colL] : 0.0);
+  const double fl = rowActive ? io.fhat[rowL] : 0.0;
+  const double scale = fmax(1.0, allMax(fmax(rowActive ? fabs(fl) : 0.0, colOn ? fabs(gC) : 0.0)));
+  const double nRowsTot = allSum(rowActive ? (own ? 2.0 : 1.0) : 0.0);
+  double zc = 0.0, zcPrev = 0.0;
+  double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
+  double s1p = s1, l1p = l1, s2p = s2, l2p = l2, vp = v, nrdPrev = 0.0, muPrev = 0.0;
+  int it = 0;
+#pragma unroll 1
+  for (; it < 60; ++it) {
+    // ---- residuals
+    const QmGather gz = qmGather(zc, red);
+    double Dz;
+    {
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NP; j += 2) { d0 += DZ[rowL * LDZ_ + j] * gz.get(j); d1 += DZ[rowL * LDZ_ + j + 1] * gz.get(j + 1); }
+      Dz = d0 + d1;
+    }
+    const double rp1 = rowActive ? (Dz - (own ? v : 0.0) + s1 - fl) : 0.0;
+    const double rp2 = (rowActive && own) ? (-v + s2) : 0.0;
+    const double rdv = (rowActive && own) ? (v - l1 - l2) : 0.0;
+    const double lamR = rowActive ? l1 : 0.0;
+    double rdz;
+    {
+      double a0 = gC, a1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NP; j += 2) { a0 += G[j * LDK_ + colL] * gz.get(j); a1 += G[(j + 1) * LDK_ + colL] * gz.get(j + 1); }  // G symmetric
+      const QmGather gl = qmGather(lamR, red);
+#pragma unroll
+      for (int i = 0; i < 56; i += 2) { a0 += DZ[i * LDZ_ + colL] * gl.get(i); a1 += DZ[(i + 1) * LDZ_ + colL] * gl.get(i + 1); }
+      rdz = colOn ? a0 + a1 : 0.0;
+    }
+    const double mu = allSum(rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
+    const double nrd = allMax(fmax(fabs(rdz), fabs(rdv)));
+    const double nrp = allMax(fmax(fabs(rp1), fabs(rp2)));
+    const double nanProbe = allSum(rdz + rdv + rp1 + rp2);  // NaN anywhere -> NaN here (fmax drops NaNs)
+    // A late Newton step of a degenerate problem can lose all accuracy (barrier weights ~1e18).  As in the oracle's
+    // solveQpIpm: a step that blows the dual residual up or yields NaN is rejected and the previous iterate returned --
+    // as converged if its complementarity was already <= 1e-8 * scale, flagged (it = 60) otherwise.
+    if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
+      zc = zcPrev; s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
+      if (!(muPrev <= 1e-8 * scale)) it = 60;
+      break;
+    }
+    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;  // same tolerances as the oracle's solveQpIpm
+    zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
+
+    // ---- K = G + DZ' diag(w) DZ: upper-triangle tiles on the matrix cores, mirrored into LDS
+    const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
+    if (lane < 56) io.wtL[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
+    QM_WAVE_SYNC();
+    {
+      QmAcc acc[TP * (TP + 1) / 2];
+      {
+        int t = 0;
+#pragma unroll
+        for (int ti = 0; ti < TP; ++ti)
+#pragma unroll
+          for (int tj = ti; tj < TP; ++tj, ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+              const double gv = G[(i < 36 ? i : 0) * LDK_ + (j < 36 ? j : 0)];
+              acc[t][r] = (i < 36 && j < 36) ? gv : 0.0;
+            }
+      }
+#pragma unroll 2
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + h;
+        const double w = io.wtL[kk];
+        double b[TP], a[TP];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {
+          const int j = t * 16 + l16;
+          const double raw = DZ[kk * LDZ_ + (j < 36 ? j : 0)];
+          b[t] = j < NP ? raw : 0.0;
+          a[t] = w * b[t];
+        }
+        qmMfmaUpper<TP>(acc, a, b, red);
+      }
+      int t = 0;
+#pragma unroll
+      for (int ti = 0; ti < TP; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < TP; ++tj, ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+            if (i < NP && j < NP) { io.Kt[i * LDK_ + j] = acc[t][r]; if (ti != tj) io.Kt[j * LDK_ + i] = acc[t][r]; }
+          }
+    }
+    QM_WAVE_SYNC();
+
+    // ---- factorisation: lane c holds column c of K (kc) and of I (ic); after step j row j is [L^T | L^-1] row j
+    double kc[NP], ic[NP], myInv = 1.0;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      const double kv = io.Kt[r * LDK_ + colL];   // K symmetric: column c read as row-major row c would conflict; this is conflict free
+      const double e = (r == lane) ? 1.0 : 0.0;
+      kc[r] = (colOn && r < n) ? kv : e;          // identity padding beyond n
+      ic[r] = e;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const double piv = qmReadLane(kc[j], j, red);
+      const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
+      const double inv = qmRsqrt(dfl);
+      kc[j] = (lane == j) ? dfl * inv : kc[j] * inv;
+      ic[j] *= inv;
+      if (lane == j) myInv = inv;                              // 1 / L_jj
+      const QmGather gk = qmGather(kc[j], red);                // L[r][j] = gk.get(r)
+#pragma unroll
+      for (int r = j + 1; r < NP; ++r) { const double f = gk.get(r); kc[r] -= f * kc[j]; ic[r] -= f * ic[j]; }
+    }
+    // lane c now holds: kc[r] = L[c][r] (r <= c), ic[r] = L^-1[r][c] (r >= c, zero above)
+
+    double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0, dzc = 0.0;
+    double alphaAff = 1.0, sigma = 0.0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + ds1 * dl1 - sigma * mu;
+      const double rc2 = pass == 0 ? s2 * l2 : s2 * l2 + ds2 * dl2 - sigma * mu;
+      const double t1 = rowActive ? (l1 * rp1 - rc1) / s1 : 0.0;
+      const double t2 = (rowActive && own) ? (l2 * rp2 - rc2) / s2 : 0.0;
+      const double rhsv = -rdv + t1 + t2;
+      const double tz = rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0;
+      // right-hand side of the reduced system
+      double acc;
+      {
+        const QmGather gt = qmGather(tz, red);
+        double a0 = -rdz, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 56; i += 2) { a0 -= DZ[i * LDZ_ + colL] * gt.get(i); a1 -= DZ[(i + 1) * LDZ_ + colL] * gt.get(i + 1); }
+        acc = colOn ? a0 + a1 : 0.0;
+      }
+      // L t = rhs (forward substitution; lane c owns row c of L)
+      double tC = 0.0;
+#pragma unroll
+      for (int r = 0; r < NP; ++r) {
+        const double tr = qmReadLane(acc * myInv, r, red);
+        if (lane == r) tC = tr;
+        acc -= (lane > r) ? kc[r] * tr : 0.0;
+      }
+      // dz = L^-T t: column c of L^-1 dotted with t
+      {
+        double d0 = 0.0, d1 = 0.0;
+        const QmGather gT = qmGather(tC, red);
+#pragma unroll
+        for (int r = 0; r < NP; r += 2) { d0 += ic[r] * gT.get(r); d1 += ic[r + 1] * gT.get(r + 1); }
+        dzc = colOn ? d0 + d1 : 0.0;
+      }
+      double Ddz;
+      {
+        const QmGather gd = qmGather(dzc, red);
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; j += 2) { d0 += DZ[rowL * LDZ_ + j] * gd.get(j); d1 += DZ[rowL * LDZ_ + j + 1] * gd.get(j + 1); }
+        Ddz = d0 + d1;
+      }
+      if (rowActive) {
+        if (own) {
+          dv = (rhsv + w1 * Ddz) / kvv;
+          ds1 = -rp1 - (Ddz - dv); ds2 = -rp2 + dv;
+          dl1 = (-rc1 - l1 * ds1) / s1; dl2 = (-rc2 - l2 * ds2) / s2;
+        } else { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
+      }
+      double amax = 1.0;
+      if (rowActive) {
+        if (ds1 < 0) amax = fmin(amax, -s1 / ds1);
+        if (dl1 < 0) amax = fmin(amax, -l1 / dl1);
+        if (own) { if (ds2 < 0) amax = fmin(amax, -s2 / ds2); if (dl2 < 0) amax = fmin(amax, -l2 / dl2); }
+      }
+      amax = allMin(amax);
+      if (pass == 0) {
+        alphaAff = amax;
+        const double muAff = allSum(rowActive ? ((s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) + (own ? (s2 + alphaAff * ds2) * (l2 + alphaAff * dl2) : 0.0)) : 0.0) / nRowsTot;
+        const double ratio = muAff / mu;
+        sigma = ratio * ratio * ratio;
+      } else {
+        const double tau = fmax(0.995, 1.0 - mu);
+        const double al = fmin(1.0, tau * amax);
+        zc += al * dzc;
+        if (rowActive) { s1 += al * ds1; l1 += al * dl1; if (own) { v += al * dv; s2 += al * ds2; l2 += al * dl2; } }
+      }
+    }
+  }
+  if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
+  *vOut = v;
+  return it;
+}
+
+}  // namespace qmk

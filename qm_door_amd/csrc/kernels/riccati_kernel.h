@@ -50,8 +50,8 @@ constexpr int R_W = R_SV + 32;                    // W [20][LDS_W]
 constexpr int R_LI = R_W + 20 * LDS_W;            // L^-1 row major [20][LDS_W]
 constexpr int R_LIT = R_LI + 20 * LDS_W;          // L^-T row major [20][LDS_W]
 constexpr int R_VEC = R_LIT + 20 * LDS_W;         // dx[32] dut[32]
-constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][128]; armijo reduction
-constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 128;
+constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][256]; armijo reduction
+constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 256;
 constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~105 KiB (dynamic LDS)
 static_assert(R_GAIN + GAIN_DOUBLES <= R_S, "forward-sweep staging must not reach the live value function");
 
@@ -87,7 +87,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
   const int N = a.N;
   double* stg = lds + R_STG; double* gn = lds + R_GAIN; double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
   double* W = lds + R_W; double* LI = lds + R_LI; double* LIT = lds + R_LIT; double* dxv = lds + R_VEC; double* dut = dxv + 32;
-  double* scr = lds + R_SCR + wave * 128; double* red = lds + R_SCR;
+  double* scr = lds + R_SCR + wave * 256; double* red = lds + R_SCR;
   const double* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const double* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
   const int* ncI = a.stageNc + size_t(inst) * (N + 1);
@@ -184,11 +184,9 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
         if (!(piv > 0.0)) status = 1;
         const double inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
         col[j] *= inv;                                     // row j of [L^T | .] / sqrt(pivot)
+        const QmGather gj = qmGather(col[j], scr);
 #pragma unroll
-        for (int r = j + 1; r < MT; ++r) {
-          const double f = qmReadLane(col[j], r, scr);     // L[r][j] (zero for r >= m~: those lanes hold identity columns)
-          col[r] -= f * col[j];
-        }
+        for (int r = j + 1; r < MT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= m~: identity columns)
       }
       if (!isH && c < 20) {
 #pragma unroll

@@ -22,6 +22,7 @@
 #endif
 #include "linesearch_kernel.h"  // DblIn
 #include "sweep_dev.h"
+#include "ipm_dev.h"
 
 namespace qmk {
 
@@ -58,7 +59,7 @@ constexpr int W_K = W_DZ + MAXM * LDZ;           // K / Cholesky [36][LDK]
 constexpr int W_G = W_K + ND * LDK;              // G = AZ^T AZ + eps [36][LDK]
 constexpr int W_VH = W_G + ND * LDK;             // Householder vectors [MAXR][40]
 constexpr int W_VEC = W_VH + MAXR * 40;          // vectors: x[36] z[36] g[36] rd[36] rhs[36] dz[36] fhat[56] lam[56] wt[56] tz[56] red[64]
-constexpr int WBC_LDS_DOUBLES = W_VEC + 6 * 36 + 4 * 56 + 64 + 8;
+constexpr int WBC_LDS_DOUBLES = W_VEC + 6 * 36 + 4 * 56 + 1024 + 8;   // red[1024]: wavefront exchange scratch (only the host emulation uses more than 64)
 constexpr int WBC_LDS_BYTES = WBC_LDS_DOUBLES * 8;
 // misc block
 constexpr int MI_FOOTPM = 0, MI_FOOTVM = 12, MI_FOOTDJV = 24, MI_FOOTPD = 36, MI_FOOTVD = 48, MI_EEPM = 60, MI_EEVM = 63, MI_EEWM = 66, MI_EEDJL = 69, MI_EEDJA = 72,
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   double* A = lds + W_A; double* bvec = lds + W_B; double* D0 = lds + W_D0; double* f0 = lds + W_F0; double* v0 = f0 + MAXM;
   double* Z = lds + W_Z; double* Zn = lds + W_ZN; double* AZ = lds + W_AZ; double* DZ = lds + W_DZ; double* K = lds + W_K; double* G = lds + W_G; double* Vh = lds + W_VH;
   double* xs = lds + W_VEC; double* zs = xs + 36; double* gs = zs + 36; double* rds = gs + 36; double* rhs = rds + 36; double* dzs = rhs + 36;
-  double* fhat = dzs + 36; double* lam = fhat + 56; double* wt = lam + 56; double* tzv = wt + 56; double* red = tzv + 56; double* ctl = red + 64;
+  double* fhat = dzs + 36; double* lam = fhat + 56; double* wt = lam + 56; double* tzv = wt + 56; double* red = tzv + 56; double* ctl = red + 1024;
 
   const int mode = a.mode[inst];
   const double period = a.period[inst], time = a.time[inst];
@@ -222,6 +223,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   for (int c = 0; c < 4; ++c) { contact[c] = contactOf(mode, c); nst += contact[c] ? 1 : 0; }
   const int nsw = 4 - nst;
 
+  for (int e = lane; e < MAXM * LDZ; e += 64) DZ[e] = 0.0;  // rows >= m0 are never written: the interior point only needs them finite
   // ---- S1: inputs
   if (lane < 55) rbd[lane] = a.rbd[size_t(inst) * 55 + lane];
   if (lane < 30) { xDes[lane] = a.xDes[size_t(inst) * 30 + lane]; uDes[lane] = a.uDes[size_t(inst) * 30 + lane]; il[lane] = a.inputLast[size_t(inst) * 30 + lane]; }
@@ -566,186 +568,18 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
     __syncthreads();
 
-    // ---- interior point iterations.  Per iteration: lane b builds row b of K = G + DZ^T diag(wt) DZ in registers, the Cholesky
-    //      runs on those register rows (pivot / column exchange through LDS, wavefront-synchronous), L^-1 is formed column per lane
-    //      and both Newton solves (predictor, corrector) are two small products with it.
-    double* Lm = K;            // L, row major [36][LDK]
-    double* Li = Zn;           // L^-1, row major [36][LDK]   (Znew is free until the null-space update)
-    double* LCp = Vh;          // pivots [36]                 (the Householder block is free as well)
-    double* LCc = Vh + 40;     // two column buffers [2][64]
-    double* invD = Vh + 40 + 128;  // 1 / L_jj [36]
-    auto allSum = [&](double v) { for (int m = 32; m >= 1; m >>= 1) v += qmShflXor(v, m, red); return v; };
-    auto allMax = [&](double v) { for (int m = 32; m >= 1; m >>= 1) v = fmax(v, qmShflXor(v, m, red)); return v; };
-    auto allMin = [&](double v) { for (int m = 32; m >= 1; m >>= 1) v = fmin(v, qmShflXor(v, m, red)); return v; };
-    const double pivotFloor = 1e-13 * allMax(lane < n ? G[lane * LDK + lane] : 0.0);
-    const double fl = rowActive ? fhat[lane] : 0.0;
-    const double scale = fmax(1.0, allMax(fmax(rowActive ? fabs(fl) : 0.0, lane < n ? fabs(gs[lane]) : 0.0)));
+    // ---- interior point iterations (ipm_dev.h): K on the matrix cores, factorisation and solves in registers
+    const double pivotFloor = 1e-13 * qmAllMax(lane < n ? G[lane * LDK + lane] : 0.0, red);
     const bool own = mOwn > 0;
-    const double nRowsTot = allSum(rowActive ? (own ? 2.0 : 1.0) : 0.0);
-    double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
-    double s1p = s1, l1p = l1, s2p = s2, l2p = l2, vp = v, nrdPrev = 0.0, muPrev = 0.0;
-    const int rowL = lane < MAXM ? lane : 0;   // idle lanes alias row 0 (results unused)
-    const int colL = lane < ND ? lane : 0;
+    const double nRowsTot = qmAllSum(rowActive ? (own ? 2.0 : 1.0) : 0.0, red);
     int it = 0;
     if (nRowsTot > 0.0) {
-#pragma unroll 1
-      for (; it < 60; ++it) {
-        // ---- residuals
-        double Dz0 = 0.0, Dz1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < ND; j += 2) { Dz0 += DZ[rowL * LDZ + j] * zs[j]; Dz1 += DZ[rowL * LDZ + j + 1] * zs[j + 1]; }
-        const double Dz = Dz0 + Dz1;
-        const double rp1 = rowActive ? (Dz - (own ? v : 0.0) + s1 - fl) : 0.0;
-        const double rp2 = (rowActive && own) ? (-v + s2) : 0.0;
-        const double rdv = (rowActive && own) ? (v - l1 - l2) : 0.0;
-        if (lane < MAXM) lam[lane] = rowActive ? l1 : 0.0;
-        __syncthreads();
-        double rdz;
-        {
-          double a0 = gs[colL], a1 = 0.0;
-#pragma unroll
-          for (int j = 0; j < ND; j += 2) { a0 += G[colL * LDK + j] * zs[j]; a1 += G[colL * LDK + j + 1] * zs[j + 1]; }
-#pragma unroll 4
-          for (int i = 0; i < m0; ++i) a0 += lam[i] * DZ[i * LDZ + colL];
-          rdz = (lane < n) ? a0 + a1 : 0.0;
-        }
-        const double mu = allSum(rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
-        const double nrd = allMax(fmax(fabs(rdz), fabs(rdv)));
-        const double nrp = allMax(fmax(fabs(rp1), fabs(rp2)));
-        const double nanProbe = allSum(rdz + rdv + rp1 + rp2);  // NaN anywhere -> NaN here (fmax drops NaNs)
-#ifdef QMGPU_EMU_DEBUG
-        if (lane == 0 && level >= 1 && inst == QMGPU_DEBUG_INST) printf("DBG inst %d level %d it %d mu %.3e nrd %.3e nrp %.3e scale %.3e floor %.3e\n", inst, level, it, mu, nrd, nrp, scale, pivotFloor);
-#endif
-        // A late Newton step of a degenerate problem can lose all accuracy (barrier weights ~1e18).  As in the oracle's
-        // solveQpIpm: a step that blows the dual residual up or yields NaN is rejected and the previous iterate returned --
-        // as converged if its complementarity was already <= 1e-8 * scale, flagged in out_status otherwise.
-        if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
-          if (lane < ND) zs[lane] = rhs[lane];
-          s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
-          if (!(muPrev <= 1e-8 * scale)) it = 60;
-          __syncthreads();
-          break;
-        }
-        if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;  // same tolerances as the oracle's solveQpIpm
-        if (lane < ND) rhs[lane] = zs[lane];
-        s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
-        // ---- weights; row colL of K in registers
-        const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
-        if (lane < MAXM) wt[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
-        __syncthreads();
-        double krow[ND];
-#pragma unroll
-        for (int a2 = 0; a2 < ND; ++a2) krow[a2] = G[colL * LDK + a2];
-#pragma unroll 2
-        for (int q = 0; q < m0; ++q) {
-          const double coef = wt[q] * DZ[q * LDZ + colL];
-#pragma unroll
-          for (int a2 = 0; a2 < ND; ++a2) krow[a2] += coef * DZ[q * LDZ + a2];
-        }
-        // ---- Cholesky on the register rows (pivots floored at pivotFloor as in the oracle's choleskyFloored)
-#pragma unroll
-        for (int j = 0; j < ND; ++j) {
-          if (j < n) {
-            if (lane == j) LCp[j] = krow[j];
-            QM_WAVE_SYNC();
-            const double d = LCp[j];
-            const double dj = sqrt(d > pivotFloor ? d : pivotFloor), idj = 1.0 / dj;
-            if (lane == j) invD[j] = idj;
-            const double l = (lane == j) ? dj : krow[j] * idj;
-            krow[j] = l;
-            LCc[(j & 1) * 64 + lane] = l;
-            QM_WAVE_SYNC();
-#pragma unroll
-            for (int q = j + 1; q < ND; ++q) krow[q] -= l * LCc[(j & 1) * 64 + q];
-          }
-        }
-        if (lane < ND) {
-#pragma unroll
-          for (int q = 0; q < ND; ++q) Lm[lane * LDK + q] = krow[q];
-        }
-        __syncthreads();
-        // ---- L^-1, column colL per lane (forward substitution on e_c), then published row major
-        {
-          double x[ND];
-#pragma unroll
-          for (int i = 0; i < ND; ++i) {
-            double sacc = (i == colL) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k2 = 0; k2 < ND; ++k2) if (k2 < i) sacc -= Lm[i * LDK + k2] * x[k2];
-            x[i] = (i < n) ? sacc * invD[i < n ? i : 0] : 0.0;
-          }
-          if (lane < ND) {
-#pragma unroll
-            for (int i = 0; i < ND; ++i) Li[i * LDK + lane] = x[i];
-          }
-        }
-        __syncthreads();
-        double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0;
-        double alphaAff = 1.0, sigma = 0.0;
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-          const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + ds1 * dl1 - sigma * mu;
-          const double rc2 = pass == 0 ? s2 * l2 : s2 * l2 + ds2 * dl2 - sigma * mu;
-          const double t1 = rowActive ? (l1 * rp1 - rc1) / s1 : 0.0;
-          const double t2 = (rowActive && own) ? (l2 * rp2 - rc2) / s2 : 0.0;
-          const double rhsv = -rdv + t1 + t2;
-          if (lane < MAXM) tzv[lane] = rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0;
-          __syncthreads();
-          {  // right-hand side of the reduced system, then t = L^-1 rhs (row colL of L^-1 from LDS)
-            double a0 = -rdz;
-#pragma unroll 4
-            for (int i = 0; i < m0; ++i) a0 -= DZ[i * LDZ + colL] * tzv[i];
-            if (lane < ND) dzs[lane] = (lane < n) ? a0 : 0.0;
-          }
-          __syncthreads();
-          {
-            double t0 = 0.0, t1b = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < ND; c2 += 2) { t0 += Li[colL * LDK + c2] * dzs[c2]; t1b += Li[colL * LDK + c2 + 1] * dzs[c2 + 1]; }
-            __syncthreads();
-            if (lane < ND) dzs[lane] = t0 + t1b;
-          }
-          __syncthreads();
-          {  // dz = L^-T t : column colL of L^-1 dotted with t
-            double t0 = 0.0, t1b = 0.0;
-#pragma unroll
-            for (int i = 0; i < ND; i += 2) { t0 += Li[i * LDK + colL] * dzs[i]; t1b += Li[(i + 1) * LDK + colL] * dzs[i + 1]; }
-            __syncthreads();
-            if (lane < ND) dzs[lane] = t0 + t1b;
-          }
-          __syncthreads();
-          double Dd0 = 0.0, Dd1 = 0.0;
-#pragma unroll
-          for (int j = 0; j < ND; j += 2) { Dd0 += DZ[rowL * LDZ + j] * dzs[j]; Dd1 += DZ[rowL * LDZ + j + 1] * dzs[j + 1]; }
-          const double Ddz = Dd0 + Dd1;
-          if (rowActive) {
-            if (own) {
-              dv = (rhsv + w1 * Ddz) / kvv;
-              ds1 = -rp1 - (Ddz - dv); ds2 = -rp2 + dv;
-              dl1 = (-rc1 - l1 * ds1) / s1; dl2 = (-rc2 - l2 * ds2) / s2;
-            } else { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
-          }
-          double amax = 1.0;
-          if (rowActive) {
-            if (ds1 < 0) amax = fmin(amax, -s1 / ds1);
-            if (dl1 < 0) amax = fmin(amax, -l1 / dl1);
-            if (own) { if (ds2 < 0) amax = fmin(amax, -s2 / ds2); if (dl2 < 0) amax = fmin(amax, -l2 / dl2); }
-          }
-          amax = allMin(amax);
-          if (pass == 0) {
-            alphaAff = amax;
-            const double muAff = allSum(rowActive ? ((s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) + (own ? (s2 + alphaAff * ds2) * (l2 + alphaAff * dl2) : 0.0)) : 0.0) / nRowsTot;
-            const double ratio = muAff / mu;
-            sigma = ratio * ratio * ratio;
-          } else {
-            const double tau = fmax(0.995, 1.0 - mu);
-            const double al = fmin(1.0, tau * amax);
-            if (lane < ND) zs[lane] += al * dzs[lane];
-            if (rowActive) { s1 += al * ds1; l1 += al * dl1; if (own) { v += al * dv; s2 += al * ds2; l2 += al * dl2; } }
-          }
-          __syncthreads();
-        }
-      }
+      IpmIo io{G, gs, DZ, fhat, K, wt, zs, red};
+      double vRow;
+      if (n <= 8) it = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
+      else if (n <= 20) it = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
+      else it = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
+      __syncthreads();
     } else {
       // no inequality rows at all: z = -G^-1 g  (LDS Cholesky; never on the hot path of the reference's task sets)
       for (int e = lane; e < n * n; e += 64) K[(e / n) * LDK + (e % n)] = G[(e / n) * LDK + (e % n)];

@@ -40,38 +40,81 @@ inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std:
 using std::acos; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::sqrt; using std::sin; using std::cos;
 using std::max; using std::min;
 
+// ---- wavefront exchange primitives.  `scratch` is >= 256 doubles of LDS private to the wavefront: two 128-double buffers used
+// alternately, so one barrier per exchange suffices (a lane can only be one exchange ahead of the slowest lane of its wavefront).
+inline thread_local unsigned g_emuXchg = 0;
+inline double* emuXchgBuf(double* scratch) { return scratch + 128 * ((g_emuXchg++) & 1u); }
+
 inline double qmShflXor(double v, int mask, double* scratch) {
   const unsigned lane = threadIdx.x & 63u;
-  scratch[lane] = v;
+  double* buf = emuXchgBuf(scratch);
+  buf[lane] = v;
   QM_WAVE_SYNC();
-  const double o = scratch[lane ^ unsigned(mask)];
-  QM_WAVE_SYNC();
-  return o;
+  return buf[lane ^ unsigned(mask)];
 }
 
 inline double qmReadLane(double v, int src, double* scratch) {
   const unsigned lane = threadIdx.x & 63u;
-  scratch[lane] = v;
+  double* buf = emuXchgBuf(scratch);
+  buf[lane] = v;
   QM_WAVE_SYNC();
-  const double o = scratch[unsigned(src) & 63u];
-  QM_WAVE_SYNC();
-  return o;
+  return buf[unsigned(src) & 63u];
 }
 
-// v_mfma_f64_16x16x4_f64 on host threads: the operands of the 64 lanes are exchanged through 128 doubles of `scratch`
-struct QmAcc { double v[4]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
-inline void qmMfma(QmAcc& c, double a, double b, double* scratch) {
+struct QmGather {
+  double vals[64];
+  double get(int src) const { return vals[src & 63]; }
+};
+inline QmGather qmGather(double v, double* scratch) {
   const unsigned lane = threadIdx.x & 63u;
-  scratch[lane] = a; scratch[64 + lane] = b;
+  double* buf = emuXchgBuf(scratch);
+  buf[lane] = v;
   QM_WAVE_SYNC();
+  QmGather g;
+  for (int i = 0; i < 64; ++i) g.vals[i] = buf[i];
+  return g;
+}
+template <class Op> inline double emuButterfly(double v, double* scratch, Op op) {
+  const unsigned lane = threadIdx.x & 63u;
+  QmGather g = qmGather(v, scratch);
+  double cur[64], nxt[64];
+  for (int i = 0; i < 64; ++i) cur[i] = g.vals[i];
+  for (int m = 32; m >= 1; m >>= 1) { for (int i = 0; i < 64; ++i) nxt[i] = op(cur[i], cur[i ^ m]); for (int i = 0; i < 64; ++i) cur[i] = nxt[i]; }
+  return cur[lane];
+}
+inline double qmAllSum(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return a + b; }); }
+inline double qmAllMax(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return std::fmax(a, b); }); }
+inline double qmAllMin(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return std::fmin(a, b); }); }
+
+// v_mfma_f64_16x16x4_f64 on host threads: lane l supplies a = A[l % 16][l / 16], b = B[l / 16][l % 16]; register r of lane l is
+// C[l / 16 + 4 r][l % 16] (layout measured on gfx950, tools/probe_mfma.hip)
+struct QmAcc { double v[4]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
+inline void emuMfmaTile(QmAcc& c, const double* A, const double* B, unsigned lane) {
   const unsigned j = lane & 15u, h = lane >> 4;
   for (unsigned r = 0; r < 4; ++r) {
     const unsigned i = h + 4 * r;
     double acc = c.v[r];
-    for (unsigned k = 0; k < 4; ++k) acc += scratch[k * 16 + i] * scratch[64 + k * 16 + j];
+    for (unsigned k = 0; k < 4; ++k) acc += A[k * 16 + i] * B[k * 16 + j];
     c.v[r] = acc;
   }
+}
+inline void qmMfma(QmAcc& c, double a, double b, double* scratch) {
+  const unsigned lane = threadIdx.x & 63u;
+  double* buf = emuXchgBuf(scratch);
+  buf[lane] = a; buf[64 + lane] = b;
   QM_WAVE_SYNC();
+  emuMfmaTile(c, buf, buf + 64, lane);
+}
+// all upper-triangle tiles of one k step with a single exchange (own region behind the 256 doubles of the plain exchanges:
+// scratch >= 256 + 2 * TP * 128 doubles)
+template <int TP> inline void qmMfmaUpper(QmAcc* acc, const double* a, const double* b, double* scratch) {
+  const unsigned lane = threadIdx.x & 63u;
+  double* buf = scratch + 256 + (TP * 128) * ((g_emuXchg++) & 1u);
+  for (int t = 0; t < TP; ++t) { buf[t * 128 + lane] = a[t]; buf[t * 128 + 64 + lane] = b[t]; }
+  QM_WAVE_SYNC();
+  int t = 0;
+  for (int ti = 0; ti < TP; ++ti)
+    for (int tj = ti; tj < TP; ++tj, ++t) emuMfmaTile(acc[t], buf + ti * 128, buf + tj * 128 + 64, lane);
 }
 inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
 
