@@ -1,7 +1,7 @@
 // ipm_dev.h -- one wavefront solves   min 1/2 z'Gz + g'z (+ 1/2 |v|^2)   s.t.  DZ z (- v) <= fhat, (v >= 0)
 // by Mehrotra's predictor-corrector interior point: the QP of one HoQp level (qm_wbc/src/HoQp.cpp:60-134) with the slack block
 // eliminated analytically.  Replaces the qpOASES call of HoQp.cpp:136-149; same iteration and tolerances as the oracle's
-// solveQpIpm (oracle/qmo_wbc.h).
+// solveQpIpm.
 //
 // NP = n padded (8 / 20 / 36) sizes every register array and loop.  Lane roles: lane i < m0 owns inequality ROW i
 // (slack, multiplier, residuals); lane c < NP owns COLUMN c (z_c, column c of K and of the identity during the factorisation).
