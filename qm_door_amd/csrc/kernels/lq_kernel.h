@@ -1,4 +1,7 @@
-// lq_node_kernel -- fused per-node LQ approximation + constraint projection.  One wavefront per shooting node.
+// ad_node_kernel + lq_node_kernel -- per-node LQ approximation and constraint projection.  One wavefront per shooting node.
+// Two launches so that each half gets the occupancy it can use: the AD sweep needs registers but no LDS (two wavefronts per
+// SIMD hide each other's waits), the projection needs ~35 KiB of LDS per node.  The AD rows (17 KiB per node: tangent rows of the
+// RK2 increment, the constraint rows and the end-effector error) cross HBM once in between.
 //
 // Replaces, per node: QMPreComputation::request (QMPreComputation.cpp:50-89),
 // QMDynamicsAD::linearApproximation x2 for the RK2 stages (QMDynamicsAD.cpp:30-33), the quadratic approximation of the
@@ -37,7 +40,14 @@ struct LqArgs {
   int* nodeMode;             // [batch][N+1]
   double* metrics;           // [batch][N+1][NODE_METRICS]
   double* debug;             // [batch][N+1][DBG_DOUBLES] or null
+  double* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
 };
+
+// AD rows: one 64-double row per differentiated scalar; entry l < 60 = d/d(x,u)_l, entry 60 = the value itself
+constexpr int AD_PHI = 0;                    // [12] RK2 increment phi = dt/2 (k1 + k2) of the momentum / base-pose states
+constexpr int AD_CD = AD_PHI + 12 * 64;      // [16] equality constraint rows
+constexpr int AD_EE = AD_CD + 16 * 64;       // [6]  end-effector pose error
+constexpr int AD_DOUBLES = AD_EE + 6 * 64;   // 2176
 
 struct DuIn {
   const double* x;
@@ -54,18 +64,21 @@ struct DuIn {
   __device__ __forceinline__ Vec3<Du> force(int c) const { return Vec3<Du>(su(3 * c), su(3 * c + 1), su(3 * c + 2)); }
 };
 
-constexpr int PAW = 52;                      // row stride of [Px | Pe | Pu] in LDS (49 used, read in groups of four)
-constexpr int CDW = 62;                      // row stride of [C | D | e] (61 used), aliases the same region
-constexpr int L_B = 0;                       // B      [30][30]
-constexpr int L_R = L_B + 900;               // R      [30][30]   (dt-scaled)
-constexpr int L_PA = L_R + 900;              // Pall   [30][PAW]  /  CD [16][CDW]
-constexpr int L_V = L_PA + 30 * PAW;         // Householder vectors [16][32] (entry 30 = beta)
-constexpr int L_RL = L_V + 16 * 32;          // R1 [16][16]
-constexpr int L_EEJ = L_RL + 256;            // EE error Jacobian [6][32]
-constexpr int L_VEC = L_EEJ + 192;           // small vectors: b[30] r[30] e[16] eeh[6] ...
-constexpr int L_RED = L_VEC + 96;            // reduction scratch [64]
-constexpr int LQ_LDS_DOUBLES = L_RED + 64;   // 4420 doubles = 34.5 KiB
-static_assert(16 * CDW <= 30 * PAW, "CD must fit in the Pall region");
+// LDS of lq_node_kernel (doubles).  Region X is reused three times: EE-free Householder vectors + R1 during the QR, the
+// transposed dense rows of [A | B] for the first product, and W = R Pall for the second.
+constexpr int PAW = 50;                      // row stride of Pall = [Px | Pe | 0 | Pu] (columns 0..29, 30, 31, 32..32+m~-1)
+constexpr int CDW = 62;                      // row stride of [C | D | e] (61 used), aliases the Pall region
+constexpr int LDR = 34, LDT = 18;            // row strides of R / Q and of the transposed dense rows
+constexpr int L_X = 0;                       // X: Vh [16][32] + R1 [16][16]  |  At [32][LDT] + Bt [32][LDT]  |  W [32][PAW]
+constexpr int L_V = L_X, L_RL = L_X + 512, L_AT = L_X, L_BT = L_X + 32 * LDT, L_W = L_X;
+constexpr int L_R = L_X + 32 * PAW;          // R [32][LDR] (dt-scaled), later Q [32][LDR]
+constexpr int L_PA = L_R + 32 * LDR;         // Pall [32][PAW]  /  CD [16][CDW]
+constexpr int L_EEJ = L_PA + 32 * PAW;       // EE error Jacobian [6][32]
+constexpr int L_VEC = L_EEJ + 192;           // b[30] r[30] e[16] eeh[6] (+2) | g30[64]
+constexpr int L_RED = L_VEC + 84 + 64;       // wavefront exchange scratch [256]
+constexpr int LQ_LDS_DOUBLES = L_RED + 256;  // 5032 doubles = 39.3 KiB: four workgroups per CU
+static_assert(16 * CDW <= 32 * PAW && 512 + 256 <= 32 * PAW && 2 * 32 * LDT <= 32 * PAW, "aliases must fit");
+static_assert(LQ_LDS_DOUBLES * 8 <= 40960, "four nodes per CU");
 
 // dot product of a broadcast LDS row with a register vector, three independent FMA chains (one wavefront per SIMD: the fp64 FMA
 // latency is hidden by instruction-level parallelism only)
@@ -85,25 +98,22 @@ __device__ __forceinline__ double waveSum(double* red, int lane, double v) {
   return s;
 }
 
-__global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
-  __shared__ double lds[LQ_LDS_DOUBLES];
+// ---- kernel 1: both RK2 stages with lane tangents; rows go straight from registers to HBM (512-byte coalesced stores)
+__global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   const int lane = threadIdx.x;
   const int node = blockIdx.x % (a.N + 1);
   const int inst = blockIdx.x / (a.N + 1);
   const bool terminal = node == a.N;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
-
-  double* Bm = lds + L_B; double* Rm = lds + L_R; double* PA = lds + L_PA; double* CD = lds + L_PA; double* Vh = lds + L_V;
-  double* RL = lds + L_RL; double* EEJ = lds + L_EEJ; double* bv = lds + L_VEC; double* rv = bv + 30; double* ev = rv + 30; double* eeh = ev + 16;
-  double* red = lds + L_RED;
+  double* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
+  auto putRow = [&](int base, int row, Du h) { ad[base + row * 64 + lane] = (lane == 60) ? h.v : h.d; };
 
   const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
   const double t = tg[node];
   const double dt = terminal ? 0.0 : tg[node + 1] - t;
   const double* x = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
   const double* u = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
-  const double* xnext = terminal ? x : x + 30;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
   const int phase = phaseAt(sched, t);
   const int mode = sched.modes[phase];
@@ -111,7 +121,6 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
   double eePosRef[3], eeQuatRef[4];
   eeReference(tTimes, tStates, a.K, t, eePosRef, eeQuatRef);
-  const double muP = terminal ? st.ee_final_mu_position : st.ee_mu_position, muO = terminal ? st.ee_final_mu_orientation : st.ee_mu_orientation;
 
   // ================================================================== phase AD: both RK2 stages with lane tangents
   Du k1[12];  // first-stage slope; after the second stage it holds phi = dt/2 (k1 + k2)
@@ -134,7 +143,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
             const Vec3<Du> od = quaternionDistance(qee, eeQuatRef);
             const Du h[6] = {p0x + r.x - eePosRef[0], p0y + r.y - eePosRef[1], p0z + r.z - eePosRef[2], od.x, od.y, od.z};
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { if (lane < 32) EEJ[q * 32 + lane] = h[q].d; eeh[q] = h[q].v; }
+            for (int q = 0; q < 6; ++q) putRow(AD_EE, q, h[q]);
           }
         },
         f, bm);
@@ -146,16 +155,16 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
           const bool contact = contactOf(mode, c);
           const Vec3<Du> r = feet.r(c);
           const Vec3<Du> vf = bm.dp + cross(bm.omega, r) + feet.v(c);
-          auto putRow = [&](int row, Du h) { if (lane < 60) CD[row * CDW + lane] = h.d; ev[row] = h.v; };
+          auto putC = [&](int row, Du h) { putRow(AD_CD, row, h); };
           if (contact) {  // zeroVelocity (QMInterface.cpp:126, 324-339)
-            putRow(nc, vf.x); putRow(nc + 1, vf.y); putRow(nc + 2, vf.z);
+            putC(nc, vf.x); putC(nc + 1, vf.y); putC(nc + 2, vf.z);
             nc += 3;
           } else {  // zeroForce (QMInterface.cpp:123-124) then normalVelocity (QMPreComputation.cpp:56-66)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) putRow(nc + q, in.su(3 * c + q));
+            for (int q = 0; q < 3; ++q) putC(nc + q, in.su(3 * c + q));
             double zp, zv;
             swingReference(st, sched, c, t, phase, zp, zv);
-            putRow(nc + 3, vf.z - zv + st.position_error_gain * (p0z + r.z - zp));
+            putC(nc + 3, vf.z - zv + st.position_error_gain * (p0z + r.z - zp));
             nc += 4;
           }
         }
@@ -167,21 +176,63 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       for (int i = 0; i < 12; ++i) k1[i] = 0.5 * dt * (k1[i] + f[i]);
     }
   }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) putRow(AD_PHI, i, k1[i]);
+  if (lane == 0) { a.stageNc[size_t(inst) * (a.N + 1) + node] = nc; a.nodeMode[size_t(inst) * (a.N + 1) + node] = mode; }
+}
+
+// ---- kernel 2: cost, projection, projected stage record
+__global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
+  __shared__ double lds[LQ_LDS_DOUBLES];
+  const int lane = threadIdx.x;
+  const int l16 = lane & 15, h = lane >> 4;
+  const int node = blockIdx.x % (a.N + 1);
+  const int inst = blockIdx.x / (a.N + 1);
+  const bool terminal = node == a.N;
+  const qmgpu_model& md = a.P->model;
+  const qmgpu_settings& st = a.P->settings;
+
+  double* Rm = lds + L_R; double* Qm = lds + L_R; double* PA = lds + L_PA; double* CD = lds + L_PA; double* Vh = lds + L_V; double* RL = lds + L_RL;
+  double* AT = lds + L_AT; double* BT = lds + L_BT; double* WL = lds + L_W;
+  double* EEJ = lds + L_EEJ; double* bv = lds + L_VEC; double* rv = bv + 30; double* ev = rv + 30; double* eeh = ev + 16; double* g30v = bv + 84;
+  double* red = lds + L_RED;
+
+  const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
+  const double t = tg[node];
+  const double dt = terminal ? 0.0 : tg[node + 1] - t;
+  const double* x = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
+  const double* u = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+  const double* xnext = terminal ? x : x + 30;
+  const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
+  const int phase = phaseAt(sched, t);
+  const int mode = sched.modes[phase];
+  const double* tTimes = a.targetTimes + size_t(inst) * a.K;
+  const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
+  const double muP = terminal ? st.ee_final_mu_position : st.ee_mu_position, muO = terminal ? st.ee_final_mu_orientation : st.ee_mu_orientation;
+
+  // ---- rows of the AD sweep (ad_node_kernel)
+  const double* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
+  int nc = 0;
+  if (!terminal) for (int k = 0; k < 4; ++k) nc += contactOf(mode, k) ? 3 : 4;
+  for (int r = 0; r < nc; ++r) { const double v = ad[AD_CD + r * 64 + lane]; if (lane < 60) CD[r * CDW + lane] = v; else if (lane == 60) ev[r] = v; }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const double v = ad[AD_EE + q * 64 + lane]; if (lane < 32) EEJ[q * 32 + lane] = v; else if (lane == 60) eeh[q] = v; }
+  double phid[12], phiv[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
+  if (lane < LDR) { Rm[30 * LDR + lane] = 0.0; Rm[31 * LDR + lane] = 0.0; }   // zero padding rows of R / Q (k = 30, 31 of the tiles)
   __syncthreads();
 
   double* rec = a.stages + (size_t(inst) * (a.N + 1) + node) * STAGE_DOUBLES;
   double* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
-  if (lane == 0) { a.stageNc[size_t(inst) * (a.N + 1) + node] = nc; a.nodeMode[size_t(inst) * (a.N + 1) + node] = mode; }
-  const Du* phi = k1;
-
-  // ================================================================== cost (lanes < 30 own a column of Q / R)
   int tIdx; double tAlpha;
   timeSegment(tTimes, a.K, t, tIdx, tAlpha);
   const int c = lane;
   double qc = 0.0, costPart = 0.0;
   const double sc = terminal ? 1.0 : dt;  // intermediate costs are scaled by dt, the terminal cost is not
-  {
-    double Qcol[30];
+
+  // state cost, column c of Q (lanes < 30): tracking + EE soft constraint (Gauss-Newton) + arm joint position soft box
+  auto stateCost = [&](double (&Qcol)[30]) {
 #pragma unroll
     for (int i = 0; i < 30; ++i) Qcol[i] = 0.0;
     if (c < 30) {
@@ -218,40 +269,32 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
         for (int k = 24; k < 30; ++k) if (k == c) Qcol[k] += dd;
       }
     }
-    if (c < 30) {
-#pragma unroll
-      for (int i = 0; i < 30; ++i) rec[OFF_QT + i * 30 + c] = sc * Qcol[i];  // Q~ is completed in place after the projection
-      if (dbg) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = sc * Qcol[i]; }
-    }
     qc *= sc;
-  }
+  };
 
   if (terminal) {
+    double Qcol[30];
+    stateCost(Qcol);
+    if (c < 30) {
+#pragma unroll
+      for (int i = 0; i < 30; ++i) rec[OFF_QT + i * 30 + c] = Qcol[i];
+      if (dbg) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = Qcol[i]; }
+    }
     const double nodeCost = waveSum(red, lane, costPart);
     if (c < 30) { rec[OFF_qt + c] = qc; if (dbg) dbg[DBG_q + c] = qc; }
     if (lane == 0) { double* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS; m[0] = nodeCost; m[1] = 0.0; m[2] = 0.0; m[3] = 0.0; }
     return;
   }
 
-  // ---- Jacobian columns of the RK2 map: Phi = x + dt/2 (k1 + k2); rows 12.. are x_j + dt v_j exactly.
-  //      A columns go straight to the stage record (completed in place below), B columns to LDS.
-  if (c < 60) {
-    double col[30];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) col[i] = phi[i].d + (c == i ? 1.0 : 0.0);
-#pragma unroll
-    for (int j = 0; j < 18; ++j) col[12 + j] = (c == 12 + j ? 1.0 : 0.0) + (c == 42 + j ? dt : 0.0);
-    if (c < 30) {
-#pragma unroll
-      for (int i = 0; i < 30; ++i) rec[OFF_AT + i * 30 + c] = col[i];
-      if (dbg) { for (int i = 0; i < 30; ++i) dbg[DBG_A + i * 30 + c] = col[i]; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 30; ++i) Bm[i * 30 + (c - 30)] = col[i];
-    }
+  // ---- Jacobian of the RK2 map Phi = x + dt/2 (k1 + k2): rows 12.. are x_j + dt v_j exactly, so only the twelve momentum /
+  //      base-pose rows of [A | B] are dense (phid).  Column `lane` of [A | B]:
+  auto abCol = [&](int i) { return i < 12 ? phid[i < 12 ? i : 0] + (c == i ? 1.0 : 0.0) : (c == i ? 1.0 : 0.0) + (c == 30 + i ? dt : 0.0); };
+  if (dbg && c < 60) {
+    for (int i = 0; i < 30; ++i) { const double v = i < 12 ? phid[i < 12 ? i : 0] + (c == i ? 1.0 : 0.0) : (c == i ? 1.0 : 0.0) + (c == 30 + i ? dt : 0.0); if (c < 30) dbg[DBG_A + i * 30 + c] = v; else dbg[DBG_B + i * 30 + (c - 30)] = v; }
   }
+  (void)abCol;
   if (lane == 0) {
-    for (int i = 0; i < 12; ++i) bv[i] = x[i] + phi[i].v - xnext[i];
+    for (int i = 0; i < 12; ++i) bv[i] = x[i] + phiv[i] - xnext[i];
     for (int j = 0; j < 18; ++j) bv[12 + j] = x[12 + j] + dt * u[12 + j] - xnext[12 + j];
   }
   // ---- input cost: R' + friction-cone and arm-velocity barriers (column c of R into LDS)
@@ -301,22 +344,14 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
         for (int k = 0; k < 12; ++k) { if (k == fo) Rcol[k] += e0; if (k == fo + 1) Rcol[k] += e1; if (k == fo + 2) Rcol[k] += e2; }
       }
 #pragma unroll
-      for (int i = 0; i < 30; ++i) Rm[i * 30 + c] = dt * Rcol[i];
+      for (int i = 0; i < 30; ++i) Rm[i * LDR + c] = dt * Rcol[i];
       rv[c] = dt * rc;
     }
   }
-  const double nodeCost = dt * waveSum(red, lane, costPart);  // (barriers inside: LDS writes above are visible below)
-
-  if (lane == 0) {
-    double dyn = 0.0, eq = 0.0;
-    for (int i = 0; i < 30; ++i) dyn += bv[i] * bv[i];
-    for (int i = 0; i < nc; ++i) eq += ev[i] * ev[i];
-    double* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS;
-    m[0] = nodeCost; m[1] = dt * dyn; m[2] = dt * eq; m[3] = 0.0;
-  }
+  __syncthreads();
   if (dbg && c < 30) {
-    for (int i = 0; i < 30; ++i) { dbg[DBG_B + i * 30 + c] = Bm[i * 30 + c]; dbg[DBG_R + i * 30 + c] = Rm[i * 30 + c]; }
-    dbg[DBG_b + c] = bv[c]; dbg[DBG_q + c] = qc; dbg[DBG_r + c] = rv[c];
+    for (int i = 0; i < 30; ++i) dbg[DBG_R + i * 30 + c] = Rm[i * LDR + c];
+    dbg[DBG_b + c] = bv[c]; dbg[DBG_r + c] = rv[c];
     for (int r = 0; r < nc; ++r) { dbg[DBG_C + r * 30 + c] = CD[r * CDW + c]; dbg[DBG_D + r * 30 + c] = CD[r * CDW + 30 + c]; }
     if (c < nc) dbg[DBG_e + c] = ev[c];
   }
@@ -376,7 +411,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     for (int i = 0; i < 30; ++i) {
       double v = 0.0;
       if (lane <= 30) { if (i < NCMAX) v = -y[i < NCMAX ? i : 0]; }
-      else if (i == nc + (lane - 31)) v = 1.0;
+      else if (lane >= 32 && i == nc + (lane - 32)) v = 1.0;
       z[i] = v;
     }
   }
@@ -387,12 +422,9 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
 #pragma unroll
     for (int i = 0; i < 30; ++i) z[i] -= s * Vh[k * 32 + i];
   }
-  const bool active = lane < 31 + nt;
-  const bool isX = lane < 30, isE = lane == 30, isU = lane > 30 && active;
-
-  // ================================================================== projected dynamics and cost
-  // row by row: o_i = (B z)_i completes A~ / b~ / B~ in the stage record, w_i = (R z)_i goes to the shared matrix W = R [Px Pe Pu]
-  double* WL = PA;
+  // lane roles of the projection columns: lane < 30 column of Px, lane 30 = Pe, lanes 32 .. 32 + m~ - 1 columns of Pu
+  const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
+  const bool active = isX || isE || isU;
   double tz = 0.0;
 #pragma unroll
   for (int i = 0; i < 30; ++i) tz += rv[i] * z[i];
@@ -404,50 +436,147 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     for (int i = 0; i < 30; ++i) rec[OFF_PE + i] = z[i];
   } else if (isU) {
 #pragma unroll
-    for (int i = 0; i < 30; ++i) rec[OFF_PU + i * MT + (lane - 31)] = z[i];
+    for (int i = 0; i < 30; ++i) rec[OFF_PU + i * MT + (lane - 32)] = z[i];
   }
-#pragma unroll 1
-  for (int i0 = 0; i0 < 30; i0 += 3) {  // three rows per trip: six independent FMA chains
-    double sb[3] = {0.0, 0.0, 0.0}, sr[3] = {0.0, 0.0, 0.0};
+  // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
-    for (int k = 0; k < 30; ++k) {
+  for (int i = 12; i < 30; ++i) {
+    if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0 : 0.0) + dt * z[i];
+    else if (isE) rec[OFF_bt + i] = bv[i] + dt * z[i];
+    else if (isU) rec[OFF_BT + i * MT + (lane - 32)] = dt * z[i];
+  }
+  __syncthreads();   // the Householder vectors (region X) and [C D e] (Pall region) are dead from here on
+  if (lane < PAW) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) { sb[r] += Bm[(i0 + r) * 30 + k] * z[k]; sr[r] += Rm[(i0 + r) * 30 + k] * z[k]; }
+    for (int i = 0; i < 30; ++i) PA[i * PAW + lane] = active ? z[i] : 0.0;
+    PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
+  }
+  {  // transposed dense rows: At[j][i] = A[i][j], Bt[k][i] = B[i][k], i < 12 (columns 12..15 and rows 30,31 zero)
+    double* dst = (lane < 30) ? AT + lane * LDT : (lane < 60 ? BT + (lane - 30) * LDT : AT + 30 * LDT + (lane - 60) * LDT);
+    const bool pad = lane >= 60;  // lanes 60..61 clear rows 30,31 of At; lanes 62..63 rows 30,31 of Bt
+    if (lane >= 62) dst = BT + (30 + lane - 62) * LDT;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0 : 0.0) : 0.0;
+  }
+  __syncthreads();
+
+  // ================================================================== products on the fp64 matrix cores
+  // (1) rows 0..11 of [A~ | b~ | B~] = [A | b | 0] + B Pall      (2) W = R Pall   -- one k loop, shared Pall operand
+  const int nTn = nt > 16 ? 4 : 3;   // 16-column tiles of Pall in use
+  {
+    QmAcc c1[4], cw[8];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = h + 4 * r, j = tn * 16 + l16;
+        const double av = AT[(j < 32 ? j : 0) * LDT + i], bb = bv[i < 30 ? i : 0];
+        c1[tn][r] = (i < 12) ? (j < 30 ? av : (j == 30 ? bb : 0.0)) : 0.0;
+        cw[tn][r] = 0.0; cw[4 + tn][r] = 0.0;
+      }
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = 4 * ks + h;
+      const double ab = BT[kk * LDT + l16], r0 = Rm[kk * LDR + l16], r1 = Rm[kk * LDR + 16 + l16];   // R symmetric: R[i][k] read as R[k][i]
+      double pb[4];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) { const int j = tn * 16 + l16; const double raw = PA[kk * PAW + (j < PAW ? j : 0)]; pb[tn] = j < PAW ? raw : 0.0; }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        if (tn < nTn) { qmMfma(c1[tn], ab, pb[tn], red); qmMfma(cw[tn], r0, pb[tn], red); qmMfma(cw[4 + tn], r1, pb[tn], red); }
+      }
+    }
+    QM_WAVE_SYNC();   // every lane has consumed At / Bt: region X becomes W
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      if (tn < nTn) {
+        const int j = tn * 16 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = h + 4 * r;
+          if (i < 12) {
+            if (j < 30) rec[OFF_AT + i * 30 + j] = c1[tn][r];
+            else if (j == 30) rec[OFF_bt + i] = c1[tn][r];
+            else if (j >= 32 && j < 32 + nt) rec[OFF_BT + i * MT + (j - 32)] = c1[tn][r];
+          }
+          if (j < PAW) { WL[i * PAW + j] = cw[tn][r]; WL[(16 + i) * PAW + j] = cw[4 + tn][r]; }
+        }
+      }
+    }
+  }
+  __syncthreads();   // R is dead: its region takes Q
+
+  // ---- state cost: column c of Q into LDS (accumulator initialisation of the last product)
+  {
+    double Qcol[30];
+    stateCost(Qcol);
+    if (c < 30) {
+#pragma unroll
+      for (int i = 0; i < 30; ++i) Qm[i * LDR + c] = sc * Qcol[i];
+      if (dbg) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = sc * Qcol[i]; dbg[DBG_q + c] = qc; }
+    }
+  }
+  const double nodeCost = dt * waveSum(red, lane, costPart);  // (barriers inside: the Q columns are visible below)
+  if (lane == 0) {
+    double dyn = 0.0, eq = 0.0;
+    for (int i = 0; i < 30; ++i) dyn += bv[i] * bv[i];
+    for (int i = 0; i < nc; ++i) eq += ev[i] * ev[i];
+    double* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS;
+    m[0] = nodeCost; m[1] = dt * dyn; m[2] = dt * eq; m[3] = 0.0;
+  }
+
+  // (3) G = Pall^T W: [Q~ | P~^T; P~ | R~] = [Q | 0; 0 | 0] + G, row / column 30 carry Pe^T R Pall (-> q~, r~)
+  {
+    // tiles (tm, tn): (0,0) (0,1) (1,0) (1,1) state block; (2,0) (2,1) (2,2) projected-input rows 0..15;
+    //                 (3,0) (3,1) (2,3) (3,2) (3,3) only when m~ > 16
+    constexpr int TM[12] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 2, 3, 3}, TN[12] = {0, 1, 0, 1, 0, 1, 2, 0, 1, 3, 2, 3};
+    const int nTiles = nt > 16 ? 12 : 7;
+    QmAcc g[12];
+#pragma unroll
+    for (int tI = 0; tI < 12; ++tI)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = TM[tI] * 16 + h + 4 * r, j = TN[tI] * 16 + l16;
+        const double qv = Qm[(i < 30 ? i : 0) * LDR + (j < 30 ? j : 0)];
+        g[tI][r] = (tI < 4 && i < 30 && j < 30) ? qv : 0.0;
+      }
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = 4 * ks + h;
+      double pa[4], wb[4];
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        const int j = tq * 16 + l16;
+        const double rp = PA[kk * PAW + (j < PAW ? j : 0)], rw = WL[kk * PAW + (j < PAW ? j : 0)];
+        pa[tq] = j < PAW ? rp : 0.0; wb[tq] = j < PAW ? rw : 0.0;
+      }
+#pragma unroll
+      for (int tI = 0; tI < 12; ++tI) { if (tI < nTiles) qmMfma(g[tI], pa[TM[tI]], wb[TN[tI]], red); }
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int i = i0 + r;
-      if (isX) rec[OFF_AT + i * 30 + lane] += sb[r];
-      else if (isE) rec[OFF_bt + i] = bv[i] + sb[r];
-      else if (isU) rec[OFF_BT + i * MT + (lane - 31)] = sb[r];
-      if (active) WL[i * PAW + lane] = sr[r];
+    for (int tI = 0; tI < 12; ++tI) {
+      if (tI < nTiles) {
+        const int j = TN[tI] * 16 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = TM[tI] * 16 + h + 4 * r;
+          const double v = g[tI][r];
+          if (i < 30) {
+            if (j < 30) rec[OFF_QT + i * 30 + j] = v;
+          } else if (i == 30) {
+            if (j < 30) g30v[j] = v;                                   // Pe^T R Px
+          } else if (i >= 32 && i < 32 + nt) {
+            if (j < 30) rec[OFF_PT + (i - 32) * 30 + j] = v;
+            else if (j == 30) g30v[i] = v;                             // Pu^T R Pe
+            else if (j >= 32 && j < 32 + nt) rec[OFF_RT + (i - 32) * MT + (j - 32)] = v;
+          }
+        }
+      }
     }
   }
   __syncthreads();
-  // G[a][lane] = sum_k W[k][a] z[k]   (= Pall_a^T R Pall_lane)
-  double g30 = 0.0;
-#pragma unroll 1
-  for (int a0 = 0; a0 < 31 + nt; a0 += 4) {  // four columns of W per trip: four independent FMA chains
-    double sg[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < 30; ++k) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sg[r] += WL[k * PAW + a0 + r] * z[k];  // columns beyond 30 + nt are padding (PAW = 50 >= 49 + 3)
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int aa = a0 + r;
-      if (aa >= 31 + nt) continue;
-      const double sv = sg[r];
-      if (aa == 30) g30 = sv;
-      if (isX) {
-        if (aa < 30) rec[OFF_QT + aa * 30 + lane] += sv;
-        else if (aa > 30) rec[OFF_PT + (aa - 31) * 30 + lane] = sv;
-      } else if (isU && aa > 30) rec[OFF_RT + (aa - 31) * MT + (lane - 31)] = sv;
-    }
-  }
-  if (isX) rec[OFF_qt + lane] = qc + tz + g30;
-  else if (isU) rec[OFF_rt + (lane - 31)] = tz + g30;
+  if (isX) rec[OFF_qt + lane] = qc + tz + g30v[lane];
+  else if (isU) rec[OFF_rt + (lane - 32)] = tz + g30v[lane];
 }
 
 }  // namespace qmk

@@ -38,7 +38,7 @@ struct qmgpu_context {
   // device buffers
   qmgpu_problem* dP = nullptr;
   double *dRw = nullptr, *dZeros = nullptr;
-  double *dTgrid = nullptr, *dX = nullptr, *dU = nullptr, *dStages = nullptr, *dMetrics = nullptr, *dGains = nullptr, *ddX = nullptr, *ddU = nullptr;
+  double *dTgrid = nullptr, *dX = nullptr, *dU = nullptr, *dStages = nullptr, *dAdRows = nullptr, *dMetrics = nullptr, *dGains = nullptr, *ddX = nullptr, *ddU = nullptr;
   double *dXt = nullptr, *dUt = nullptr, *dInstStats = nullptr, *dDebug = nullptr;
   int *dStageNc = nullptr, *dNodeMode = nullptr;
   // policy evaluation outputs feeding the WBC inside qmgpu_cycle_batch
@@ -99,6 +99,7 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     ctx->dX = ctx->alloc<double>(B * N1 * 30);
     ctx->dU = ctx->alloc<double>(B * N * 30);
     ctx->dStages = ctx->alloc<double>(B * N1 * STAGE_DOUBLES);
+    ctx->dAdRows = ctx->alloc<double>(B * N1 * AD_DOUBLES);
     ctx->dMetrics = ctx->alloc<double>(B * N1 * NODE_METRICS);
     ctx->dGains = ctx->alloc<double>(B * N * GAIN_DOUBLES);
     ctx->ddX = ctx->alloc<double>(B * N1 * 30);
@@ -187,7 +188,8 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, a->warm_x, a->warm_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU};
   QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
   LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
-            a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr};
+            a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows};
+  QM_LAUNCH(ad_node_kernel, B * (N + 1), 64, s, la);
   QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
   RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
