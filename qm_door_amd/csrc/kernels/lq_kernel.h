@@ -64,20 +64,20 @@ struct DuIn {
   __device__ __forceinline__ Vec3<Du> force(int c) const { return Vec3<Du>(su(3 * c), su(3 * c + 1), su(3 * c + 2)); }
 };
 
-// LDS of lq_node_kernel (doubles).  Region X is reused three times: EE-free Householder vectors + R1 during the QR, the
-// transposed dense rows of [A | B] for the first product, and W = R Pall for the second.
+// LDS of lq_node_kernel (doubles).  Region X is reused three times: the orthogonal factor Q and Y = R1^-T [C | e] after the QR,
+// the transposed dense rows of [A | B] for the first product, and W = R Pall for the second.
 constexpr int PAW = 50;                      // row stride of Pall = [Px | Pe | 0 | Pu] (columns 0..29, 30, 31, 32..32+m~-1)
 constexpr int CDW = 62;                      // row stride of [C | D | e] (61 used), aliases the Pall region
 constexpr int LDR = 34, LDT = 18;            // row strides of R / Q and of the transposed dense rows
-constexpr int L_X = 0;                       // X: Vh [16][32] + R1 [16][16]  |  At [32][LDT] + Bt [32][LDT]  |  W [32][PAW]
-constexpr int L_V = L_X, L_RL = L_X + 512, L_AT = L_X, L_BT = L_X + 32 * LDT, L_W = L_X;
-constexpr int L_R = L_X + 32 * PAW;          // R [32][LDR] (dt-scaled), later Q [32][LDR]
+constexpr int L_X = 0;                       // X: Q [32][LDR] + Y [16][LDR]  |  At [32][LDT] + Bt [32][LDT]  |  W [32][PAW]
+constexpr int L_AT = L_X, L_BT = L_X + 32 * LDT, L_W = L_X;
+constexpr int L_R = L_X + 48 * LDR;          // R [32][LDR] (dt-scaled), later Q [32][LDR]   (X holds Q [32][LDR] + Y [16][LDR] = 1632)
 constexpr int L_PA = L_R + 32 * LDR;         // Pall [32][PAW]  /  CD [16][CDW]
 constexpr int L_EEJ = L_PA + 32 * PAW;       // EE error Jacobian [6][32]
 constexpr int L_VEC = L_EEJ + 192;           // b[30] r[30] e[16] eeh[6] (+2) | g30[64]
 constexpr int L_RED = L_VEC + 84 + 64;       // wavefront exchange scratch [256]
 constexpr int LQ_LDS_DOUBLES = L_RED + 256;  // 5032 doubles = 39.3 KiB: four workgroups per CU
-static_assert(16 * CDW <= 32 * PAW && 512 + 256 <= 32 * PAW && 2 * 32 * LDT <= 32 * PAW, "aliases must fit");
+static_assert(16 * CDW <= 32 * PAW && 32 * PAW <= 48 * LDR && 2 * 32 * LDT <= 48 * LDR, "aliases must fit");
 static_assert(LQ_LDS_DOUBLES * 8 <= 40960, "four nodes per CU");
 
 // dot product of a broadcast LDS row with a register vector, three independent FMA chains (one wavefront per SIMD: the fp64 FMA
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
 
-  double* Rm = lds + L_R; double* Qm = lds + L_R; double* PA = lds + L_PA; double* CD = lds + L_PA; double* Vh = lds + L_V; double* RL = lds + L_RL;
+  double* Rm = lds + L_R; double* Qm = lds + L_R; double* PA = lds + L_PA; double* CD = lds + L_PA; 
   double* AT = lds + L_AT; double* BT = lds + L_BT; double* WL = lds + L_W;
   double* EEJ = lds + L_EEJ; double* bv = lds + L_VEC; double* rv = bv + 30; double* ev = rv + 30; double* eeh = ev + 16; double* g30v = bv + 84;
   double* red = lds + L_RED;
@@ -214,9 +214,17 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const double* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
   int nc = 0;
   if (!terminal) for (int k = 0; k < 4; ++k) nc += contactOf(mode, k) ? 3 : 4;
-  for (int r = 0; r < nc; ++r) { const double v = ad[AD_CD + r * 64 + lane]; if (lane < 60) CD[r * CDW + lane] = v; else if (lane == 60) ev[r] = v; }
+  {
+    double cdv[NCMAX], eev[6];   // all global loads in flight before the first LDS store
 #pragma unroll
-  for (int q = 0; q < 6; ++q) { const double v = ad[AD_EE + q * 64 + lane]; if (lane < 32) EEJ[q * 32 + lane] = v; else if (lane == 60) eeh[q] = v; }
+    for (int r = 0; r < NCMAX; ++r) cdv[r] = ad[AD_CD + (r < nc ? r : 0) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) eev[q] = ad[AD_EE + q * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < NCMAX; ++r) { if (r < nc) { if (lane < 60) CD[r * CDW + lane] = cdv[r]; else if (lane == 60) ev[r] = cdv[r]; } }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { if (lane < 32) EEJ[q * 32 + lane] = eev[q]; else if (lane == 60) eeh[q] = eev[q]; }
+  }
   double phid[12], phiv[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
@@ -357,99 +365,111 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   }
 
   // ================================================================== projection: Householder QR of D^T (30 x nc)
-  // lane j < nc owns column j of D^T (= row j of D); lane c < 31 owns column c of [C | e]
-  double z[30];
+  // Lane j < 16 owns column j of D^T (row j of D), lane 16 + c column c of the 30 x 30 identity: every reflector is applied to
+  // both, so the identity lanes end up with Q^T.  The reflector of step k is built by EVERY lane from column k, fetched with
+  // v_readlane from lane k: no LDS hand-off, no divergent branch, no barrier inside the factorisation.
+  const int nt = 30 - nc;  // projected input dimension m~
   {
-    double dcol[30];
+    double ce[NCMAX];   // my column of [C | e] (lanes <= 30)
 #pragma unroll
-    for (int i = 0; i < 30; ++i) dcol[i] = (lane < nc) ? CD[lane * CDW + 30 + i] : 0.0;
-    double ce[NCMAX];
+    for (int r = 0; r < NCMAX; ++r) {
+      const double cv = CD[(r < nc ? r : 0) * CDW + (lane < 30 ? lane : 0)], evr = ev[r];
+      ce[r] = (r < nc) ? (lane < 30 ? cv : (lane == 30 ? evr : 0.0)) : 0.0;
+    }
+    double qcol[30];
 #pragma unroll
-    for (int r = 0; r < NCMAX; ++r) ce[r] = (lane < 30 && r < nc) ? CD[r * CDW + lane] : ((lane == 30 && r < nc) ? ev[r] : 0.0);
-    __syncthreads();  // the [C D e] region is free from here on (it becomes W = R Pall)
-#pragma unroll 1
-    for (int k = 0; k < nc; ++k) {
-      if (lane == k) {
-        double n2 = 0.0, dk = 0.0;
+    for (int i = 0; i < 30; ++i) {
+      const double dv = CD[(lane < nc ? lane : 0) * CDW + 30 + i];
+      qcol[i] = lane < 16 ? (lane < nc ? dv : 0.0) : ((lane < 46 && i == lane - 16) ? 1.0 : 0.0);
+    }
+    __syncthreads();  // the [C D e] region is free from here on (it becomes Pall)
 #pragma unroll
-        for (int i = 0; i < 30; ++i) { if (i >= k) n2 += dcol[i] * dcol[i]; if (i == k) dk = dcol[i]; }
-        const double nrm = sqrt(n2);
+    for (int k = 0; k < NCMAX; ++k) {
+      if (k < nc) {
+        double v[30];
+        double n2a = 0.0, n2b = 0.0;
+#pragma unroll
+        for (int i = k; i < 30; ++i) { v[i] = qmReadLane(qcol[i], k, red); if ((i - k) & 1) n2b += v[i] * v[i]; else n2a += v[i] * v[i]; }
+        const double dk = v[k], tail2 = (n2a + n2b) - dk * dk;
+        const double nrm = sqrt(n2a + n2b);
         const double alpha = dk > 0.0 ? -nrm : nrm;
-        double vn = 0.0;
+        v[k] = dk - alpha;
+        const double vn = tail2 + v[k] * v[k];
+        const double beta = vn > 0.0 ? 2.0 / vn : 0.0;
+        double sa = 0.0, sb = 0.0;
 #pragma unroll
-        for (int i = 0; i < 30; ++i) {
-          const double v = (i > k) ? dcol[i] : ((i == k) ? dk - alpha : 0.0);
-          Vh[k * 32 + i] = v;
-          vn += v * v;
-          if (i == k) dcol[i] = alpha; else if (i > k) dcol[i] = 0.0;
-        }
-        Vh[k * 32 + 30] = vn > 0.0 ? 2.0 / vn : 0.0;
-      }
-      __syncthreads();
-      if (lane > k && lane < nc) {
-        double s = dot30(Vh + k * 32, dcol) * Vh[k * 32 + 30];
+        for (int i = k; i < 30; ++i) { if ((i - k) & 1) sb += v[i] * qcol[i]; else sa += v[i] * qcol[i]; }
+        const double sf = (sa + sb) * beta;
 #pragma unroll
-        for (int i = 0; i < 30; ++i) dcol[i] -= s * Vh[k * 32 + i];
+        for (int i = k; i < 30; ++i) qcol[i] = (lane == k) ? (i == k ? alpha : 0.0) : qcol[i] - sf * v[i];
       }
     }
-    // R1 (upper triangular, nc x nc): lane j holds column j
-    if (lane < 16) {
-#pragma unroll
-      for (int i = 0; i < NCMAX; ++i) RL[i * 16 + lane] = (lane < nc) ? dcol[i] : (i == lane ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    // Y = R1^-T [C | e]  (forward substitution, column per lane), then z = -Q [Y; 0]  /  z = Q e_{nc+j}
+    // Y = R1^-T [C | e]: forward substitution, R1[k][i] (k <= i) lives in lane i, register k
     double y[NCMAX];
 #pragma unroll
     for (int i = 0; i < NCMAX; ++i) {
-      double s = ce[i];
+      double sacc = ce[i];
 #pragma unroll
-      for (int k = 0; k < NCMAX; ++k) if (k < i) s -= RL[k * 16 + i] * y[k];
-      y[i] = (i < nc) ? s / RL[i * 16 + i] : 0.0;
+      for (int k = 0; k < i; ++k) sacc -= qmReadLane(qcol[k], i, red) * y[k];
+      const double d = qmReadLane(qcol[i], i, red);
+      y[i] = (i < nc) ? sacc / d : 0.0;
     }
+    // publish Y (rows k < 16, my column) and Q (lane 16 + c holds row c of Q) in region X
+    double* Ym = lds + L_X + 32 * LDR;
+    double* Qs = lds + L_X;
+    if (lane < 32) {
 #pragma unroll
-    for (int i = 0; i < 30; ++i) {
-      double v = 0.0;
-      if (lane <= 30) { if (i < NCMAX) v = -y[i < NCMAX ? i : 0]; }
-      else if (lane >= 32 && i == nc + (lane - 32)) v = 1.0;
-      z[i] = v;
+      for (int k = 0; k < NCMAX; ++k) Ym[k * LDR + lane] = lane <= 30 ? y[k] : 0.0;
+    }
+    if (lane >= 16 && lane < 48) {   // lanes 46, 47 clear the padding rows 30, 31
+#pragma unroll
+      for (int r = 0; r < 30; ++r) Qs[(lane - 16) * LDR + r] = lane < 46 ? qcol[r] : 0.0;
     }
   }
-  const int nt = 30 - nc;  // projected input dimension m~
-#pragma unroll 1
-  for (int k = nc - 1; k >= 0; --k) {
-    const double s = dot30(Vh + k * 32, z) * Vh[k * 32 + 30];
-#pragma unroll
-    for (int i = 0; i < 30; ++i) z[i] -= s * Vh[k * 32 + i];
-  }
-  // lane roles of the projection columns: lane < 30 column of Px, lane 30 = Pe, lanes 32 .. 32 + m~ - 1 columns of Pu
+  __syncthreads();
   const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
-  const bool active = isX || isE || isU;
-  double tz = 0.0;
+  {
+    // [Px | Pe] = -Q1 Y on the matrix cores; Pu = Q2 copied column by column
+    const double* Ym = lds + L_X + 32 * LDR;
+    const double* Qs = lds + L_X;
+    QmAcc pc[4];
 #pragma unroll
-  for (int i = 0; i < 30; ++i) tz += rv[i] * z[i];
-  if (isX) {
+    for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-    for (int i = 0; i < 30; ++i) rec[OFF_PX + i * 30 + lane] = z[i];
-  } else if (isE) {
+      for (int r = 0; r < 4; ++r) pc[t4][r] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 30; ++i) rec[OFF_PE + i] = z[i];
-  } else if (isU) {
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kk = 4 * ks + h;
+      const double a0 = -Qs[l16 * LDR + kk], a1 = -Qs[(16 + l16) * LDR + kk];
+      const double b0 = Ym[kk * LDR + l16], b1 = Ym[kk * LDR + 16 + l16];
+      qmMfma(pc[0], a0, b0, red); qmMfma(pc[1], a0, b1, red); qmMfma(pc[2], a1, b0, red); qmMfma(pc[3], a1, b1, red);
+    }
 #pragma unroll
-    for (int i = 0; i < 30; ++i) rec[OFF_PU + i * MT + (lane - 32)] = z[i];
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;
+        PA[i * PAW + j] = (i < 30 && j <= 30) ? pc[t4][r] : 0.0;    // rows 30,31 and column 31 are zero padding
+        if (i < 30) { if (j < 30) rec[OFF_PX + i * 30 + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + i] = pc[t4][r]; }
+      }
+    if (lane >= 32 && lane < PAW) {
+#pragma unroll
+      for (int i = 0; i < 30; ++i) {
+        const double qv = Qs[i * LDR + (isU ? nc + (lane - 32) : 0)];
+        PA[i * PAW + lane] = isU ? qv : 0.0;
+        if (isU) rec[OFF_PU + i * MT + (lane - 32)] = qv;
+      }
+      PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
+    }
   }
+  __syncthreads();   // Pall complete; Q / Y (region X) are dead
   // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
   for (int i = 12; i < 30; ++i) {
-    if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0 : 0.0) + dt * z[i];
-    else if (isE) rec[OFF_bt + i] = bv[i] + dt * z[i];
-    else if (isU) rec[OFF_BT + i * MT + (lane - 32)] = dt * z[i];
-  }
-  __syncthreads();   // the Householder vectors (region X) and [C D e] (Pall region) are dead from here on
-  if (lane < PAW) {
-#pragma unroll
-    for (int i = 0; i < 30; ++i) PA[i * PAW + lane] = active ? z[i] : 0.0;
-    PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
+    const double pv = PA[i * PAW + (lane < PAW ? lane : 0)];
+    if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0 : 0.0) + dt * pv;
+    else if (isE) rec[OFF_bt + i] = bv[i] + dt * pv;
+    else if (isU) rec[OFF_BT + i * MT + (lane - 32)] = dt * pv;
   }
   {  // transposed dense rows: At[j][i] = A[i][j], Bt[k][i] = B[i][k], i < 12 (columns 12..15 and rows 30,31 zero)
     double* dst = (lane < 30) ? AT + lane * LDT : (lane < 60 ? BT + (lane - 30) * LDT : AT + 30 * LDT + (lane - 60) * LDT);
@@ -458,6 +478,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0 : 0.0) : 0.0;
   }
+  if (lane < 30) Rm[lane * LDR + 30] = rv[lane];   // column 30 of R = r: row 30 of W = R Pall becomes r^T Pall
   __syncthreads();
 
   // ================================================================== products on the fp64 matrix cores
@@ -575,6 +596,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     }
   }
   __syncthreads();
+  const double tz = WL[30 * PAW + (lane < PAW ? lane : 0)];   // r^T Pall (row 30 of W)
   if (isX) rec[OFF_qt + lane] = qc + tz + g30v[lane];
   else if (isU) rec[OFF_rt + (lane - 32)] = tz + g30v[lane];
 }
