@@ -205,10 +205,10 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
                        double* q, double* r, double* C, double* D, double* e, int32_t* nc);
 
 /* Device time (ms) of each kernel of the last timed call, measured with HIP events on the handle's stream:
- * [0] lq_node  [1] riccati  [2] line search + update  [3] wbc  [4] whole call */
-int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms5);
+ * [0] ad_node  [1] lq_node (projection)  [2] riccati  [3] line search + update  [4] wbc  [5] whole call */
+int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms6);
 /* Same, averaged over the last `last_calls` timed calls (event ring of 256 calls; no per-call host sync is needed). */
-int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms5);
+int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6);
 int qmgpu_enable_timing(qmgpu_handle h, int enable);
 /* Allocate / enable the per-node dump read by qmgpu_debug_get_lq (off by default: 37 KiB per node). */
 int qmgpu_enable_debug(qmgpu_handle h, int enable);

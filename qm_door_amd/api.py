@@ -108,12 +108,12 @@ class GpuSolver:
         return R
 
     def last_kernel_ms(self):
-        ms = (abi.d * 5)()
+        ms = (abi.d * 6)()
         abi.check(self.lib, self.lib.qmgpu_last_kernel_ms(self.handle, ms))
         return list(ms)
 
     def kernel_ms_mean(self, last_calls):
-        ms = (abi.d * 5)()
+        ms = (abi.d * 6)()
         abi.check(self.lib, self.lib.qmgpu_kernel_ms_mean(self.handle, int(last_calls), ms))
         return list(ms)
 

@@ -6,8 +6,9 @@
 // NP = n padded (8 / 20 / 36) sizes every register array and loop.  Lane roles: lane i < m0 owns inequality ROW i
 // (slack, multiplier, residuals); lane c < NP owns COLUMN c (z_c, column c of K and of the identity during the factorisation).
 //   K = G + DZ' diag(w) DZ    on the fp64 matrix cores (16x16 tiles, upper triangle, mirrored into LDS)
-//   K = L L', L^-1            row operations on [K | I], one column per lane in registers, multipliers broadcast by v_readlane
-//   dz = L^-T (L^-1 rhs)      forward substitution + one dot product per lane, operands broadcast by v_readlane
+//   K = L L'                  row operations, one column per lane in registers, multipliers broadcast by v_readlane
+//   L t = rhs, L' dz = t      substitutions with the pivots' results broadcast by v_readlane (backward stable: no explicit
+//                             inverse -- the barrier weights reach 1e14 in the last iterations)
 // Nothing on the dependent chain of an iteration goes through LDS except the K tiles and the DZ rows/columns themselves.
 #pragma once
 #include "gpu_rt.h"
@@ -133,14 +134,13 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     }
     QM_WAVE_SYNC();
 
-    // ---- factorisation: lane c holds column c of K (kc) and of I (ic); after step j row j is [L^T | L^-1] row j
-    double kc[NP], ic[NP], myInv = 1.0;
+    // ---- factorisation K = L L^T by row operations: lane c holds column c of K in kc; after step j, kc[j] of lane c is
+    //      L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
+    double kc[NP], myInv = 1.0;
 #pragma unroll
     for (int r = 0; r < NP; ++r) {
-      const double kv = io.Kt[r * LDK_ + colL];   // K symmetric: column c read as row-major row c would conflict; this is conflict free
-      const double e = (r == lane) ? 1.0 : 0.0;
-      kc[r] = (colOn && r < n) ? kv : e;          // identity padding beyond n
-      ic[r] = e;
+      const double kv = io.Kt[r * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
+      kc[r] = (colOn && r < n) ? kv : ((r == lane) ? 1.0 : 0.0);   // identity padding beyond n
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -148,13 +148,23 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
       const double inv = qmRsqrt(dfl);
       kc[j] = (lane == j) ? dfl * inv : kc[j] * inv;
-      ic[j] *= inv;
       if (lane == j) myInv = inv;                              // 1 / L_jj
       const QmGather gk = qmGather(kc[j], red);                // L[r][j] = gk.get(r)
 #pragma unroll
-      for (int r = j + 1; r < NP; ++r) { const double f = gk.get(r); kc[r] -= f * kc[j]; ic[r] -= f * ic[j]; }
+      for (int r = j + 1; r < NP; ++r) kc[r] -= gk.get(r) * kc[j];
     }
-    // lane c now holds: kc[r] = L[c][r] (r <= c), ic[r] = L^-1[r][c] (r >= c, zero above)
+    // the back substitution L^T dz = t walks the COLUMNS of L^T: U[r][c] (c > r) sits in lane c, register r.  One transpose
+    // through LDS per factorisation puts it into lane r, register c.
+    QM_WAVE_SYNC();
+    if (lane < NP) {
+#pragma unroll
+      for (int r = 0; r < NP; ++r) io.Kt[lane * LDK_ + r] = kc[r];
+    }
+    QM_WAVE_SYNC();
+    double uc[NP];
+#pragma unroll
+    for (int cc = 0; cc < NP; ++cc) uc[cc] = io.Kt[cc * LDK_ + colL];   // U[lane][cc] for cc > lane
+    QM_WAVE_SYNC();
 
     double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0, dzc = 0.0;
     double alphaAff = 1.0, sigma = 0.0;
@@ -183,13 +193,16 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         if (lane == r) tC = tr;
         acc -= (lane > r) ? kc[r] * tr : 0.0;
       }
-      // dz = L^-T t: column c of L^-1 dotted with t
+      // L^T dz = t (back substitution; lane r owns row r of L^T in uc)
       {
-        double d0 = 0.0, d1 = 0.0;
-        const QmGather gT = qmGather(tC, red);
+        double bacc = tC;
 #pragma unroll
-        for (int r = 0; r < NP; r += 2) { d0 += ic[r] * gT.get(r); d1 += ic[r + 1] * gT.get(r + 1); }
-        dzc = colOn ? d0 + d1 : 0.0;
+        for (int cc = NP - 1; cc >= 0; --cc) {
+          const double dc = qmReadLane(bacc * myInv, cc, red);
+          if (lane == cc) dzc = dc;
+          bacc -= (lane < cc) ? uc[cc] * dc : 0.0;
+        }
+        dzc = colOn ? dzc : 0.0;
       }
       double Ddz;
       {

@@ -47,9 +47,9 @@ struct qmgpu_context {
   double* dWbcScratch = nullptr;
   std::vector<void*> allocations;
   bool timing = false, debugLq = false;
-  // HIP-event ring: one set of 6 events per call while timing is enabled, read back without a per-call sync
+  // HIP-event ring: one set of 7 events per call while timing is enabled, read back without a per-call sync
   static constexpr int kRing = 256;
-  hipEvent_t ring[kRing][6];
+  hipEvent_t ring[kRing][7];
   int ringKind[kRing];  // bit0: mpc recorded, bit1: wbc recorded
   long callCount = 0;   // calls recorded since timing was enabled
   hipEvent_t* ev = nullptr;
@@ -190,6 +190,7 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
             a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows};
   QM_LAUNCH(ad_node_kernel, B * (N + 1), 64, s, la);
+  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[6], s));
   QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
   RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
@@ -220,18 +221,23 @@ static void finishTiming(qmgpu_handle h, bool mpc, bool wbc) {
   h->ringKind[h->callCount % qmgpu_context::kRing] = (mpc ? 1 : 0) | (wbc ? 2 : 0);
   ++h->callCount;
 }
-// elapsed times of one recorded call: [lq, riccati, linesearch, wbc, whole]
-static void readTiming(qmgpu_handle h, long call, double* ms5) {
+// elapsed times of one recorded call: [ad_node, lq_node, riccati, linesearch, wbc, whole]  (events: 0 start, 6 after ad, 1 after lq, 2, 3, 4/5 wbc)
+static void readTiming(qmgpu_handle h, long call, double* ms6) {
   hipEvent_t* ev = h->ring[call % qmgpu_context::kRing];
   const int kind = h->ringKind[call % qmgpu_context::kRing];
   const bool mpc = kind & 1, wbc = kind & 2;
   HIP_CHECK(hipEventSynchronize(ev[wbc ? 5 : 3]));
   float ms = 0.f;
-  for (int i = 0; i < 5; ++i) ms5[i] = 0.0;
-  if (mpc) for (int i = 0; i < 3; ++i) { HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); ms5[i] = ms; }
-  if (wbc) { HIP_CHECK(hipEventElapsedTime(&ms, ev[4], ev[5])); ms5[3] = ms; }
+  for (int i = 0; i < 6; ++i) ms6[i] = 0.0;
+  if (mpc) {
+    HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[6])); ms6[0] = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev[6], ev[1])); ms6[1] = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev[1], ev[2])); ms6[2] = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, ev[2], ev[3])); ms6[3] = ms;
+  }
+  if (wbc) { HIP_CHECK(hipEventElapsedTime(&ms, ev[4], ev[5])); ms6[4] = ms; }
   HIP_CHECK(hipEventElapsedTime(&ms, ev[mpc ? 0 : 4], ev[wbc ? 5 : 3]));
-  ms5[4] = ms;
+  ms6[5] = ms;
 }
 
 int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args) {
@@ -295,22 +301,22 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
   });
 }
 
-int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms5) {
-  if (!h || !ms5) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
+int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms6) {
+  if (!h || !ms6) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
   return guarded([&]() {
     if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
-    readTiming(h, h->callCount - 1, ms5);
+    readTiming(h, h->callCount - 1, ms6);
   });
 }
 
-int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms5) {
-  if (!h || !ms5 || last_calls < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad argument");
+int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6) {
+  if (!h || !ms6 || last_calls < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad argument");
   return guarded([&]() {
     if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
     const long n = std::min<long>(std::min<long>(last_calls, h->callCount), qmgpu_context::kRing);
-    double acc[5] = {0, 0, 0, 0, 0};
-    for (long c = h->callCount - n; c < h->callCount; ++c) { double m[5]; readTiming(h, c, m); for (int i = 0; i < 5; ++i) acc[i] += m[i]; }
-    for (int i = 0; i < 5; ++i) ms5[i] = acc[i] / double(n);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (long c = h->callCount - n; c < h->callCount; ++c) { double m[6]; readTiming(h, c, m); for (int i = 0; i < 6; ++i) acc[i] += m[i]; }
+    for (int i = 0; i < 6; ++i) ms6[i] = acc[i] / double(n);
   });
 }
 
