@@ -55,7 +55,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     double Dz;
     {
       double d0 = 0.0, d1 = 0.0;
-#pragma unroll
+#pragma unroll 2
       for (int j = 0; j < NP; j += 2) { d0 += DZ[rowL * LDZ_ + j] * gz.get(j); d1 += DZ[rowL * LDZ_ + j + 1] * gz.get(j + 1); }
       Dz = d0 + d1;
     }
@@ -66,10 +66,10 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     double rdz;
     {
       double a0 = gC, a1 = 0.0;
-#pragma unroll
+#pragma unroll 2
       for (int j = 0; j < NP; j += 2) { a0 += G[j * LDK_ + colL] * gz.get(j); a1 += G[(j + 1) * LDK_ + colL] * gz.get(j + 1); }  // G symmetric
       const QmGather gl = qmGather(lamR, red);
-#pragma unroll
+#pragma unroll 2
       for (int i = 0; i < 56; i += 2) { a0 += DZ[i * LDZ_ + colL] * gl.get(i); a1 += DZ[(i + 1) * LDZ_ + colL] * gl.get(i + 1); }
       rdz = colOn ? a0 + a1 : 0.0;
     }
@@ -181,7 +181,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       {
         const QmGather gt = qmGather(tz, red);
         double a0 = -rdz, a1 = 0.0;
-#pragma unroll
+#pragma unroll 2
         for (int i = 0; i < 56; i += 2) { a0 -= DZ[i * LDZ_ + colL] * gt.get(i); a1 -= DZ[(i + 1) * LDZ_ + colL] * gt.get(i + 1); }
         acc = colOn ? a0 + a1 : 0.0;
       }
@@ -208,7 +208,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       {
         const QmGather gd = qmGather(dzc, red);
         double d0 = 0.0, d1 = 0.0;
-#pragma unroll
+#pragma unroll 2
         for (int j = 0; j < NP; j += 2) { d0 += DZ[rowL * LDZ_ + j] * gd.get(j); d1 += DZ[rowL * LDZ_ + j + 1] * gd.get(j + 1); }
         Ddz = d0 + d1;
       }
