@@ -108,6 +108,19 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   const qmgpu_settings& st = a.P->settings;
   double* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
   auto putRow = [&](int base, int row, Du h) { ad[base + row * 64 + lane] = (lane == 60) ? h.v : h.d; };
+  // Foot positions / joint-induced velocities wait in LDS (lane-private columns, conflict free) until the base twist is known
+  // at the end of the sweep: 96 VGPRs less for the register allocator during the tree sweep.
+  __shared__ double park[4 * 12 * 64];
+  auto parkFoot = [&](int c, const Vec3<Du>& r, const Vec3<Du>& v) {
+    double* p = park + (c * 12) * 64 + lane;
+    p[0] = r.x.v; p[64] = r.x.d; p[128] = r.y.v; p[192] = r.y.d; p[256] = r.z.v; p[320] = r.z.d;
+    p[384] = v.x.v; p[448] = v.x.d; p[512] = v.y.v; p[576] = v.y.d; p[640] = v.z.v; p[704] = v.z.d;
+  };
+  auto loadFoot = [&](int c, Vec3<Du>& r, Vec3<Du>& v) {
+    const double* p = park + (c * 12) * 64 + lane;
+    r = Vec3<Du>(Du(p[0], p[64]), Du(p[128], p[192]), Du(p[256], p[320]));
+    v = Vec3<Du>(Du(p[384], p[448]), Du(p[512], p[576]), Du(p[640], p[704]));
+  };
 
   const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
   const double t = tg[node];
@@ -130,12 +143,11 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
 #pragma unroll 1
   for (int stage = 0; stage < (terminal ? 1 : 2); ++stage) {
     const DuIn in{x, u, lane, stage ? dt : 0.0, k1};
-    Feet<Du> feet;
     Du f[12];
     BaseMotion<Du> bm;
     const Du p0x = in.sx(6) + in.dtS * k1[6], p0y = in.sx(7) + in.dtS * k1[7], p0z = in.sx(8) + in.dtS * k1[8];
     centroidalSweep<Du>(
-        md, st.gravity, in, [&](int c, Vec3<Du> r, Vec3<Du> v) { feet.set(c, r, v); },
+        md, st.gravity, in, [&](int c, Vec3<Du> r, Vec3<Du> v) { parkFoot(c, r, v); },
         [&](Vec3<Du> r, const Mat3<Du>& R) {
           if (stage == 0) {  // end-effector pose error (EndEffectorConstraint.cpp:36-78), rows -> LDS
             Du qee[4];
@@ -153,8 +165,9 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
           const bool contact = contactOf(mode, c);
-          const Vec3<Du> r = feet.r(c);
-          const Vec3<Du> vf = bm.dp + cross(bm.omega, r) + feet.v(c);
+          Vec3<Du> r, vj;
+          loadFoot(c, r, vj);
+          const Vec3<Du> vf = bm.dp + cross(bm.omega, r) + vj;
           auto putC = [&](int row, Du h) { putRow(AD_CD, row, h); };
           if (contact) {  // zeroVelocity (QMInterface.cpp:126, 324-339)
             putC(nc, vf.x); putC(nc + 1, vf.y); putC(nc + 2, vf.z);
