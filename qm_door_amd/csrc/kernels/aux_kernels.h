@@ -13,10 +13,7 @@ __global__ void __launch_bounds__(64) input_weight_kernel(const qmgpu_problem* P
   __shared__ double RJ[12 * 12];
   const int lane = threadIdx.x;
   const qmgpu_model& md = P->model;
-  Du k1[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) k1[i] = Du(0.0);
-  const DuIn in{P->settings.initial_state, zeros, lane, 0.0, k1};
+  const DuIn in{P->settings.initial_state, zeros, lane, 0.0, nullptr};   // dtS == 0: the parked first-stage slope is never read
   Feet<Du> feet;
   Du f[12];
   BaseMotion<Du> bm;

@@ -54,11 +54,12 @@ struct DuIn {
   const double* u;
   int lane;
   double dtS;
-  const Du* k1;  // [12] first-stage slope (zero while dtS == 0)
+  const double* k1p;  // first-stage slope parked in LDS (lane-private column): entry i = (k1p[2 i * 64], k1p[(2 i + 1) * 64]); unused while dtS == 0
   __device__ __forceinline__ Du sx(int i) const { return Du(x[i], lane == i ? 1.0 : 0.0); }
   __device__ __forceinline__ Du su(int i) const { return Du(u[i], lane == 30 + i ? 1.0 : 0.0); }
-  __device__ __forceinline__ Du hn(int i) const { return sx(i) + dtS * k1[i]; }
-  __device__ __forceinline__ Du euler(int i) const { return sx(9 + i) + dtS * k1[9 + i]; }
+  __device__ __forceinline__ Du k1(int i) const { return Du(k1p[(2 * i) * 64], k1p[(2 * i + 1) * 64]); }
+  __device__ __forceinline__ Du hn(int i) const { return dtS != 0.0 ? sx(i) + dtS * k1(i) : sx(i); }
+  __device__ __forceinline__ Du euler(int i) const { return dtS != 0.0 ? sx(9 + i) + dtS * k1(9 + i) : sx(9 + i); }
   __device__ __forceinline__ Du q(int j) const { return sx(12 + j) + dtS * su(12 + j); }
   __device__ __forceinline__ Du qd(int j) const { return su(12 + j); }
   __device__ __forceinline__ Vec3<Du> force(int c) const { return Vec3<Du>(su(3 * c), su(3 * c + 1), su(3 * c + 2)); }
@@ -136,16 +137,15 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   eeReference(tTimes, tStates, a.K, t, eePosRef, eeQuatRef);
 
   // ================================================================== phase AD: both RK2 stages with lane tangents
-  Du k1[12];  // first-stage slope; after the second stage it holds phi = dt/2 (k1 + k2)
-#pragma unroll
-  for (int i = 0; i < 12; ++i) k1[i] = Du(0.0);
+  __shared__ double parkK[24 * 64];   // first-stage slope k1 (12 dual numbers per lane), parked during the second sweep
+  double* k1p = parkK + lane;
   int nc = 0;
 #pragma unroll 1
   for (int stage = 0; stage < (terminal ? 1 : 2); ++stage) {
-    const DuIn in{x, u, lane, stage ? dt : 0.0, k1};
+    const DuIn in{x, u, lane, stage ? dt : 0.0, k1p};
     Du f[12];
     BaseMotion<Du> bm;
-    const Du p0x = in.sx(6) + in.dtS * k1[6], p0y = in.sx(7) + in.dtS * k1[7], p0z = in.sx(8) + in.dtS * k1[8];
+    const Du p0x = in.sx(6), p0y = in.sx(7), p0z = in.sx(8);   // base position (only the first stage uses it: EE error, swing height)
     centroidalSweep<Du>(
         md, st.gravity, in, [&](int c, Vec3<Du> r, Vec3<Du> v) { parkFoot(c, r, v); },
         [&](Vec3<Du> r, const Mat3<Du>& R) {
@@ -182,15 +182,18 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
           }
         }
       }
+      if (terminal) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) k1[i] = f[i];
+        for (int i = 0; i < 12; ++i) putRow(AD_PHI, i, f[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { k1p[(2 * i) * 64] = f[i].v; k1p[(2 * i + 1) * 64] = f[i].d; }
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) k1[i] = 0.5 * dt * (k1[i] + f[i]);
+      for (int i = 0; i < 12; ++i) putRow(AD_PHI, i, 0.5 * dt * (in.k1(i) + f[i]));   // phi = dt/2 (k1 + k2)
     }
   }
-#pragma unroll
-  for (int i = 0; i < 12; ++i) putRow(AD_PHI, i, k1[i]);
   if (lane == 0) { a.stageNc[size_t(inst) * (a.N + 1) + node] = nc; a.nodeMode[size_t(inst) * (a.N + 1) + node] = mode; }
 }
 
