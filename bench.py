@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BATCH_PER_GPU = 256
 HORIZON_N = 100
+TRAFFIC_FILE = "r01b_traffic.json"   # rocprofv3 PMC passes of this same command, summarised (bytes per launch)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public spec, v_mfma_f64_16x16x4_f64 (not listed in MI355X_MICROARCH.md)
 
 
@@ -147,6 +148,12 @@ def main():
         roof_kernel = dom_name if dom_name in flops else "riccati_kernel"
         kms = kernel_ms[names.index(roof_kernel)]
         achieved = flops[roof_kernel] / (kms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/, see its _how field)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            traffic = tr.get(roof_kernel, {}).get("bytes")
+        except OSError:
+            pass
         out = {
             "metric": "MPC+WBC cycles/sec (AlienGo+Z1, N=100)",
             "value": world * B * args.steps / elapsed,
@@ -164,7 +171,7 @@ def main():
                        "batch_per_gpu": B, "horizon_nodes": N, "gait": "trot", "seed": 0, "results_finite_and_converged": ok,
                        "collective": "all_gather(X,U,tau,mode) over RCCL" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "note": "algorithmic dense-contraction FLOPs of SURVEY.md 8(d) per launch / HIP-event kernel time; fp64 matrix peak is the public spec; "
                                  "the path is latency bound, not MFMA bound (DESIGN.md)",
                          "kernel_ms": dict(zip(names + ["whole_call"], kernel_ms)),

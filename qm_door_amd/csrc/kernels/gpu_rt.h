@@ -20,6 +20,7 @@ __device__ __forceinline__ double qmReadLane(double v, int src, double* scratch)
 // One v_mfma_f64_16x16x4_f64: C[16x16] += A[16x4] B[4x16].  Operand / result layout measured on gfx950 (tools/probe_mfma.hip):
 //   lane l supplies a = A[l % 16][l / 16] and b = B[l / 16][l % 16]; accumulator register r of lane l is C[l / 16 + 4 r][l % 16].
 typedef double QmAcc __attribute__((ext_vector_type(4)));
+typedef double QmD2 __attribute__((ext_vector_type(2)));   // 16-byte load/store unit (a native vector: stays in registers, unlike HIP's double2 struct)
 __device__ __forceinline__ void qmMfma(QmAcc& c, double a, double b, double* scratch) { (void)scratch; c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ double qmRsqrt(double x) { return rsqrt(x); }
 // upper-triangle tile set of a symmetric product: acc[(ti,tj), ti <= tj] += A_ti B_tj for one k step of 4
@@ -40,6 +41,13 @@ __device__ __forceinline__ QmGather qmGather(double v, double* scratch) { (void)
 __device__ __forceinline__ double qmAllSum(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64); return v; }
 __device__ __forceinline__ double qmAllMax(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64)); return v; }
 __device__ __forceinline__ double qmAllMin(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64)); return v; }
+// Workgroup barrier that orders LDS traffic only: waits for this wavefront's LDS operations, then s_barrier.  Unlike
+// __syncthreads() it does not drain outstanding global loads (vmcnt), so a register-staged prefetch of the next stage stays in
+// flight across the barriers of the current one.  Use only where the data exchanged through the barrier lives in LDS.
+#define QM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// kernels that can only ever have one wavefront per SIMD (LDS bound): let the register allocator use the whole file instead of
+// spilling to stay under the two-waves budget
+#define QM_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
 // dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)

@@ -40,10 +40,11 @@ struct RiccatiArgs {
 constexpr int RICCATI_WAVES = 4;
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
 constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48;
-constexpr int R_STG = 0;                          // staged record: OFF_PX doubles backward; the whole record forward (over Y)
-constexpr int R_Y = R_STG + OFF_PX + 4;           // Y [32][LDS_Y]
+constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
+constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
+constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
+constexpr int R_Y = R_STG + 2 * STG_B;            // Y [32][LDS_Y]
 constexpr int R_T = R_Y + 32 * LDS_Y;             // T [32][LDS_Y]
-constexpr int R_GAIN = R_STG + STAGE_DOUBLES;     // staged gains (forward only; aliases Y / T)
 constexpr int R_S = R_T + 32 * LDS_Y;             // S [32][LDS_S]
 constexpr int R_SV = R_S + 32 * LDS_S;            // s [32]
 constexpr int R_W = R_SV + 32;                    // W [20][LDS_W]
@@ -53,28 +54,35 @@ constexpr int R_VEC = R_LIT + 20 * LDS_W;         // dx[32] dut[32]
 constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][256]; armijo reduction
 constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 256;
 constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~105 KiB (dynamic LDS)
-static_assert(R_GAIN + GAIN_DOUBLES <= R_S, "forward-sweep staging must not reach the live value function");
+static_assert(2 * STG_F <= RICCATI_LDS_DOUBLES, "forward-sweep staging fits");
 
 // Register-staged HBM -> LDS copy for a whole workgroup: issue() puts PF 16-byte loads per thread in flight, commit() drains
 // them into LDS.  Between the two the workgroup computes on the *current* stage, so the memory latency of the next stage is
 // hidden without a second LDS buffer.
 template <int PF, int NTHR> struct StagePrefetch {
-  double2 v[PF];
+  // named members, not an array: an array indexed inside (even fully unrolled) loops was left in scratch memory by the compiler
+  // in this kernel, which turned the prefetch into an HBM round trip (profiles/r01b_notes.md)
+  static_assert(PF <= 13, "add members");
+  QmD2 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12;
+#define QM_PF_FOR_EACH(X) X(0, v0) X(1, v1) X(2, v2) X(3, v3) X(4, v4) X(5, v5) X(6, v6) X(7, v7) X(8, v8) X(9, v9) X(10, v10) X(11, v11) X(12, v12)
   __device__ __forceinline__ void issue(const double* src, int n, int tid) {
-    const double2* s2 = reinterpret_cast<const double2*>(src);
+    const QmD2* s2 = reinterpret_cast<const QmD2*>(src);
     const int n2 = n >> 1;
-#pragma unroll
-    for (int k = 0; k < PF; ++k) { const int idx = tid + k * NTHR; v[k] = s2[idx < n2 ? idx : tid]; }
+#define QM_PF_ISSUE(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; V = s2[idx < n2 ? idx : tid]; }
+    QM_PF_FOR_EACH(QM_PF_ISSUE)
+#undef QM_PF_ISSUE
   }
   __device__ __forceinline__ void commit(double* dst, int n, int tid) const {
-    double2* d2 = reinterpret_cast<double2*>(dst);
+    QmD2* d2 = reinterpret_cast<QmD2*>(dst);
     const int n2 = n >> 1;
-#pragma unroll
-    for (int k = 0; k < PF; ++k) { const int idx = tid + k * NTHR; if (idx < n2) d2[idx] = v[k]; }
+#define QM_PF_COMMIT(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (idx < n2) d2[idx] = V; }
+    QM_PF_FOR_EACH(QM_PF_COMMIT)
+#undef QM_PF_COMMIT
   }
+#undef QM_PF_FOR_EACH
 };
 
-template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(RiccatiArgs a) {
+template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIMD riccati_kernel(RiccatiArgs a) {
   static_assert(NW == 4, "tile ownership below is written for four wavefronts");
   QM_DYNAMIC_LDS(lds);
   constexpr int NTHR = NW * 64;
@@ -85,7 +93,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
   const int l16 = lane & 15, h = lane >> 4;   // MFMA operand coordinates of this lane
   const int inst = blockIdx.x;
   const int N = a.N;
-  double* stg = lds + R_STG; double* gn = lds + R_GAIN; double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
+  double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
   double* W = lds + R_W; double* LI = lds + R_LI; double* LIT = lds + R_LIT; double* dxv = lds + R_VEC; double* dut = dxv + 32;
   double* scr = lds + R_SCR + wave * 256; double* red = lds + R_SCR;
   const double* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
@@ -102,12 +110,14 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
-    pf.commit(stg, OFF_PX, tid);
+    pf.commit(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_PX, tid);
   }
   __syncthreads();
 
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
+    const double* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
+    double* stgNext = lds + R_STG + ((k + 1) & 1) * STG_B;    // buffer of stage k - 1
     const int nt = 30 - ncI[k];
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
@@ -136,7 +146,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
 #pragma unroll
       for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
-    __syncthreads();
+    QM_LDS_BARRIER();
     if (wave < nTiles) {
       QmAcc c0, c1;
 #pragma unroll
@@ -166,7 +176,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
 #pragma unroll
       for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r]; if (mtTiles == 2) T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
-    __syncthreads();
+    QM_LDS_BARRIER();
     // ---- P3: H = L L^T and L^-1 by row operations on [H | I]; lane c < 32 holds column c of H, lane 32 + c column c of I
     if (wave == 0) {
       const bool isH = lane < 32;
@@ -193,7 +203,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
         for (int r = 0; r < MT; ++r) { const double v = (c < nt && r < nt) ? col[r] : 0.0; LI[r * LDS_W + c] = v; LIT[c * LDS_W + r] = v; }
       }
     }
-    __syncthreads();
+    pf.commit(stgNext, OFF_PX, tid);   // stage k - 1 lands in the other buffer: wavefronts 1..3 do it while wavefront 0 factorises
+    QM_LDS_BARRIER();
     // ---- P4: W = L^-1 [G | g]: wavefront w owns tile (w >> 1, w & 1)
     const int tm = wave >> 1, tn = wave & 1;
     {
@@ -208,7 +219,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int i = tm * 16 + h + 4 * r; if (i < 20) W[i * LDS_W + tn * 16 + l16] = c[r]; }
     }
-    __syncthreads();
+    QM_LDS_BARRIER();
     // ---- P5: [K | k] = -L^-T W -> gains
     {
       QmAcc c;
@@ -259,21 +270,20 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
         if (i < 30) { if (j < 30) S[i * LDS_S + j] = c[r]; else if (j == 30) sv[i] = c[r]; }
       }
     }
-    __syncthreads();
-    pf.commit(stg, OFF_PX, tid);
-    __syncthreads();
+    QM_LDS_BARRIER();
   }
 
   // ================================================================== forward substitution
   // wavefront 0: du~ = K dx + k, du = Pe + Px dx + Pu du~ ; wavefront 1: dx+ = A~ dx + B~ du~ + b~ ; everybody prefetches
   constexpr int WX = 1 % NW;
+  __syncthreads();   // full barrier: the gains written to HBM by every wavefront are read back by all of them below
   {
     StagePrefetch<PFR, NTHR> pr;
     StagePrefetch<PFG, NTHR> pg;
     pr.issue(stagesI, STAGE_DOUBLES, tid);
     pg.issue(gainsI, GAIN_DOUBLES, tid);
-    pr.commit(stg, STAGE_DOUBLES, tid);
-    pg.commit(gn, GAIN_DOUBLES, tid);
+    pr.commit(lds + R_STG, STAGE_DOUBLES, tid);
+    pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
   if (tid < 30) dxv[tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
   double armijo = 0.0;
@@ -282,6 +292,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
   for (int k = 0; k < N; ++k) {
     const int nt = 30 - ncI[k];
     const int kn = k + 1 < N ? k + 1 : k;
+    const double* stg = lds + R_STG + (k & 1) * STG_F; const double* gn = stg + STAGE_DOUBLES;
+    double* stgNext = lds + R_STG + ((k + 1) & 1) * STG_F;
     StagePrefetch<PFR, NTHR> pr;
     StagePrefetch<PFG, NTHR> pg;
     pr.issue(stagesI + size_t(kn) * STAGE_DOUBLES, STAGE_DOUBLES, tid);
@@ -293,7 +305,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
       for (int c = 0; c < 30; c += 2) { s0 += gn[OFF_KFB + lane * 30 + c] * dxv[c]; s1 += gn[OFF_KFB + lane * 30 + c + 1] * dxv[c + 1]; }
       dut[lane] = s0 + s1;
     }
-    __syncthreads();
+    QM_LDS_BARRIER();
     double nx = 0.0;
     if (wave == 0 && lane < 30) {  // du = Pe + Px dx + Pu du~
       double s0 = stg[OFF_PE + lane], s1 = 0.0;
@@ -311,11 +323,11 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) riccati_kernel(Ricc
       armijo += stg[OFF_qt + lane] * dxv[lane];
     }
     if (wave == WX && lane >= 32 && lane < 32 + nt) armijo += stg[OFF_rt + (lane - 32)] * dut[lane - 32];
-    __syncthreads();
+    QM_LDS_BARRIER();
     if (wave == WX && lane < 30) dxv[lane] = nx;
-    pr.commit(stg, STAGE_DOUBLES, tid);
-    pg.commit(gn, GAIN_DOUBLES, tid);
-    __syncthreads();
+    pr.commit(stgNext, STAGE_DOUBLES, tid);
+    pg.commit(stgNext + STAGE_DOUBLES, GAIN_DOUBLES, tid);
+    QM_LDS_BARRIER();
   }
   if (wave == WX && lane < 30) {
     a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxv[lane];

@@ -27,6 +27,8 @@ inline std::barrier<>* g_emuBarrier = nullptr;
 inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one per 64-lane wavefront of the running workgroup
 
 #define __global__
+#define QM_ONE_WAVE_PER_SIMD
+#define QM_LDS_BARRIER() __syncthreads()
 #define __device__
 #define __host__
 #define __forceinline__ inline
@@ -88,6 +90,7 @@ inline double qmAllMin(double v, double* scratch) { return emuButterfly(v, scrat
 
 // v_mfma_f64_16x16x4_f64 on host threads: lane l supplies a = A[l % 16][l / 16], b = B[l / 16][l % 16]; register r of lane l is
 // C[l / 16 + 4 r][l % 16] (layout measured on gfx950, tools/probe_mfma.hip)
+struct QmD2 { double x, y; };
 struct QmAcc { double v[4]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
 inline void emuMfmaTile(QmAcc& c, const double* A, const double* B, unsigned lane) {
   const unsigned j = lane & 15u, h = lane >> 4;
