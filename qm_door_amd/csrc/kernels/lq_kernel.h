@@ -81,6 +81,9 @@ constexpr int LQ_LDS_DOUBLES = L_RED + 256;  // 5032 doubles = 39.3 KiB: four wo
 static_assert(16 * CDW <= 32 * PAW && 32 * PAW <= 48 * LDR && 2 * 32 * LDT <= 48 * LDR, "aliases must fit");
 static_assert(LQ_LDS_DOUBLES * 8 <= 40960, "four nodes per CU");
 
+// Both kernels of this file run one wavefront per workgroup: LDS hand-offs between lanes need no hardware barrier (a wavefront's
+// LDS operations complete in issue order), only the compiler fence QM_WAVE_SYNC() -- and, unlike __syncthreads(), that does not
+// wait for the global stores of the stage record that are still in flight.
 // dot product of a broadcast LDS row with a register vector, three independent FMA chains (one wavefront per SIMD: the fp64 FMA
 // latency is hidden by instruction-level parallelism only)
 __device__ __forceinline__ double dot30(const double* row, const double (&z)[30]) {
@@ -92,10 +95,10 @@ __device__ __forceinline__ double dot30(const double* row, const double (&z)[30]
 
 __device__ __forceinline__ double waveSum(double* red, int lane, double v) {
   red[lane] = v;
-  __syncthreads();
+  QM_WAVE_SYNC();
   double s = 0.0;
   for (int i = 0; i < 64; ++i) s += red[i];
-  __syncthreads();
+  QM_WAVE_SYNC();
   return s;
 }
 
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
   if (lane < LDR) { Rm[30 * LDR + lane] = 0.0; Rm[31 * LDR + lane] = 0.0; }   // zero padding rows of R / Q (k = 30, 31 of the tiles)
-  __syncthreads();
+  QM_WAVE_SYNC();
 
   double* rec = a.stages + (size_t(inst) * (a.N + 1) + node) * STAGE_DOUBLES;
   double* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       rv[c] = dt * rc;
     }
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
   if (dbg && c < 30) {
     for (int i = 0; i < 30; ++i) dbg[DBG_R + i * 30 + c] = Rm[i * LDR + c];
     dbg[DBG_b + c] = bv[c]; dbg[DBG_r + c] = rv[c];
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       const double dv = CD[(lane < nc ? lane : 0) * CDW + 30 + i];
       qcol[i] = lane < 16 ? (lane < nc ? dv : 0.0) : ((lane < 46 && i == lane - 16) ? 1.0 : 0.0);
     }
-    __syncthreads();  // the [C D e] region is free from here on (it becomes Pall)
+    QM_WAVE_SYNC();  // the [C D e] region is free from here on (it becomes Pall)
 #pragma unroll
     for (int k = 0; k < NCMAX; ++k) {
       if (k < nc) {
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       for (int r = 0; r < 30; ++r) Qs[(lane - 16) * LDR + r] = lane < 46 ? qcol[r] : 0.0;
     }
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
   const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
   {
     // [Px | Pe] = -Q1 Y on the matrix cores; Pu = Q2 copied column by column
@@ -478,7 +481,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
     }
   }
-  __syncthreads();   // Pall complete; Q / Y (region X) are dead
+  QM_WAVE_SYNC();   // Pall complete; Q / Y (region X) are dead
   // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
   for (int i = 12; i < 30; ++i) {
@@ -495,7 +498,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0 : 0.0) : 0.0;
   }
   if (lane < 30) Rm[lane * LDR + 30] = rv[lane];   // column 30 of R = r: row 30 of W = R Pall becomes r^T Pall
-  __syncthreads();
+  QM_WAVE_SYNC();
 
   // ================================================================== products on the fp64 matrix cores
   // (1) rows 0..11 of [A~ | b~ | B~] = [A | b | 0] + B Pall      (2) W = R Pall   -- one k loop, shared Pall operand
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       }
     }
   }
-  __syncthreads();   // R is dead: its region takes Q
+  QM_WAVE_SYNC();   // R is dead: its region takes Q
 
   // ---- state cost: column c of Q into LDS (accumulator initialisation of the last product)
   {
@@ -611,7 +614,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       }
     }
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
   const double tz = WL[30 * PAW + (lane < PAW ? lane : 0)];   // r^T Pall (row 30 of W)
   if (isX) rec[OFF_qt + lane] = qc + tz + g30v[lane];
   else if (isU) rec[OFF_rt + (lane - 32)] = tz + g30v[lane];

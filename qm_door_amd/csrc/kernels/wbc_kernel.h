@@ -161,9 +161,9 @@ __device__ __forceinline__ void symMul(const double* I6, const double* v, double
   o[0] = I6[0] * v[0] + I6[1] * v[1] + I6[2] * v[2]; o[1] = I6[1] * v[0] + I6[3] * v[1] + I6[4] * v[2]; o[2] = I6[2] * v[0] + I6[4] * v[1] + I6[5] * v[2];
 }
 
-__device__ __forceinline__ double wbcSum(double* red, int lane, double v) { red[lane] = v; __syncthreads(); double s = 0; for (int i = 0; i < 64; ++i) s += red[i]; __syncthreads(); return s; }
-__device__ __forceinline__ double wbcMax(double* red, int lane, double v) { red[lane] = v; __syncthreads(); double s = red[0]; for (int i = 1; i < 64; ++i) s = fmax(s, red[i]); __syncthreads(); return s; }
-__device__ __forceinline__ double wbcMin(double* red, int lane, double v) { red[lane] = v; __syncthreads(); double s = red[0]; for (int i = 1; i < 64; ++i) s = fmin(s, red[i]); __syncthreads(); return s; }
+__device__ __forceinline__ double wbcSum(double* red, int lane, double v) { red[lane] = v; QM_WAVE_SYNC(); double s = 0; for (int i = 0; i < 64; ++i) s += red[i]; QM_WAVE_SYNC(); return s; }
+__device__ __forceinline__ double wbcMax(double* red, int lane, double v) { red[lane] = v; QM_WAVE_SYNC(); double s = red[0]; for (int i = 1; i < 64; ++i) s = fmax(s, red[i]); QM_WAVE_SYNC(); return s; }
+__device__ __forceinline__ double wbcMin(double* red, int lane, double v) { red[lane] = v; QM_WAVE_SYNC(); double s = red[0]; for (int i = 1; i < 64; ++i) s = fmin(s, red[i]); QM_WAVE_SYNC(); return s; }
 
 // In-place Cholesky of the n x n matrix K (row stride LDK) in LDS, lane = row; pivots are floored at floorv
 // (1e-13 x the largest diagonal entry of the level's cost Hessian G, as in the oracle's choleskyFloored).
@@ -172,15 +172,15 @@ __device__ inline void ldsCholesky(double* K, int n, int lane, double floorv) {
   for (int j = 0; j < n; ++j) {
     const double d = K[j * LDK + j];
     const double dj = sqrt(d > floorv ? d : floorv);
-    __syncthreads();
+    QM_WAVE_SYNC();
     if (lane == j) K[j * LDK + j] = dj;
     else if (lane > j && lane < n) K[lane * LDK + j] = K[lane * LDK + j] / dj;
-    __syncthreads();
+    QM_WAVE_SYNC();
     if (lane > j && lane < n) {
       const double lij = K[lane * LDK + j];
       for (int q = j + 1; q <= lane; ++q) K[lane * LDK + q] -= lij * K[q * LDK + j];
     }
-    __syncthreads();
+    QM_WAVE_SYNC();
   }
 }
 // Solve L L^T x = y in place (y in LDS), lane = row.
@@ -188,18 +188,18 @@ __device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane)
 #pragma unroll 1
   for (int j = 0; j < n; ++j) {
     const double xj = y[j] / L[j * LDK + j];
-    __syncthreads();
+    QM_WAVE_SYNC();
     if (lane == j) y[j] = xj;
     else if (lane > j && lane < n) y[lane] -= L[lane * LDK + j] * xj;
-    __syncthreads();
+    QM_WAVE_SYNC();
   }
 #pragma unroll 1
   for (int j = n - 1; j >= 0; --j) {
     const double xj = y[j] / L[j * LDK + j];
-    __syncthreads();
+    QM_WAVE_SYNC();
     if (lane == j) y[j] = xj;
     else if (lane < j) y[lane] -= L[j * LDK + lane] * xj;
-    __syncthreads();
+    QM_WAVE_SYNC();
   }
 }
 
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   // ---- S1: inputs
   if (lane < 55) rbd[lane] = a.rbd[size_t(inst) * 55 + lane];
   if (lane < 30) { xDes[lane] = a.xDes[size_t(inst) * 30 + lane]; uDes[lane] = a.uDes[size_t(inst) * 30 + lane]; il[lane] = a.inputLast[size_t(inst) * 30 + lane]; }
-  __syncthreads();
+  QM_WAVE_SYNC();
   // ---- S2: Pinocchio coordinates of the measured state (WbcBase.cpp:150-156)
   if (lane == 0) {
     for (int i = 0; i < 3; ++i) { qM[i] = rbd[3 + i]; qM[3 + i] = rbd[i]; vM[i] = rbd[24 + 3 + i]; }
@@ -241,11 +241,11 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     for (int i = 0; i < 6; ++i) qD[i] = xDes[6 + i];
   }
   if (lane < 30) a.inputLast[size_t(inst) * 30 + lane] = uDes[lane];  // WbcBase.cpp:225
-  __syncthreads();
+  QM_WAVE_SYNC();
 
   // ---- S3: measured pass (zero generalized acceleration -> bias terms)
   bodyPass(md, qM, vM, nullptr, body, dof, lane);
-  __syncthreads();
+  QM_WAVE_SYNC();
   // body wrenches for the nonlinear effects: f = m (a_c + g), n = I alpha + w x I w
   if (lane < QMGPU_NB) {
     const double* o = body + lane * 33;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     symMul(o + 15, o + 21, Iw_w); symMul(o + 15, o + 24, Iw_al); cross3(o + 21, Iw_w, t);
     for (int i = 0; i < 3; ++i) { wr[lane * 3 + i] = md.mass[lane] * (acc[i] + (i == 2 ? st.gravity : 0.0)); wr[57 + lane * 3 + i] = Iw_al[i] + t[i]; }
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
   // ---- S4: lane k = generalized velocity k: nle_k, column k of M, Jacobian columns
   if (lane < NVV) {
     const int k = lane;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     }
     for (int i = 0; i < 9; ++i) mi[MI_EERM + i] = o[i];
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
 
   // ---- S5: desired pass.  v_des base from the centroidal map (WbcBase.cpp:217-219) with the MPC's own sweep.
   {
@@ -326,9 +326,9 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     centroidalSweep<double>(md, st.gravity, din, [&](int, Vec3<double>, Vec3<double>) {}, [&](Vec3<double>, const Mat3<double>&) {}, f, bm);
     if (lane == 0) for (int i = 0; i < 6; ++i) vD[i] = f[6 + i];
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
   bodyPass(md, qD, vD, mi + MI_JACC, body, dof, lane);
-  __syncthreads();
+  QM_WAVE_SYNC();
   if (lane == 0) {
     // momentum rate produced by (v_des, joint accelerations, zero base acceleration): Adot v + Aj qdd_j (WbcBase.cpp:231-234)
     double ct[3] = {0, 0, 0};
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     for (int i = 0; i < 3; ++i) { mi[MI_EEPD + i] = pos[i]; mi[MI_EEVD + i] = vel[i]; }
     for (int i = 0; i < 9; ++i) mi[MI_EERD + i] = body[md.ee_body * 33 + i];
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
 
   // ================================================================== hierarchical QP
   int status = 0;
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   // ---- task 0 inequality rows (kept hard, with their slacks, by the lower levels): torque limits + friction pyramid (+ zero rows)
   const int m0 = 36 + 5 * nst + 3 * nsw;
   for (int e = lane; e < MAXM * ND; e += 64) D0[e] = 0.0;
-  __syncthreads();
+  QM_WAVE_SYNC();
   if (lane < 18) {  // WbcBase.cpp:392-415; the LF leg limits are reused for every leg (WbcBase.cpp:599-600)
     const int i = lane;
     for (int j = 0; j < NVV; ++j) { D0[i * ND + j] = M[(6 + i) * NVV + j]; D0[(18 + i) * ND + j] = -M[(6 + i) * NVV + j]; }
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     }
     for (int r = 36; r < m0; ++r) f0[r] = 0.0;
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
 
   const int numLevels = 4;  // level 3 = minimum-norm completion (task x = 0) of whatever no task pinned
   int n = ND;  // current null-space dimension
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     if (n == 0) break;  // FLY: nothing left to decide
     // ---- assemble this level's equality task A x = b  (rows r)
     for (int e = lane; e < MAXR * ND; e += 64) A[e] = 0.0;
-    __syncthreads();
+    QM_WAVE_SYNC();
     int r = 0;
     if (level == 0) {
       r = 18;
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
         bvec[lane] = mi[MI_BACC + q] + st.kp_base_linear * (qD[q] - qM[q]) + st.kd_base_linear * (vD[q] - vM[q]);
       }
     }
-    __syncthreads();
+    QM_WAVE_SYNC();
 
 #ifdef QMGPU_EMU_DEBUG
     if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d r %d n %d b:", level, r, n); for (int i = 0; i < r; ++i) printf(" %.10g", bvec[i]); printf("\n"); }
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
       if (level > 0) { for (int q = 0; q < ND; ++q) s -= D0[lane * ND + q] * xs[q]; s += v0[lane]; }
       fhat[lane] = s;
     }
-    __syncthreads();
+    QM_WAVE_SYNC();
     // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
     for (int e = lane; e < ND * ND; e += 64) {
       const int i = e / ND, j = e % ND;
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     if (lane < ND) { double s = 0.0; if (lane < n) for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
     // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
-    __syncthreads();
+    QM_WAVE_SYNC();
 
     // ---- interior point iterations (ipm_dev.h): K on the matrix cores, factorisation and solves in registers
     const double pivotFloor = 1e-13 * qmAllMax(lane < n ? G[lane * LDK + lane] : 0.0, red);
@@ -579,16 +579,16 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
       if (n <= 8) it = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
       else if (n <= 20) it = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
       else it = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
-      __syncthreads();
+      QM_WAVE_SYNC();
     } else {
       // no inequality rows at all: z = -G^-1 g  (LDS Cholesky; never on the hot path of the reference's task sets)
       for (int e = lane; e < n * n; e += 64) K[(e / n) * LDK + (e % n)] = G[(e / n) * LDK + (e % n)];
       if (lane < n) dzs[lane] = -gs[lane];
-      __syncthreads();
+      QM_WAVE_SYNC();
       ldsCholesky(K, n, lane, pivotFloor);
       ldsCholSolve(K, n, dzs, lane);
       if (lane < n) zs[lane] = dzs[lane];
-      __syncthreads();
+      QM_WAVE_SYNC();
     }
     if (it >= 60) status |= (1 << level);
     // ---- x = x_prev + Z z (HoQp.h:31-34); keep the slack solution of task 0 (HoQp.cpp:152-158)
@@ -597,10 +597,10 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     // slack solution of task 0 = max(0, D x - f): the interior point leaves inactive slacks at O(sqrt(mu)) (degenerate
     // complementarity); the exact minimiser -- what qpOASES hands to the next level -- is restored from z.
     if (level == 0 && lane < m0) { double dzv = 0.0; for (int j = 0; j < n; ++j) dzv += DZ[lane * LDZ + j] * zs[j]; v0[lane] = fmax(0.0, dzv - fhat[lane]); }
-    __syncthreads();
+    QM_WAVE_SYNC();
     if (lane < ND) xs[lane] = xn;
 #ifdef QMGPU_EMU_DEBUG
-    __syncthreads();
+    QM_WAVE_SYNC();
     if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d it %d x:", level, it); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
 #endif
     if (level == numLevels - 1) break;
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
             Vh[kk * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
           }
         }
-        __syncthreads();
+        QM_WAVE_SYNC();
         const bool indep = ctl[0] > tol2;
         if (indep && lane > j && lane < r) {
           double s = 0.0;
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
 #pragma unroll
           for (int i = 0; i < ND; ++i) dcol[i] -= s * Vh[kk * 40 + i];
         }
-        __syncthreads();
+        QM_WAVE_SYNC();
         if (indep) ++kk;
       }
       const int rank = kk, nNew = n - rank;
@@ -666,13 +666,13 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
           Zn[i * LDZ + lane] = s;
         }
       }
-      __syncthreads();
+      QM_WAVE_SYNC();
       for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
       n = nNew;
-      __syncthreads();
+      QM_WAVE_SYNC();
     }
   }
-  __syncthreads();
+  QM_WAVE_SYNC();
   // ---- updateCmd (WbcBase.cpp:580-595): tau = [M_j, -J_j^T] x + h_j
   if (lane < ND) a.out[size_t(inst) * 54 + lane] = xs[lane];
   if (lane < 18) {
