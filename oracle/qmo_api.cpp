@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdio>
 #include <memory>
+#include <thread>
 
 #include "qmo_mpc.h"
 #include "qmo_wbc.h"
@@ -188,6 +189,27 @@ double qmo_time_cycles(const qmgpu_problem* P, int count, int N, const double* x
     double il[30] = {0}, out[54];
     wbcUpdate(*P, 0, X.data(), U.data(), rbds + i * 55, md[0], 0.002, 20.0, il, out);
   }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// Same, instances spread over `threads` host threads (thread t takes instances t, t + threads, ...): the "all hardware threads
+// over instances" baseline of SURVEY.md 8(d).  Every solve is self-contained (thread_local scratch only).
+double qmo_time_cycles_mt(const qmgpu_problem* P, int count, int N, const double* x0s, int K, const double* ttimes, const double* tstates, int nEv, const double* ev,
+                          const int32_t* modes, const double* rbds, int lineSearch, int threads) {
+  if (threads < 1) threads = 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([=]() {
+      std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(8);
+      std::vector<int32_t> md(N + 1);
+      for (int i = t; i < count; i += threads) {
+        qmo_mpc_solve(P, N, 0.0, x0s + i * 30, nullptr, K, ttimes, tstates, nEv, ev, modes, nullptr, nullptr, lineSearch, T.data(), X.data(), U.data(), md.data(), st.data());
+        double il[30] = {0}, out[54];
+        wbcUpdate(*P, 0, X.data(), U.data(), rbds + i * 55, md[0], 0.002, 20.0, il, out);
+      }
+    });
+  for (auto& th : pool) th.join();
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 

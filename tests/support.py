@@ -151,9 +151,12 @@ class Oracle:
         ra, rd = int(dims[0]), int(dims[1])
         return dict(A=A[:ra], b=b[:ra], D=D[:rd], f=f[:rd])
 
-    def time_cycles(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, line_search=True):
-        self.lib.qmo_time_cycles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        return self.lib.qmo_time_cycles(C.byref(self.P), count, N, p(x0s), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), p(rbds), int(line_search))
+    def time_cycles(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, line_search=True, threads=1):
+        """Seconds of wall clock for `count` MPC+WBC cycles on `threads` host threads (instances interleaved over the threads)."""
+        self.lib.qmo_time_cycles_mt.restype = C.c_double
+        self.lib.qmo_time_cycles_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_int]
+        return self.lib.qmo_time_cycles_mt(C.byref(self.P), count, N, p(x0s), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), p(rbds), int(line_search), int(threads))
 
 
 def load_problem(lib):
