@@ -142,6 +142,15 @@ int qmgpu_mode_from_string(const char* name); /* "LF_RH" -> 9, unknown -> -1 */
 int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, double t_end,
                     int32_t* num_events, double* event_times /*[MAX_EVENTS]*/, int32_t* modes /*[MAX_EVENTS+1]*/);
 
+/* Shooting grid over [t0, tf] the way upstream ocs2::timeDiscretizationWithEvents lays it out for the SQP solver built at
+ * qm_controllers/src/QMController.cpp:288-289 (dt = task.info:79): steps of dt, every event time inside (t0, tf) becomes a
+ * node and the dt stepping restarts from it; a remainder shorter than 1e-3 dt is merged into its neighbour.  Upstream keeps a
+ * (pre-event, post-event) node pair at the same time; with the identity jump map of this robot the zero-length stage is a
+ * no-op and only one node is emitted (a node takes the mode that starts at its time).
+ * Writes num_nodes_minus_1 (= N to pass as qmgpu_mpc_args::num_nodes) and grid[0..N].  QMGPU_ERR_CAPACITY if N > max_nodes. */
+int qmgpu_time_grid_with_events(double t0, double tf, double dt, int32_t num_events, const double* event_times,
+                                int32_t max_nodes, int32_t* num_nodes_minus_1, double* grid);
+
 /* ---- device context ---------------------------------------------------------------------------- */
 int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, qmgpu_handle* out);
 int qmgpu_destroy(qmgpu_handle h);

@@ -70,6 +70,16 @@ class GaitSchedule:
         return n.value, np.array(ev[:]), np.array(md[:], dtype=np.int32)
 
 
+def time_grid_with_events(t0, tf, dt, event_times, max_nodes=1024, lib=None):
+    """Shooting grid with the mode-switch times as nodes (upstream timeDiscretizationWithEvents); returns (N, grid[N + 1])."""
+    lib = lib or abi.load_library()
+    ev = np.ascontiguousarray(event_times, dtype=np.float64)
+    n = abi.i32(0)
+    grid = np.zeros(max_nodes + 1)
+    abi.check(lib, lib.qmgpu_time_grid_with_events(t0, tf, dt, len(ev), ev.ctypes.data_as(C.POINTER(abi.d)), max_nodes, C.byref(n), grid.ctypes.data_as(C.POINTER(abi.d))))
+    return n.value, grid[:n.value + 1].copy()
+
+
 class GpuSolver:
     """Owns a qmgpu handle (device scratch + stream)."""
 

@@ -345,4 +345,22 @@ int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, dou
   return QMGPU_OK;
 }
 
+int qmgpu_time_grid_with_events(double t0, double tf, double dt, int32_t num_events, const double* event_times, int32_t max_nodes, int32_t* n_out, double* grid) {
+  if (!(dt > 0.0) || !(tf > t0) || !n_out || !grid || (num_events > 0 && !event_times)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad time grid arguments");
+  const double eps = 1e-3 * dt;
+  std::vector<double> g{t0};
+  int nextEv = 0;
+  while (nextEv < num_events && event_times[nextEv] <= t0 + eps) ++nextEv;   // events at or before t0 are already in force
+  while (g.back() < tf - eps) {
+    double t = g.back() + dt;
+    if (nextEv < num_events && event_times[nextEv] <= t + eps && event_times[nextEv] < tf - eps) t = event_times[nextEv++];
+    if (t > tf - eps) t = tf;
+    g.push_back(t);
+  }
+  if (int(g.size()) - 1 > max_nodes) return setError(QMGPU_ERR_CAPACITY, "time grid needs more nodes than max_nodes");
+  *n_out = int(g.size()) - 1;
+  for (size_t i = 0; i < g.size(); ++i) grid[i] = g[i];
+  return QMGPU_OK;
+}
+
 }  // extern "C"

@@ -59,3 +59,27 @@ def test_sqp_iteration_matches_oracle(interface, oracle, N, B):
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
         assert r["stats"][i][4] == ref["stats"][4] and r["stats"][i][5] == ref["stats"][5]
         assert np.allclose(r["stats"][i][:4], ref["stats"][:4], rtol=1e-8, atol=1e-10)
+
+
+def test_event_aligned_grid_matches_oracle(interface, oracle):
+    """Shooting grid with the mode switches as nodes (qmgpu_time_grid_with_events, non-uniform dt) -- same bar as the uniform grid."""
+    import gpu_harness as G
+    from qm_door_amd import api
+    B = 2
+    dt = interface.problem.settings.dt
+    x_nom = interface.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=2)
+    tgt = S.nominal_target(oracle, x_nom)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.04)
+    N, grid = api.time_grid_with_events(0.0, 0.6, dt, ev[:nev], lib=interface.lib)
+    assert N > 40 and (np.diff(grid) < 0.9 * dt).any()          # at least one shortened step before a switch
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N, time_grid=np.tile(grid, (B, 1)))
+    sol.mpc(mb.args)
+    r = mb.results()
+    for i in range(B):
+        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md, time_grid=grid)
+        assert np.array_equal(r["T"][i], grid) and np.array_equal(r["mode"][i], ref["mode"])
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())

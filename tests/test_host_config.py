@@ -109,3 +109,25 @@ def test_tile_gait(hip_lib):
     g = gs.template("trot")
     nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
     assert hip_lib.qmgpu_tile_gait(C.byref(g), 0.0, 0.0, 100.0, C.byref(nn), e, m) == abi.ERR_CAPACITY
+
+
+def test_time_grid_with_events(hip_lib):
+    from qm_door_amd import api
+    dt = 0.015
+    n, g = api.time_grid_with_events(0.0, 0.3, dt, [0.05, 0.2, 0.4], lib=hip_lib)
+    assert g[0] == 0.0 and g[-1] == 0.3 and n == len(g) - 1
+    assert 0.05 in g and 0.2 in g and 0.4 not in g                     # events inside the horizon are nodes
+    steps = np.diff(g)
+    assert (steps > 1e-3 * dt).all() and (steps <= dt * (1 + 1e-9)).all()
+    k = int(np.where(g == 0.05)[0][0])
+    assert np.isclose(g[k + 1], 0.05 + dt)                              # the dt stepping restarts from the event
+    # no events: the plain uniform grid; an event closer than 1e-3 dt to a grid point does not create a sliver
+    n2, g2 = api.time_grid_with_events(1.0, 1.0 + 10 * dt, dt, [], lib=hip_lib)
+    assert n2 == 10 and np.allclose(g2, 1.0 + dt * np.arange(11))
+    n3, g3 = api.time_grid_with_events(0.0, 0.15, dt, [0.03 + 1e-6 * dt], lib=hip_lib)
+    assert n3 == 10 and (np.diff(g3) > 0.9 * dt).all()
+    # capacity
+    import ctypes as C
+    from qm_door_amd import abi
+    buf = (abi.d * 8)(); nn = abi.i32(0)
+    assert hip_lib.qmgpu_time_grid_with_events(0.0, 1.0, dt, 0, None, 7, C.byref(nn), buf) == abi.ERR_CAPACITY
