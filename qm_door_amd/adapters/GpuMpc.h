@@ -50,8 +50,8 @@ class GpuSqpSolver final : public ocs2::SolverBase {
 
   void runImpl(ocs2::scalar_t initTime, const ocs2::vector_t& initState, ocs2::scalar_t finalTime) override {
     // 1. time grid with events: upstream timeDiscretizationWithEvents(initTime, finalTime, dt, eventTimes); the device accepts an
-    //    arbitrary grid through qmgpu_mpc_args::time_grid.  (Event nodes -- pre/post pairs with dt = 0 -- are a documented gap of
-    //    round 1: the grid passed here contains each event time once.)
+    //    arbitrary grid through qmgpu_mpc_args::time_grid.  qmgpu_time_grid_with_events emits each event time once (upstream's
+    //    zero-length pre/post pair is a no-op for this robot's identity jump map).
     const auto& modeSchedule = ref_->getModeSchedule();
     std::vector<double> grid = makeGrid(initTime, finalTime, P_.settings.dt, modeSchedule.eventTimes);
     const int N = static_cast<int>(grid.size()) - 1;
@@ -64,16 +64,10 @@ class GpuSqpSolver final : public ocs2::SolverBase {
     haveSolution_ = true;
   }
   static std::vector<double> makeGrid(double t0, double tf, double dt, const std::vector<double>& events) {
-    std::vector<double> g{t0};
-    double t = t0;
-    size_t e = 0;
-    while (e < events.size() && events[e] <= t0) ++e;
-    while (t < tf - 1e-9) {
-      double next = std::min(t + dt, tf);
-      if (e < events.size() && events[e] < next - 1e-9) { next = events[e]; ++e; }
-      g.push_back(next);
-      t = next;
-    }
+    std::vector<double> g(1025);
+    int32_t n = 0;
+    if (qmgpu_time_grid_with_events(t0, tf, dt, static_cast<int32_t>(events.size()), events.data(), 1024, &n, g.data()) != QMGPU_OK) throw std::runtime_error(qmgpu_last_error());
+    g.resize(n + 1);
     return g;
   }
   void stageAndSolve(const std::vector<double>& grid, const ocs2::vector_t& x0, const ocs2::ModeSchedule& ms);
