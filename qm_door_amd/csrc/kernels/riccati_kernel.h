@@ -39,7 +39,7 @@ struct RiccatiArgs {
 
 constexpr int RICCATI_WAVES = 4;
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
-constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48;
+constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34;
 constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
 constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
 constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
@@ -94,6 +94,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const int inst = blockIdx.x;
   const int N = a.N;
   double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
+  double* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)
   double* W = lds + R_W; double* LI = lds + R_LI; double* LIT = lds + R_LIT; double* dxv = lds + R_VEC; double* dut = dxv + 32;
   double* scr = lds + R_SCR + wave * 256; double* red = lds + R_SCR;
   const double* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
@@ -263,11 +264,21 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[8 + ks] = -W[kk * LDS_W + tm * 16 + l16]; bw[8 + ks] = W[kk * LDS_W + j]; }
 #pragma unroll
       for (int ks = 0; ks < 13; ++ks) qmMfma(c, av[ks], bw[ks], scr);
-      // nobody reads S or s between P1 and the end of the stage: store in place
+      // The raw result goes to a scratch square (T is dead; stride 34 makes both the row and the column walk conflict free), s' in
+      // place; after the barrier S = (C + C^T) / 2.  Without the symmetrisation the antisymmetric part of the rounding error is
+      // propagated by the OPEN-loop dynamics (it sees A~^T . A~ but not the cancelling G^T H^-1 G) and grows ~1.13x per stage.
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
-        if (i < 30) { if (j < 30) S[i * LDS_S + j] = c[r]; else if (j == 30) sv[i] = c[r]; }
+        TS[i * LDS_TS + j] = c[r];
+        if (i < 30 && j == 30) sv[i] = c[r];
+      }
+      QM_LDS_BARRIER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tm * 16 + h + 4 * r;
+        const double up = TS[i * LDS_TS + j], lo = TS[j * LDS_TS + i];
+        if (i < 30 && j < 30) S[i * LDS_S + j] = 0.5 * (up + lo);
       }
     }
     QM_LDS_BARRIER();

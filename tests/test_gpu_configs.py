@@ -1,0 +1,93 @@
+"""-m gpu: the other BASELINE.json configurations as parity cases.
+
+  config 3: batch 2048, randomised base pose + EE target (the 8-GPU weak-scaling workload, here all on one GPU)
+  config 5: mixed gait schedule stance -> trot -> flying_trot -> static_walk (nc in {12, 14, 16, 13}, FLY nodes), N = 200, batch 1024,
+            fp64 only (the fp32 half of the sweep is not built)
+Sampled instances are compared with the oracle at the north_star tolerance; the whole batch must be finite, factorised and carry
+bit-exact mode tables.
+"""
+import numpy as np
+import pytest
+
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_schedule(t_end):
+    """Templates of gait.info laid end to end: 0.4 s stance, then trot / flying_trot / static_walk cycles until t_end."""
+    from qm_door_amd import abi, api
+    gs = api.GaitSchedule()
+    ev, md = [], [15]
+    t = 0.4
+    names = ["trot", "flying_trot", "static_walk"]
+    k = 0
+    while t < t_end:
+        g = gs.template(names[k % 3]); k += 1
+        for i in range(g.num_modes):
+            m = int(g.modes[i])
+            if m == md[-1]:
+                t += g.switching_times[i + 1] - g.switching_times[i]
+                continue
+            ev.append(t); md.append(m)
+            t += g.switching_times[i + 1] - g.switching_times[i]
+    ev.append(t); md.append(15)
+    assert len(ev) <= abi.MAX_EVENTS
+    evp = np.full(abi.MAX_EVENTS, 1e300); evp[:len(ev)] = ev
+    mdp = np.full(abi.MAX_EVENTS + 1, 15, dtype=np.int32); mdp[:len(md)] = md
+    return len(ev), evp, mdp
+
+
+def test_config5_mixed_gaits_n200_batch1024(interface, oracle):
+    import gpu_harness as G
+    B, N = 1024, 200
+    dt = interface.problem.settings.dt
+    x_nom = interface.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=3)
+    tgt = S.nominal_target(oracle, x_nom)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = _mixed_schedule(N * dt + 0.2)
+    modes = np.array([oracle.mode_at(ev[:nev], md[:nev + 1], k * dt) for k in range(N + 1)], dtype=np.int32)
+    assert {15, 9, 6, 0}.issubset(set(modes.tolist())) and len(set(modes.tolist())) >= 6      # stance, trot pair, FLY, three-leg phases
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.mpc(mb.args)
+    r = mb.results()
+    assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and (r["stats"][:, 7] == 0).all()
+    assert np.array_equal(r["mode"], np.tile(modes, (B, 1)))
+    for i in (0, 511, 1023):
+        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        assert r["stats"][i][4] == ref["stats"][4]
+
+
+def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
+    import gpu_harness as G
+    import torch
+    B, N = 2048, 100
+    rng = np.random.default_rng(1)
+    x_nom = interface.initial_state
+    x0 = np.tile(x_nom, (B, 1))
+    xy = rng.uniform(-0.5, 0.5, (B, 2)); yaw = rng.uniform(-0.5, 0.5, B)
+    x0[:, 6:8] = xy; x0[:, 9] = yaw
+    ts = np.zeros((B, 1, 37)); tt = np.zeros((B, 1))
+    for i in range(B):   # target = hold the randomised base pose; EE = base + Rz(yaw) (0.6, 0, 0.036) + U(-0.1, 0.1)^3, yaw-only orientation
+        c, s = np.cos(yaw[i]), np.sin(yaw[i])
+        ee = np.r_[xy[i, 0] + c * 0.6, xy[i, 1] + s * 0.6, x_nom[8] + 0.036] + rng.uniform(-0.1, 0.1, 3)
+        ts[i, 0] = np.r_[x0[i], ee, 0.0, 0.0, np.sin(yaw[i] / 2), np.cos(yaw[i] / 2)]
+    nev, ev, md = S.trot_schedule(N * interface.problem.settings.dt + 1.0)
+    rbd = np.zeros((B, 55)); rbd[:, 0:3] = x0[:, 9:12]; rbd[:, 3:6] = x0[:, 6:9]; rbd[:, 6:24] = x0[:, 12:30]
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    wb = G.WbcBatch(rbd, np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
+    sol.cycle(mb.args, G.dev(np.zeros(B), torch.float64), wb.args)
+    r, w = mb.results(), wb.results()
+    assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(w["out"]).all()
+    assert (r["stats"][:, 7] == 0).all() and (w["status"] == 0).all()
+    for i in (0, 1000, 2047):
+        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        st, out, _ = oracle.wbc_update(ref["X"][0], ref["U"][0], rbd[i], int(ref["mode"][0]), 0.002, 20.0, np.zeros(30))
+        assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
