@@ -208,6 +208,36 @@ int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args);
 /* One control cycle per robot: MPC solve, policy evaluation at t_eval, WBC.  */
 int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t_eval /*[batch]*/, qmgpu_wbc_args* wbc);
 
+/* ---- front end of a control cycle: what sits immediately before the MPC call ----------
+ * (1) state estimate -> MPC observation: rbdState[55] -> centroidal state x[30] with the yaw unwrapped against the previous
+ *     observation (QMController::updateStateEstimation, qm_controllers/src/QMController.cpp:239-244; upstream
+ *     CentroidalModelRbdConversions::computeCentroidalStateFromRbdModel);
+ * (2) command -> TargetTrajectories (two knots of 37-dim states), the free functions of
+ *     qm_controllers/src/QmTargetTrajectoriesPublisher_node.cpp:
+ *       kind 0  hold           the initial target of QMController::starting (QMController.cpp:107-113)
+ *       kind 1  base cmd_vel   cmdVelToTargetTrajectories (:89-129), command = (vx, vy, vz, yaw rate) in the base frame
+ *       kind 2  EE cmd_vel     EeCmdVelToTargetTrajectories (:134-188)
+ *       kind 3  EE goal pose   EEgoalPoseToTargetTrajectories (:195-238) + positionCommandCallback (:240-254),
+ *                              command = position (3) + quaternion x y z w (4)
+ * The outputs plug straight into the MPC arguments: x0, target_times, target_states with num_target_knots = 2. */
+typedef struct qmgpu_frontend_args {
+  int32_t batch;
+  const double* rbd_measured;   /* [batch][55] */
+  const double* time;           /* [batch] observation time */
+  const double* yaw_last;       /* [batch] yaw of the previous observation, or NULL (no unwrapping) */
+  const int32_t* command_kind;  /* [batch] 0..3 */
+  const double* command;        /* [batch][7] */
+  double* last_ee_target;       /* [batch][7] in/out: lastEeTarget_ of the publisher (position + quaternion xyzw) */
+  const double* feet_height;    /* [batch] mean z of the contact feet (FEET_HEIGHT, :27-35), or NULL -> 0 */
+  double arm_dist;              /* StartingPosition.h:13 (0.6) */
+  double start_x, start_y, start_psi; /* StartingPosition.h:9-12 (-2, 0, 0): only kind 0 uses them */
+  double* x0;                   /* [batch][30] out */
+  double* target_times;         /* [batch][2] out */
+  double* target_states;        /* [batch][2][37] out */
+} qmgpu_frontend_args;
+
+int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* args);
+
 /* Diagnostics used by the parity tests: per-node LQ blocks of the last qmgpu_mpc_solve_batch
  * (before projection: A B b | Q R q r | C D e ; nc rows valid).  Host pointers, any may be NULL. */
 int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double* B, double* b, double* Q, double* R,

@@ -179,6 +179,73 @@ int qmo_wbc_task(const qmgpu_problem* P, int variant, const double* xDes, const 
 }
 
 // CPU baseline: time `count` full MPC(+WBC) cycles, returns seconds.
+
+// ---- front end of a control cycle
+// x0: upstream CentroidalModelRbdConversions::computeCentroidalStateFromRbdModel as used at qm_controllers/src/QMController.cpp:239-244:
+//     Pinocchio velocity v = [v_lin, ZYX Euler rates (from the world angular velocity), joint rates], x = [A(q) v / m ; q], yaw unwrapped.
+// targets: qm_controllers/src/QmTargetTrajectoriesPublisher_node.cpp:59-254 and QMController.cpp:107-113 (kind 0).
+void qmo_frontend(const qmgpu_problem* P, const double* rbd, double time, int haveYawLast, double yawLast, int kind, const double* cmd, double* lastEe, double feetHeight,
+                  double armDist, double startX, double startY, double startPsi, double* x0, double* tt /*2*/, double* ts /*2x37*/) {
+  const qmgpu_settings& st = P->settings;
+  double q[NV], v[NV];
+  for (int i = 0; i < 3; ++i) { q[i] = rbd[3 + i]; q[3 + i] = rbd[i]; v[i] = rbd[27 + i]; }
+  for (int j = 0; j < 18; ++j) { q[6 + j] = rbd[6 + j]; v[6 + j] = rbd[30 + j]; }
+  { const double sz = std::sin(q[3]), cz = std::cos(q[3]), sy = std::sin(q[4]), cy = std::cos(q[4]);
+    const double wx = rbd[24], wy = rbd[25], wz = rbd[26], tmp = cz * wx / cy + sz * wy / cy;
+    v[3] = sy * tmp + wz; v[4] = -sz * wx + cz * wy; v[5] = tmp; }
+  Kin<double> k; forwardKinematics<double>(P->model, q, k);
+  double Am[6][NV]; centroidalMomentumMatrix(P->model, k, Am);
+  for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < NV; ++j) s += Am[i][j] * v[j]; x0[i] = s / P->model.total_mass; }
+  for (int j = 0; j < NV; ++j) x0[6 + j] = q[j];
+  if (haveYawLast) { double d = std::fmod(x0[9] - yawLast + M_PI, 2 * M_PI); if (d < 0) d += 2 * M_PI; x0[9] = yawLast + d - M_PI; }
+
+  const double T = st.time_horizon, zRef = st.com_height + feetHeight;
+  const double* ee = rbd + 48; const double* bc = x0 + 6;
+  double s0[37] = {0}, s1[37] = {0}, tReach = time + T;
+  for (int j = 0; j < 18; ++j) s0[12 + j] = s1[12 + j] = st.default_joint_state[j];
+  s0[6] = bc[0]; s0[7] = bc[1]; s0[8] = zRef; s0[9] = bc[3];
+  auto rotQ = [](const double* qq, const double* vv, double* o) {   // Eigen::Quaterniond::toRotationMatrix() * v, qq = (x, y, z, w)
+    const double x = qq[0], y = qq[1], z = qq[2], w = qq[3];
+    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)}, {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                            {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+    for (int i = 0; i < 3; ++i) o[i] = R[i][0] * vv[0] + R[i][1] * vv[1] + R[i][2] * vv[2];
+  };
+  if (kind == 1) {
+    const M3<double> Rb = axisRotation<double>(2, bc[3]) * axisRotation<double>(1, bc[4]) * axisRotation<double>(0, bc[5]);   // getRotationMatrixFromZyxEulerAngles
+    double vr[3]; for (int i = 0; i < 3; ++i) vr[i] = Rb.m[i][0] * cmd[0] + Rb.m[i][1] * cmd[1] + Rb.m[i][2] * cmd[2];
+    s1[6] = bc[0] + vr[0] * T; s1[7] = bc[1] + vr[1] * T; s1[8] = zRef; s1[9] = bc[3] + cmd[3] * T;
+    const double d = std::sqrt((lastEe[0] - ee[0]) * (lastEe[0] - ee[0]) + (lastEe[1] - ee[1]) * (lastEe[1] - ee[1]) + (lastEe[2] - ee[2]) * (lastEe[2] - ee[2]));
+    if (d > 0.1) for (int i = 0; i < 3; ++i) lastEe[i] = ee[i];
+    for (int i = 0; i < 7; ++i) s0[30 + i] = s1[30 + i] = lastEe[i];
+    for (int i = 0; i < 3; ++i) s0[i] = s1[i] = vr[i];
+  } else if (kind == 2) {
+    const double qi[4] = {0, 0, -std::sin(bc[3] / 2), std::cos(bc[3] / 2)};
+    double tmp[3], vr[3]; rotQ(qi, cmd, tmp); rotQ(ee + 3, tmp, vr);
+    double e2[7]; for (int i = 0; i < 7; ++i) e2[i] = ee[i];
+    e2[0] = ee[0] + vr[0] * T; e2[1] = ee[1] + vr[1] * T; e2[2] = lastEe[2]; e2[3] = lastEe[3]; e2[4] = lastEe[4];
+    e2[5] = ee[5] + std::sin(vr[2] * T / 2); e2[6] = ee[6] + std::cos(vr[2] * T / 2);
+    const double yaw = std::atan2(2.0 * (e2[6] * e2[5] + e2[3] * e2[4]), 1.0 - 2.0 * (e2[4] * e2[4] + e2[5] * e2[5]));
+    s1[6] = e2[0] - armDist * std::cos(bc[3]); s1[7] = e2[1] - armDist * std::sin(bc[3]); s1[8] = zRef; s1[9] = yaw;
+    for (int i = 0; i < 7; ++i) { s0[30 + i] = ee[i]; s1[30 + i] = e2[i]; }
+  } else if (kind == 3) {
+    const double yaw = std::atan2(2.0 * (cmd[6] * cmd[5] + cmd[3] * cmd[4]), 1.0 - 2.0 * (cmd[4] * cmd[4] + cmd[5] * cmd[5]));
+    s1[6] = cmd[0] - armDist * std::cos(yaw); s1[7] = cmd[1] - armDist * std::sin(yaw); s1[8] = zRef; s1[9] = yaw;
+    const V3<double> od = quaternionDistance<double>(ee + 3, cmd + 3);
+    const double disp = std::sqrt((cmd[0] - ee[0]) * (cmd[0] - ee[0]) + (cmd[1] - ee[1]) * (cmd[1] - ee[1]) + (cmd[2] - ee[2]) * (cmd[2] - ee[2]));
+    const double rot = std::sqrt(od[0] * od[0] + od[1] * od[1] + od[2] * od[2]);
+    tReach = time + std::max(rot / st.target_rotation_velocity, disp / st.target_displacement_velocity);
+    for (int i = 0; i < 7; ++i) { s0[30 + i] = ee[i]; s1[30 + i] = cmd[i]; lastEe[i] = cmd[i]; }
+  } else {
+    for (int i = 0; i < 24; ++i) s0[i] = x0[i];
+    for (int i = 0; i < 6; ++i) s0[24 + i] = st.initial_state[24 + i];
+    s0[30] = startX + armDist * std::cos(startPsi); s0[31] = startY + armDist * std::sin(startPsi); s0[32] = st.com_height + rbd[5];
+    s0[33] = 0; s0[34] = 0; s0[35] = std::sin(startPsi / 2); s0[36] = std::cos(startPsi / 2);
+    for (int i = 0; i < 37; ++i) s1[i] = s0[i];
+  }
+  tt[0] = time; tt[1] = tReach;
+  for (int i = 0; i < 37; ++i) { ts[i] = s0[i]; ts[37 + i] = s1[i]; }
+}
+
 double qmo_time_cycles(const qmgpu_problem* P, int count, int N, const double* x0s /*count x 30*/, int K, const double* ttimes, const double* tstates, int nEv,
                        const double* ev, const int32_t* modes, const double* rbds /*count x 55*/, int lineSearch) {
   std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(8);

@@ -75,6 +75,16 @@ class WbcArgs(C.Structure):
     ]
 
 
+class FrontendArgs(C.Structure):
+    _fields_ = [
+        ("batch", i32),
+        ("rbd_measured", C.c_void_p), ("time", C.c_void_p), ("yaw_last", C.c_void_p), ("command_kind", C.c_void_p), ("command", C.c_void_p),
+        ("last_ee_target", C.c_void_p), ("feet_height", C.c_void_p),
+        ("arm_dist", d), ("start_x", d), ("start_y", d), ("start_psi", d),
+        ("x0", C.c_void_p), ("target_times", C.c_void_p), ("target_states", C.c_void_p),
+    ]
+
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 DATA_DIR = os.path.join(PKG_DIR, "data")
 LIB_PATH = os.path.join(PKG_DIR, "libqmgpu.so")
@@ -83,7 +93,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libqmgpu.so")
 SYMBOLS = [
     "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_time_grid_with_events",
     "qmgpu_create", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
-    "qmgpu_policy_eval_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
+    "qmgpu_policy_eval_batch", "qmgpu_frontend_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
     "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_kernel_ms_mean",
 ]
 
@@ -123,6 +133,7 @@ def load_library(path=None):
     lib.qmgpu_load_problem.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Problem)]
     lib.qmgpu_load_gait.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(Gait)]
     lib.qmgpu_mode_from_string.argtypes = [C.c_char_p]
+    lib.qmgpu_frontend_batch.argtypes = [C.c_void_p, C.POINTER(FrontendArgs)]
     lib.qmgpu_tile_gait.argtypes = [C.POINTER(Gait), d, d, d, C.POINTER(i32), C.POINTER(d), C.POINTER(i32)]
     lib.qmgpu_time_grid_with_events.argtypes = [d, d, d, i32, C.POINTER(d), i32, C.POINTER(i32), C.POINTER(d)]
     lib.qmgpu_create.argtypes = [C.POINTER(Problem), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

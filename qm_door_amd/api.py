@@ -150,6 +150,21 @@ class GpuSolver:
         a._keep = (state_desired, input_desired, rbd, mode, period, time, input_last, out, out_status)
         return a
 
+    @staticmethod
+    def frontend_args(batch, rbd, time, command_kind, command, last_ee_target, x0, target_times, target_states, yaw_last=None, feet_height=None,
+                      arm_dist=0.6, start_x=-2.0, start_y=0.0, start_psi=0.0):
+        """Defaults are the constants of qm_controllers/include/qm_controllers/StartingPosition.h:9-13."""
+        a = abi.FrontendArgs()
+        a.batch, a.arm_dist, a.start_x, a.start_y, a.start_psi = batch, arm_dist, start_x, start_y, start_psi
+        for name, val in (("rbd_measured", rbd), ("time", time), ("yaw_last", yaw_last), ("command_kind", command_kind), ("command", command),
+                          ("last_ee_target", last_ee_target), ("feet_height", feet_height), ("x0", x0), ("target_times", target_times), ("target_states", target_states)):
+            setattr(a, name, _ptr(val))
+        a._keep = (rbd, time, yaw_last, command_kind, command, last_ee_target, feet_height, x0, target_times, target_states)
+        return a
+
+    def frontend(self, args):
+        abi.check(self.lib, self.lib.qmgpu_frontend_batch(self.handle, C.byref(args)))
+
     def mpc(self, args):
         abi.check(self.lib, self.lib.qmgpu_mpc_solve_batch(self.handle, C.byref(args)))
 

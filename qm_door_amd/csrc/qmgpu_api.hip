@@ -21,6 +21,7 @@
 #include "kernels/lq_kernel.h"
 #include "kernels/riccati_kernel.h"
 #include "kernels/wbc_kernel.h"
+#include "kernels/frontend_kernel.h"
 
 using namespace qmhost;
 using namespace qmk;
@@ -249,6 +250,16 @@ int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const doub
   if (!h || !t_grid || !X || !U || !modes || !t_eval || !x_out || !u_out || !mode_out || batch < 1 || num_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments");
   return guarded([&]() {
     QM_LAUNCH(policy_eval_kernel, (batch + 63) / 64, 64, h->stream, batch, num_nodes, t_grid, X, U, modes, t_eval, x_out, u_out, mode_out);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* a) {
+  if (!h || !a || a->batch < 1 || !a->rbd_measured || !a->time || !a->command_kind || !a->command || !a->last_ee_target || !a->x0 || !a->target_times || !a->target_states)
+    return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad front-end arguments");
+  return guarded([&]() {
+    FrontendArgs fa{h->dP, *a};
+    QM_LAUNCH(frontend_kernel, (a->batch + 63) / 64, 64, h->stream, fa);
     HIP_CHECK(hipGetLastError());
   });
 }

@@ -151,6 +151,16 @@ class Oracle:
         ra, rd = int(dims[0]), int(dims[1])
         return dict(A=A[:ra], b=b[:ra], D=D[:rd], f=f[:rd])
 
+    def frontend(self, rbd, time, kind, cmd, last_ee, yaw_last=None, feet_height=0.0, arm_dist=0.6, start=(-2.0, 0.0, 0.0)):
+        x0, tt, ts = np.zeros(30), np.zeros(2), np.zeros((2, 37))
+        le = np.array(last_ee, dtype=np.float64)
+        self.lib.qmo_frontend.restype = None
+        self.lib.qmo_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.qmo_frontend(C.byref(self.P), p(np.ascontiguousarray(rbd)), time, int(yaw_last is not None), float(yaw_last or 0.0), int(kind), p(np.ascontiguousarray(cmd)),
+                              p(le), feet_height, arm_dist, start[0], start[1], start[2], p(x0), p(tt), p(ts))
+        return x0, tt, ts, le
+
     def time_cycles(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, line_search=True, threads=1):
         """Seconds of wall clock for `count` MPC+WBC cycles on `threads` host threads (instances interleaved over the threads)."""
         self.lib.qmo_time_cycles_mt.restype = C.c_double

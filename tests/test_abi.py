@@ -25,14 +25,14 @@ def test_struct_layout_matches_c():
     src = r'''
     #include <stdio.h>
     #include "qmgpu.h"
-    int main(void) { printf("%zu %zu %zu %zu %zu %zu\n", sizeof(qmgpu_model), sizeof(qmgpu_settings), sizeof(qmgpu_problem), sizeof(qmgpu_gait),
-                            sizeof(qmgpu_mpc_args), sizeof(qmgpu_wbc_args)); return 0; }
+    int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(qmgpu_model), sizeof(qmgpu_settings), sizeof(qmgpu_problem), sizeof(qmgpu_gait),
+                            sizeof(qmgpu_mpc_args), sizeof(qmgpu_wbc_args), sizeof(qmgpu_frontend_args)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(S.ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
-    assert sizes == [C.sizeof(abi.Model), C.sizeof(abi.Settings), C.sizeof(abi.Problem), C.sizeof(abi.Gait), C.sizeof(abi.MpcArgs), C.sizeof(abi.WbcArgs)]
+    assert sizes == [C.sizeof(abi.Model), C.sizeof(abi.Settings), C.sizeof(abi.Problem), C.sizeof(abi.Gait), C.sizeof(abi.MpcArgs), C.sizeof(abi.WbcArgs), C.sizeof(abi.FrontendArgs)]
 
 
 def test_no_cpu_fallback(hip_lib, interface):

@@ -1,0 +1,120 @@
+"""Front end of a control cycle: rbdState -> centroidal state, command -> TargetTrajectories."""
+import numpy as np
+import pytest
+
+import support as S
+
+
+def _cases(interface, oracle, n, seed=5):
+    rng = np.random.default_rng(seed)
+    x_nom = interface.initial_state
+    out = []
+    for i in range(n):
+        x = x_nom + rng.uniform(-1, 1, 30) * np.r_[np.zeros(6), 0.5, 0.5, 0.05, 2.5, 0.1, 0.1, np.full(18, 0.2)]
+        v = rng.uniform(-1, 1, 24) * 0.5                       # [omega_world(3), v_lin(3), qj_dot(18)] as the estimator reports them
+        rbd = S.rbd_from_state(oracle, x, v)
+        kind = i % 4
+        if kind == 3:
+            yaw = rng.uniform(-1, 1)
+            cmd = np.r_[rbd[48:51] + rng.uniform(-0.3, 0.3, 3), 0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)]
+        else:
+            cmd = np.r_[rng.uniform(-0.5, 0.5, 4), np.zeros(3)]
+        last_ee = np.r_[rbd[48:51] + rng.uniform(-0.15, 0.15, 3), rbd[51:55]]
+        out.append(dict(rbd=rbd, time=rng.uniform(0, 30), kind=kind, cmd=cmd, last_ee=last_ee, yaw_last=x[9] + rng.choice([-2, 0, 2]) * np.pi + rng.uniform(-0.2, 0.2),
+                        feet=rng.uniform(0, 0.05)))
+    return out
+
+
+def test_oracle_centroidal_state_is_momentum_consistent(interface, oracle):
+    """x0[0:6] * m equals the momentum the flow map's own base-velocity inversion is built on: feeding x0 and the measured joint
+    rates back through the flow map must return the measured base twist (rows 6..11 of f)."""
+    for c in _cases(interface, oracle, 6):
+        x0, _, _, _ = oracle.frontend(c["rbd"], c["time"], 0, c["cmd"], c["last_ee"])
+        u = np.zeros(30); u[12:] = c["rbd"][30:48]
+        f = oracle.flow_map(x0, u)
+        assert np.allclose(f[6:9], c["rbd"][27:30], atol=1e-10)            # base linear velocity
+        sz, cz, sy, cy = np.sin(x0[9]), np.cos(x0[9]), np.sin(x0[10]), np.cos(x0[10])
+        wx, wy, wz = c["rbd"][24:27]
+        tmp = cz * wx / cy + sz * wy / cy
+        assert np.allclose(f[9:12], [sy * tmp + wz, -sz * wx + cz * wy, tmp], atol=1e-10)   # ZYX Euler rates of the measured angular velocity
+        assert np.array_equal(x0[6:12], np.r_[c["rbd"][3:6], c["rbd"][0:3]]) and np.array_equal(x0[12:], c["rbd"][6:24])
+
+
+def test_oracle_targets_follow_the_publisher_rules(interface, oracle):
+    st = interface.problem.settings
+    T = st.time_horizon
+    for c in _cases(interface, oracle, 8):
+        x0, tt, ts, le = oracle.frontend(c["rbd"], c["time"], c["kind"], c["cmd"], c["last_ee"], yaw_last=c["yaw_last"], feet_height=c["feet"])
+        assert abs(x0[9] - c["yaw_last"]) <= np.pi + 1e-12 and np.isclose(np.sin(x0[9]), np.sin(c["rbd"][0]))     # unwrapped, same angle
+        assert tt[0] == c["time"] and np.array_equal(ts[:, 12:30], np.tile(st.default_joint_state[:], (2, 1))) or c["kind"] == 0
+        if c["kind"] in (1, 2, 3):
+            assert np.isclose(ts[0, 8], st.com_height + c["feet"]) and np.isclose(ts[1, 8], st.com_height + c["feet"]) and (ts[:, 10:12] == 0).all()
+        if c["kind"] == 1:
+            assert np.isclose(tt[1], c["time"] + T) and np.allclose(ts[1, 6:8] - x0[6:8], ts[0, 0:2] * T) and np.isclose(ts[1, 9], x0[9] + c["cmd"][3] * T)
+            moved = np.linalg.norm(c["last_ee"][:3] - c["rbd"][48:51]) > 0.1
+            assert np.array_equal(le[:3], c["rbd"][48:51] if moved else c["last_ee"][:3]) and np.array_equal(ts[0, 30:], le) and np.array_equal(ts[1, 30:], le)
+        if c["kind"] == 3:
+            assert np.array_equal(ts[1, 30:], c["cmd"]) and np.array_equal(le, c["cmd"]) and np.array_equal(ts[0, 30:], c["rbd"][48:55])
+            yaw = 2 * np.arctan2(c["cmd"][5], c["cmd"][6])
+            assert np.allclose(ts[1, 6:8], c["cmd"][:2] - 0.6 * np.array([np.cos(yaw), np.sin(yaw)])) and np.isclose(ts[1, 9], yaw)
+            disp = np.linalg.norm(c["cmd"][:3] - c["rbd"][48:51])
+            assert tt[1] - c["time"] >= disp / st.target_displacement_velocity - 1e-12
+        if c["kind"] == 0:
+            assert np.array_equal(ts[0], ts[1]) and np.array_equal(ts[0, :24], x0[:24]) and np.isclose(ts[0, 30], -2 + 0.6)
+
+
+@pytest.mark.gpu
+def test_frontend_matches_oracle(interface, oracle):
+    import gpu_harness as G
+    import torch
+    cs = _cases(interface, oracle, 16)
+    B = len(cs)
+    f64 = torch.float64
+    rbd = G.dev(np.array([c["rbd"] for c in cs]), f64); tm = G.dev(np.array([c["time"] for c in cs]), f64)
+    yl = G.dev(np.array([c["yaw_last"] for c in cs]), f64); kd = G.dev(np.array([c["kind"] for c in cs]), torch.int32)
+    cmd = G.dev(np.array([c["cmd"] for c in cs]), f64); le = G.dev(np.array([c["last_ee"] for c in cs]), f64); fh = G.dev(np.array([c["feet"] for c in cs]), f64)
+    x0 = torch.zeros((B, 30), dtype=f64, device="cuda"); tt = torch.zeros((B, 2), dtype=f64, device="cuda"); ts = torch.zeros((B, 2, 37), dtype=f64, device="cuda")
+    sol = G.make_solver(interface, B, 4)
+    sol.frontend(sol.frontend_args(B, rbd, tm, kd, cmd, le, x0, tt, ts, yaw_last=yl, feet_height=fh))
+    torch.cuda.synchronize()
+    x0, tt, ts, le = x0.cpu().numpy(), tt.cpu().numpy(), ts.cpu().numpy(), le.cpu().numpy()
+    for i, c in enumerate(cs):
+        rx, rt, rs, rl = oracle.frontend(c["rbd"], c["time"], c["kind"], c["cmd"], c["last_ee"], yaw_last=c["yaw_last"], feet_height=c["feet"])
+        assert np.abs(x0[i] - rx).max() <= 1e-12 * max(1.0, np.abs(rx).max()), (i, c["kind"])      # two formulations of A(q) v
+        assert np.abs(tt[i] - rt).max() <= 1e-12 * max(1.0, np.abs(rt).max()) and np.abs(ts[i] - rs).max() <= 1e-12 * max(1.0, np.abs(rs).max()), (i, c["kind"])
+        assert np.abs(le[i] - rl).max() <= 1e-15
+
+
+@pytest.mark.gpu
+def test_frontend_mpc_wbc_chain_stays_on_device(interface, oracle):
+    """estimate + command -> front end -> MPC (two-knot targets, EE slerp) -> policy -> WBC without leaving the GPU, against the same chain on the oracle."""
+    import gpu_harness as G
+    import torch
+    from qm_door_amd import api
+    cs = [c for c in _cases(interface, oracle, 12, seed=9) if c["kind"] in (1, 3)][:4]
+    for c in cs:
+        c["time"] = 0.2
+    B, N = len(cs), 30
+    f64 = torch.float64
+    rbd_np = np.array([c["rbd"] for c in cs])
+    rbd = G.dev(rbd_np, f64); tm = G.dev(np.array([c["time"] for c in cs]), f64); kd = G.dev(np.array([c["kind"] for c in cs]), torch.int32)
+    cmd = G.dev(np.array([c["cmd"] for c in cs]), f64); le = G.dev(np.array([c["last_ee"] for c in cs]), f64)
+    x0 = torch.zeros((B, 30), dtype=f64, device="cuda"); tt = torch.zeros((B, 2), dtype=f64, device="cuda"); ts = torch.zeros((B, 2, 37), dtype=f64, device="cuda")
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.25)
+    sn = G.dev(np.full(B, nev, dtype=np.int32), torch.int32); se = G.dev(np.tile(ev, (B, 1)), f64); sm = G.dev(np.tile(md, (B, 1)), torch.int32)
+    oT = torch.zeros((B, N + 1), dtype=f64, device="cuda"); oX = torch.zeros((B, N + 1, 30), dtype=f64, device="cuda"); oU = torch.zeros((B, N, 30), dtype=f64, device="cuda")
+    oM = torch.zeros((B, N + 1), dtype=torch.int32, device="cuda"); oS = torch.zeros((B, 8), dtype=f64, device="cuda")
+    sol = G.make_solver(interface, B, N)
+    sol.frontend(sol.frontend_args(B, rbd, tm, kd, cmd, le, x0, tt, ts))
+    margs = api.GpuSolver.mpc_args(B, N, x0, tt, ts, sn, se, sm, oT, oX, oU, oM, oS, t0=tm)
+    wb = G.WbcBatch(rbd_np, np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
+    sol.cycle(margs, tm, wb.args)
+    torch.cuda.synchronize()
+    X, U, w = oX.cpu().numpy(), oU.cpu().numpy(), wb.results()
+    for i, c in enumerate(cs):
+        rx, rt, rs, _ = oracle.frontend(c["rbd"], c["time"], c["kind"], c["cmd"], c["last_ee"])
+        ref = oracle.mpc_solve(N, c["time"], rx, rt, rs, nev, ev, md)
+        assert np.abs(X[i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(U[i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        st, out, _ = oracle.wbc_update(ref["X"][0], ref["U"][0], c["rbd"], int(ref["mode"][0]), 0.002, 20.0, np.zeros(30))
+        assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
