@@ -81,7 +81,14 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
     if (warmU) for (int i = 0; i < 30; ++i) U[k * 30 + i] = warmU[k * 30 + i];
     else weightCompensatingInput(*P, pr.ms.modeAt(tg[k]), &U[k * 30]);
   }
-  const SqpResult r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
+  // sqp.sqpIteration iterations (task.info:77, 1 in the reference's configuration), each warm-started from the previous iterate.
+  // Upstream stops early when the step or the cost change falls below deltaTol / costTol; a further iteration of a converged
+  // problem is idempotent to those tolerances, so the restatement always runs the configured count.
+  SqpResult r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
+  for (int it = 1; it < P->settings.sqp_iterations && r.status == 0; ++it) {
+    X = r.X; U = r.U;
+    r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
+  }
   for (int k = 0; k <= N; ++k) { outT[k] = tg[k]; outMode[k] = pr.ms.modeAt(tg[k]); }
   std::copy(r.X.begin(), r.X.end(), outX);
   std::copy(r.U.begin(), r.U.end(), outU);

@@ -186,21 +186,26 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   const int B = a->batch, N = a->num_nodes;
   hipStream_t s = h->stream;
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[0], s));
-  InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, a->warm_x, a->warm_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU};
-  QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
-  LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
-            a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows};
-  QM_LAUNCH(ad_node_kernel, B * (N + 1), 64, s, la);
-  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[6], s));
-  QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
-  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
-  RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
-  QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
-  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
-  LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
-            a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
-  QM_LAUNCH(linesearch_kernel, B, (N + 1 <= 128 ? 128 : 256), s, ls);
-  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[3], s));
+  // sqp.sqpIteration iterations (task.info:77; 1 in the reference's configuration): later iterations warm-start from the iterate the
+  // line search just wrote to the caller's output buffers.  No early exit on convergence (see the oracle's note).
+  const int iterations = h->hostProblem.settings.sqp_iterations > 1 ? h->hostProblem.settings.sqp_iterations : 1;
+  for (int it = 0; it < iterations; ++it) {
+    InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, it == 0 ? a->warm_x : a->out_x, it == 0 ? a->warm_u : a->out_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU};
+    QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
+    LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
+              a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows};
+    QM_LAUNCH(ad_node_kernel, B * (N + 1), 64, s, la);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[6], s));
+    QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
+    RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
+    QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
+    LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
+              a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
+    QM_LAUNCH(linesearch_kernel, B, (N + 1 <= 128 ? 128 : 256), s, ls);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[3], s));
+  }
   HIP_CHECK(hipGetLastError());
   h->lastBatch = B; h->lastN = N;
 }

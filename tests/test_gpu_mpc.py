@@ -83,3 +83,28 @@ def test_event_aligned_grid_matches_oracle(interface, oracle):
         assert np.array_equal(r["T"][i], grid) and np.array_equal(r["mode"][i], ref["mode"])
         assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+
+
+def test_three_sqp_iterations_match_oracle(oracle):
+    """sqp.sqpIteration > 1: the iterations chain on the device, each warm-started from the last line-search result."""
+    import gpu_harness as G
+    from qm_door_amd import api
+    itf = api.QMInterface()
+    itf.problem.settings.sqp_iterations = 3
+    orc3 = S.Oracle(itf.problem)
+    B, N = 2, 40
+    x0 = S.perturbed_states(itf.initial_state, B, seed=6)
+    tgt = S.nominal_target(oracle, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.1)
+    sol = G.make_solver(itf, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.mpc(mb.args)
+    r = mb.results()
+    for i in range(B):
+        one = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        ref = orc3.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert ref["stats"][1] < 0.2 * one["stats"][1]                       # the extra iterations did shrink the constraint violation it started from
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        assert np.allclose(r["stats"][i][:4], ref["stats"][:4], rtol=1e-6, atol=1e-9)
