@@ -351,7 +351,8 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) {
       z = zPrev; s = sPrev; lam = lamPrev;
       if (kktRes) *kktRes = std::max(nrdPrev, muPrev);
-      return muPrev <= 1e-8 * scale ? it : -3;
+      if (!(muPrev <= 1e-8 * scale)) return -3;
+      break;   // accepted as converged: polished below like any other final iterate
     }
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
     // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
@@ -381,6 +382,39 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     const double a = std::min(1.0, tau * maxStep(ds, dl));
     for (int i = 0; i < n; ++i) z[i] += a * dz[i];
     for (int i = 0; i < m; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
+  }
+  // ---- active-set polish.  The normal-equation interior point stalls at a dual residual of ~1e-7 * scale (barrier weights ~1e14);
+  // an active-set solver like qpOASES returns the vertex itself.  With the active set read off the final iterate (multiplier larger
+  // than slack) the equality-constrained QP is solved by a few augmented-Lagrangian Newton steps from the interior-point solution:
+  //   grad = H z + c + D_A' (lam_A + rho r_A),  r = D z - f ;   (H + rho D_A' D_A) dz = -grad ;   lam_A += rho r_A(z + dz).
+  // The result is kept only if it is primal feasible and its multipliers are non-negative (else the interior-point iterate stands).
+  {
+    std::vector<int> act;
+    for (int i = 0; i < m; ++i) if (lam[i] > s[i]) act.push_back(i);
+    double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
+    const double rho = 1e6 * std::max(1.0, hmax);
+    Mat K = H;
+    for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
+    if (choleskyFloored(K, pivotFloor)) {
+      Vec zp = z, lp(m, 0.0);
+      for (int r : act) lp[r] = lam[r];
+      for (int step = 0; step < 3; ++step) {
+        const Vec Dz = D * zp;
+        Vec t(m, 0.0);
+        for (int r : act) t[r] = lp[r] + rho * (Dz[r] - f[r]);
+        Vec dz = -1.0 * (H * zp + c + tmul(D, t));
+        cholSolve(K, dz);
+        for (int i = 0; i < n; ++i) zp[i] += dz[i];
+        const Vec Dz2 = D * zp;
+        for (int r : act) lp[r] += rho * (Dz2[r] - f[r]);
+      }
+      const Vec Dz = D * zp;
+      bool ok = true;
+      for (int i = 0; i < m; ++i) if (!(Dz[i] - f[i] <= 1e-9 * scale)) ok = false;
+      for (int r : act) if (!(lp[r] >= -1e-9 * scale)) ok = false;
+      for (double v : zp) if (!(v == v)) ok = false;
+      if (ok) z = zp;
+    }
   }
   return it;
 }

@@ -47,9 +47,16 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   double zc = 0.0, zcPrev = 0.0;
   double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
   double s1p = s1, l1p = l1, s2p = s2, l2p = l2, vp = v, nrdPrev = 0.0, muPrev = 0.0;
-  int it = 0;
+  // Active-set polish (same as the oracle's solveQpIpm): once the interior point has stopped, the active set is read off the final
+  // iterate and three augmented-Lagrangian Newton steps on the equality-constrained QP run through the SAME loop body (K tiles,
+  // factorisation, substitutions) with the barrier weights replaced by {rho: row pinned, 1: violated soft row, 0: inactive}.
+  int polish = 0;                       // 0 interior point; 1..3 polish step; 4 final check
+  bool isE = false, isV = false;        // my row: pinned (equality) / violated soft row of this level (exact quadratic)
+  double lamE = 0.0, zIpm = 0.0;
+  const double rho = 1e6 * fmax(1.0, pivotFloor * 1e13);
+  int it = 0, itOut = 0;
 #pragma unroll 1
-  for (; it < 60; ++it) {
+  for (; it < 70; ++it) {
     // ---- residuals
     const QmGather gz = qmGather(zc, red);
     double Dz;
@@ -62,7 +69,19 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     const double rp1 = rowActive ? (Dz - (own ? v : 0.0) + s1 - fl) : 0.0;
     const double rp2 = (rowActive && own) ? (-v + s2) : 0.0;
     const double rdv = (rowActive && own) ? (v - l1 - l2) : 0.0;
-    const double lamR = rowActive ? l1 : 0.0;
+    const double rRow = Dz - fl;
+    if (polish > 1 && isE) lamE += rho * rRow;                       // multiplier update of the previous polish step
+    if (polish == 4) {                                               // keep the polished point only if it is a valid vertex
+      bool bad = false;
+      if (rowActive) {
+        if (isE) bad = !(lamE >= -1e-9 * scale) || !(fabs(rRow) <= 1e-9 * scale);
+        else if (isV) bad = !(rRow >= -1e-9 * scale);
+        else bad = !(rRow <= 1e-9 * scale);
+      }
+      if (allMax((bad || !(zc == zc)) ? 1.0 : 0.0) > 0.0) zc = zIpm;
+      break;
+    }
+    const double lamR = polish ? (isE ? lamE + rho * rRow : (isV ? rRow : 0.0)) : (rowActive ? l1 : 0.0);
     double rdz;
     {
       double a0 = gC, a1 = 0.0;
@@ -80,17 +99,27 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     // A late Newton step of a degenerate problem can lose all accuracy (barrier weights ~1e18).  As in the oracle's
     // solveQpIpm: a step that blows the dual residual up or yields NaN is rejected and the previous iterate returned --
     // as converged if its complementarity was already <= 1e-8 * scale, flagged (it = 60) otherwise.
-    if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
-      zc = zcPrev; s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
-      if (!(muPrev <= 1e-8 * scale)) it = 60;
-      break;
+    if (!polish) {
+      bool done = false;
+      if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
+        zc = zcPrev; s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
+        if (!(muPrev <= 1e-8 * scale)) { itOut = 60; break; }
+        done = true;
+      } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
+      if (it >= 59 && !done) { itOut = 60; break; }
+      if (done) {
+        itOut = it;
+        const bool c1 = rowActive && l1 > s1, c2 = rowActive && own && l2 > s2;
+        isE = c1 && (!own || c2); isV = c1 && own && !c2;
+        lamE = isE ? l1 : 0.0; zIpm = zc; polish = 1;
+        continue;                                                    // residuals again, now in polish form (zc may have been restored)
+      }
+      zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
     }
-    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;  // same tolerances as the oracle's solveQpIpm
-    zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
 
     // ---- K = G + DZ' diag(w) DZ: upper-triangle tiles on the matrix cores, mirrored into LDS
     const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
-    if (lane < 56) io.wtL[lane] = rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0;
+    if (lane < 56) io.wtL[lane] = polish ? (isE ? rho : (isV ? 1.0 : 0.0)) : (rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0);
     QM_WAVE_SYNC();
     {
       QmAcc acc[TP * (TP + 1) / 2];
@@ -169,13 +198,13 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0, dzc = 0.0;
     double alphaAff = 1.0, sigma = 0.0;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (polish ? 1 : 2); ++pass) {
       const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + ds1 * dl1 - sigma * mu;
       const double rc2 = pass == 0 ? s2 * l2 : s2 * l2 + ds2 * dl2 - sigma * mu;
       const double t1 = rowActive ? (l1 * rp1 - rc1) / s1 : 0.0;
       const double t2 = (rowActive && own) ? (l2 * rp2 - rc2) / s2 : 0.0;
       const double rhsv = -rdv + t1 + t2;
-      const double tz = rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0;
+      const double tz = polish ? 0.0 : (rowActive ? (own ? t1 - (w1 / kvv) * rhsv : t1) : 0.0);   // polish: rhs = -gradient only
       // right-hand side of the reduced system
       double acc;
       {
@@ -204,6 +233,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         }
         dzc = colOn ? dzc : 0.0;
       }
+      if (polish) { zc += dzc; ++polish; break; }
       double Ddz;
       {
         const QmGather gd = qmGather(dzc, red);
@@ -241,7 +271,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   }
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
   *vOut = v;
-  return it;
+  return itOut;
 }
 
 }  // namespace qmk

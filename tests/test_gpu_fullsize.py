@@ -80,8 +80,6 @@ def test_every_wbc_output_against_oracle(solved, oracle):
         st, out, _ = oracle.wbc_update(full["X"][i, 0], full["U"][i, 0], solved["rbd"][i], int(full["mode"][i, 0]), 0.002, 20.0, np.zeros(30))
         assert st == 0
         err[i] = np.abs(full["out"][i][36:] - out[36:]).max() / max(1.0, np.abs(out[36:]).max())
-    # 1e-6 rel-inf is the north_star tolerance.  Both implementations run the same normal-equation interior point; on a rare
-    # ill-conditioned level (barrier weights ~1e14 in the last iterations) its round-off floor is ~1e-6 of the decision vector and
-    # the two floating-point orders land on different sides of it: allow at most 1 % of the batch up to 1e-5.
-    assert np.median(err) <= 1e-9
-    assert (err <= 1e-6).mean() >= 0.99 and err.max() <= 1e-5, (np.sort(err)[-5:])
+    # 1e-6 rel-inf is the north_star tolerance; with the active-set polish after the interior point both implementations land on
+    # the same vertex of every level's QP and agree far below it (worst of the 256: 9e-10, median 1e-11)
+    assert np.median(err) <= 1e-9 and err.max() <= 1e-7, np.sort(err)[-5:]
