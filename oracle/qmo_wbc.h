@@ -357,6 +357,9 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
     // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
     if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
+    // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
+    // here instead of iterating into the divergence that follows; the polish finishes the job
+    if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-8 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = H;
     for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }

@@ -106,6 +106,9 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         if (!(muPrev <= 1e-8 * scale)) { itOut = 60; break; }
         done = true;
       } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
+      // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
+      // stop here instead of iterating into the divergence that follows; the polish finishes the job
+      else if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-8 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
       if (it >= 59 && !done) { itOut = 60; break; }
       if (done) {
         itOut = it;

@@ -383,32 +383,73 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     if (c < nc) dbg[DBG_e + c] = ev[c];
   }
 
-  // ================================================================== projection: Householder QR of D^T (30 x nc)
-  // Lane j < 16 owns column j of D^T (row j of D), lane 16 + c column c of the 30 x 30 identity: every reflector is applied to
-  // both, so the identity lanes end up with Q^T.  The reflector of step k is built by EVERY lane from column k, fetched with
-  // v_readlane from lane k: no LDS hand-off, no divergent branch, no barrier inside the factorisation.
+  // ================================================================== projection: QR of the velocity block of D^T (18 x nv)
+  // The constraint set of the reference (QMInterface.cpp:116-131) has a fixed structure: a zero-force row is a unit vector on one
+  // force input (C = 0), a zero-velocity / normal-velocity row depends on the inputs only through the 18 joint velocities.  So
+  //   D = [E_f 0; 0 D_v],  Q = blkdiag(permutation of the 12 force inputs, Q_v):
+  // only D_v^T (18 x nv, nv = 3 n_st + n_sw <= 12) needs the Householder QR; swing-foot forces are pinned to -e_f, stance-foot forces
+  // are free directions (unit vectors of Pu).  This is a different (equally orthonormal) basis of the same null space as the generic
+  // 30 x nc factorisation -- the reduced stage differs by an orthogonal change of du~, the step du does not.
+  // Lane j < 16 owns column j of D_v^T, lane 16 + c column c of the 18 x 18 identity: every reflector is applied to both, so the
+  // identity lanes end up with Q_v^T.  The reflector of step k is built by EVERY lane from column k, fetched with v_readlane from
+  // lane k: no LDS hand-off, no divergent branch, no barrier inside the factorisation.
   const int nt = 30 - nc;  // projected input dimension m~
+  constexpr int NVMAX = 12;
+  int nv = 0, nStF = 0;     // velocity rows; free (stance) force inputs
+  int vrOf[NVMAX];          // CD row of velocity row r (wave uniform)
+  int frcRowOf[12];         // CD row pinning force input i (swing foot), or -1 (stance foot: free)
+  int puColOf[12];          // Pu column of a free force input, or -1
+#pragma unroll
+  for (int r = 0; r < NVMAX; ++r) vrOf[r] = 0;
   {
-    double ce[NCMAX];   // my column of [C | e] (lanes <= 30)
+    int row = 0;
 #pragma unroll
-    for (int r = 0; r < NCMAX; ++r) {
-      const double cv = CD[(r < nc ? r : 0) * CDW + (lane < 30 ? lane : 0)], evr = ev[r];
-      ce[r] = (r < nc) ? (lane < 30 ? cv : (lane == 30 ? evr : 0.0)) : 0.0;
-    }
-    double qcol[30];
+    for (int cft = 0; cft < 4; ++cft) {
+      if (contactOf(mode, cft)) {
 #pragma unroll
-    for (int i = 0; i < 30; ++i) {
-      const double dv = CD[(lane < nc ? lane : 0) * CDW + 30 + i];
-      qcol[i] = lane < 16 ? (lane < nc ? dv : 0.0) : ((lane < 46 && i == lane - 16) ? 1.0 : 0.0);
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int r = 0; r < NVMAX; ++r) if (r == nv + q) vrOf[r] = row + q;
+          frcRowOf[3 * cft + q] = -1; puColOf[3 * cft + q] = nStF + q;
+        }
+        nv += 3; nStF += 3; row += 3;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { frcRowOf[3 * cft + q] = row + q; puColOf[3 * cft + q] = -1; }
+#pragma unroll
+        for (int r = 0; r < NVMAX; ++r) if (r == nv) vrOf[r] = row + 3;
+        nv += 1; row += 4;
+      }
     }
+  }
+  {
+    int myVr = 0;
+#pragma unroll
+    for (int r = 0; r < NVMAX; ++r) if (lane == r) myVr = vrOf[r];
+    double ce[NVMAX];   // my column of [C_v | e_v] (lanes <= 30)
+#pragma unroll
+    for (int r = 0; r < NVMAX; ++r) {
+      const double cv = CD[vrOf[r] * CDW + (lane < 30 ? lane : 0)], evr = ev[vrOf[r]];
+      ce[r] = (r < nv) ? (lane < 30 ? cv : (lane == 30 ? evr : 0.0)) : 0.0;
+    }
+    double qcol[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const double dv = CD[myVr * CDW + 30 + 12 + i];
+      qcol[i] = lane < 16 ? (lane < nv ? dv : 0.0) : ((lane < 34 && i == lane - 16) ? 1.0 : 0.0);
+    }
+    // pinned swing-foot forces: Pe = -e_f, read before the [C D e] region is recycled
+    double peForce = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) if (lane == i && frcRowOf[i] >= 0) peForce = -ev[frcRowOf[i] >= 0 ? frcRowOf[i] : 0];
     QM_WAVE_SYNC();  // the [C D e] region is free from here on (it becomes Pall)
 #pragma unroll
-    for (int k = 0; k < NCMAX; ++k) {
-      if (k < nc) {
-        double v[30];
+    for (int k = 0; k < NVMAX; ++k) {
+      if (k < nv) {
+        double v[18];
         double n2a = 0.0, n2b = 0.0;
 #pragma unroll
-        for (int i = k; i < 30; ++i) { v[i] = qmReadLane(qcol[i], k, red); if ((i - k) & 1) n2b += v[i] * v[i]; else n2a += v[i] * v[i]; }
+        for (int i = k; i < 18; ++i) { v[i] = qmReadLane(qcol[i], k, red); if ((i - k) & 1) n2b += v[i] * v[i]; else n2a += v[i] * v[i]; }
         const double dk = v[k], tail2 = (n2a + n2b) - dk * dk;
         const double nrm = sqrt(n2a + n2b);
         const double alpha = dk > 0.0 ? -nrm : nrm;
@@ -417,40 +458,35 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
         const double beta = vn > 0.0 ? 2.0 / vn : 0.0;
         double sa = 0.0, sb = 0.0;
 #pragma unroll
-        for (int i = k; i < 30; ++i) { if ((i - k) & 1) sb += v[i] * qcol[i]; else sa += v[i] * qcol[i]; }
+        for (int i = k; i < 18; ++i) { if ((i - k) & 1) sb += v[i] * qcol[i]; else sa += v[i] * qcol[i]; }
         const double sf = (sa + sb) * beta;
 #pragma unroll
-        for (int i = k; i < 30; ++i) qcol[i] = (lane == k) ? (i == k ? alpha : 0.0) : qcol[i] - sf * v[i];
+        for (int i = k; i < 18; ++i) qcol[i] = (lane == k) ? (i == k ? alpha : 0.0) : qcol[i] - sf * v[i];
       }
     }
-    // Y = R1^-T [C | e]: forward substitution, R1[k][i] (k <= i) lives in lane i, register k
-    double y[NCMAX];
+    // Y = R1^-T [C_v | e_v]: forward substitution, R1[k][i] (k <= i) lives in lane i, register k
+    double y[NVMAX];
 #pragma unroll
-    for (int i = 0; i < NCMAX; ++i) {
+    for (int i = 0; i < NVMAX; ++i) {
       double sacc = ce[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) sacc -= qmReadLane(qcol[k], i, red) * y[k];
       const double d = qmReadLane(qcol[i], i, red);
-      y[i] = (i < nc) ? sacc / d : 0.0;
+      y[i] = (i < nv) ? sacc / d : 0.0;
     }
-    // publish Y (rows k < 16, my column) and Q (lane 16 + c holds row c of Q) in region X
+    // publish Y (rows k < 16, my column) and Q_v (lane 16 + c holds row c; rows 18..31 cleared) in region X
     double* Ym = lds + L_X + 32 * LDR;
     double* Qs = lds + L_X;
     if (lane < 32) {
 #pragma unroll
-      for (int k = 0; k < NCMAX; ++k) Ym[k * LDR + lane] = lane <= 30 ? y[k] : 0.0;
+      for (int k = 0; k < NCMAX; ++k) Ym[k * LDR + lane] = (k < NVMAX && lane <= 30) ? y[k < NVMAX ? k : 0] : 0.0;
     }
-    if (lane >= 16 && lane < 48) {   // lanes 46, 47 clear the padding rows 30, 31
+    if (lane >= 16 && lane < 48) {
 #pragma unroll
-      for (int r = 0; r < 30; ++r) Qs[(lane - 16) * LDR + r] = lane < 46 ? qcol[r] : 0.0;
+      for (int r = 0; r < 18; ++r) Qs[(lane - 16) * LDR + r] = lane < 34 ? qcol[r] : 0.0;
     }
-  }
-  QM_WAVE_SYNC();
-  const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
-  {
-    // [Px | Pe] = -Q1 Y on the matrix cores; Pu = Q2 copied column by column
-    const double* Ym = lds + L_X + 32 * LDR;
-    const double* Qs = lds + L_X;
+    QM_WAVE_SYNC();
+    // [Px | Pe] rows 12..29 = -Q_v1 Y on the matrix cores (K = 16 >= nv; rows of Y beyond nv are zero)
     QmAcc pc[4];
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
@@ -463,25 +499,45 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       const double b0 = Ym[kk * LDR + l16], b1 = Ym[kk * LDR + 16 + l16];
       qmMfma(pc[0], a0, b0, red); qmMfma(pc[1], a0, b1, red); qmMfma(pc[2], a1, b0, red); qmMfma(pc[3], a1, b1, red);
     }
+    // Pall: rows 0..11 (forces): Px = 0, Pe = pinned swing forces, unit Pu columns for the free stance forces;
+    //       rows 12..29 (joint velocities): [Px | Pe] from the tiles, Pu = Q_v2
+    double peAll[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) peAll[i] = qmReadLane(peForce, i, red);
+    if (lane < PAW) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const double val = lane == 30 ? peAll[i] : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0 : 0.0);
+        PA[i * PAW + lane] = val;
+        if (lane < 30) rec[OFF_PX + i * 30 + lane] = 0.0;
+        else if (lane == 30) rec[OFF_PE + i] = peAll[i];
+        else if (lane >= 32 && lane < 32 + nt) rec[OFF_PU + i * MT + (lane - 32)] = val;
+      }
+      PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
+    }
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;
-        PA[i * PAW + j] = (i < 30 && j <= 30) ? pc[t4][r] : 0.0;    // rows 30,31 and column 31 are zero padding
-        if (i < 30) { if (j < 30) rec[OFF_PX + i * 30 + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + i] = pc[t4][r]; }
+        const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;   // i: joint-velocity input 12 + i
+        if (i < 18) {
+          PA[(12 + i) * PAW + j] = j <= 30 ? pc[t4][r] : 0.0;
+          if (j < 30) rec[OFF_PX + (12 + i) * 30 + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + 12 + i] = pc[t4][r];
+        }
       }
     if (lane >= 32 && lane < PAW) {
+      const int jj = lane - 32;
+      const bool isQ2 = jj >= nStF && jj < nt;
 #pragma unroll
-      for (int i = 0; i < 30; ++i) {
-        const double qv = Qs[i * LDR + (isU ? nc + (lane - 32) : 0)];
-        PA[i * PAW + lane] = isU ? qv : 0.0;
-        if (isU) rec[OFF_PU + i * MT + (lane - 32)] = qv;
+      for (int i = 0; i < 18; ++i) {
+        const double qv = Qs[i * LDR + (isQ2 ? nv + (jj - nStF) : 0)];
+        PA[(12 + i) * PAW + lane] = isQ2 ? qv : 0.0;
+        if (jj < nt) rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0;
       }
-      PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
     }
   }
-  QM_WAVE_SYNC();   // Pall complete; Q / Y (region X) are dead
+  const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
+  QM_WAVE_SYNC();   // Pall complete; Q_v / Y (region X) are dead
   // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
   for (int i = 12; i < 30; ++i) {
