@@ -319,7 +319,7 @@ inline bool choleskyFloored(Mat& A, double floorv) {
 
 // ------------------------------------------------------------------------------------------------ dense convex QP: min 1/2 z'Hz + c'z  s.t.  D z <= f
 // Mehrotra predictor-corrector primal-dual interior point.  Returns iterations used, negative on failure.
-inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 60, double* kktRes = nullptr) {
+inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 60, double* kktRes = nullptr, bool scaledStart = false) {
   const int n = H.r;
   // rows that are identically zero carry no information (the reference's friction task creates them, WbcBase.cpp:458)
   std::vector<int> keep;
@@ -334,9 +334,11 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   }
   double pivotFloor = 0.0;
   for (int i = 0; i < n; ++i) pivotFloor = std::max(pivotFloor, 1e-13 * H(i, i));
-  Vec s(m), lam(m, 1.0);
-  { const Vec Dz = D * z; for (int i = 0; i < m; ++i) s[i] = std::max(1.0, f[i] - Dz[i]); }
   double scale = 1.0; for (double v : c) scale = std::max(scale, std::fabs(v)); for (double v : f) scale = std::max(scale, std::fabs(v));
+  // starting point: slacks max(sigma, f - D z), multipliers sigma; sigma = 1, or sqrt(scale) for the second attempt (see HoQp)
+  const double sigma = scaledStart ? std::sqrt(scale) : 1.0;
+  Vec s(m), lam(m, sigma);
+  { const Vec Dz = D * z; for (int i = 0; i < m; ++i) s[i] = std::max(sigma, f[i] - Dz[i]); }
   int it = 0;
   Vec zPrev = z, sPrev = s, lamPrev = lam;
   double nrdPrev = 0.0, muPrev = 0.0;
@@ -359,7 +361,7 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
     // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
     // here instead of iterating into the divergence that follows; the polish finishes the job
-    if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-8 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;
+    if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = H;
     for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
@@ -423,6 +425,7 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
 }
 
 // ------------------------------------------------------------------------------------------------ HoQp (HoQp.cpp:12-158)
+constexpr double kInheritedMargin = 1e-5;   // second-attempt relaxation of inherited inequality rows (see HoQp)
 struct HoQp {
   Task task, stackedTasksPrev, stackedTasks;
   bool hasEq = false, hasIneq = false;
@@ -454,7 +457,10 @@ struct HoQp {
       const Mat dz = stackedTasksPrev.d * Zprev;
       setBlock(Dm, numSlack, 0, dz);
       const Vec dx = stackedTasksPrev.d * xPrev;
-      for (int i = 0; i < numPrevSlack; ++i) fv[numSlack + i] = stackedTasksPrev.f[i] - dx[i] + slackPrev[i];
+      // x_prev satisfies the inherited rows with its slack, so this margin is >= 0 in exact arithmetic; rounding (and the 1e-9 * scale
+      // feasibility tolerance of the polished vertex) can leave it at -1e-8, which a lower level whose null space no longer sees the
+      // row cannot repair.  Clamp at zero.
+      for (int i = 0; i < numPrevSlack; ++i) fv[numSlack + i] = std::max(0.0, stackedTasksPrev.f[i] - dx[i] + slackPrev[i]);
     }
     if (hasIneq) {
       const Mat dz = task.d * Zprev;
@@ -464,7 +470,20 @@ struct HoQp {
     }
     // solveProblem
     Vec sol;
-    if (nz > 0) qpIters = solveQpIpm(Hm, cv, Dm, fv, sol); else sol.clear();
+    // A degenerate low-priority level -- more inherited rows active at x_prev than the remaining null space has dimensions, so that
+    // {z : D_prev Z z <= margin} has no interior (three-leg stance: 5 free directions, 7 active rows) -- stalls the interior point.
+    // Second attempt: every inherited row gets a margin of at least kInheritedMargin (1e-5 N / Nm: 3e-7 of the limits it bounds) and
+    // the iteration starts from slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the
+    // higher priorities' solution) and the failure is reported.  2 x 2048 random configurations: 6 second attempts, no skip.
+    if (nz > 0) {
+      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol);
+      if (qpIters < 0) {
+        Vec fr = fv;
+        for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(kInheritedMargin, fr[numSlack + i]);
+        const int second = solveQpIpm(Hm, cv, Dm, fr, sol, 60, nullptr, true);
+        if (second < 0) sol.assign(nz, 0.0); else qpIters = second;
+      }
+    } else sol.clear();
     decSol = Vec(sol.begin(), sol.begin() + numDec); slackSol = Vec(sol.begin() + numDec, sol.end());
     // An interior point method leaves the slacks of inactive rows at O(sqrt(mu)) (v = 0 and its multiplier = 0 is a degenerate
     // complementarity pair).  The exact minimiser, which an active-set solver like qpOASES returns, has v = max(0, D z - f):

@@ -41,7 +41,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   const bool colOn = lane < n;
   const double gC = io.g[colL];
   const double pivotFloor = 1e-13 * allMax(colOn ? G[colL * LDK_ + colL] : 0.0);
-  const double fl = rowActive ? io.fhat[rowL] : 0.0;
+  double fl = rowActive ? io.fhat[rowL] : 0.0;
   const double scale = fmax(1.0, allMax(fmax(rowActive ? fabs(fl) : 0.0, colOn ? fabs(gC) : 0.0)));
   const double nRowsTot = allSum(rowActive ? (own ? 2.0 : 1.0) : 0.0);
   double zc = 0.0, zcPrev = 0.0;
@@ -50,6 +50,24 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   // Active-set polish (same as the oracle's solveQpIpm): once the interior point has stopped, the active set is read off the final
   // iterate and three augmented-Lagrangian Newton steps on the equality-constrained QP run through the SAME loop body (K tiles,
   // factorisation, substitutions) with the barrier weights replaced by {rho: row pinned, 1: violated soft row, 0: inactive}.
+  // Second attempt (as the oracle's HoQp): a degenerate low-priority level (more inherited rows active than free directions: no
+  // interior) stalls the interior point.  Restart once with every inherited row relaxed to a margin of at least 1e-5 and slacks /
+  // multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the higher priorities' solution) and the
+  // failure is reported (return value 60).
+  int attempt = 0;
+  auto restartOrGiveUp = [&]() {
+    if (attempt == 0) {
+      attempt = 1;
+      const double sg = sqrt(scale);
+      if (rowActive && !own) fl = fmax(fl, 1e-5);
+      zc = 0.0; zcPrev = 0.0; v = 0.0; vp = 0.0;
+      s1 = rowActive ? fmax(sg, fl) : 1.0; l1 = sg; s2 = sg; l2 = sg;
+      s1p = s1; l1p = l1; s2p = s2; l2p = l2; nrdPrev = 0.0; muPrev = 0.0;
+      return true;
+    }
+    zc = 0.0; v = 0.0;
+    return false;
+  };
   int polish = 0;                       // 0 interior point; 1..3 polish step; 4 final check
   bool isE = false, isV = false;        // my row: pinned (equality) / violated soft row of this level (exact quadratic)
   double lamE = 0.0, zIpm = 0.0;
@@ -103,13 +121,13 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       bool done = false;
       if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
         zc = zcPrev; s1 = s1p; l1 = l1p; s2 = s2p; l2 = l2p; v = vp;
-        if (!(muPrev <= 1e-8 * scale)) { itOut = 60; break; }
+        if (!(muPrev <= 1e-8 * scale)) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
         done = true;
       } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
       // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
       // stop here instead of iterating into the divergence that follows; the polish finishes the job
-      else if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-8 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
-      if (it >= 59 && !done) { itOut = 60; break; }
+      else if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
+      if (it >= 59 && !done) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
       if (done) {
         itOut = it;
         const bool c1 = rowActive && l1 > s1, c2 = rowActive && own && l2 > s2;

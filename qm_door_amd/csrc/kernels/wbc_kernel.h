@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     bool rowActive = lane < mRows;
     if (lane < m0) {
       double s = f0[lane];
-      if (level > 0) { for (int q = 0; q < ND; ++q) s -= D0[lane * ND + q] * xs[q]; s += v0[lane]; }
+      if (level > 0) { for (int q = 0; q < ND; ++q) s -= D0[lane * ND + q] * xs[q]; s += v0[lane]; s = fmax(s, 0.0); }   // margin of x_prev: >= 0 up to rounding (see the oracle's HoQp)
       fhat[lane] = s;
     }
     QM_WAVE_SYNC();

@@ -74,3 +74,43 @@ def test_cycle_matches_oracle(interface, oracle):
         ud = a * ref["U"][0] + (1 - a) * ref["U"][1]
         st, out, _ = oracle.wbc_update(xd, ud, rbd[i], int(ref["mode"][0]), 0.002, 20.0, il[i])
         assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wbc_stress_all_modes_converge(interface, oracle, variant):
+    """2048 random instances over every contact mode of gait.info: all three levels converge everywhere; 48 samples vs the oracle."""
+    import gpu_harness as G
+    rng = np.random.default_rng(17 + variant)
+    B = 2048
+    x_nom, m = interface.initial_state, interface.robot_mass
+    modes_all = np.array([15, 9, 6, 0, 10, 5, 13, 7, 14, 11], dtype=np.int32)
+    mode = modes_all[rng.integers(0, len(modes_all), B)]
+    xd = x_nom[None, :] + rng.uniform(-1, 1, (B, 30)) * 0.03
+    xm = x_nom[None, :] + rng.uniform(-1, 1, (B, 30)) * 0.02
+    vm = rng.uniform(-1, 1, (B, 24)) * 0.1
+    u = np.zeros((B, 30))
+    for i in range(B):
+        flags = [(int(mode[i]) >> (3 - c)) & 1 for c in range(4)]
+        for c in range(4):
+            if flags[c]:
+                u[i, 3 * c + 2] = m * 9.81 / max(1, sum(flags))
+    u[:, :12] += rng.uniform(-1, 1, (B, 12)) * 2.0 * (u[:, :12] != 0)
+    u[:, 12:] = rng.uniform(-1, 1, (B, 18)) * 0.1
+    il = u + rng.uniform(-1, 1, (B, 30)) * 0.002
+    t = np.where(rng.uniform(size=B) < 0.2, 5.0, 20.0)
+    rbd = np.zeros((B, 55))
+    rbd[:, 0:3] = xm[:, 9:12]; rbd[:, 3:6] = xm[:, 6:9]; rbd[:, 6:24] = xm[:, 12:30]; rbd[:, 24:48] = vm
+    sol = G.make_solver(interface, B, 4)
+    wb = G.WbcBatch(rbd, np.full(B, 0.002), t, il, xd, u, mode, variant)
+    sol.wbc(wb.args)
+    r = wb.results()
+    assert np.isfinite(r["out"]).all()
+    assert (r["status"] == 0).all(), (np.nonzero(r["status"])[0][:10], r["status"][np.nonzero(r["status"])[0][:10]])
+    errs = []
+    for i in rng.choice(B, 48, replace=False):
+        st, ref, _ = oracle.wbc_update(xd[i], u[i], rbd[i], int(mode[i]), 0.002, float(t[i]), il[i], variant)
+        assert st == 0
+        errs.append(np.abs(r["out"][i][36:] - ref[36:]).max() / max(1.0, np.abs(ref[36:]).max()))
+    # Random (not MPC-consistent) desired states make some lowest-priority levels nearly degenerate LPs whose minimiser moves by 1e-2
+    # when an inherited bound moves by 1e-5; the 1e-6 bar is asserted on the MPC-driven workloads (test_gpu_fullsize, test_gpu_configs).
+    assert np.median(errs) <= 1e-8 and np.quantile(errs, 0.85) <= 1e-6 and max(errs) <= 1e-4, np.sort(errs)[-8:]
