@@ -472,17 +472,18 @@ struct HoQp {
     Vec sol;
     // A degenerate low-priority level -- more inherited rows active at x_prev than the remaining null space has dimensions, so that
     // {z : D_prev Z z <= margin} has no interior (three-leg stance: 5 free directions, 7 active rows) -- stalls the interior point.
-    // Second attempt: every inherited row gets a margin of at least kInheritedMargin (1e-5 N / Nm: 3e-7 of the limits it bounds) and
-    // the iteration starts from slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the
+    // Further attempts: every inherited row gets a margin of at least kInheritedMargin (1e-5 N / Nm: 3e-7 of the limits it bounds), then
+    // 100x that, and the iteration starts from slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the
     // higher priorities' solution) and the failure is reported.  2 x 2048 random configurations: 6 second attempts, no skip.
     if (nz > 0) {
       qpIters = solveQpIpm(Hm, cv, Dm, fv, sol);
-      if (qpIters < 0) {
+      for (int attempt = 1; attempt <= 2 && qpIters < 0; ++attempt) {
         Vec fr = fv;
-        for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(kInheritedMargin, fr[numSlack + i]);
-        const int second = solveQpIpm(Hm, cv, Dm, fr, sol, 60, nullptr, true);
-        if (second < 0) sol.assign(nz, 0.0); else qpIters = second;
+        const double margin = attempt == 1 ? kInheritedMargin : 100.0 * kInheritedMargin;   // 1e-5, then 1e-3
+        for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(margin, fr[numSlack + i]);
+        qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 60, nullptr, true);
       }
+      if (qpIters < 0) sol.assign(nz, 0.0);
     } else sol.clear();
     decSol = Vec(sol.begin(), sol.begin() + numDec); slackSol = Vec(sol.begin() + numDec, sol.end());
     // An interior point method leaves the slacks of inactive rows at O(sqrt(mu)) (v = 0 and its multiplier = 0 is a degenerate

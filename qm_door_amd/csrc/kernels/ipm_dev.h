@@ -51,15 +51,15 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   // iterate and three augmented-Lagrangian Newton steps on the equality-constrained QP run through the SAME loop body (K tiles,
   // factorisation, substitutions) with the barrier weights replaced by {rho: row pinned, 1: violated soft row, 0: inactive}.
   // Second attempt (as the oracle's HoQp): a degenerate low-priority level (more inherited rows active than free directions: no
-  // interior) stalls the interior point.  Restart once with every inherited row relaxed to a margin of at least 1e-5 and slacks /
-  // multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the higher priorities' solution) and the
+  // interior) stalls the interior point.  Restart (twice at most) with every inherited row relaxed to a margin of at least 1e-5, then
+  // 1e-3, and slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the higher priorities' solution) and the
   // failure is reported (return value 60).
   int attempt = 0;
   auto restartOrGiveUp = [&]() {
-    if (attempt == 0) {
-      attempt = 1;
+    if (attempt < 2) {
+      ++attempt;
       const double sg = sqrt(scale);
-      if (rowActive && !own) fl = fmax(fl, 1e-5);
+      if (rowActive && !own) fl = fmax(fl, attempt == 1 ? 1e-5 : 1e-3);   // second attempt 1e-5, third 1e-3 (still < 1e-4 of the limits)
       zc = 0.0; zcPrev = 0.0; v = 0.0; vp = 0.0;
       s1 = rowActive ? fmax(sg, fl) : 1.0; l1 = sg; s2 = sg; l2 = sg;
       s1p = s1; l1p = l1; s2p = s2; l2p = l2; nrdPrev = 0.0; muPrev = 0.0;

@@ -7,36 +7,160 @@
 
 namespace qmk {
 
+// ---- leaf-to-root accumulation of one kinematic chain in JOINT-LOCAL frames ------------------------------------------------------
+// Every joint origin has rpy = 0 and a coordinate axis, so crossing joint b is an elementary rotation E(q_b) about one axis plus a
+// constant offset: rotating the subtree's composite quantities costs a 2-D rotation per vector and a 2x2 similarity for the inertia,
+// instead of the general R I R^T per body of a root-to-leaf sweep in world axes (less than half the fp64 instructions).  Momentum is
+// linear in the joint rates, so the momentum a joint contributes is just (composite inertia of its subtree) x (joint twist) -- no
+// forward velocity pass is needed: one backward pass per chain yields mass moments, inertia, joint-induced momentum and the
+// position / velocity (/ orientation) of the frame at the chain's tip, all in the frame of the chain's root and about its origin.
+template <class T> struct ChainAcc {
+  double M;            // composite mass
+  Vec3<T> h;           // first moment  sum m c
+  Sym3<T> I;           // inertia about the current origin
+  Vec3<T> l, k;        // momentum caused by the joint rates of the subtree (k about the current origin)
+  Vec3<T> p, vf;       // tip frame: position, velocity caused by the joint rates
+};
+
+template <class T> __device__ __forceinline__ void rotAxis(int axis, T cs, T sn, Vec3<T>& v) {
+  if (axis == 0) { const T a = v.y, b = v.z; v.y = cs * a - sn * b; v.z = sn * a + cs * b; }
+  else if (axis == 1) { const T a = v.z, b = v.x; v.z = cs * a - sn * b; v.x = sn * a + cs * b; }
+  else { const T a = v.x, b = v.y; v.x = cs * a - sn * b; v.y = sn * a + cs * b; }
+}
+template <class T> __device__ __forceinline__ Vec3<T> axisCross(int axis, const Vec3<T>& v) {  // e_axis x v
+  if (axis == 0) return Vec3<T>(T(0.0), T(0.0) - v.z, v.y);
+  if (axis == 1) return Vec3<T>(v.z, T(0.0), T(0.0) - v.x);
+  return Vec3<T>(T(0.0) - v.y, v.x, T(0.0));
+}
+template <class T> __device__ __forceinline__ Vec3<T> symColumn(int axis, const Sym3<T>& S) {
+  if (axis == 0) return Vec3<T>(S.xx, S.xy, S.xz);
+  if (axis == 1) return Vec3<T>(S.xy, S.yy, S.yz);
+  return Vec3<T>(S.xz, S.yz, S.zz);
+}
+// E S E^T for the rotation E about `axis`; (i, j) is the rotated plane, k the axis: entries II JJ IJ IK JK (KK unchanged)
+template <class T> __device__ __forceinline__ void rotPlane(T c2, T s2, T cs, T sn, T& II, T& JJ, T& IJ, T& IK, T& JK) {
+  const T d = 0.5 * (II - JJ), m = 0.5 * (II + JJ);
+  const T t = d * c2 - IJ * s2;
+  const T nij = d * s2 + IJ * c2;
+  II = m + t; JJ = m - t; IJ = nij;
+  const T a = IK, b = JK;
+  IK = cs * a - sn * b; JK = sn * a + cs * b;
+}
+template <class T> __device__ __forceinline__ void rotSym(int axis, T cs, T sn, Sym3<T>& S) {
+  const T c2 = cs * cs - sn * sn, s2 = 2.0 * (cs * sn);
+  if (axis == 0) rotPlane(c2, s2, cs, sn, S.yy, S.zz, S.yz, S.xy, S.xz);        // plane (y, z), axis x
+  else if (axis == 1) rotPlane(c2, s2, cs, sn, S.zz, S.xx, S.xz, S.yz, S.xy);   // plane (z, x), axis y
+  else rotPlane(c2, s2, cs, sn, S.xx, S.yy, S.xy, S.xz, S.yz);                  // plane (x, y), axis z
+}
+
+// add body b (its own frame = the current frame) to the composite: constants only
+template <class T> __device__ __forceinline__ void addBody(const qmgpu_model& md, int b, ChainAcc<T>& c) {
+  const double m = md.mass[b], cx = md.com[b][0], cy = md.com[b][1], cz = md.com[b][2];
+  const double* in = md.inertia[b];
+  c.M += m;
+  c.h = c.h + Vec3<T>(T(m * cx), T(m * cy), T(m * cz));
+  c.I.xx = c.I.xx + (in[0] + m * (cy * cy + cz * cz)); c.I.yy = c.I.yy + (in[3] + m * (cx * cx + cz * cz)); c.I.zz = c.I.zz + (in[5] + m * (cx * cx + cy * cy));
+  c.I.xy = c.I.xy + (in[1] - m * cx * cy); c.I.xz = c.I.xz + (in[2] - m * cx * cz); c.I.yz = c.I.yz + (in[4] - m * cy * cz);
+}
+
+// cross joint b towards its parent: joint-rate contributions, rotation E(q), shift of the origin by the constant offset
+// joint axes of the AlienGo+Z1 tree (checked against the loaded model in qmgpu_create): compile-time constants, so that the
+// three-way axis selections below fold away and the sweep is straight-line code whose model-constant loads can be issued early
+__device__ constexpr int LEG_AXIS[3] = {0, 1, 1};
+__device__ constexpr int ARM_AXIS[6] = {2, 1, 1, 1, 2, 0};
+
+template <class T, class RotExtra> __device__ __forceinline__ void crossJoint(const qmgpu_model& md, int b, int axis, T q, T qd, ChainAcc<T>& c, RotExtra&& rotExtra) {
+  c.l = c.l + qd * axisCross(axis, c.h);
+  c.k = c.k + qd * symColumn(axis, c.I);
+  c.vf = c.vf + qd * axisCross(axis, c.p);
+  T sn, cs;
+  sincosT(q, sn, cs);
+  rotAxis(axis, cs, sn, c.h); rotAxis(axis, cs, sn, c.l); rotAxis(axis, cs, sn, c.k); rotAxis(axis, cs, sn, c.p); rotAxis(axis, cs, sn, c.vf);
+  rotSym(axis, cs, sn, c.I);
+  rotExtra(axis, cs, sn);
+  const double ox = md.joint_offset[b][0], oy = md.joint_offset[b][1], oz = md.joint_offset[b][2], M = c.M;
+  // k about the new origin, inertia about the new origin (uses h about the old one), then h and the tip position
+  c.k = c.k + Vec3<T>(oy * c.l.z - oz * c.l.y, oz * c.l.x - ox * c.l.z, ox * c.l.y - oy * c.l.x);
+  c.I.xx = c.I.xx + (2.0 * (oy * c.h.y + oz * c.h.z) + M * (oy * oy + oz * oz));
+  c.I.yy = c.I.yy + (2.0 * (ox * c.h.x + oz * c.h.z) + M * (ox * ox + oz * oz));
+  c.I.zz = c.I.zz + (2.0 * (ox * c.h.x + oy * c.h.y) + M * (ox * ox + oy * oy));
+  c.I.xy = c.I.xy - ((ox * c.h.y + oy * c.h.x) + M * ox * oy);
+  c.I.xz = c.I.xz - ((ox * c.h.z + oz * c.h.x) + M * ox * oz);
+  c.I.yz = c.I.yz - ((oy * c.h.z + oz * c.h.y) + M * oy * oz);
+  c.h = c.h + Vec3<T>(T(M * ox), T(M * oy), T(M * oz));
+  c.p = c.p + Vec3<T>(T(ox), T(oy), T(oz));
+}
+
+template <class T> __device__ __forceinline__ Sym3<T> similarity(const Mat3<T>& R, const Sym3<T>& S) {  // R S R^T
+  const Vec3<T> a0 = S.xx * R.c0 + S.xy * R.c1 + S.xz * R.c2;   // (R S) column 0
+  const Vec3<T> a1 = S.xy * R.c0 + S.yy * R.c1 + S.yz * R.c2;
+  const Vec3<T> a2 = S.xz * R.c0 + S.yz * R.c1 + S.zz * R.c2;
+  Sym3<T> W;
+  W.xx = a0.x * R.c0.x + a1.x * R.c1.x + a2.x * R.c2.x;
+  W.xy = a0.x * R.c0.y + a1.x * R.c1.y + a2.x * R.c2.y;
+  W.xz = a0.x * R.c0.z + a1.x * R.c1.z + a2.x * R.c2.z;
+  W.yy = a0.y * R.c0.y + a1.y * R.c1.y + a2.y * R.c2.y;
+  W.yz = a0.y * R.c0.z + a1.y * R.c1.z + a2.y * R.c2.z;
+  W.zz = a0.z * R.c0.z + a1.z * R.c1.z + a2.z * R.c2.z;
+  return W;
+}
+
 // In must provide: T hn(i) i<6 ; T euler(i) i<3 ; T q(j), T qd(j) j<18 (joint order) ; Vec3<T> force(c) c<4 (contact order)
-// onEE(r_ee_rel_base, R_ee) is called once, onFoot(c, r_rel_base, v_joint_only, force) four times.
+// onEE(r_ee_rel_base, R_ee) is called once, onFoot(c, r_rel_base, v_joint_only) four times (world axes, relative to the base origin).
 template <class T, class In, class FootFn, class EeFn>
 __device__ __forceinline__ void centroidalSweep(const qmgpu_model& md, double gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, T f[12], BaseMotion<T>& bm) {
   T sz, cz, sy, cy;
-  ChainState<T> base;
-  baseRotation(in.euler(0), in.euler(1), in.euler(2), base.R, sz, cz, sy, cy);
-  Accum<T> acc;
-  accumulateBody(md, 0, base, acc);
-  {
-    ChainState<T> s = base;
-#pragma unroll 1
-    for (int a = 0; a < 6; ++a) bodyStep(md, 13 + a, in.q(12 + a), in.qd(12 + a), s, acc);
-    onEE(s.r + mul(s.R, md.ee_offset[0], md.ee_offset[1], md.ee_offset[2]), s.R);
+  Mat3<T> R0;
+  baseRotation(in.euler(0), in.euler(1), in.euler(2), R0, sz, cz, sy, cy);
+  // totals in the base frame, about the base origin; start with the base body itself
+  ChainAcc<T> tot;
+  tot.M = 0.0;
+  addBody(md, 0, tot);
+  auto absorb = [&](const ChainAcc<T>& c) {
+    tot.M += c.M; tot.h = tot.h + c.h; tot.l = tot.l + c.l; tot.k = tot.k + c.k;
+    tot.I.xx = tot.I.xx + c.I.xx; tot.I.xy = tot.I.xy + c.I.xy; tot.I.xz = tot.I.xz + c.I.xz; tot.I.yy = tot.I.yy + c.I.yy; tot.I.yz = tot.I.yz + c.I.yz; tot.I.zz = tot.I.zz + c.I.zz;
+  };
+  {  // arm: bodies 18 .. 13, tip = end-effector frame (its orientation is carried along)
+    ChainAcc<T> c;
+    c.M = 0.0;
+    c.p = Vec3<T>(T(md.ee_offset[0]), T(md.ee_offset[1]), T(md.ee_offset[2]));
+    Mat3<T> Re;
+    Re.c0 = Vec3<T>(T(1.0), T(0.0), T(0.0)); Re.c1 = Vec3<T>(T(0.0), T(1.0), T(0.0)); Re.c2 = Vec3<T>(T(0.0), T(0.0), T(1.0));
+#pragma unroll
+    for (int a = 5; a >= 0; --a) {
+      addBody(md, 13 + a, c);
+      crossJoint(md, 13 + a, ARM_AXIS[a], in.q(12 + a), in.qd(12 + a), c, [&](int axis, T cs, T sn) { rotAxis(axis, cs, sn, Re.c0); rotAxis(axis, cs, sn, Re.c1); rotAxis(axis, cs, sn, Re.c2); });
+    }
+    absorb(c);
+    Mat3<T> Rw;
+    Rw.c0 = mul(R0, Re.c0); Rw.c1 = mul(R0, Re.c1); Rw.c2 = mul(R0, Re.c2);
+    onEE(mul(R0, c.p), Rw);
   }
   Vec3<T> fsum, tsum;
 #pragma unroll 1
   for (int leg = 0; leg < 4; ++leg) {
-    ChainState<T> s = base;
+    int cft = 0;
+    for (int k = 1; k < 4; ++k) if (md.foot_body[k] == 3 + 3 * leg) cft = k;
+    ChainAcc<T> c;
+    c.M = 0.0;
+    c.p = Vec3<T>(T(md.foot_offset[cft][0]), T(md.foot_offset[cft][1]), T(md.foot_offset[cft][2]));
 #pragma unroll
-    for (int j = 0; j < 3; ++j) bodyStep(md, 1 + 3 * leg + j, in.q(3 * leg + j), in.qd(3 * leg + j), s, acc);
-    int c = 0;
-    for (int k = 1; k < 4; ++k) if (md.foot_body[k] == 3 + 3 * leg) c = k;
-    const Vec3<T> lo = mul(s.R, md.foot_offset[c][0], md.foot_offset[c][1], md.foot_offset[c][2]);
-    const Vec3<T> r = s.r + lo, v = s.vo + cross(s.w, lo);
-    const Vec3<T> F = in.force(c);
+    for (int j = 2; j >= 0; --j) {
+      addBody(md, 1 + 3 * leg + j, c);
+      crossJoint(md, 1 + 3 * leg + j, LEG_AXIS[j], in.q(3 * leg + j), in.qd(3 * leg + j), c, [](int, T, T) {});
+    }
+    absorb(c);
+    const Vec3<T> r = mul(R0, c.p), v = mul(R0, c.vf);
+    const Vec3<T> F = in.force(cft);
     fsum = fsum + F;
     tsum = tsum + cross(r, F);
-    onFoot(c, r, v);
+    onFoot(cft, r, v);
   }
+  Accum<T> acc;
+  acc.M1 = mul(R0, tot.h);
+  acc.hl = mul(R0, tot.l);
+  acc.ha = mul(R0, tot.k);
+  acc.Io = similarity(R0, tot.I);
   T hn[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) hn[i] = in.hn(i);

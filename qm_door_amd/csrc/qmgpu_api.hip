@@ -73,6 +73,8 @@ static void checkTopology(const qmgpu_model& m) {
   bool seen[4] = {false, false, false, false};
   for (int c = 0; c < 4; ++c) { const int b = m.foot_body[c]; ok = ok && (b == 3 || b == 6 || b == 9 || b == 12); if (ok) seen[b / 3 - 1] = true; }
   ok = ok && seen[0] && seen[1] && seen[2] && seen[3] && m.ee_body == 18;
+  for (int l = 0; l < 4; ++l) for (int j = 0; j < 3; ++j) ok = ok && m.axis[1 + 3 * l + j] == LEG_AXIS[j];   // the tree sweep hard-codes the joint axes
+  for (int a = 0; a < 6; ++a) ok = ok && m.axis[13 + a] == ARM_AXIS[a];
   if (!ok) throw UnsupportedModel("kernels are specialised to the AlienGo+Z1 topology (4 x 3-joint legs + 6-joint arm)");
 }
 
