@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BATCH_PER_GPU = 256
 HORIZON_N = 100
-TRAFFIC_FILE = "r01c_traffic.json"   # rocprofv3 PMC passes of this same command, summarised (bytes per launch)
+TRAFFIC_FILE = "r01d_traffic.json"   # rocprofv3 PMC passes of this same command, summarised (bytes per launch)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public spec, v_mfma_f64_16x16x4_f64 (not listed in MI355X_MICROARCH.md)
 
 
@@ -148,10 +148,9 @@ def main():
             cnt = int((nc == v).sum())
             for k, f in node_flops(int(v)).items():
                 flops[k] += cnt * f
-        dom = int(np.argmax(kernel_ms[:5]))
-        dom_name = names[dom]
+        dom_name = max(flops, key=lambda k: kernel_ms[names.index(k)])   # longest launch among the kernels that carry algorithmic FLOPs
         path_flops = flops["ad_node_kernel"] + flops["lq_node_kernel"] + flops["riccati_kernel"]
-        roof_kernel = dom_name if dom_name in flops else "riccati_kernel"
+        roof_kernel = dom_name
         kms = kernel_ms[names.index(roof_kernel)]
         achieved = flops[roof_kernel] / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/, see its _how field)
