@@ -28,6 +28,7 @@ inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one p
 
 #define __global__
 #define QM_ONE_WAVE_PER_SIMD
+#define QM_SCHED_FENCE()
 #define QM_LDS_BARRIER() __syncthreads()
 #define __device__
 #define __host__

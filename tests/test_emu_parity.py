@@ -80,3 +80,52 @@ def test_emu_wbc(emu):
         assert s == 0
         assert np.abs(out[i] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
         assert np.array_equal(il[i], il_ref)
+
+
+def test_emu_mixed_modes_and_event_grid(emu):
+    """Flight / three-leg / stance nodes (m~ = 14, 17, 18 tile paths of the MFMA kernels) on an event-aligned, non-uniform grid."""
+    itf, orc = emu
+    from qm_door_amd import abi as _abi
+    gs = api.GaitSchedule(lib=itf.lib)
+    ev, md, t = [], [15], 0.06
+    for name in ("flying_trot", "static_walk"):
+        g = gs.template(name)
+        for i in range(g.num_modes):
+            m = int(g.modes[i]); d = 0.25 * (g.switching_times[i + 1] - g.switching_times[i])     # compressed so that 24 nodes see every mode
+            if m != md[-1]:
+                ev.append(t); md.append(m)
+            t += d
+    ev.append(t); md.append(15)
+    nev = len(ev)
+    evp = np.full(_abi.MAX_EVENTS, 1e300); evp[:nev] = ev
+    mdp = np.full(_abi.MAX_EVENTS + 1, 15, dtype=np.int32); mdp[:len(md)] = md
+    N, grid = api.time_grid_with_events(0.0, 0.36, itf.problem.settings.dt, ev, max_nodes=64, lib=itf.lib)
+    B = 1
+    x0 = S.perturbed_states(itf.initial_state, B, seed=8)
+    tgt = S.nominal_target(orc, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, 8))
+    a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), evp[None, :].copy(), mdp[None, :].copy(), oT, oX, oU, oM, oS, time_grid=grid[None, :].copy())
+    sol.mpc(a)
+    ref = orc.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, evp, mdp, time_grid=grid)
+    assert {0, 15}.issubset(set(oM[0].tolist())) and len(set(oM[0].tolist())) >= 4 and (np.diff(grid) < 0.9 * itf.problem.settings.dt).any()
+    assert np.array_equal(oM[0], ref["mode"]) and np.array_equal(oT[0], grid)
+    assert np.abs(oX[0] - ref["X"]).max() <= 1e-8 * max(1.0, np.abs(ref["X"]).max())
+    assert np.abs(oU[0] - ref["U"]).max() <= 1e-8 * max(1.0, np.abs(ref["U"]).max())
+
+
+def test_emu_frontend(emu):
+    itf, orc = emu
+    import test_frontend as TF
+    cs = TF._cases(itf, orc, 8, seed=21)
+    B = len(cs)
+    rbd = np.array([c["rbd"] for c in cs]); tm = np.array([c["time"] for c in cs]); yl = np.array([c["yaw_last"] for c in cs])
+    kd = np.array([c["kind"] for c in cs], dtype=np.int32); cmd = np.array([c["cmd"] for c in cs]); le = np.array([c["last_ee"] for c in cs]); fh = np.array([c["feet"] for c in cs])
+    x0, tt, ts = np.zeros((B, 30)), np.zeros((B, 2)), np.zeros((B, 2, 37))
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=4)
+    sol.frontend(sol.frontend_args(B, rbd, tm, kd, cmd, le, x0, tt, ts, yaw_last=yl, feet_height=fh))
+    for i, c in enumerate(cs):
+        rx, rt, rs, rl = orc.frontend(c["rbd"], c["time"], c["kind"], c["cmd"], c["last_ee"], yaw_last=c["yaw_last"], feet_height=c["feet"])
+        assert np.abs(x0[i] - rx).max() <= 1e-12 * max(1.0, np.abs(rx).max()) and np.abs(ts[i] - rs).max() <= 1e-12 * max(1.0, np.abs(rs).max())
+        assert np.abs(tt[i] - rt).max() <= 1e-12 * max(1.0, np.abs(rt).max()) and np.abs(le[i] - rl).max() <= 1e-15
