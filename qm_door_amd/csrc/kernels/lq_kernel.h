@@ -76,7 +76,8 @@ constexpr int L_R = L_X + 48 * LDR;          // R [32][LDR] (dt-scaled), later Q
 constexpr int L_PA = L_R + 32 * LDR;         // Pall [32][PAW]  /  CD [16][CDW]
 constexpr int L_EEJ = L_PA + 32 * PAW;       // EE error Jacobian [6][32]
 constexpr int L_VEC = L_EEJ + 192;           // b[30] r[30] e[16] eeh[6] (+2) | g30[64]
-constexpr int L_RED = L_VEC + 84 + 64;       // wavefront exchange scratch [256]
+constexpr int L_XU = L_VEC + 84 + 64;        // x[32] u[32] x_next[32] x_ref[32]
+constexpr int L_RED = L_XU + 128;            // wavefront exchange scratch [256]
 constexpr int LQ_LDS_DOUBLES = L_RED + 256;  // 5032 doubles = 39.3 KiB: four workgroups per CU
 static_assert(16 * CDW <= 32 * PAW && 32 * PAW <= 48 * LDR && 2 * 32 * LDT <= 48 * LDR, "aliases must fit");
 static_assert(LQ_LDS_DOUBLES * 8 <= 40960, "four nodes per CU");
@@ -219,9 +220,11 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
   const double t = tg[node];
   const double dt = terminal ? 0.0 : tg[node + 1] - t;
-  const double* x = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
-  const double* u = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
-  const double* xnext = terminal ? x : x + 30;
+  const double* xG = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
+  const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+  // x, u, x_next and the reference state are read many times with wave-uniform indices: one vector load each into LDS instead of
+  // chains of dependent scalar loads (one wavefront per SIMD has nothing to hide their latency with)
+  double* x = lds + L_XU; double* u = x + 32; double* xnext = x + 64; double* xref = x + 96;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
   const int phase = phaseAt(sched, t);
   const int mode = sched.modes[phase];
@@ -254,6 +257,11 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   double* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
   int tIdx; double tAlpha;
   timeSegment(tTimes, a.K, t, tIdx, tAlpha);
+  if (lane < 30) {
+    x[lane] = xG[lane]; u[lane] = uG[lane]; xnext[lane] = terminal ? xG[lane] : xG[30 + lane];
+    xref[lane] = xReference(tStates, a.K, tIdx, tAlpha, lane);
+  }
+  QM_WAVE_SYNC();
   const int c = lane;
   double qc = 0.0, costPart = 0.0;
   const double sc = terminal ? 1.0 : dt;  // intermediate costs are scaled by dt, the terminal cost is not
@@ -280,11 +288,11 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
 #pragma unroll
       for (int i = 0; i < 30; ++i) {
         const double qw = st.Q[i * 30 + c];
-        Qdx += qw * (x[i] - xReference(tStates, a.K, tIdx, tAlpha, i));
+        Qdx += qw * (x[i] - xref[i]);
         Qcol[i] += qw;
       }
       qc += Qdx;
-      costPart += 0.5 * (x[c] - xReference(tStates, a.K, tIdx, tAlpha, c)) * Qdx;
+      costPart += 0.5 * (x[c < 30 ? c : 0] - xref[c < 30 ? c : 0]) * Qdx;
       if (c >= 24) {  // arm joint position soft box (QMInterface.cpp:177-219)
         const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta};
         const double lo = md.q_lower[c - 12], up = md.q_upper[c - 12];
