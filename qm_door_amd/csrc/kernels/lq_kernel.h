@@ -130,8 +130,12 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
   const double t = tg[node];
   const double dt = terminal ? 0.0 : tg[node + 1] - t;
-  const double* x = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
-  const double* u = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+  const double* xG = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
+  const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+  __shared__ double xu[64];   // x | u staged once: the sweep reads them with wave-uniform indices
+  if (lane < 30) { xu[lane] = xG[lane]; xu[32 + lane] = uG[lane]; }
+  QM_WAVE_SYNC();
+  const double* x = xu; const double* u = xu + 32;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
   const int phase = phaseAt(sched, t);
   const int mode = sched.modes[phase];
