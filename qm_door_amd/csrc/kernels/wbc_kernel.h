@@ -23,6 +23,7 @@
 #include "linesearch_kernel.h"  // DblIn
 #include "sweep_dev.h"
 #include "ipm_dev.h"
+#include "wave_gemm.h"
 
 namespace qmk {
 
@@ -530,19 +531,11 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     const int mRows = mOwn + mPrev;  // <= 56, one row per lane
     const double* AZp = AZ;
     if (level == 3) AZp = Z;  // A = I  =>  A Z = Z
-    else
-      for (int e = lane; e < r * n; e += 64) {
-        const int i = e / n, j = e % n;
-        double s = 0.0;
-        for (int q = 0; q < ND; ++q) s += A[i * ND + q] * Z[q * LDZ + j];
-        AZ[i * LDZ + j] = s;
-      }
-    for (int e = lane; e < m0 * ND; e += 64) {  // columns >= n are zero padding: the register code below always spans 36 columns
-      const int i = e / ND, j = e % ND;
-      double s = 0.0;
-      if (j < n) for (int q = 0; q < ND; ++q) s += D0[i * ND + q] * Z[q * LDZ + j];
-      DZ[i * LDZ + j] = s;
-    }
+    else waveGemm<false>(A, ND, Z, LDZ, r, n, ND, lane, red, [&](int i, int j, double v) { AZ[i * LDZ + j] = v; });
+    // D Z on the matrix cores; columns >= n stay zero padding (the interior point always spans whole tiles)
+    for (int e = lane; e < m0 * LDZ; e += 64) DZ[e] = 0.0;
+    QM_WAVE_SYNC();
+    waveGemm<false>(D0, ND, Z, LDZ, m0, n, ND, lane, red, [&](int i, int j, double v) { DZ[i * LDZ + j] = v; });
     if (lane < r) {  // A x_prev - b (temporarily in tzv)
       double s;
       if (level == 3) s = xs[lane];
@@ -557,12 +550,9 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     }
     QM_WAVE_SYNC();
     // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
-    for (int e = lane; e < ND * ND; e += 64) {
-      const int i = e / ND, j = e % ND;
-      double s = 0.0;
-      if (i < n && j < n) { s = (i == j) ? 1e-12 : 0.0; for (int q = 0; q < r; ++q) s += AZp[q * LDZ + i] * AZp[q * LDZ + j]; }
-      G[i * LDK + j] = s;
-    }
+    for (int e = lane; e < ND * LDK; e += 64) G[e] = 0.0;
+    QM_WAVE_SYNC();
+    waveGemm<true>(AZp, LDZ, AZp, LDZ, n, n, r, lane, red, [&](int i, int j, double v) { G[i * LDK + j] = v + (i == j ? 1e-12 : 0.0); });
     if (lane < ND) { double s = 0.0; if (lane < n) for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
     // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
