@@ -647,15 +647,13 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
 #pragma unroll
         for (int i = 0; i < ND; ++i) nv[i] -= s * Vh[k * 40 + i];
       }
+      // Z N on the matrix cores: the null vectors (one per lane) pass through LDS (the K scratch is free here)
       if (lane < nNew) {
-#pragma unroll 1
-        for (int i = 0; i < ND; ++i) {
-          double s = 0.0;
 #pragma unroll
-          for (int q = 0; q < ND; ++q) s += Z[i * LDZ + q] * nv[q];
-          Zn[i * LDZ + lane] = s;
-        }
+        for (int q = 0; q < ND; ++q) K[q * LDK + lane] = nv[q];
       }
+      QM_WAVE_SYNC();
+      waveGemm<false>(Z, LDZ, K, LDK, ND, nNew, ND, lane, red, [&](int i, int j, double v) { Zn[i * LDZ + j] = v; });
       QM_WAVE_SYNC();
       for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
       n = nNew;
