@@ -39,7 +39,7 @@ struct RiccatiArgs {
 
 constexpr int RICCATI_WAVES = 4;
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
-constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34;
+constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LT = 49;   // LDS_LT odd: lane c writes row c of L^-T without bank conflicts
 constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
 constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
 constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
@@ -49,8 +49,8 @@ constexpr int R_S = R_T + 32 * LDS_Y;             // S [32][LDS_S]
 constexpr int R_SV = R_S + 32 * LDS_S;            // s [32]
 constexpr int R_W = R_SV + 32;                    // W [20][LDS_W]
 constexpr int R_LI = R_W + 20 * LDS_W;            // L^-1 row major [20][LDS_W]
-constexpr int R_LIT = R_LI + 20 * LDS_W;          // L^-T row major [20][LDS_W]
-constexpr int R_VEC = R_LIT + 20 * LDS_W;         // dx[32] dut[32]
+constexpr int R_LIT = R_LI + 20 * LDS_W;          // L^-T row major [20][LDS_LT]
+constexpr int R_VEC = R_LIT + 20 * LDS_LT + 4;    // dx[32] dut[32]
 constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][256]; armijo reduction
 constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 256;
 constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~105 KiB (dynamic LDS)
@@ -107,7 +107,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const double* rec = stagesI + size_t(N) * STAGE_DOUBLES;
     for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0; }
     if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0;
-    for (int e = tid; e < 3 * 20 * LDS_W; e += NTHR) W[e] = 0.0;        // W, L^-1, L^-T (contiguous)
+    for (int e = tid; e < 2 * 20 * LDS_W + 20 * LDS_LT; e += NTHR) W[e] = 0.0;        // W, L^-1, L^-T (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
@@ -189,19 +189,30 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const double hv = T[r * LDS_Y + 32 + (lane < MT ? lane : 0)];
         col[r] = (isH && lane < nt && r < nt) ? hv : e;
       }
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {   // steps j >= m~ meet identity columns (pivot 1, multipliers 0): no branch, one basic block
-        const double piv = qmReadLane(col[j], j, scr);
+      // steps j >= m~ meet identity columns (pivot 1, multipliers 0): no branch, one basic block.  The reciprocal square root of
+      // pivot j + 1 is started right after row j + 1 has received its update, so its latency hides behind the remaining updates.
+      double inv;
+      {
+        const double piv = qmReadLane(col[0], 0, scr);
         if (!(piv > 0.0)) status = 1;
-        const double inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+        inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+      }
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
         col[j] *= inv;                                     // row j of [L^T | .] / sqrt(pivot)
         const QmGather gj = qmGather(col[j], scr);
+        if (j + 1 < MT) {
+          col[j + 1] -= gj.get(j + 1) * col[j];
+          const double piv = qmReadLane(col[j + 1], j + 1, scr);
+          if (!(piv > 0.0)) status = 1;
+          inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+        }
 #pragma unroll
-        for (int r = j + 1; r < MT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= m~: identity columns)
+        for (int r = j + 2; r < MT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= m~: identity columns)
       }
       if (!isH && c < 20) {
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { const double v = (c < nt && r < nt) ? col[r] : 0.0; LI[r * LDS_W + c] = v; LIT[c * LDS_W + r] = v; }
+        for (int r = 0; r < MT; ++r) { const double v = (c < nt && r < nt) ? col[r] : 0.0; LI[r * LDS_W + c] = v; LIT[c * LDS_LT + r] = v; }
       }
     }
     pf.commit(stgNext, OFF_PX, tid);   // stage k - 1 lands in the other buffer: wavefronts 1..3 do it while wavefront 0 factorises
@@ -214,7 +225,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       for (int r = 0; r < 4; ++r) c[r] = 0.0;
       double av[5], bw[5];
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = LIT[kk * LDS_W + tm * 16 + l16]; bw[ks] = T[kk * LDS_Y + tn * 16 + l16]; }   // L^-1[i][k] = L^-T[k][i]
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = LIT[kk * LDS_LT + tm * 16 + l16]; bw[ks] = T[kk * LDS_Y + tn * 16 + l16]; }   // L^-1[i][k] = L^-T[k][i]
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
 #pragma unroll
