@@ -50,6 +50,7 @@ __device__ __forceinline__ double qmAllMin(double v, double* scratch) { (void)sc
 #define QM_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 // scheduling fence: keeps the compiler from hoisting a long run of v_readlane broadcasts (two SGPRs each) ahead of their uses
 #define QM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QM_POISON_LDS(ptr, count)   // host emulation only: fills LDS with NaN at kernel start
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)
 // dynamic LDS (keeps the base 16-byte aligned: no static __shared__ may precede it in the same kernel)

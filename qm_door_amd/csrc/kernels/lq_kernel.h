@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
 // ---- kernel 2: cost, projection, projected stage record
 __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   __shared__ double lds[LQ_LDS_DOUBLES];
+  QM_POISON_LDS(lds, LQ_LDS_DOUBLES);
   const int lane = threadIdx.x;
   const int l16 = lane & 15, h = lane >> 4;
   const int node = blockIdx.x % (a.N + 1);
@@ -566,6 +567,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0 : 0.0) : 0.0;
   }
   if (lane < 30) Rm[lane * LDR + 30] = rv[lane];   // column 30 of R = r: row 30 of W = R Pall becomes r^T Pall
+  if (lane < 32) Rm[lane * LDR + 31] = 0.0;        // column 31 is read as tile padding: it must be zero, not whatever the LDS held
   QM_WAVE_SYNC();
 
   // ================================================================== products on the fp64 matrix cores

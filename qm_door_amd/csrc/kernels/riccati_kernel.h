@@ -85,6 +85,7 @@ template <int PF, int NTHR> struct StagePrefetch {
 template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIMD riccati_kernel(RiccatiArgs a) {
   static_assert(NW == 4, "tile ownership below is written for four wavefronts");
   QM_DYNAMIC_LDS(lds);
+  QM_POISON_LDS(lds, RICCATI_LDS_DOUBLES);
   constexpr int NTHR = NW * 64;
   constexpr int PFB = (OFF_PX / 2 + NTHR - 1) / NTHR;
   constexpr int PFR = (STAGE_DOUBLES / 2 + NTHR - 1) / NTHR;

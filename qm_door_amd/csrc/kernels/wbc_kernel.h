@@ -206,6 +206,7 @@ __device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane)
 
 __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   QM_DYNAMIC_LDS(lds);
+  QM_POISON_LDS(lds, WBC_LDS_DOUBLES);
   const int lane = threadIdx.x, inst = blockIdx.x;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;

@@ -7,6 +7,7 @@
 // emulation library, libqmgpu.so is built by hipcc only and refuses to run without a HIP device.
 #pragma once
 #include <barrier>
+#include <limits>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -28,6 +29,9 @@ inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one p
 
 #define __global__
 #define QM_ONE_WAVE_PER_SIMD
+// LDS is not zeroed between workgroups on the GPU: the emulation poisons it so that a read of never-written LDS that reaches the
+// arithmetic (a zero-padded tile operand, say) turns the results into NaN instead of passing by luck
+#define QM_POISON_LDS(ptr, count) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < int(count); ++i_) (ptr)[i_] = std::numeric_limits<double>::quiet_NaN(); __syncthreads(); } while (0)
 #define QM_SCHED_FENCE()
 #define QM_LDS_BARRIER() __syncthreads()
 #define __device__
@@ -152,7 +156,9 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
-inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? 0 : 1; }
+// device memory is not zeroed by the driver: the emulation fills it with 0xFF (NaN as double, -1 as int32) so that reads of scratch
+// that no kernel wrote show up in the results
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (*p) std::memset(*p, 0xFF, n ? n : 1); return *p ? 0 : 1; }
 inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return 0; }
