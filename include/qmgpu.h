@@ -249,6 +249,9 @@ int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms6);
 /* Same, averaged over the last `last_calls` timed calls (event ring of 256 calls; no per-call host sync is needed). */
 int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6);
 int qmgpu_enable_timing(qmgpu_handle h, int enable);
+/* Test aid: fills every scratch buffer behind the handle and the LDS of every CU with NaN, so that a kernel reading memory that
+ * nothing wrote in this call shows up as NaN in the results instead of passing on left-over values. */
+int qmgpu_debug_poison(qmgpu_handle h);
 /* Allocate / enable the per-node dump read by qmgpu_debug_get_lq (off by default: 37 KiB per node). */
 int qmgpu_enable_debug(qmgpu_handle h, int enable);
 

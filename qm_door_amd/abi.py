@@ -94,7 +94,7 @@ SYMBOLS = [
     "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_time_grid_with_events",
     "qmgpu_create", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
     "qmgpu_policy_eval_batch", "qmgpu_frontend_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
-    "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_kernel_ms_mean",
+    "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_debug_poison", "qmgpu_kernel_ms_mean",
 ]
 
 _lib = None
@@ -150,6 +150,7 @@ def load_library(path=None):
     lib.qmgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.qmgpu_kernel_ms_mean.argtypes = [C.c_void_p, C.c_int, C.POINTER(d)]
     lib.qmgpu_enable_debug.argtypes = [C.c_void_p, C.c_int]
+    lib.qmgpu_debug_poison.argtypes = [C.c_void_p]
     if path is None:
         _lib = lib
     return lib

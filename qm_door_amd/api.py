@@ -109,6 +109,9 @@ class GpuSolver:
     def enable_timing(self, on=True):
         abi.check(self.lib, self.lib.qmgpu_enable_timing(self.handle, int(on)))
 
+    def debug_poison(self):
+        abi.check(self.lib, self.lib.qmgpu_debug_poison(self.handle))
+
     def enable_debug(self, on=True):
         abi.check(self.lib, self.lib.qmgpu_enable_debug(self.handle, int(on)))
 

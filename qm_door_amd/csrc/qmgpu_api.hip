@@ -57,10 +57,12 @@ struct qmgpu_context {
   double lastMs[5] = {0, 0, 0, 0, 0};
   int lastBatch = 0, lastN = 0;
 
-  template <class T> T* alloc(size_t count) {
+  std::vector<std::pair<void*, size_t>> scratch;   // buffers every call rewrites (qmgpu_debug_poison fills them with NaN)
+  template <class T> T* alloc(size_t count, bool isScratch = true) {
     void* p = nullptr;
     HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
     allocations.push_back(p);
+    if (isScratch) scratch.emplace_back(p, count * sizeof(T));
     return static_cast<T*>(p);
   }
 };
@@ -95,9 +97,9 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     HIP_CHECK(hipStreamCreate(&ctx->ownStream));
     ctx->stream = ctx->ownStream;
     const size_t B = size_t(max_batch), N1 = size_t(max_nodes) + 1, N = size_t(max_nodes);
-    ctx->dP = ctx->alloc<qmgpu_problem>(1);
-    ctx->dRw = ctx->alloc<double>(900);
-    ctx->dZeros = ctx->alloc<double>(64);
+    ctx->dP = ctx->alloc<qmgpu_problem>(1, false);
+    ctx->dRw = ctx->alloc<double>(900, false);
+    ctx->dZeros = ctx->alloc<double>(64, false);
     ctx->dTgrid = ctx->alloc<double>(B * N1);
     ctx->dX = ctx->alloc<double>(B * N1 * 30);
     ctx->dU = ctx->alloc<double>(B * N * 30);
@@ -165,6 +167,26 @@ int qmgpu_enable_timing(qmgpu_handle h, int enable) {
   h->timing = enable != 0;
   h->callCount = 0;
   return QMGPU_OK;
+}
+
+// fills one CU's worth of LDS with NaN; launched with many more workgroups than CUs so that every CU gets some
+__global__ void __launch_bounds__(256) lds_poison_kernel(int doubles, double* sink) {
+  QM_DYNAMIC_LDS(lds);
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  for (int e = threadIdx.x; e < doubles; e += 256) lds[e] = nan;
+  __syncthreads();
+  if (sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) sink[0] = lds[1];   // keeps the stores alive
+}
+
+int qmgpu_debug_poison(qmgpu_handle h) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() {
+    for (auto& sc : h->scratch) HIP_CHECK(hipMemsetAsync(sc.first, 0xFF, sc.second, h->stream));
+    constexpr int kDoubles = 160 * 1024 / 8;
+    HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(lds_poison_kernel, kDoubles * 8));
+    QM_LAUNCH_DYN(lds_poison_kernel, 4096, 256, kDoubles * 8, h->stream, kDoubles, static_cast<double*>(nullptr));
+    HIP_CHECK(hipGetLastError());
+  });
 }
 
 int qmgpu_enable_debug(qmgpu_handle h, int enable) {

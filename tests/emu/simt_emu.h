@@ -124,6 +124,7 @@ template <int TP> inline void qmMfmaUpper(QmAcc* acc, const double* a, const dou
   for (int ti = 0; ti < TP; ++ti)
     for (int tj = ti; tj < TP; ++tj, ++t) emuMfmaTile(acc[t], buf + ti * 128, buf + tj * 128 + 64, lane);
 }
+inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
 
 template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {

@@ -108,3 +108,23 @@ def test_three_sqp_iterations_match_oracle(oracle):
         assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
         assert np.allclose(r["stats"][i][:4], ref["stats"][:4], rtol=1e-6, atol=1e-9)
+
+
+def test_results_do_not_depend_on_leftover_memory(interface, oracle):
+    """Device scratch and every CU's LDS are filled with NaN before the call (qmgpu_debug_poison): a kernel that reads something no
+    kernel of this call wrote -- a zero-padding row of a matrix tile, say -- would turn the trajectories into NaN."""
+    import gpu_harness as G
+    import torch
+    B, N = 4, 8
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, B, N, seed=12)
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    rbd = np.array([S.rbd_from_state(oracle, x0[i]) for i in range(B)])
+    wb = G.WbcBatch(rbd, np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
+    for _ in range(3):
+        sol.debug_poison()
+        sol.cycle(mb.args, G.dev(np.zeros(B), torch.float64), wb.args)
+        r, w = mb.results(), wb.results()
+        assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(w["out"]).all() and (r["stats"][:, 7] == 0).all()
+    ref = oracle.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
+    assert np.abs(r["X"][0] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
