@@ -51,6 +51,7 @@ def test_config5_mixed_gaits_n200_batch1024(interface, oracle):
     assert {15, 9, 6, 0}.issubset(set(modes.tolist())) and len(set(modes.tolist())) >= 6      # stance, trot pair, FLY, three-leg phases
     sol = G.make_solver(interface, B, N)
     mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.debug_poison()          # every tile path (m~ = 14, 16, 17, 18) runs on NaN-filled scratch / LDS: nothing may read leftovers
     sol.mpc(mb.args)
     r = mb.results()
     assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and (r["stats"][:, 7] == 0).all()

@@ -102,6 +102,7 @@ def test_wbc_stress_all_modes_converge(interface, oracle, variant):
     rbd[:, 0:3] = xm[:, 9:12]; rbd[:, 3:6] = xm[:, 6:9]; rbd[:, 6:24] = xm[:, 12:30]; rbd[:, 24:48] = vm
     sol = G.make_solver(interface, B, 4)
     wb = G.WbcBatch(rbd, np.full(B, 0.002), t, il, xd, u, mode, variant)
+    sol.debug_poison()
     sol.wbc(wb.args)
     r = wb.results()
     assert np.isfinite(r["out"]).all()
