@@ -73,6 +73,9 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   double lamE = 0.0, zIpm = 0.0;
   const double rho = 1e6 * fmax(1.0, pivotFloor * 1e13);
   int it = 0, itOut = 0;
+  double kc[NP], uc[NP], myInv = 1.0;   // factor of the current K (row c of L, row c of L^T): survives across the polish steps, whose K is constant
+#pragma unroll
+  for (int r = 0; r < NP; ++r) { kc[r] = 0.0; uc[r] = 0.0; }
 #pragma unroll 1
   for (; it < 70; ++it) {
     // ---- residuals
@@ -138,83 +141,84 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
     }
 
-    // ---- K = G + DZ' diag(w) DZ: upper-triangle tiles on the matrix cores, mirrored into LDS
     const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
-    if (lane < 56) io.wtL[lane] = polish ? (isE ? rho : (isV ? 1.0 : 0.0)) : (rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0);
-    QM_WAVE_SYNC();
-    {
-      QmAcc acc[TP * (TP + 1) / 2];
+    if (polish <= 1) {   // the polish steps share one matrix: build and factorise it once
+      // ---- K = G + DZ' diag(w) DZ: upper-triangle tiles on the matrix cores, mirrored into LDS
+      if (lane < 56) io.wtL[lane] = polish ? (isE ? rho : (isV ? 1.0 : 0.0)) : (rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0);
+      QM_WAVE_SYNC();
       {
+        QmAcc acc[TP * (TP + 1) / 2];
+        {
+          int t = 0;
+  #pragma unroll
+          for (int ti = 0; ti < TP; ++ti)
+  #pragma unroll
+            for (int tj = ti; tj < TP; ++tj, ++t)
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+                const double gv = G[(i < 36 ? i : 0) * LDK_ + (j < 36 ? j : 0)];
+                acc[t][r] = (i < 36 && j < 36) ? gv : 0.0;
+              }
+        }
+  #pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kk = 4 * ks + h;
+          const double w = io.wtL[kk];
+          double b[TP], a[TP];
+  #pragma unroll
+          for (int t = 0; t < TP; ++t) {
+            const int j = t * 16 + l16;
+            const double raw = DZ[kk * LDZ_ + (j < 36 ? j : 0)];
+            b[t] = j < NP ? raw : 0.0;
+            a[t] = w * b[t];
+          }
+          qmMfmaUpper<TP>(acc, a, b, red);
+        }
         int t = 0;
-#pragma unroll
+  #pragma unroll
         for (int ti = 0; ti < TP; ++ti)
-#pragma unroll
+  #pragma unroll
           for (int tj = ti; tj < TP; ++tj, ++t)
-#pragma unroll
+  #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
-              const double gv = G[(i < 36 ? i : 0) * LDK_ + (j < 36 ? j : 0)];
-              acc[t][r] = (i < 36 && j < 36) ? gv : 0.0;
+              if (i < NP && j < NP) { io.Kt[i * LDK_ + j] = acc[t][r]; if (ti != tj) io.Kt[j * LDK_ + i] = acc[t][r]; }
             }
       }
-#pragma unroll 2
-      for (int ks = 0; ks < KS; ++ks) {
-        const int kk = 4 * ks + h;
-        const double w = io.wtL[kk];
-        double b[TP], a[TP];
-#pragma unroll
-        for (int t = 0; t < TP; ++t) {
-          const int j = t * 16 + l16;
-          const double raw = DZ[kk * LDZ_ + (j < 36 ? j : 0)];
-          b[t] = j < NP ? raw : 0.0;
-          a[t] = w * b[t];
-        }
-        qmMfmaUpper<TP>(acc, a, b, red);
-      }
-      int t = 0;
-#pragma unroll
-      for (int ti = 0; ti < TP; ++ti)
-#pragma unroll
-        for (int tj = ti; tj < TP; ++tj, ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
-            if (i < NP && j < NP) { io.Kt[i * LDK_ + j] = acc[t][r]; if (ti != tj) io.Kt[j * LDK_ + i] = acc[t][r]; }
-          }
-    }
-    QM_WAVE_SYNC();
+      QM_WAVE_SYNC();
 
-    // ---- factorisation K = L L^T by row operations: lane c holds column c of K in kc; after step j, kc[j] of lane c is
-    //      L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
-    double kc[NP], myInv = 1.0;
-#pragma unroll
-    for (int r = 0; r < NP; ++r) {
-      const double kv = io.Kt[r * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
-      kc[r] = (colOn && r < n) ? kv : ((r == lane) ? 1.0 : 0.0);   // identity padding beyond n
+      // ---- factorisation K = L L^T by row operations: lane c holds column c of K in kc; after step j, kc[j] of lane c is
+      //      L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
+      myInv = 1.0;
+  #pragma unroll
+      for (int r = 0; r < NP; ++r) {
+        const double kv = io.Kt[r * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
+        kc[r] = (colOn && r < n) ? kv : ((r == lane) ? 1.0 : 0.0);   // identity padding beyond n
+      }
+  #pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const double piv = qmReadLane(kc[j], j, red);
+        const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
+        const double inv = qmRsqrt(dfl);
+        kc[j] = (lane == j) ? dfl * inv : kc[j] * inv;
+        if (lane == j) myInv = inv;                              // 1 / L_jj
+        const QmGather gk = qmGather(kc[j], red);                // L[r][j] = gk.get(r)
+  #pragma unroll
+        for (int r = j + 1; r < NP; ++r) kc[r] -= gk.get(r) * kc[j];
+      }
+      // the back substitution L^T dz = t walks the COLUMNS of L^T: U[r][c] (c > r) sits in lane c, register r.  One transpose
+      // through LDS per factorisation puts it into lane r, register c.
+      QM_WAVE_SYNC();
+      if (lane < NP) {
+  #pragma unroll
+        for (int r = 0; r < NP; ++r) io.Kt[lane * LDK_ + r] = kc[r];
+      }
+      QM_WAVE_SYNC();
+  #pragma unroll
+      for (int cc = 0; cc < NP; ++cc) uc[cc] = io.Kt[cc * LDK_ + colL];   // U[lane][cc] for cc > lane
+      QM_WAVE_SYNC();
     }
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const double piv = qmReadLane(kc[j], j, red);
-      const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
-      const double inv = qmRsqrt(dfl);
-      kc[j] = (lane == j) ? dfl * inv : kc[j] * inv;
-      if (lane == j) myInv = inv;                              // 1 / L_jj
-      const QmGather gk = qmGather(kc[j], red);                // L[r][j] = gk.get(r)
-#pragma unroll
-      for (int r = j + 1; r < NP; ++r) kc[r] -= gk.get(r) * kc[j];
-    }
-    // the back substitution L^T dz = t walks the COLUMNS of L^T: U[r][c] (c > r) sits in lane c, register r.  One transpose
-    // through LDS per factorisation puts it into lane r, register c.
-    QM_WAVE_SYNC();
-    if (lane < NP) {
-#pragma unroll
-      for (int r = 0; r < NP; ++r) io.Kt[lane * LDK_ + r] = kc[r];
-    }
-    QM_WAVE_SYNC();
-    double uc[NP];
-#pragma unroll
-    for (int cc = 0; cc < NP; ++cc) uc[cc] = io.Kt[cc * LDK_ + colL];   // U[lane][cc] for cc > lane
-    QM_WAVE_SYNC();
 
     double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0, dzc = 0.0;
     double alphaAff = 1.0, sigma = 0.0;
