@@ -131,7 +131,7 @@ int qmo_wbc_update(const qmgpu_problem* P, int variant, const double* xDes, cons
 int qmo_qp_solve(int n, int m, const double* H, const double* c, const double* D, const double* f, double* z, double* kktRes) {
   Mat Hm = Mat::from(H, n, n), Dm = m > 0 ? Mat::from(D, m, n) : Mat(0, n);
   Vec cv(c, c + n), fv(f, f + m), zv;
-  const int it = solveQpIpm(Hm, cv, Dm, fv, zv, 60, kktRes);
+  const int it = solveQpIpm(Hm, cv, Dm, fv, zv, 40, kktRes);
   for (int i = 0; i < n; ++i) z[i] = zv[i];
   return it;
 }

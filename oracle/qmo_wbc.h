@@ -319,7 +319,7 @@ inline bool choleskyFloored(Mat& A, double floorv) {
 
 // ------------------------------------------------------------------------------------------------ dense convex QP: min 1/2 z'Hz + c'z  s.t.  D z <= f
 // Mehrotra predictor-corrector primal-dual interior point.  Returns iterations used, negative on failure.
-inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 60, double* kktRes = nullptr, bool scaledStart = false) {
+inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, bool scaledStart = false) {
   const int n = H.r;
   // rows that are identically zero carry no information (the reference's friction task creates them, WbcBase.cpp:458)
   std::vector<int> keep;
@@ -339,61 +339,12 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   const double sigma = scaledStart ? std::sqrt(scale) : 1.0;
   Vec s(m), lam(m, sigma);
   { const Vec Dz = D * z; for (int i = 0; i < m; ++i) s[i] = std::max(sigma, f[i] - Dz[i]); }
-  int it = 0;
-  Vec zPrev = z, sPrev = s, lamPrev = lam;
-  double nrdPrev = 0.0, muPrev = 0.0;
-  for (; it < maxIter; ++it) {
-    const Vec rd = H * z + c + tmul(D, lam);
-    Vec rp = D * z + s - f;
-    double mu = dot(s, lam) / m;
-    double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
-    // Late iterations of degenerate problems (rows active with a zero multiplier) push the barrier weights to ~1e18 and the
-    // Newton step can lose all accuracy.  A step that blows the dual residual up (or produces NaN) is rejected: the previous
-    // iterate is returned, as converged if its complementarity was already <= 1e-8 * scale, flagged otherwise.
-    if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) {
-      z = zPrev; s = sPrev; lam = lamPrev;
-      if (kktRes) *kktRes = std::max(nrdPrev, muPrev);
-      if (!(muPrev <= 1e-8 * scale)) return -3;
-      break;   // accepted as converged: polished below like any other final iterate
-    }
-    if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
-    // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
-    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
-    // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
-    // here instead of iterating into the divergence that follows; the polish finishes the job
-    if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;
-    zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
-    Mat K = H;
-    for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
-    if (!choleskyFloored(K, pivotFloor)) return -2;
-    auto solve = [&](const Vec& rc, Vec& dz, Vec& ds, Vec& dl) {
-      Vec t(m); for (int i = 0; i < m; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
-      dz = -1.0 * (rd + tmul(D, t));
-      cholSolve(K, dz);
-      const Vec Ddz = D * dz;
-      ds.resize(m); dl.resize(m);
-      for (int i = 0; i < m; ++i) { ds[i] = -rp[i] - Ddz[i]; dl[i] = (-rc[i] - lam[i] * ds[i]) / s[i]; }
-    };
-    auto maxStep = [&](const Vec& ds, const Vec& dl) { double a = 1.0; for (int i = 0; i < m; ++i) { if (ds[i] < 0) a = std::min(a, -s[i] / ds[i]); if (dl[i] < 0) a = std::min(a, -lam[i] / dl[i]); } return a; };
-    Vec rc(m), dz, ds, dl;
-    for (int i = 0; i < m; ++i) rc[i] = s[i] * lam[i];
-    solve(rc, dz, ds, dl);
-    const double aAff = maxStep(ds, dl);
-    double muAff = 0; for (int i = 0; i < m; ++i) muAff += (s[i] + aAff * ds[i]) * (lam[i] + aAff * dl[i]); muAff /= m;
-    const double sigma = std::pow(muAff / mu, 3.0);
-    for (int i = 0; i < m; ++i) rc[i] = s[i] * lam[i] + ds[i] * dl[i] - sigma * mu;
-    solve(rc, dz, ds, dl);
-    const double tau = std::max(0.995, 1.0 - mu);
-    const double a = std::min(1.0, tau * maxStep(ds, dl));
-    for (int i = 0; i < n; ++i) z[i] += a * dz[i];
-    for (int i = 0; i < m; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
-  }
   // ---- active-set polish.  The normal-equation interior point stalls at a dual residual of ~1e-7 * scale (barrier weights ~1e14);
   // an active-set solver like qpOASES returns the vertex itself.  With the active set read off the final iterate (multiplier larger
   // than slack) the equality-constrained QP is solved by a few augmented-Lagrangian Newton steps from the interior-point solution:
   //   grad = H z + c + D_A' (lam_A + rho r_A),  r = D z - f ;   (H + rho D_A' D_A) dz = -grad ;   lam_A += rho r_A(z + dz).
   // The result is kept only if it is primal feasible and its multipliers are non-negative (else the interior-point iterate stands).
-  {
+  auto tryPolish = [&]() -> bool {
     std::vector<int> act;
     for (int i = 0; i < m; ++i) if (lam[i] > s[i]) act.push_back(i);
     double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
@@ -418,9 +369,66 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
       for (int i = 0; i < m; ++i) if (!(Dz[i] - f[i] <= 1e-9 * scale)) ok = false;
       for (int r : act) if (!(lp[r] >= -1e-9 * scale)) ok = false;
       for (double v : zp) if (!(v == v)) ok = false;
-      if (ok) z = zp;
+      if (ok) { z = zp; return true; }
     }
+    return false;
+  };
+  int it = 0;
+  bool earlyTried = false;
+  Vec zPrev = z, sPrev = s, lamPrev = lam;
+  double nrdPrev = 0.0, muPrev = 0.0;
+  for (; it < maxIter; ++it) {
+    const Vec rd = H * z + c + tmul(D, lam);
+    Vec rp = D * z + s - f;
+    double mu = dot(s, lam) / m;
+    double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
+    // Late iterations of degenerate problems (rows active with a zero multiplier) push the barrier weights to ~1e18 and the
+    // Newton step can lose all accuracy.  A step that blows the dual residual up (or produces NaN) is rejected: the previous
+    // iterate is returned, as converged if its complementarity was already <= 1e-8 * scale, flagged otherwise.
+    if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) {
+      z = zPrev; s = sPrev; lam = lamPrev;
+      if (kktRes) *kktRes = std::max(nrdPrev, muPrev);
+      if (!(muPrev <= 1e-8 * scale)) return -3;
+      break;   // accepted as converged: polished below like any other final iterate
+    }
+    if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
+    // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
+    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
+    // the polish is first tried as soon as the active set can be read off (mu <= 1e-8 scale): an accepted vertex is exact whatever
+    // iterate it started from; a rejected one leaves z, s, lam untouched and the interior point goes on
+    if (!earlyTried && nrd <= 1e-5 * scale && nrp <= 1e-7 * scale && mu <= 1e-8 * scale) { earlyTried = true; if (tryPolish()) return it; }
+    // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
+    // here instead of iterating into the divergence that follows; the polish finishes the job
+    if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;
+    zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
+    Mat K = H;
+    for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
+    if (!choleskyFloored(K, pivotFloor)) return -2;
+    auto solve = [&](const Vec& rc, Vec& dz, Vec& ds, Vec& dl) {
+      Vec t(m); for (int i = 0; i < m; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
+      dz = -1.0 * (rd + tmul(D, t));
+      cholSolve(K, dz);
+      const Vec Ddz = D * dz;
+      ds.resize(m); dl.resize(m);
+      for (int i = 0; i < m; ++i) { ds[i] = -rp[i] - Ddz[i]; dl[i] = (-rc[i] - lam[i] * ds[i]) / s[i]; }
+    };
+    auto maxStep = [&](const Vec& ds, const Vec& dl) { double a = 1.0; for (int i = 0; i < m; ++i) { if (ds[i] < 0) a = std::min(a, -s[i] / ds[i]); if (dl[i] < 0) a = std::min(a, -lam[i] / dl[i]); } return a; };
+    Vec rc(m), dz, ds, dl;
+    for (int i = 0; i < m; ++i) rc[i] = s[i] * lam[i];
+    solve(rc, dz, ds, dl);
+    const double aAff = maxStep(ds, dl);
+    double muAff = 0; for (int i = 0; i < m; ++i) muAff += (s[i] + aAff * ds[i]) * (lam[i] + aAff * dl[i]); muAff /= m;
+    const double sigma = std::pow(muAff / mu, 3.0);
+    const double cw = std::min(1.0, 4.0 * aAff);
+    for (int i = 0; i < m; ++i) rc[i] = s[i] * lam[i] + cw * ds[i] * dl[i] - sigma * mu;
+    solve(rc, dz, ds, dl);
+    const double tau = std::max(0.995, 1.0 - mu);
+    const double a = std::min(1.0, tau * maxStep(ds, dl));
+    for (int i = 0; i < n; ++i) z[i] += a * dz[i];
+    for (int i = 0; i < m; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
   }
+  if (it >= maxIter) return -4;   // iteration cap: a failure like the others (HoQp retries from a different starting point)
+  tryPolish();
   return it;
 }
 
@@ -481,7 +489,7 @@ struct HoQp {
         Vec fr = fv;
         const double margin = attempt == 1 ? kInheritedMargin : 100.0 * kInheritedMargin;   // 1e-5, then 1e-3
         for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(margin, fr[numSlack + i]);
-        qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 60, nullptr, true);
+        qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 40, nullptr, true);
       }
       if (qpIters < 0) sol.assign(nz, 0.0);
     } else sol.clear();

@@ -55,6 +55,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   // 1e-3, and slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the higher priorities' solution) and the
   // failure is reported (return value 60).
   int attempt = 0;
+  bool early = false, earlyTried = false;   // early polish attempt in flight / already tried
   auto restartOrGiveUp = [&]() {
     if (attempt < 2) {
       ++attempt;
@@ -63,12 +64,15 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       zc = 0.0; zcPrev = 0.0; v = 0.0; vp = 0.0;
       s1 = rowActive ? fmax(sg, fl) : 1.0; l1 = sg; s2 = sg; l2 = sg;
       s1p = s1; l1p = l1; s2p = s2; l2p = l2; nrdPrev = 0.0; muPrev = 0.0;
+      early = false; earlyTried = false;
       return true;
     }
     zc = 0.0; v = 0.0;
     return false;
   };
   int polish = 0;                       // 0 interior point; 1..3 polish step; 4 final check
+  // the polish is first tried as soon as the active set can be read (mu <= 1e-8 scale): an accepted
+                                            // vertex is exact whatever iterate it started from, a rejected one resumes the interior point
   bool isE = false, isV = false;        // my row: pinned (equality) / violated soft row of this level (exact quadratic)
   double lamE = 0.0, zIpm = 0.0;
   const double rho = 1e6 * fmax(1.0, pivotFloor * 1e13);
@@ -99,7 +103,9 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         else if (isV) bad = !(rRow >= -1e-9 * scale);
         else bad = !(rRow <= 1e-9 * scale);
       }
-      if (allMax((bad || !(zc == zc)) ? 1.0 : 0.0) > 0.0) zc = zIpm;
+      const bool rejected = allMax((bad || !(zc == zc)) ? 1.0 : 0.0) > 0.0;
+      if (rejected) zc = zIpm;
+      if (rejected && early) { early = false; polish = 0; continue; }   // back to the interior point (its slacks / multipliers were not touched)
       break;
     }
     const double lamR = polish ? (isE ? lamE + rho * rRow : (isV ? rRow : 0.0)) : (rowActive ? l1 : 0.0);
@@ -127,10 +133,11 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         if (!(muPrev <= 1e-8 * scale)) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
         done = true;
       } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
+      else if (!earlyTried && nrd <= 1e-5 * scale && nrp <= 1e-7 * scale && mu <= 1e-8 * scale) { done = true; early = true; earlyTried = true; }
       // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
       // stop here instead of iterating into the divergence that follows; the polish finishes the job
       else if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
-      if (it >= 59 && !done) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
+      if (it >= 39 && !done) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
       if (done) {
         itOut = it;
         const bool c1 = rowActive && l1 > s1, c2 = rowActive && own && l2 > s2;
@@ -221,11 +228,11 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     }
 
     double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0, dzc = 0.0;
-    double alphaAff = 1.0, sigma = 0.0;
+    double alphaAff = 1.0, sigma = 0.0, cw = 1.0;
 #pragma unroll 1
     for (int pass = 0; pass < (polish ? 1 : 2); ++pass) {
-      const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + ds1 * dl1 - sigma * mu;
-      const double rc2 = pass == 0 ? s2 * l2 : s2 * l2 + ds2 * dl2 - sigma * mu;
+      const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + cw * ds1 * dl1 - sigma * mu;
+      const double rc2 = pass == 0 ? s2 * l2 : s2 * l2 + cw * ds2 * dl2 - sigma * mu;
       const double t1 = rowActive ? (l1 * rp1 - rc1) / s1 : 0.0;
       const double t2 = (rowActive && own) ? (l2 * rp2 - rc2) / s2 : 0.0;
       const double rhsv = -rdv + t1 + t2;
@@ -286,6 +293,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         const double muAff = allSum(rowActive ? ((s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) + (own ? (s2 + alphaAff * ds2) * (l2 + alphaAff * dl2) : 0.0)) : 0.0) / nRowsTot;
         const double ratio = muAff / mu;
         sigma = ratio * ratio * ratio;
+        cw = fmin(1.0, 4.0 * alphaAff);
       } else {
         const double tau = fmax(0.995, 1.0 - mu);
         const double al = fmin(1.0, tau * amax);
