@@ -65,22 +65,35 @@ struct DuIn {
   __device__ __forceinline__ Vec3<Du> force(int c) const { return Vec3<Du>(su(3 * c), su(3 * c + 1), su(3 * c + 2)); }
 };
 
-// LDS of lq_node_kernel (doubles).  Region X is reused three times: the orthogonal factor Q and Y = R1^-T [C | e] after the QR,
-// the transposed dense rows of [A | B] for the first product, and W = R Pall for the second.
-constexpr int PAW = 50;                      // row stride of Pall = [Px | Pe | 0 | Pu] (columns 0..29, 30, 31, 32..32+m~-1)
-constexpr int CDW = 62;                      // row stride of [C | D | e] (61 used), aliases the Pall region
-constexpr int LDR = 34, LDT = 18;            // row strides of R / Q and of the transposed dense rows
-constexpr int L_X = 0;                       // X: Q [32][LDR] + Y [16][LDR]  |  At [32][LDT] + Bt [32][LDT]  |  W [32][PAW]
-constexpr int L_AT = L_X, L_BT = L_X + 32 * LDT, L_W = L_X;
-constexpr int L_R = L_X + 48 * LDR;          // R [32][LDR] (dt-scaled), later Q [32][LDR]   (X holds Q [32][LDR] + Y [16][LDR] = 1632)
-constexpr int L_PA = L_R + 32 * LDR;         // Pall [32][PAW]  /  CD [16][CDW]
-constexpr int L_EEJ = L_PA + 32 * PAW;       // EE error Jacobian [6][32]
-constexpr int L_VEC = L_EEJ + 192;           // b[30] r[30] e[16] eeh[6] (+2) | g30[64]
-constexpr int L_XU = L_VEC + 84 + 64;        // x[32] u[32] x_next[32] x_ref[32]
-constexpr int L_RED = L_XU + 128;            // wavefront exchange scratch [256]
-constexpr int LQ_LDS_DOUBLES = L_RED + 256;  // 5032 doubles = 39.3 KiB: four workgroups per CU
-static_assert(16 * CDW <= 32 * PAW && 32 * PAW <= 48 * LDR && 2 * 32 * LDT <= 48 * LDR, "aliases must fit");
-static_assert(LQ_LDS_DOUBLES * 8 <= 40960, "four nodes per CU");
+// LDS of lq_node_kernel (doubles): 19.7 KiB per node, eight nodes per CU = TWO wavefronts per SIMD.  The kernel is latency bound
+// (readlane chains, LDS round trips, dependent matrix-core accumulations): at one wavefront per SIMD it ran 1.10 ms per launch.
+// What keeps it this small:
+//   * Pall = [Px | Pe | 0 | Pu] is stored for its 18 dense joint-velocity rows only; the 12 force rows are unit vectors / pinned
+//     values and are synthesised into the matrix-core operands from registers;
+//   * R' and Q never enter LDS: the operand / accumulator entries are assembled where they are needed from the constant
+//     matrices (global, L1 resident) plus the few barrier terms parked in LDS;
+//   * W = R Pall is produced and consumed one 16-column tile at a time;
+//   * region X is recycled four times.
+constexpr int PAW = 50;                      // row stride of the dense rows of Pall (columns 0..29 Px, 30 Pe, 31 zero, 32..32+m~-1 Pu)
+constexpr int CDW = 49;                      // row stride of [C | D_v] (48 used: the 30 state columns and the 18 joint-velocity columns)
+constexpr int LDQ = 18, LDY = 34, LDT = 18, LDW = 17;
+constexpr int X_DOUBLES = 1152;
+constexpr int L_X = 0;                       // X: x u x_next x_ref [4][32] | Q_v [32][LDQ] + Y [16][LDY] | At [32][LDT] + Bt [32][LDT] | W tile [32][LDW]
+constexpr int L_XU = L_X, L_QS = L_X, L_YM = L_X + 32 * LDQ, L_AT = L_X, L_BT = L_X + 32 * LDT, L_WT = L_X;
+constexpr int L_PA = L_X + X_DOUBLES;        // rows 12..29 of Pall [18][PAW]  /  [C | D_v] [16][CDW]
+constexpr int L_EEJ = L_PA + 18 * PAW;       // EE error Jacobian [6][32]
+constexpr int L_VEC = L_EEJ + 192;           // b[30] r[30] e[16] eeh[6] (+2) | fin[64] | pe[12] fb[36] ddp[6] ddv[6] (+4)
+constexpr int L_RED = L_VEC + 84 + 64 + 64;  // wavefront exchange scratch
+#ifdef QMGPU_HOST_EMULATION
+constexpr int RED_DOUBLES = 256;             // the emulated cross-lane primitives exchange through this scratch
+#else
+constexpr int RED_DOUBLES = 64;
+#endif
+constexpr int LQ_LDS_DOUBLES = L_RED + RED_DOUBLES;
+static_assert(16 * CDW <= 18 * PAW && 32 * LDQ + 16 * LDY <= X_DOUBLES && 2 * 32 * LDT <= X_DOUBLES && 32 * LDW <= X_DOUBLES, "aliases must fit");
+#ifndef QMGPU_HOST_EMULATION
+static_assert(LQ_LDS_DOUBLES * 8 <= 20480, "eight nodes per CU");
+#endif
 
 // Both kernels of this file run one wavefront per workgroup: LDS hand-offs between lanes need no hardware barrier (a wavefront's
 // LDS operations complete in issue order), only the compiler fence QM_WAVE_SYNC() -- and, unlike __syncthreads(), that does not
@@ -206,7 +219,7 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
 }
 
 // ---- kernel 2: cost, projection, projected stage record
-__global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) lq_node_kernel(LqArgs a) {
   __shared__ double lds[LQ_LDS_DOUBLES];
   QM_POISON_LDS(lds, LQ_LDS_DOUBLES);
   const int lane = threadIdx.x;
@@ -217,9 +230,10 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
 
-  double* Rm = lds + L_R; double* Qm = lds + L_R; double* PA = lds + L_PA; double* CD = lds + L_PA; 
-  double* AT = lds + L_AT; double* BT = lds + L_BT; double* WL = lds + L_W;
-  double* EEJ = lds + L_EEJ; double* bv = lds + L_VEC; double* rv = bv + 30; double* ev = rv + 30; double* eeh = ev + 16; double* g30v = bv + 84;
+  double* PA = lds + L_PA; double* CD = lds + L_PA;
+  double* AT = lds + L_AT; double* BT = lds + L_BT; double* WT = lds + L_WT;
+  double* EEJ = lds + L_EEJ; double* bv = lds + L_VEC; double* rv = bv + 30; double* ev = rv + 30; double* eeh = ev + 16;
+  double* fin = bv + 84; double* pev = fin + 64; double* fb = pev + 12; double* ddp = fb + 36; double* ddv = ddp + 6;
   double* red = lds + L_RED;
 
   const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
@@ -228,7 +242,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   const double* xG = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
   const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
   // x, u, x_next and the reference state are read many times with wave-uniform indices: one vector load each into LDS instead of
-  // chains of dependent scalar loads (one wavefront per SIMD has nothing to hide their latency with)
+  // chains of dependent scalar loads.  They live in region X and are dead before the QR publishes its factors there.
   double* x = lds + L_XU; double* u = x + 32; double* xnext = x + 64; double* xref = x + 96;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
   const int phase = phaseAt(sched, t);
@@ -247,16 +261,18 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     for (int r = 0; r < NCMAX; ++r) cdv[r] = ad[AD_CD + (r < nc ? r : 0) * 64 + lane];
 #pragma unroll
     for (int q = 0; q < 6; ++q) eev[q] = ad[AD_EE + q * 64 + lane];
+    // [C | D_v]: state columns from lanes 0..29, joint-velocity columns (inputs 12..29) from lanes 42..59, e from lane 60.  The
+    // force columns of D are not kept: a zero-force row is a unit vector there, a velocity row is zero (see the projection below).
 #pragma unroll
-    for (int r = 0; r < NCMAX; ++r) { if (r < nc) { if (lane < 60) CD[r * CDW + lane] = cdv[r]; else if (lane == 60) ev[r] = cdv[r]; } }
+    for (int r = 0; r < NCMAX; ++r) {
+      if (r < nc) { if (lane < 30) CD[r * CDW + lane] = cdv[r]; else if (lane >= 42 && lane < 60) CD[r * CDW + lane - 12] = cdv[r]; else if (lane == 60) ev[r] = cdv[r]; }
+    }
 #pragma unroll
     for (int q = 0; q < 6; ++q) { if (lane < 32) EEJ[q * 32 + lane] = eev[q]; else if (lane == 60) eeh[q] = eev[q]; }
   }
   double phid[12], phiv[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
-  if (lane < LDR) { Rm[30 * LDR + lane] = 0.0; Rm[31 * LDR + lane] = 0.0; }   // zero padding rows of R / Q (k = 30, 31 of the tiles)
-  QM_WAVE_SYNC();
 
   double* rec = a.stages + (size_t(inst) * (a.N + 1) + node) * STAGE_DOUBLES;
   double* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
@@ -271,54 +287,53 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   double qc = 0.0, costPart = 0.0;
   const double sc = terminal ? 1.0 : dt;  // intermediate costs are scaled by dt, the terminal cost is not
 
-  // state cost, column c of Q (lanes < 30): tracking + EE soft constraint (Gauss-Newton) + arm joint position soft box
-  auto stateCost = [&](double (&Qcol)[30]) {
-#pragma unroll
-    for (int i = 0; i < 30; ++i) Qcol[i] = 0.0;
+  // ---- state cost, gradient entry c (lanes < 30): tracking + EE soft constraint (Gauss-Newton) + arm joint position soft box.
+  //      The Hessian is never formed column-wise: qEntry(i, j) below assembles single entries where they are needed.
+  {
+    double dd = 0.0;
     if (c < 30) {
-      double ej[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) ej[q] = EEJ[q * 32 + c];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const double mu = q < 3 ? muP : muO;
-        qc += mu * eeh[q] * ej[q];
-#pragma unroll
-        for (int i = 0; i < 30; ++i) Qcol[i] += mu * EEJ[q * 32 + i] * ej[q];
-      }
+      for (int q = 0; q < 6; ++q) qc += (q < 3 ? muP : muO) * eeh[q] * EEJ[q * 32 + c];
       if (c < 6) costPart += 0.5 * (c < 3 ? muP : muO) * eeh[c] * eeh[c];
     }
     if (!terminal && c < 30) {
-      double Qdx = 0.0;
+      double Qdx0 = 0.0, Qdx1 = 0.0;
 #pragma unroll
-      for (int i = 0; i < 30; ++i) {
-        const double qw = st.Q[i * 30 + c];
-        Qdx += qw * (x[i] - xref[i]);
-        Qcol[i] += qw;
+      for (int i = 0; i < 30; i += 2) {
+        Qdx0 += st.Q[i * 30 + c] * (x[i] - xref[i]);
+        Qdx1 += st.Q[(i + 1) * 30 + c] * (x[i + 1] - xref[i + 1]);
       }
+      const double Qdx = Qdx0 + Qdx1;
       qc += Qdx;
-      costPart += 0.5 * (x[c < 30 ? c : 0] - xref[c < 30 ? c : 0]) * Qdx;
+      costPart += 0.5 * (x[c] - xref[c]) * Qdx;
       if (c >= 24) {  // arm joint position soft box (QMInterface.cpp:177-219)
         const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta};
         const double lo = md.q_lower[c - 12], up = md.q_upper[c - 12];
         const double hl = x[c] - lo, hu = up - x[c];
         costPart += bp.value(hl) + bp.value(hu) - (bp.value(-lo) + bp.value(up));
         qc += bp.d1(hl) - bp.d1(hu);
-        const double dd = bp.d2(hl) + bp.d2(hu);
-#pragma unroll
-        for (int k = 24; k < 30; ++k) if (k == c) Qcol[k] += dd;
+        dd = bp.d2(hl) + bp.d2(hu);
       }
     }
+    if (c >= 24 && c < 30) ddp[c - 24] = dd;
     qc *= sc;
+  }
+  QM_WAVE_SYNC();
+  // entry (i, j) of the state-cost Hessian (unscaled); i, j may be any lane-dependent indices < 32
+  auto qEntry = [&](int i, int j) {
+    const int ic = i < 30 ? i : 0, jc = j < 30 ? j : 0;
+    double v = terminal ? 0.0 : st.Q[ic * 30 + jc];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v += (q < 3 ? muP : muO) * EEJ[q * 32 + ic] * EEJ[q * 32 + jc];
+    const double dg = ddp[ic >= 24 ? ic - 24 : 0];
+    if (ic == jc && ic >= 24) v += dg;
+    return (i < 30 && j < 30) ? v : 0.0;
   };
 
   if (terminal) {
-    double Qcol[30];
-    stateCost(Qcol);
     if (c < 30) {
-#pragma unroll
-      for (int i = 0; i < 30; ++i) rec[OFF_QT + i * 30 + c] = Qcol[i];
-      if (dbg) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = Qcol[i]; }
+#pragma unroll 6
+      for (int i = 0; i < 30; ++i) { const double v = qEntry(i, c); rec[OFF_QT + i * 30 + c] = v; if (dbg) dbg[DBG_Q + i * 30 + c] = v; }
     }
     const double nodeCost = waveSum(red, lane, costPart);
     if (c < 30) { rec[OFF_qt + c] = qc; if (dbg) dbg[DBG_q + c] = qc; }
@@ -327,31 +342,30 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   }
 
   // ---- Jacobian of the RK2 map Phi = x + dt/2 (k1 + k2): rows 12.. are x_j + dt v_j exactly, so only the twelve momentum /
-  //      base-pose rows of [A | B] are dense (phid).  Column `lane` of [A | B]:
-  auto abCol = [&](int i) { return i < 12 ? phid[i < 12 ? i : 0] + (c == i ? 1.0 : 0.0) : (c == i ? 1.0 : 0.0) + (c == 30 + i ? dt : 0.0); };
+  //      base-pose rows of [A | B] are dense (phid).
   if (dbg && c < 60) {
     for (int i = 0; i < 30; ++i) { const double v = i < 12 ? phid[i < 12 ? i : 0] + (c == i ? 1.0 : 0.0) : (c == i ? 1.0 : 0.0) + (c == 30 + i ? dt : 0.0); if (c < 30) dbg[DBG_A + i * 30 + c] = v; else dbg[DBG_B + i * 30 + (c - 30)] = v; }
   }
-  (void)abCol;
   if (lane == 0) {
     for (int i = 0; i < 12; ++i) bv[i] = x[i] + phiv[i] - xnext[i];
     for (int j = 0; j < 18; ++j) bv[12 + j] = x[12 + j] + dt * u[12 + j] - xnext[12 + j];
   }
-  // ---- input cost: R' + friction-cone and arm-velocity barriers (column c of R into LDS)
+  // ---- input cost: R' + friction-cone and arm-velocity barriers.  Lane c < 30 forms the gradient entry c and the barrier terms
+  //      of its column; the terms go to LDS (fb: four 3x3 friction blocks, ddv: arm-velocity diagonal), R' itself stays in HBM / L1.
   {
     int nStance = 0;
     for (int k = 0; k < 4; ++k) nStance += contactOf(mode, k) ? 1 : 0;
     const double fzNom = nStance > 0 ? md.total_mass * st.gravity / nStance : 0.0;
     if (c < 30) {
-      double Rdu = 0.0;
-      double Rcol[30];
+      double Rdu0 = 0.0, Rdu1 = 0.0;
 #pragma unroll
-      for (int i = 0; i < 30; ++i) {
-        const double unom = (i < 12 && (i % 3) == 2 && contactOf(mode, i / 3)) ? fzNom : 0.0;
-        const double rw = a.Rw[i * 30 + c];
-        Rdu += rw * (u[i] - unom);
-        Rcol[i] = rw;
+      for (int i = 0; i < 30; i += 2) {
+        const double un0 = (i < 12 && (i % 3) == 2 && contactOf(mode, i / 3)) ? fzNom : 0.0;
+        const double un1 = (i + 1 < 12 && ((i + 1) % 3) == 2 && contactOf(mode, (i + 1) / 3)) ? fzNom : 0.0;
+        Rdu0 += a.Rw[i * 30 + c] * (u[i] - un0);
+        Rdu1 += a.Rw[(i + 1) * 30 + c] * (u[i + 1] - un1);
       }
+      const double Rdu = Rdu0 + Rdu1;
       const double unomc = (c < 12 && (c % 3) == 2 && contactOf(mode, c / 3)) ? fzNom : 0.0;
       double rc = Rdu;
       costPart += 0.5 * (u[c] - unomc) * Rdu;
@@ -361,39 +375,55 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
         const double vl = u[c] - st.arm_vel_lower[i], vu = st.arm_vel_upper[i] - u[c];
         costPart += bvel.value(vl) + bvel.value(vu) - (bvel.value(-st.arm_vel_lower[i]) + bvel.value(st.arm_vel_upper[i]));
         rc += bvel.d1(vl) - bvel.d1(vu);
-        const double dd = bvel.d2(vl) + bvel.d2(vu);
-#pragma unroll
-        for (int k = 24; k < 30; ++k) if (k == c) Rcol[k] += dd;
+        ddv[i] = bvel.d2(vl) + bvel.d2(vu);
       }
-      if (c < 12 && contactOf(mode, c / 3)) {  // friction cone barrier (QMInterface.cpp:344-358), column c of its 3x3 block
-        const Barrier bf{st.friction_barrier_mu, st.friction_barrier_delta};
-        const int fo = 3 * (c / 3), ac = c % 3;
-        const double fx = u[fo], fy = u[fo + 1], fz = u[fo + 2];
-        const double F = sqrt(fx * fx + fy * fy + st.friction_regularization), F3 = F * F * F;
-        const double h = st.friction_coefficient * fz - F;
-        const double gx = -fx / F, gy = -fy / F, gz = st.friction_coefficient;
-        const double hxx = -(fy * fy + st.friction_regularization) / F3 - st.friction_hessian_shift, hxy = fx * fy / F3;
-        const double hyy = -(fx * fx + st.friction_regularization) / F3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
-        const double gac = ac == 0 ? gx : (ac == 1 ? gy : gz);
-        const double h0 = ac == 0 ? hxx : (ac == 1 ? hxy : 0.0), h1 = ac == 0 ? hxy : (ac == 1 ? hyy : 0.0), h2 = ac == 2 ? hzz : 0.0;
-        const double p1 = bf.d1(h), p2 = bf.d2(h);
-        if (ac == 0) costPart += bf.value(h);
-        rc += p1 * gac;
-        const double e0 = p2 * gx * gac + p1 * h0, e1 = p2 * gy * gac + p1 * h1, e2 = p2 * gz * gac + p1 * h2;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) { if (k == fo) Rcol[k] += e0; if (k == fo + 1) Rcol[k] += e1; if (k == fo + 2) Rcol[k] += e2; }
+      if (c < 12) {
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        if (contactOf(mode, c / 3)) {  // friction cone barrier (QMInterface.cpp:344-358), column c % 3 of its 3x3 block
+          const Barrier bf{st.friction_barrier_mu, st.friction_barrier_delta};
+          const int fo = 3 * (c / 3), ac = c % 3;
+          const double fx = u[fo], fy = u[fo + 1], fz = u[fo + 2];
+          const double F = sqrt(fx * fx + fy * fy + st.friction_regularization), F3 = F * F * F;
+          const double hh = st.friction_coefficient * fz - F;
+          const double gx = -fx / F, gy = -fy / F, gz = st.friction_coefficient;
+          const double hxx = -(fy * fy + st.friction_regularization) / F3 - st.friction_hessian_shift, hxy = fx * fy / F3;
+          const double hyy = -(fx * fx + st.friction_regularization) / F3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
+          const double gac = ac == 0 ? gx : (ac == 1 ? gy : gz);
+          const double h0 = ac == 0 ? hxx : (ac == 1 ? hxy : 0.0), h1 = ac == 0 ? hxy : (ac == 1 ? hyy : 0.0), h2 = ac == 2 ? hzz : 0.0;
+          const double p1 = bf.d1(hh), p2 = bf.d2(hh);
+          if (ac == 0) costPart += bf.value(hh);
+          rc += p1 * gac;
+          e0 = p2 * gx * gac + p1 * h0; e1 = p2 * gy * gac + p1 * h1; e2 = p2 * gz * gac + p1 * h2;
+        }
+        const int fo = 3 * (c / 3), ac = c % 3;      // fb[input k][column of its foot's block]
+        fb[(fo + 0) * 3 + ac] = e0; fb[(fo + 1) * 3 + ac] = e1; fb[(fo + 2) * 3 + ac] = e2;
       }
-#pragma unroll
-      for (int i = 0; i < 30; ++i) Rm[i * LDR + c] = dt * Rcol[i];
       rv[c] = dt * rc;
     }
   }
   QM_WAVE_SYNC();
+  // entry (k, i) of the dt-scaled input-cost Hessian, extended by column 30 = r (so that row 30 of W = R Pall is r^T Pall) and a
+  // zero column 31; rows >= 30 are zero
+  auto rEntry = [&](int k, int i) {
+    const int kc = k < 30 ? k : 0, ic = i < 30 ? i : 0;
+    double v = a.Rw[kc * 30 + ic];
+    const double fbv = fb[(kc < 12 ? kc : 0) * 3 + ic % 3], dv = ddv[kc >= 24 ? kc - 24 : 0];
+    if (kc < 12 && ic < 12 && kc / 3 == ic / 3) v += fbv;
+    if (kc == ic && kc >= 24) v += dv;
+    v *= dt;
+    const double rk = rv[kc];
+    return k < 30 ? (i < 30 ? v : (i == 30 ? rk : 0.0)) : 0.0;
+  };
   if (dbg && c < 30) {
-    for (int i = 0; i < 30; ++i) dbg[DBG_R + i * 30 + c] = Rm[i * LDR + c];
+    for (int i = 0; i < 30; ++i) dbg[DBG_R + i * 30 + c] = rEntry(i, c);
     dbg[DBG_b + c] = bv[c]; dbg[DBG_r + c] = rv[c];
-    for (int r = 0; r < nc; ++r) { dbg[DBG_C + r * 30 + c] = CD[r * CDW + c]; dbg[DBG_D + r * 30 + c] = CD[r * CDW + 30 + c]; }
+    for (int r = 0; r < nc; ++r) { dbg[DBG_C + r * 30 + c] = ad[AD_CD + r * 64 + c]; dbg[DBG_D + r * 30 + c] = ad[AD_CD + r * 64 + 30 + c]; }
     if (c < nc) dbg[DBG_e + c] = ev[c];
+  }
+  double dynSq = 0.0, eqSq = 0.0;   // lane 0: node metrics (x, u, ... leave LDS below)
+  if (lane == 0) {
+    for (int i = 0; i < 30; ++i) dynSq += bv[i] * bv[i];
+    for (int i = 0; i < nc; ++i) eqSq += ev[i] * ev[i];
   }
 
   // ================================================================== projection: QR of the velocity block of D^T (18 x nv)
@@ -435,6 +465,33 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       }
     }
   }
+  // Pall operand of the matrix cores, element (k, j) with k = 4 ks + h (this lane's row of k step ks) and j = 16 tq + l16:
+  // rows k < 12 (force inputs, k steps 0..2) are synthesised -- Pe = pinned swing force in column 30, a unit entry in the Pu column
+  // of a free stance force --, rows 12..29 come from LDS, rows 30 and 31 are zero.
+  double peK[3]; int puK[3];
+  {
+    double peForce = 0.0;   // pinned swing-foot forces: Pe = -e_f
+#pragma unroll
+    for (int i = 0; i < 12; ++i) if (lane == i && frcRowOf[i] >= 0) peForce = -ev[frcRowOf[i] >= 0 ? frcRowOf[i] : 0];
+    if (lane < 12) pev[lane] = peForce;
+    QM_WAVE_SYNC();
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int kk = 4 * ks + h;
+      peK[ks] = pev[kk];
+      int pu = -1;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) if (kk == i) pu = puColOf[i];
+      puK[ks] = pu;
+    }
+  }
+  auto pallOp = [&](int ks, int tq) {
+    const int j = tq * 16 + l16;
+    if (ks < 3) return j == 30 ? peK[ks] : ((j >= 32 && j - 32 == puK[ks]) ? 1.0 : 0.0);
+    const int kk = 4 * ks + h;
+    const double raw = PA[((kk < 30 ? kk : 12) - 12) * PAW + (j < PAW ? j : 0)];
+    return (kk < 30 && j < PAW) ? raw : 0.0;
+  };
   {
     int myVr = 0;
 #pragma unroll
@@ -448,14 +505,10 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
     double qcol[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
-      const double dv = CD[myVr * CDW + 30 + 12 + i];
+      const double dv = CD[myVr * CDW + 30 + i];
       qcol[i] = lane < 16 ? (lane < nv ? dv : 0.0) : ((lane < 34 && i == lane - 16) ? 1.0 : 0.0);
     }
-    // pinned swing-foot forces: Pe = -e_f, read before the [C D e] region is recycled
-    double peForce = 0.0;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) if (lane == i && frcRowOf[i] >= 0) peForce = -ev[frcRowOf[i] >= 0 ? frcRowOf[i] : 0];
-    QM_WAVE_SYNC();  // the [C D e] region is free from here on (it becomes Pall)
+    QM_WAVE_SYNC();  // the [C D_v] region is free from here on (it becomes Pall); so is x | u | x_next | x_ref in region X
 #pragma unroll
     for (int k = 0; k < NVMAX; ++k) {
       if (k < nv) {
@@ -488,15 +541,15 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       y[i] = (i < nv) ? sacc / d : 0.0;
     }
     // publish Y (rows k < 16, my column) and Q_v (lane 16 + c holds row c; rows 18..31 cleared) in region X
-    double* Ym = lds + L_X + 32 * LDR;
-    double* Qs = lds + L_X;
+    double* Ym = lds + L_YM;
+    double* Qs = lds + L_QS;
     if (lane < 32) {
 #pragma unroll
-      for (int k = 0; k < NCMAX; ++k) Ym[k * LDR + lane] = (k < NVMAX && lane <= 30) ? y[k < NVMAX ? k : 0] : 0.0;
+      for (int k = 0; k < NCMAX; ++k) Ym[k * LDY + lane] = (k < NVMAX && lane <= 30) ? y[k < NVMAX ? k : 0] : 0.0;
     }
     if (lane >= 16 && lane < 48) {
 #pragma unroll
-      for (int r = 0; r < 18; ++r) Qs[(lane - 16) * LDR + r] = lane < 34 ? qcol[r] : 0.0;
+      for (int r = 0; r < 18; ++r) Qs[(lane - 16) * LDQ + r] = lane < 34 ? qcol[r] : 0.0;
     }
     QM_WAVE_SYNC();
     // [Px | Pe] rows 12..29 = -Q_v1 Y on the matrix cores (K = 16 >= nv; rows of Y beyond nv are zero)
@@ -508,25 +561,21 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kk = 4 * ks + h;
-      const double a0 = -Qs[l16 * LDR + kk], a1 = -Qs[(16 + l16) * LDR + kk];
-      const double b0 = Ym[kk * LDR + l16], b1 = Ym[kk * LDR + 16 + l16];
+      const double a0 = -Qs[l16 * LDQ + kk], a1 = -Qs[(16 + l16) * LDQ + kk];
+      const double b0 = Ym[kk * LDY + l16], b1 = Ym[kk * LDY + 16 + l16];
       qmMfma(pc[0], a0, b0, red); qmMfma(pc[1], a0, b1, red); qmMfma(pc[2], a1, b0, red); qmMfma(pc[3], a1, b1, red);
     }
-    // Pall: rows 0..11 (forces): Px = 0, Pe = pinned swing forces, unit Pu columns for the free stance forces;
-    //       rows 12..29 (joint velocities): [Px | Pe] from the tiles, Pu = Q_v2
-    double peAll[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) peAll[i] = qmReadLane(peForce, i, red);
+    // Pall: rows 0..11 (forces): Px = 0, Pe = pinned swing forces, unit Pu columns for the free stance forces (record only);
+    //       rows 12..29 (joint velocities): [Px | Pe] from the tiles, Pu = Q_v2 (record and LDS)
     if (lane < PAW) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
-        const double val = lane == 30 ? peAll[i] : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0 : 0.0);
-        PA[i * PAW + lane] = val;
+        const double pe = pev[i];
+        const double val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0 : 0.0);
         if (lane < 30) rec[OFF_PX + i * 30 + lane] = 0.0;
-        else if (lane == 30) rec[OFF_PE + i] = peAll[i];
+        else if (lane == 30) rec[OFF_PE + i] = pe;
         else if (lane >= 32 && lane < 32 + nt) rec[OFF_PU + i * MT + (lane - 32)] = val;
       }
-      PA[30 * PAW + lane] = 0.0; PA[31 * PAW + lane] = 0.0;
     }
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
@@ -534,7 +583,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;   // i: joint-velocity input 12 + i
         if (i < 18) {
-          PA[(12 + i) * PAW + j] = j <= 30 ? pc[t4][r] : 0.0;
+          PA[i * PAW + j] = j <= 30 ? pc[t4][r] : 0.0;
           if (j < 30) rec[OFF_PX + (12 + i) * 30 + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + 12 + i] = pc[t4][r];
         }
       }
@@ -543,8 +592,8 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
       const bool isQ2 = jj >= nStF && jj < nt;
 #pragma unroll
       for (int i = 0; i < 18; ++i) {
-        const double qv = Qs[i * LDR + (isQ2 ? nv + (jj - nStF) : 0)];
-        PA[(12 + i) * PAW + lane] = isQ2 ? qv : 0.0;
+        const double qv = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
+        PA[i * PAW + lane] = isQ2 ? qv : 0.0;
         if (jj < nt) rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0;
       }
     }
@@ -554,7 +603,7 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
   // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
   for (int i = 12; i < 30; ++i) {
-    const double pv = PA[i * PAW + (lane < PAW ? lane : 0)];
+    const double pv = PA[(i - 12) * PAW + (lane < PAW ? lane : 0)];
     if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0 : 0.0) + dt * pv;
     else if (isE) rec[OFF_bt + i] = bv[i] + dt * pv;
     else if (isU) rec[OFF_BT + i * MT + (lane - 32)] = dt * pv;
@@ -566,15 +615,13 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0 : 0.0) : 0.0;
   }
-  if (lane < 30) Rm[lane * LDR + 30] = rv[lane];   // column 30 of R = r: row 30 of W = R Pall becomes r^T Pall
-  if (lane < 32) Rm[lane * LDR + 31] = 0.0;        // column 31 is read as tile padding: it must be zero, not whatever the LDS held
   QM_WAVE_SYNC();
 
   // ================================================================== products on the fp64 matrix cores
-  // (1) rows 0..11 of [A~ | b~ | B~] = [A | b | 0] + B Pall      (2) W = R Pall   -- one k loop, shared Pall operand
+  // (1) rows 0..11 of [A~ | b~ | B~] = [A | b | 0] + B Pall
   const int nTn = nt > 16 ? 4 : 3;   // 16-column tiles of Pall in use
   {
-    QmAcc c1[4], cw[8];
+    QmAcc c1[4];
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -582,21 +629,14 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
         const int i = h + 4 * r, j = tn * 16 + l16;
         const double av = AT[(j < 32 ? j : 0) * LDT + i], bb = bv[i < 30 ? i : 0];
         c1[tn][r] = (i < 12) ? (j < 30 ? av : (j == 30 ? bb : 0.0)) : 0.0;
-        cw[tn][r] = 0.0; cw[4 + tn][r] = 0.0;
       }
-#pragma unroll 2
+#pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int kk = 4 * ks + h;
-      const double ab = BT[kk * LDT + l16], r0 = Rm[kk * LDR + l16], r1 = Rm[kk * LDR + 16 + l16];   // R symmetric: R[i][k] read as R[k][i]
-      double pb[4];
+      const double ab = BT[kk * LDT + l16];
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) { const int j = tn * 16 + l16; const double raw = PA[kk * PAW + (j < PAW ? j : 0)]; pb[tn] = j < PAW ? raw : 0.0; }
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        if (tn < nTn) { qmMfma(c1[tn], ab, pb[tn], red); qmMfma(cw[tn], r0, pb[tn], red); qmMfma(cw[4 + tn], r1, pb[tn], red); }
-      }
+      for (int tn = 0; tn < 4; ++tn) { if (tn < nTn) qmMfma(c1[tn], ab, pallOp(ks, tn), red); }
     }
-    QM_WAVE_SYNC();   // every lane has consumed At / Bt: region X becomes W
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       if (tn < nTn) {
@@ -609,85 +649,82 @@ __global__ void __launch_bounds__(64) lq_node_kernel(LqArgs a) {
             else if (j == 30) rec[OFF_bt + i] = c1[tn][r];
             else if (j >= 32 && j < 32 + nt) rec[OFF_BT + i * MT + (j - 32)] = c1[tn][r];
           }
-          if (j < PAW) { WL[i * PAW + j] = cw[tn][r]; WL[(16 + i) * PAW + j] = cw[4 + tn][r]; }
         }
       }
     }
   }
-  QM_WAVE_SYNC();   // R is dead: its region takes Q
-
-  // ---- state cost: column c of Q into LDS (accumulator initialisation of the last product)
-  {
-    double Qcol[30];
-    stateCost(Qcol);
-    if (c < 30) {
-#pragma unroll
-      for (int i = 0; i < 30; ++i) Qm[i * LDR + c] = sc * Qcol[i];
-      if (dbg) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = sc * Qcol[i]; dbg[DBG_q + c] = qc; }
-    }
-  }
-  const double nodeCost = dt * waveSum(red, lane, costPart);  // (barriers inside: the Q columns are visible below)
+  QM_WAVE_SYNC();   // every lane has consumed At / Bt: region X becomes the W tile
+  const double nodeCost = dt * waveSum(red, lane, costPart);
   if (lane == 0) {
-    double dyn = 0.0, eq = 0.0;
-    for (int i = 0; i < 30; ++i) dyn += bv[i] * bv[i];
-    for (int i = 0; i < nc; ++i) eq += ev[i] * ev[i];
     double* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS;
-    m[0] = nodeCost; m[1] = dt * dyn; m[2] = dt * eq; m[3] = 0.0;
+    m[0] = nodeCost; m[1] = dt * dynSq; m[2] = dt * eqSq; m[3] = 0.0;
   }
+  if (dbg && c < 30) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = sc * qEntry(i, c); dbg[DBG_q + c] = qc; }
 
-  // (3) G = Pall^T W: [Q~ | P~^T; P~ | R~] = [Q | 0; 0 | 0] + G, row / column 30 carry Pe^T R Pall (-> q~, r~)
+  // (2) W = R Pall and (3) G = Pall^T W, [Q~ | P~^T; P~ | R~] = [Q | 0; 0 | 0] + G, one 16-column tile of W at a time: the tile goes
+  // through LDS (accumulator layout -> operand layout) and is consumed by the tiles (tm, tn) of G that the record needs:
+  //   tn = 0, 1: tm = 0, 1 (state block, row 30 carries Pe^T R Px), 2 and 3 (P~; tm = 3 only when m~ > 16)
+  //   tn = 2, 3: tm = 2, 3 (R~; column 30 of tn = 1 carries Pu^T R Pe)
+  // Row 30 of W is r^T Pall; together with row / column 30 of G it completes q~ and r~ (fin).
   {
-    // tiles (tm, tn): (0,0) (0,1) (1,0) (1,1) state block; (2,0) (2,1) (2,2) projected-input rows 0..15;
-    //                 (3,0) (3,1) (2,3) (3,2) (3,3) only when m~ > 16
-    constexpr int TM[12] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 2, 3, 3}, TN[12] = {0, 1, 0, 1, 0, 1, 2, 0, 1, 3, 2, 3};
-    const int nTiles = nt > 16 ? 12 : 7;
-    QmAcc g[12];
+    fin[lane] = 0.0;
+    double r0[8], r1[8];   // R operand (symmetric: R[i][k] read as R[k][i]), shared by all tiles
 #pragma unroll
-    for (int tI = 0; tI < 12; ++tI)
+    for (int ks = 0; ks < 8; ++ks) { const int kk = 4 * ks + h; r0[ks] = rEntry(kk, l16); r1[ks] = rEntry(kk, 16 + l16); }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = TM[tI] * 16 + h + 4 * r, j = TN[tI] * 16 + l16;
-        const double qv = Qm[(i < 30 ? i : 0) * LDR + (j < 30 ? j : 0)];
-        g[tI][r] = (tI < 4 && i < 30 && j < 30) ? qv : 0.0;
-      }
-#pragma unroll 2
-    for (int ks = 0; ks < 8; ++ks) {
-      const int kk = 4 * ks + h;
-      double pa[4], wb[4];
+    for (int tn = 0; tn < 4; ++tn) {
+      if (tn < nTn) {
+        QmAcc wA, wB;
 #pragma unroll
-      for (int tq = 0; tq < 4; ++tq) {
-        const int j = tq * 16 + l16;
-        const double rp = PA[kk * PAW + (j < PAW ? j : 0)], rw = WL[kk * PAW + (j < PAW ? j : 0)];
-        pa[tq] = j < PAW ? rp : 0.0; wb[tq] = j < PAW ? rw : 0.0;
-      }
+        for (int r = 0; r < 4; ++r) { wA[r] = 0.0; wB[r] = 0.0; }
 #pragma unroll
-      for (int tI = 0; tI < 12; ++tI) { if (tI < nTiles) qmMfma(g[tI], pa[TM[tI]], wb[TN[tI]], red); }
-    }
+        for (int ks = 0; ks < 8; ++ks) { const double pb = pallOp(ks, tn); qmMfma(wA, r0[ks], pb, red); qmMfma(wB, r1[ks], pb, red); }
+        QM_WAVE_SYNC();   // the previous tile's readers are done
 #pragma unroll
-    for (int tI = 0; tI < 12; ++tI) {
-      if (tI < nTiles) {
-        const int j = TN[tI] * 16 + l16;
+        for (int r = 0; r < 4; ++r) { const int i = h + 4 * r; WT[i * LDW + l16] = wA[r]; WT[(16 + i) * LDW + l16] = wB[r]; }
+        if (h == 2) fin[tn * 16 + l16] += wB[3];  // row 30 of W
+        QM_WAVE_SYNC();
+        const bool top = tn < 2;         // tiles tm = 0, 1
+        const bool low3 = nt > 16;       // tile tm = 3
+        QmAcc g[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = TM[tI] * 16 + h + 4 * r;
-          const double v = g[tI][r];
-          if (i < 30) {
-            if (j < 30) rec[OFF_QT + i * 30 + j] = v;
-          } else if (i == 30) {
-            if (j < 30) g30v[j] = v;                                   // Pe^T R Px
-          } else if (i >= 32 && i < 32 + nt) {
-            if (j < 30) rec[OFF_PT + (i - 32) * 30 + j] = v;
-            else if (j == 30) g30v[i] = v;                             // Pu^T R Pe
-            else if (j >= 32 && j < 32 + nt) rec[OFF_RT + (i - 32) * MT + (j - 32)] = v;
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) g[tm][r] = (tm < 2 && tn < 2) ? sc * qEntry(tm * 16 + h + 4 * r, tn * 16 + l16) : 0.0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const int kk = 4 * ks + h;
+          const double wb = WT[kk * LDW + l16];
+          if (top) { qmMfma(g[0], pallOp(ks, 0), wb, red); qmMfma(g[1], pallOp(ks, 1), wb, red); }
+          qmMfma(g[2], pallOp(ks, 2), wb, red);
+          if (low3) qmMfma(g[3], pallOp(ks, 3), wb, red);
+        }
+        const int j = tn * 16 + l16;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+          if ((tm < 2 && top) || tm == 2 || (tm == 3 && low3)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = tm * 16 + h + 4 * r;
+              const double v = g[tm][r];
+              if (i < 30) {
+                if (j < 30) rec[OFF_QT + i * 30 + j] = v;
+              } else if (i == 30) {
+                if (j < 30) fin[j] += v;                                   // Pe^T R Px
+              } else if (i >= 32 && i < 32 + nt) {
+                if (j < 30) rec[OFF_PT + (i - 32) * 30 + j] = v;
+                else if (j == 30) fin[i] += v;                             // Pu^T R Pe
+                else if (j >= 32 && j < 32 + nt) rec[OFF_RT + (i - 32) * MT + (j - 32)] = v;
+              }
+            }
           }
         }
       }
     }
   }
   QM_WAVE_SYNC();
-  const double tz = WL[30 * PAW + (lane < PAW ? lane : 0)];   // r^T Pall (row 30 of W)
-  if (isX) rec[OFF_qt + lane] = qc + tz + g30v[lane];
-  else if (isU) rec[OFF_rt + (lane - 32)] = tz + g30v[lane];
+  if (isX) rec[OFF_qt + lane] = qc + fin[lane];
+  else if (isU) rec[OFF_rt + (lane - 32)] = fin[lane];
 }
 
 }  // namespace qmk
