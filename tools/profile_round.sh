@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repository root):
+#   bash tools/profile_round.sh r01f
+# writes gpurun_out/prof_<tag>/ (kernel trace of `bench.py --no-cpu-baseline`), gpurun_out/pmc_<tag>_{sq,fetch,write}/ (PMC passes,
+# counters only -- never combined with a trace domain) and gpurun_out/bench_<tag>.json (the full bench line, CPU baseline included).
+# Afterwards, here: python tools/make_profile_summaries.py <tag>   ->  profiles/<tag>_*.
+set -u
+tag=$1
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/pmc_${tag}_sq -o pmc -- python $R/bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch -o pmc -- python $R/bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write -o pmc -- python $R/bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
+cd $R
+python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+tail -1 gpurun_out/bench_$tag.json
