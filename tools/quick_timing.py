@@ -20,3 +20,5 @@ ms = sol.kernel_ms_mean(5)
 print("ms  ad %.3f  lq %.3f  riccati %.3f  linesearch %.3f  wbc %.3f  total %.3f  -> %.0f cycles/s" % (*ms, B / ms[5] * 1e3))
 r = mb.results(); w = wb.results()
 print("checksum X %.12e U %.12e tau %.12e status %s" % (np.abs(r["X"]).sum(), np.abs(r["U"]).sum(), np.abs(w["out"][:, 36:]).sum(), np.unique(w["status"])))
+st = r["stats"]
+print("line search: alpha", np.unique(st[:, 4], return_counts=True), "step type", np.unique(st[:, 5], return_counts=True))
