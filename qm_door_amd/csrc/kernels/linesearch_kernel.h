@@ -134,7 +134,13 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
   const double* X = a.X + size_t(inst) * (N + 1) * 30; const double* U = a.U + size_t(inst) * N * 30;
   const double* dX = a.dX + size_t(inst) * (N + 1) * 30; const double* dU = a.dU + size_t(inst) * N * 30;
-  double* Xt = a.Xt + size_t(inst) * (N + 1) * 30; double* Ut = a.Ut + size_t(inst) * N * 30;
+  // Two consecutive trial steps (alpha, alpha * decay) are evaluated side by side when the horizon fits half the workgroup: the
+  // second half of the threads would otherwise idle, and a launch is as slow as its slowest instance -- one instance of the batch
+  // that rejects the full step no longer doubles the kernel time.  Acceptance is tested in the sequential order, so the result is
+  // the one of FilterLinesearch's loop.
+  const int half = (N + 1 <= nthr / 2) ? nthr / 2 : nthr;
+  const int nTr = nthr / half, myTr = tid / half, ltid = tid - myTr * half;
+  double* Xt = a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30; double* Ut = a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
 
   // baseline performance (sum of the LQ kernel's node metrics)
   double m0 = 0.0, d0 = 0.0, e0 = 0.0;
@@ -156,11 +162,12 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   bool accepted = false;
 #pragma unroll 1
   for (int trial = 0; trial < 64; ++trial) {
-    for (int e = tid; e < (N + 1) * 30; e += nthr) Xt[e] = X[e] + alpha * dX[e];
-    for (int e = tid; e < N * 30; e += nthr) Ut[e] = U[e] + alpha * dU[e];
+    const double alphaMine = myTr ? alpha * st.alpha_decay : alpha;
+    for (int e = ltid; e < (N + 1) * 30; e += half) Xt[e] = X[e] + alphaMine * dX[e];
+    for (int e = ltid; e < N * 30; e += half) Ut[e] = U[e] + alphaMine * dU[e];
     __syncthreads();
     double cs = 0.0, ds = 0.0, es = 0.0;
-    for (int k = tid; k <= N; k += nthr) {
+    for (int k = ltid; k <= N; k += half) {
       double c, d, e;
       const bool term = k == N;
       nodePerformance(*a.P, a.Rw, sched, tTimes, tStates, a.K, tg[k], term ? 0.0 : tg[k + 1] - tg[k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
@@ -169,23 +176,31 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;
     __syncthreads();
     if (tid == 0) {
-      double s0 = 0, s1 = 0, s2 = 0;
-      for (int i = 0; i < nthr; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; }
-      const double m1 = s0, v1 = sqrt(s1 + s2);
-      bool acc; int type;
-      // upstream FilterLinesearch::acceptStep
-      if (!a.lineSearch) { acc = true; type = 0; }
-      else if (v1 > st.g_max) { acc = v1 < (1.0 - st.gamma_c) * viol0; type = 1; }
-      else if (v1 < st.g_min && viol0 < st.g_min && alpha * armijo < 0.0) { acc = m1 < merit0 + st.armijo_factor * alpha * armijo; type = 3; }
-      else { acc = m1 < merit0 - st.gamma_c * viol0 || v1 < (1.0 - st.gamma_c) * viol0; type = 2; }
-      ctl[2] = m1; ctl[3] = v1; ctl[4] = acc ? 1.0 : 0.0; ctl[5] = double(type);
+      double acc = 0.0, accAlpha = alpha, m1 = merit0, v1 = viol0; int type = 0;
+      for (int tr = 0; tr < nTr && acc == 0.0; ++tr) {
+        const double al = tr ? alpha * st.alpha_decay : alpha;
+        if (tr && al < st.alpha_min) break;        // the sequential loop would have stopped before this trial
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int i = tr * half; i < (tr + 1) * half; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; }
+        m1 = s0; v1 = sqrt(s1 + s2);
+        bool ok;
+        // upstream FilterLinesearch::acceptStep
+        if (!a.lineSearch) { ok = true; type = 0; }
+        else if (v1 > st.g_max) { ok = v1 < (1.0 - st.gamma_c) * viol0; type = 1; }
+        else if (v1 < st.g_min && viol0 < st.g_min && al * armijo < 0.0) { ok = m1 < merit0 + st.armijo_factor * al * armijo; type = 3; }
+        else { ok = m1 < merit0 - st.gamma_c * viol0 || v1 < (1.0 - st.gamma_c) * viol0; type = 2; }
+        accAlpha = al;
+        if (ok) acc = 1.0;
+      }
+      ctl[2] = m1; ctl[3] = v1; ctl[4] = acc; ctl[5] = double(type); ctl[6] = accAlpha;
     }
     __syncthreads();
     merit1 = ctl[2]; viol1 = ctl[3]; stepType = int(ctl[5]);
     accepted = ctl[4] != 0.0;
+    const double lastAlpha = ctl[6];
     __syncthreads();
-    if (accepted) break;
-    alpha *= st.alpha_decay;
+    if (accepted) { alpha = lastAlpha; break; }
+    alpha = lastAlpha * st.alpha_decay;
     if (alpha < st.alpha_min) break;
   }
   if (!accepted) { alpha = 0.0; stepType = 4; merit1 = merit0; viol1 = viol0; }

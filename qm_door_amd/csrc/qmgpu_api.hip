@@ -109,8 +109,8 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     ctx->dGains = ctx->alloc<double>(B * N * GAIN_DOUBLES);
     ctx->ddX = ctx->alloc<double>(B * N1 * 30);
     ctx->ddU = ctx->alloc<double>(B * N * 30);
-    ctx->dXt = ctx->alloc<double>(B * N1 * 30);
-    ctx->dUt = ctx->alloc<double>(B * N * 30);
+    ctx->dXt = ctx->alloc<double>(2 * B * N1 * 30);   // two trial steps are evaluated side by side (linesearch_kernel)
+    ctx->dUt = ctx->alloc<double>(2 * B * N * 30);
     ctx->dInstStats = ctx->alloc<double>(B * 4);
     ctx->dStageNc = ctx->alloc<int>(B * N1);
     ctx->dNodeMode = ctx->alloc<int>(B * N1);
@@ -227,7 +227,7 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
     LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
               a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
-    QM_LAUNCH(linesearch_kernel, B, (N + 1 <= 128 ? 128 : 256), s, ls);
+    QM_LAUNCH(linesearch_kernel, B, 256, s, ls);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[3], s));
   }
   HIP_CHECK(hipGetLastError());
