@@ -180,6 +180,7 @@ def main():
                          "note": "algorithmic dense-contraction FLOPs of SURVEY.md 8(d) per launch / HIP-event kernel time; fp64 matrix peak is the public spec; "
                                  "the path is latency bound, not MFMA bound (DESIGN.md)",
                          "kernel_ms": dict(zip(names + ["whole_call"], kernel_ms)),
+                         "kernel_frac": {k: flops[k] / (kernel_ms[names.index(k)] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS for k in flops},
                          "path_achieved": path_flops / (kernel_ms[5] * 1e-3) / 1e12, "path_frac": path_flops / (kernel_ms[5] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
