@@ -374,7 +374,7 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     return false;
   };
   int it = 0;
-  bool earlyTried = false;
+  int earlyTries = 0; double lastTryMu = 1e300;
   Vec zPrev = z, sPrev = s, lamPrev = lam;
   double nrdPrev = 0.0, muPrev = 0.0;
   for (; it < maxIter; ++it) {
@@ -394,9 +394,13 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
     // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
     if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
-    // the polish is first tried as soon as the active set can be read off (mu <= 1e-8 scale): an accepted vertex is exact whatever
-    // iterate it started from; a rejected one leaves z, s, lam untouched and the interior point goes on
-    if (!earlyTried && nrd <= 1e-5 * scale && nrp <= 1e-7 * scale && mu <= 1e-8 * scale) { earlyTried = true; if (tryPolish()) return it; }
+    // the polish is first tried as soon as the active set can plausibly be read off (mu <= 1e-6 scale; at most twice, the second time
+    // only after the complementarity has dropped another 100x): an accepted vertex is exact whatever iterate it started from; a
+    // rejected one leaves z, s, lam untouched and the interior point goes on
+    if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) {
+      ++earlyTries; lastTryMu = mu;
+      if (tryPolish()) return it;
+    }
     // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
     // here instead of iterating into the divergence that follows; the polish finishes the job
     if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;

@@ -55,7 +55,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   // 1e-3, and slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the higher priorities' solution) and the
   // failure is reported (return value 60).
   int attempt = 0;
-  bool early = false, earlyTried = false;   // early polish attempt in flight / already tried
+  bool early = false; int earlyTries = 0; double lastTryMu = 1e300;   // early polish attempt in flight / attempts so far / complementarity at the last one
   auto restartOrGiveUp = [&]() {
     if (attempt < 2) {
       ++attempt;
@@ -64,14 +64,14 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       zc = 0.0; zcPrev = 0.0; v = 0.0; vp = 0.0;
       s1 = rowActive ? fmax(sg, fl) : 1.0; l1 = sg; s2 = sg; l2 = sg;
       s1p = s1; l1p = l1; s2p = s2; l2p = l2; nrdPrev = 0.0; muPrev = 0.0;
-      early = false; earlyTried = false;
+      early = false; earlyTries = 0; lastTryMu = 1e300;
       return true;
     }
     zc = 0.0; v = 0.0;
     return false;
   };
   int polish = 0;                       // 0 interior point; 1..3 polish step; 4 final check
-  // the polish is first tried as soon as the active set can be read (mu <= 1e-8 scale): an accepted
+  // the polish is first tried as soon as the active set can plausibly be read (mu <= 1e-6 scale, at most twice): an accepted
                                             // vertex is exact whatever iterate it started from, a rejected one resumes the interior point
   bool isE = false, isV = false;        // my row: pinned (equality) / violated soft row of this level (exact quadratic)
   double lamE = 0.0, zIpm = 0.0;
@@ -133,7 +133,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         if (!(muPrev <= 1e-8 * scale)) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
         done = true;
       } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
-      else if (!earlyTried && nrd <= 1e-5 * scale && nrp <= 1e-7 * scale && mu <= 1e-8 * scale) { done = true; early = true; earlyTried = true; }
+      else if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) { done = true; early = true; ++earlyTries; lastTryMu = mu; }
       // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
       // stop here instead of iterating into the divergence that follows; the polish finishes the job
       else if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
