@@ -37,10 +37,40 @@ struct QmGather {
   __device__ __forceinline__ double get(int src) const { return qmReadLane(v, src, nullptr); }
 };
 __device__ __forceinline__ QmGather qmGather(double v, double* scratch) { (void)scratch; return QmGather{v}; }
-// wavefront all-reduces (xor butterfly: every lane ends with the same value)
-__device__ __forceinline__ double qmAllSum(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64); return v; }
-__device__ __forceinline__ double qmAllMax(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64)); return v; }
-__device__ __forceinline__ double qmAllMin(double v, double* scratch) { (void)scratch; for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64)); return v; }
+// wavefront all-reduces (butterfly: every lane ends with the same value, bit for bit -- the operation is commutative and both
+// partners of a step combine the same pair).  Steps 1, 2 (quad permutes), 4 (row_half_mirror: quads are uniform by then) and 8
+// (row_mirror) are DPP moves, steps 16 and 32 the row / half-wave swaps of gfx950 (v_permlane16_swap, v_permlane32_swap): ~25
+// VALU instructions, no LDS round trip.  The __shfl_xor butterfly compiles to twelve ds_bpermute_b32 on a dependent chain; the
+// interior point of the WBC runs about ten all-reduces per iteration.
+template <int CTRL> __device__ __forceinline__ double qmDppMove(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qmRowXor16(double v, bool oddRow) {    // value of lane ^ 16
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(int(oddRow ? r1[0] : r1[1]), int(oddRow ? r0[0] : r0[1]));
+}
+__device__ __forceinline__ double qmHalfXor32(double v, bool upper) {   // value of lane ^ 32
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(int(upper ? r1[0] : r1[1]), int(upper ? r0[0] : r0[1]));
+}
+template <class Op> __device__ __forceinline__ double qmAllReduce(double v, Op op) {
+  const unsigned lane = threadIdx.x;
+  v = op(v, qmDppMove<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = op(v, qmDppMove<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = op(v, qmDppMove<0x141>(v));   // row_half_mirror
+  v = op(v, qmDppMove<0x140>(v));   // row_mirror
+  v = op(v, qmRowXor16(v, (lane >> 4) & 1));
+  v = op(v, qmHalfXor32(v, (lane & 32) != 0));
+  return v;
+}
+__device__ __forceinline__ double qmAllSum(double v, double* scratch) { (void)scratch; return qmAllReduce(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double qmAllMax(double v, double* scratch) { (void)scratch; return qmAllReduce(v, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double qmAllMin(double v, double* scratch) { (void)scratch; return qmAllReduce(v, [](double a, double b) { return fmin(a, b); }); }
 // Workgroup barrier that orders LDS traffic only: waits for this wavefront's LDS operations, then s_barrier.  Unlike
 // __syncthreads() it does not drain outstanding global loads (vmcnt), so a register-staged prefetch of the next stage stays in
 // flight across the barriers of the current one.  Use only where the data exchanged through the barrier lives in LDS.

@@ -86,7 +86,8 @@ template <class Op> inline double emuButterfly(double v, double* scratch, Op op)
   QmGather g = qmGather(v, scratch);
   double cur[64], nxt[64];
   for (int i = 0; i < 64; ++i) cur[i] = g.vals[i];
-  for (int m = 32; m >= 1; m >>= 1) { for (int i = 0; i < 64; ++i) nxt[i] = op(cur[i], cur[i ^ m]); for (int i = 0; i < 64; ++i) cur[i] = nxt[i]; }
+  for (int m = 1; m <= 32; m <<= 1) { for (int i = 0; i < 64; ++i) nxt[i] = op(cur[i], cur[i ^ m]);   // same pairing order as the DPP butterfly of gpu_rt.h
+    for (int i = 0; i < 64; ++i) cur[i] = nxt[i]; }
   return cur[lane];
 }
 inline double qmAllSum(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return a + b; }); }
