@@ -87,8 +87,11 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     double Dz;
     {
       double d0 = 0.0, d1 = 0.0;
-#pragma unroll 2
-      for (int j = 0; j < NP; j += 2) { d0 += DZ[rowL * LDZ_ + j] * gz.get(j); d1 += DZ[rowL * LDZ_ + j + 1] * gz.get(j + 1); }
+#pragma unroll 1
+      for (int j = 0; j < NP; j += 4) {   // four LDS reads in flight, then the multiply-adds (a lone wavefront has nothing else to hide them)
+        const double t0 = DZ[rowL * LDZ_ + j], t1 = DZ[rowL * LDZ_ + j + 1], t2 = DZ[rowL * LDZ_ + j + 2], t3 = DZ[rowL * LDZ_ + j + 3];
+        d0 += t0 * gz.get(j); d1 += t1 * gz.get(j + 1); d0 += t2 * gz.get(j + 2); d1 += t3 * gz.get(j + 3);
+      }
       Dz = d0 + d1;
     }
     const double rp1 = rowActive ? (Dz - (own ? v : 0.0) + s1 - fl) : 0.0;
@@ -112,11 +115,20 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     double rdz;
     {
       double a0 = gC, a1 = 0.0;
-#pragma unroll 2
-      for (int j = 0; j < NP; j += 2) { a0 += G[j * LDK_ + colL] * gz.get(j); a1 += G[(j + 1) * LDK_ + colL] * gz.get(j + 1); }  // G symmetric
+#pragma unroll 1
+      for (int j = 0; j < NP; j += 4) {   // G symmetric
+        const double t0 = G[j * LDK_ + colL], t1 = G[(j + 1) * LDK_ + colL], t2 = G[(j + 2) * LDK_ + colL], t3 = G[(j + 3) * LDK_ + colL];
+        a0 += t0 * gz.get(j); a1 += t1 * gz.get(j + 1); a0 += t2 * gz.get(j + 2); a1 += t3 * gz.get(j + 3);
+      }
       const QmGather gl = qmGather(lamR, red);
-#pragma unroll 2
-      for (int i = 0; i < 56; i += 2) { a0 += DZ[i * LDZ_ + colL] * gl.get(i); a1 += DZ[(i + 1) * LDZ_ + colL] * gl.get(i + 1); }
+#pragma unroll 1
+      for (int i = 0; i < 56; i += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) { a0 += t[q] * gl.get(i + q); a1 += t[q + 1] * gl.get(i + q + 1); }
+      }
       rdz = colOn ? a0 + a1 : 0.0;
     }
     const double mu = allSum(rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
@@ -242,8 +254,14 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       {
         const QmGather gt = qmGather(tz, red);
         double a0 = -rdz, a1 = 0.0;
-#pragma unroll 2
-        for (int i = 0; i < 56; i += 2) { a0 -= DZ[i * LDZ_ + colL] * gt.get(i); a1 -= DZ[(i + 1) * LDZ_ + colL] * gt.get(i + 1); }
+#pragma unroll 1
+        for (int i = 0; i < 56; i += 8) {
+          double t[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) { a0 -= t[q] * gt.get(i + q); a1 -= t[q + 1] * gt.get(i + q + 1); }
+        }
         acc = colOn ? a0 + a1 : 0.0;
       }
       // L t = rhs (forward substitution; lane c owns row c of L)
@@ -270,8 +288,11 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       {
         const QmGather gd = qmGather(dzc, red);
         double d0 = 0.0, d1 = 0.0;
-#pragma unroll 2
-        for (int j = 0; j < NP; j += 2) { d0 += DZ[rowL * LDZ_ + j] * gd.get(j); d1 += DZ[rowL * LDZ_ + j + 1] * gd.get(j + 1); }
+#pragma unroll 1
+        for (int j = 0; j < NP; j += 4) {
+          const double t0 = DZ[rowL * LDZ_ + j], t1 = DZ[rowL * LDZ_ + j + 1], t2 = DZ[rowL * LDZ_ + j + 2], t3 = DZ[rowL * LDZ_ + j + 3];
+          d0 += t0 * gd.get(j); d1 += t1 * gd.get(j + 1); d0 += t2 * gd.get(j + 2); d1 += t3 * gd.get(j + 3);
+        }
         Ddz = d0 + d1;
       }
       if (rowActive) {
