@@ -88,7 +88,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   QM_POISON_LDS(lds, RICCATI_LDS_DOUBLES);
   constexpr int NTHR = NW * 64;
   constexpr int PFB = (OFF_PX / 2 + NTHR - 1) / NTHR;
-  constexpr int PFR = (STAGE_DOUBLES / 2 + NTHR - 1) / NTHR;
+  // forward sweep: only A~ B~ (the head of the record) and b~ q~ r~ Px Pu Pe (its tail) are read; Q~ P~ R~ in between are not
+  constexpr int FWD_HEAD = OFF_QT, FWD_TAIL0 = OFF_bt, FWD_TAIL = STAGE_DOUBLES - OFF_bt;
+  static_assert(FWD_HEAD % 2 == 0 && FWD_TAIL0 % 2 == 0 && FWD_TAIL % 2 == 0, "16-byte units");
+  constexpr int PFH = (FWD_HEAD / 2 + NTHR - 1) / NTHR, PFT = (FWD_TAIL / 2 + NTHR - 1) / NTHR;
   constexpr int PFG = (GAIN_DOUBLES / 2 + NTHR - 1) / NTHR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, h = lane >> 4;   // MFMA operand coordinates of this lane
@@ -301,11 +304,14 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   constexpr int WX = 1 % NW;
   __syncthreads();   // full barrier: the gains written to HBM by every wavefront are read back by all of them below
   {
-    StagePrefetch<PFR, NTHR> pr;
+    StagePrefetch<PFH, NTHR> ph;
+    StagePrefetch<PFT, NTHR> pt;
     StagePrefetch<PFG, NTHR> pg;
-    pr.issue(stagesI, STAGE_DOUBLES, tid);
+    ph.issue(stagesI, FWD_HEAD, tid);
+    pt.issue(stagesI + FWD_TAIL0, FWD_TAIL, tid);
     pg.issue(gainsI, GAIN_DOUBLES, tid);
-    pr.commit(lds + R_STG, STAGE_DOUBLES, tid);
+    ph.commit(lds + R_STG, FWD_HEAD, tid);
+    pt.commit(lds + R_STG + FWD_TAIL0, FWD_TAIL, tid);
     pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
   if (tid < 30) dxv[tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
@@ -317,9 +323,11 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const int kn = k + 1 < N ? k + 1 : k;
     const double* stg = lds + R_STG + (k & 1) * STG_F; const double* gn = stg + STAGE_DOUBLES;
     double* stgNext = lds + R_STG + ((k + 1) & 1) * STG_F;
-    StagePrefetch<PFR, NTHR> pr;
+    StagePrefetch<PFH, NTHR> ph;
+    StagePrefetch<PFT, NTHR> pt;
     StagePrefetch<PFG, NTHR> pg;
-    pr.issue(stagesI + size_t(kn) * STAGE_DOUBLES, STAGE_DOUBLES, tid);
+    ph.issue(stagesI + size_t(kn) * STAGE_DOUBLES, FWD_HEAD, tid);
+    pt.issue(stagesI + size_t(kn) * STAGE_DOUBLES + FWD_TAIL0, FWD_TAIL, tid);
     pg.issue(gainsI + size_t(kn) * GAIN_DOUBLES, GAIN_DOUBLES, tid);
     if (wave == 0 && lane < 30) a.dX[(size_t(inst) * (N + 1) + k) * 30 + lane] = dxv[lane];
     if (wave == 0 && lane < nt) {
@@ -348,7 +356,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     if (wave == WX && lane >= 32 && lane < 32 + nt) armijo += stg[OFF_rt + (lane - 32)] * dut[lane - 32];
     QM_LDS_BARRIER();
     if (wave == WX && lane < 30) dxv[lane] = nx;
-    pr.commit(stgNext, STAGE_DOUBLES, tid);
+    ph.commit(stgNext, FWD_HEAD, tid);
+    pt.commit(stgNext + FWD_TAIL0, FWD_TAIL, tid);
     pg.commit(stgNext + STAGE_DOUBLES, GAIN_DOUBLES, tid);
     QM_LDS_BARRIER();
   }
