@@ -122,12 +122,12 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       }
       const QmGather gl = qmGather(lamR, red);
 #pragma unroll 1
-      for (int i = 0; i < 56; i += 8) {
-        double t[8];
+      for (int i = 0; i < 56; i += 14) {
+        double t[14];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
+        for (int q = 0; q < 14; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) { a0 += t[q] * gl.get(i + q); a1 += t[q + 1] * gl.get(i + q + 1); }
+        for (int q = 0; q < 14; q += 2) { a0 += t[q] * gl.get(i + q); a1 += t[q + 1] * gl.get(i + q + 1); }
       }
       rdz = colOn ? a0 + a1 : 0.0;
     }
@@ -180,19 +180,28 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
                 acc[t][r] = (i < 36 && j < 36) ? gv : 0.0;
               }
         }
-  #pragma unroll 2
-        for (int ks = 0; ks < KS; ++ks) {
-          const int kk = 4 * ks + h;
-          const double w = io.wtL[kk];
-          double b[TP], a[TP];
+        static_assert(KS % 7 == 0, "operand batches of seven k steps");
+  #pragma unroll 1
+        for (int k0 = 0; k0 < KS; k0 += 7) {   // the operands of seven k steps are read from LDS before the first matrix-core instruction
+          double wv[7], bv[7][TP];
   #pragma unroll
-          for (int t = 0; t < TP; ++t) {
-            const int j = t * 16 + l16;
-            const double raw = DZ[kk * LDZ_ + (j < 36 ? j : 0)];
-            b[t] = j < NP ? raw : 0.0;
-            a[t] = w * b[t];
+          for (int q = 0; q < 7; ++q) {
+            const int kk = 4 * (k0 + q) + h;
+            wv[q] = io.wtL[kk];
+  #pragma unroll
+            for (int t = 0; t < TP; ++t) {
+              const int j = t * 16 + l16;
+              const double raw = DZ[kk * LDZ_ + (j < 36 ? j : 0)];
+              bv[q][t] = j < NP ? raw : 0.0;
+            }
           }
-          qmMfmaUpper<TP>(acc, a, b, red);
+  #pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            double a[TP];
+  #pragma unroll
+            for (int t = 0; t < TP; ++t) a[t] = wv[q] * bv[q][t];
+            qmMfmaUpper<TP>(acc, a, bv[q], red);
+          }
         }
         int t = 0;
   #pragma unroll
@@ -255,12 +264,12 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         const QmGather gt = qmGather(tz, red);
         double a0 = -rdz, a1 = 0.0;
 #pragma unroll 1
-        for (int i = 0; i < 56; i += 8) {
-          double t[8];
+        for (int i = 0; i < 56; i += 14) {
+          double t[14];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
+          for (int q = 0; q < 14; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
 #pragma unroll
-          for (int q = 0; q < 8; q += 2) { a0 -= t[q] * gt.get(i + q); a1 -= t[q + 1] * gt.get(i + q + 1); }
+          for (int q = 0; q < 14; q += 2) { a0 -= t[q] * gt.get(i + q); a1 -= t[q + 1] * gt.get(i + q + 1); }
         }
         acc = colOn ? a0 + a1 : 0.0;
       }
