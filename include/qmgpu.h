@@ -55,7 +55,7 @@ extern "C" {
 #define QMGPU_NWBC_DEC 36
 #define QMGPU_NWBC_OUT 54
 #define QMGPU_MAX_EVENTS 40 /* per-instance mode-schedule capacity */
-#define QMGPU_NSTATS 8
+#define QMGPU_NSTATS 10
 
 typedef enum qmgpu_status {
   QMGPU_OK = 0,
@@ -92,6 +92,7 @@ typedef struct qmgpu_settings {
   double liftoff_velocity, touchdown_velocity, swing_height, touchdown_after_horizon, swing_time_scale;
   /* sqp + mpc (task.info:76-93,139-149); alpha_decay/alpha_min/gamma_c/armijo are OCS2 defaults */
   double dt, time_horizon, delta_tol, g_max, g_min, alpha_decay, alpha_min, gamma_c, armijo_factor;
+  double cost_tol;                     /* sqp.costTol (upstream default 1e-4): convergence test between SQP iterations */
   int32_t sqp_iterations, reserved0;
   /* cost (task.info:193-288) */
   double initial_state[QMGPU_NX];
@@ -179,7 +180,8 @@ typedef struct qmgpu_mpc_args {
   double* out_x;                       /* [batch][N+1][30] */
   double* out_u;                       /* [batch][N][30] */
   int32_t* out_mode;                   /* [batch][N+1] */
-  double* out_stats;                   /* [batch][NSTATS]: merit0, violation0, merit1, violation1, alpha, step_type, armijo, status */
+  double* out_stats;                   /* [batch][NSTATS]: merit0, violation0, merit1, violation1, alpha, step_type, armijo, status,
+                                          SQP iterations performed, convergence (1 iteration limit, 2 step size, 3 metrics, 4 primal step) */
 } qmgpu_mpc_args;
 
 int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args);

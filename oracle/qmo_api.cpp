@@ -81,18 +81,19 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
     if (warmU) for (int i = 0; i < 30; ++i) U[k * 30 + i] = warmU[k * 30 + i];
     else weightCompensatingInput(*P, pr.ms.modeAt(tg[k]), &U[k * 30]);
   }
-  // sqp.sqpIteration iterations (task.info:77, 1 in the reference's configuration), each warm-started from the previous iterate.
-  // Upstream stops early when the step or the cost change falls below deltaTol / costTol; a further iteration of a converged
-  // problem is idempotent to those tolerances, so the restatement always runs the configured count.
+  // sqp.sqpIteration iterations at most (task.info:77, 1 in the reference's configuration), each warm-started from the previous
+  // iterate, with upstream's convergence test (SqpSolver::checkConvergence) after every one.
   SqpResult r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
-  for (int it = 1; it < P->settings.sqp_iterations && r.status == 0; ++it) {
+  int iterations = 1, convergence = sqpConvergence(P->settings, 0, r);
+  for (int it = 1; convergence == 0 && r.status == 0; ++it) {
     X = r.X; U = r.U;
     r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
+    ++iterations; convergence = sqpConvergence(P->settings, it, r);
   }
   for (int k = 0; k <= N; ++k) { outT[k] = tg[k]; outMode[k] = pr.ms.modeAt(tg[k]); }
   std::copy(r.X.begin(), r.X.end(), outX);
   std::copy(r.U.begin(), r.U.end(), outU);
-  if (stats) { stats[0] = r.merit0; stats[1] = r.viol0; stats[2] = r.merit1; stats[3] = r.viol1; stats[4] = r.alpha; stats[5] = r.stepType; stats[6] = r.armijo; stats[7] = r.status; }
+  if (stats) { stats[0] = r.merit0; stats[1] = r.viol0; stats[2] = r.merit1; stats[3] = r.viol1; stats[4] = r.alpha; stats[5] = r.stepType; stats[6] = r.armijo; stats[7] = r.status; stats[8] = iterations; stats[9] = convergence; }
   return r.status;
 }
 

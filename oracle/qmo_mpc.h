@@ -398,7 +398,17 @@ struct SqpResult {
   double merit0 = 0, viol0 = 0, merit1 = 0, viol1 = 0, alpha = 0, armijo = 0;
   int stepType = 0;  // 0 unknown, 1 constraint, 2 dual, 3 cost, 4 zero
   int status = 0;
+  double dxNorm = 0, duNorm = 0;  // l2 norms of the step directions over the whole horizon (upstream trajectoryNorm)
 };
+
+// upstream SqpSolver::checkConvergence: 0 not converged, 1 iteration limit, 2 step size, 3 metrics, 4 primal step
+inline int sqpConvergence(const qmgpu_settings& st, int iteration, const SqpResult& r) {
+  if (iteration + 1 >= st.sqp_iterations) return 1;
+  if (r.alpha < st.alpha_min) return 2;
+  if (std::fabs(r.merit1 - r.merit0) < st.cost_tol && r.viol1 < st.g_min) return 3;
+  if (r.alpha * r.dxNorm < st.delta_tol && r.alpha * r.duNorm < st.delta_tol) return 4;
+  return 0;
+}
 
 // One SQP iteration over the grid tgrid[0..N]; X [(N+1)*30], U [N*30] hold the initial guess.
 inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, const double* x0, const std::vector<double>& X, const std::vector<double>& U,
@@ -453,6 +463,7 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
     merit = cost; viol = std::sqrt(dyn + eq);
   };
   SqpResult res; res.armijo = armijo;
+  { double sx = 0, su = 0; for (double v : dX) sx += v * v; for (double v : dU) su += v * v; res.dxNorm = std::sqrt(sx); res.duNorm = std::sqrt(su); }
   performance(X, U, res.merit0, res.viol0);
   double alpha = 1.0;
   std::vector<double> Xn(X.size()), Un(U.size());

@@ -10,7 +10,7 @@ import os
 NX, NU, NV, NJ, NB, NC = 30, 30, 24, 18, 19, 4
 NTARGET, NRBD, NWBC_DEC, NWBC_OUT = 37, 55, 36, 54
 MAX_EVENTS = 40
-NSTATS = 8
+NSTATS = 10
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_FILE_NOT_FOUND, ERR_PARSE, ERR_UNSUPPORTED_MODEL = 1, 2, 3, 4
@@ -35,7 +35,7 @@ class Settings(C.Structure):
         ("position_error_gain", d), ("phase_transition_stance_time", d),
         ("liftoff_velocity", d), ("touchdown_velocity", d), ("swing_height", d), ("touchdown_after_horizon", d), ("swing_time_scale", d),
         ("dt", d), ("time_horizon", d), ("delta_tol", d), ("g_max", d), ("g_min", d), ("alpha_decay", d), ("alpha_min", d), ("gamma_c", d),
-        ("armijo_factor", d), ("sqp_iterations", i32), ("reserved0", i32),
+        ("armijo_factor", d), ("cost_tol", d), ("sqp_iterations", i32), ("reserved0", i32),
         ("initial_state", d * NX), ("Q", d * (NX * NX)), ("R_task", d * (NU * NU)),
         ("ee_mu_position", d), ("ee_mu_orientation", d), ("ee_final_mu_position", d), ("ee_final_mu_orientation", d),
         ("friction_coefficient", d), ("friction_barrier_mu", d), ("friction_barrier_delta", d), ("friction_regularization", d),

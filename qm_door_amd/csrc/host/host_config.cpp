@@ -189,6 +189,7 @@ static void loadSettings(const std::string& taskFile, const std::string& referen
   s.dt = infoDouble(task, "sqp.dt");
   s.sqp_iterations = int(infoDoubleOr(task, "sqp.sqpIteration", 1));
   s.delta_tol = infoDoubleOr(task, "sqp.deltaTol", 1e-6);
+  s.cost_tol = infoDoubleOr(task, "sqp.costTol", 1e-4);
   s.g_max = infoDoubleOr(task, "sqp.g_max", 1e6);
   s.g_min = infoDoubleOr(task, "sqp.g_min", 1e-6);
   s.alpha_decay = 0.5; s.alpha_min = 1e-4; s.gamma_c = 1e-6; s.armijo_factor = 1e-4;  // upstream ocs2_sqp / FilterLinesearch defaults

@@ -48,12 +48,16 @@ struct InitArgs {
   const double* t0; const double* x0; const double* timeGrid; const double* warmX; const double* warmU;
   const int* schedNum; const double* schedTimes; const int* schedModes;
   double* tgrid; double* X; double* U;
+  int iteration;   // SQP iteration of this call (0 = first)
+  int* done;       // [batch] convergence flags: cleared by iteration 0, set by linesearch_kernel; later iterations skip converged instances
 };
 
 // Time grid + initial trajectories: previous solution when given, else QMInitializer::compute (QMInitializer.cpp:33-41):
 // u = weight-compensating input for the contact flags at t_k, x_{k+1} = x_k.  x[0] is always the measured state.
 __global__ void mpc_init_kernel(InitArgs a) {
   const int inst = blockIdx.x;
+  if (a.iteration == 0) { if (threadIdx.x == 0) a.done[inst] = 0; }
+  else if (a.done[inst]) return;
   const qmgpu_settings& st = a.P->settings;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
   for (int k = threadIdx.x; k <= a.N; k += blockDim.x) {

@@ -23,6 +23,8 @@ struct LsArgs {
   const int* nodeMode;
   double* Xt; double* Ut;   // trial trajectories (scratch) [batch][N+1][30], [batch][N][30]
   double* outT; double* outX; double* outU; int* outMode; double* outStats;
+  int iteration;   // SQP iteration of this call
+  int* done;       // [batch] convergence flags (see InitArgs)
 };
 
 struct DblIn {
@@ -126,6 +128,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __shared__ double red[3 * 256];
   __shared__ double ctl[8];
   const int inst = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  if (a.done[inst]) return;   // converged in an earlier iteration of this call: outputs and statistics stay as they are
   const int N = a.N;
   const qmgpu_settings& st = a.P->settings;
   const double* tg = a.tgrid + size_t(inst) * (N + 1);
@@ -209,9 +212,28 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   for (int e = tid; e < (N + 1) * 30; e += nthr) oX[e] = X[e] + alpha * dX[e];
   for (int e = tid; e < N * 30; e += nthr) oU[e] = U[e] + alpha * dU[e];
   for (int k = tid; k <= N; k += nthr) { a.outT[size_t(inst) * (N + 1) + k] = tg[k]; a.outMode[size_t(inst) * (N + 1) + k] = a.nodeMode[size_t(inst) * (N + 1) + k]; }
-  if (tid == 0 && a.outStats) {
-    double* s = a.outStats + size_t(inst) * QMGPU_NSTATS;
-    s[0] = merit0; s[1] = viol0; s[2] = merit1; s[3] = viol1; s[4] = alpha; s[5] = double(stepType); s[6] = armijo; s[7] = ricStatus;
+  // ---- upstream SqpSolver::checkConvergence: iteration limit, step size, metrics, primal step (l2 norms over the whole horizon)
+  double sx = 0.0, su = 0.0;
+  for (int e = tid; e < (N + 1) * 30; e += nthr) sx += dX[e] * dX[e];
+  for (int e = tid; e < N * 30; e += nthr) su += dU[e] * dU[e];
+  __syncthreads();
+  red[tid] = sx; red[256 + tid] = su;
+  __syncthreads();
+  if (tid == 0) {
+    double s0 = 0, s1 = 0;
+    for (int i = 0; i < nthr; ++i) { s0 += red[i]; s1 += red[256 + i]; }
+    int conv = 0;
+    if (a.iteration + 1 >= st.sqp_iterations) conv = 1;
+    else if (alpha < st.alpha_min) conv = 2;
+    else if (fabs(merit1 - merit0) < st.cost_tol && viol1 < st.g_min) conv = 3;
+    else if (alpha * sqrt(s0) < st.delta_tol && alpha * sqrt(s1) < st.delta_tol) conv = 4;
+    if (ricStatus != 0.0 && conv == 0) conv = 2;   // a failed factorisation leaves the iterate where it was: nothing more to do
+    a.done[inst] = conv;
+    if (a.outStats) {
+      double* s = a.outStats + size_t(inst) * QMGPU_NSTATS;
+      s[0] = merit0; s[1] = viol0; s[2] = merit1; s[3] = viol1; s[4] = alpha; s[5] = double(stepType); s[6] = armijo; s[7] = ricStatus;
+      s[8] = double(a.iteration + 1); s[9] = double(conv);
+    }
   }
 }
 

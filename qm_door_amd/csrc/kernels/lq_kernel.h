@@ -41,6 +41,7 @@ struct LqArgs {
   double* metrics;           // [batch][N+1][NODE_METRICS]
   double* debug;             // [batch][N+1][DBG_DOUBLES] or null
   double* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
+  const int* done;           // [batch] instances whose SQP iterations have converged are skipped
 };
 
 // AD rows: one 64-double row per differentiated scalar; entry l < 60 = d/d(x,u)_l, entry 60 = the value itself
@@ -121,6 +122,7 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   const int lane = threadIdx.x;
   const int node = blockIdx.x % (a.N + 1);
   const int inst = blockIdx.x / (a.N + 1);
+  if (a.done[inst]) return;
   const bool terminal = node == a.N;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
@@ -226,6 +228,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int l16 = lane & 15, h = lane >> 4;
   const int node = blockIdx.x % (a.N + 1);
   const int inst = blockIdx.x / (a.N + 1);
+  if (a.done[inst]) return;
   const bool terminal = node == a.N;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;

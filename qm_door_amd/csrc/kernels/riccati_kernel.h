@@ -35,6 +35,7 @@ struct RiccatiArgs {
   double* dX;             // [batch][N+1][30]
   double* dU;             // [batch][N][30]
   double* instStats;      // [batch][4]: armijo descent metric, status, -, -
+  const int* done;        // [batch] converged instances are skipped
 };
 
 constexpr int RICCATI_WAVES = 4;
@@ -96,6 +97,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, h = lane >> 4;   // MFMA operand coordinates of this lane
   const int inst = blockIdx.x;
+  if (a.done[inst]) return;   // workgroup uniform
   const int N = a.N;
   double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
   double* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)

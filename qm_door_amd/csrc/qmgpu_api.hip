@@ -41,7 +41,7 @@ struct qmgpu_context {
   double *dRw = nullptr, *dZeros = nullptr;
   double *dTgrid = nullptr, *dX = nullptr, *dU = nullptr, *dStages = nullptr, *dAdRows = nullptr, *dMetrics = nullptr, *dGains = nullptr, *ddX = nullptr, *ddU = nullptr;
   double *dXt = nullptr, *dUt = nullptr, *dInstStats = nullptr, *dDebug = nullptr;
-  int *dStageNc = nullptr, *dNodeMode = nullptr;
+  int *dStageNc = nullptr, *dNodeMode = nullptr, *dDone = nullptr;
   // policy evaluation outputs feeding the WBC inside qmgpu_cycle_batch
   double *dPolX = nullptr, *dPolU = nullptr;
   int* dPolMode = nullptr;
@@ -114,6 +114,7 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     ctx->dInstStats = ctx->alloc<double>(B * 4);
     ctx->dStageNc = ctx->alloc<int>(B * N1);
     ctx->dNodeMode = ctx->alloc<int>(B * N1);
+    ctx->dDone = ctx->alloc<int>(B);
     ctx->dPolX = ctx->alloc<double>(B * 30);
     ctx->dPolU = ctx->alloc<double>(B * 30);
     ctx->dPolMode = ctx->alloc<int>(B);
@@ -211,22 +212,23 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   hipStream_t s = h->stream;
   if (h->timing) HIP_CHECK(hipEventRecord(h->ev[0], s));
   // sqp.sqpIteration iterations (task.info:77; 1 in the reference's configuration): later iterations warm-start from the iterate the
-  // line search just wrote to the caller's output buffers.  No early exit on convergence (see the oracle's note).
+  // line search just wrote to the caller's output buffers.  After every iteration the line-search kernel applies upstream's convergence
+  // test per instance; the kernels of the following iterations return at once for the instances that have converged.
   const int iterations = h->hostProblem.settings.sqp_iterations > 1 ? h->hostProblem.settings.sqp_iterations : 1;
   for (int it = 0; it < iterations; ++it) {
-    InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, it == 0 ? a->warm_x : a->out_x, it == 0 ? a->warm_u : a->out_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU};
+    InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, it == 0 ? a->warm_x : a->out_x, it == 0 ? a->warm_u : a->out_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU, it, h->dDone};
     QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
     LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
-              a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows};
+              a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows, h->dDone};
     QM_LAUNCH(ad_node_kernel, B * (N + 1), 64, s, la);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[6], s));
     QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
-    RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats};
+    RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats, h->dDone};
     QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
     LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
-              a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
+              a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats, it, h->dDone};
     QM_LAUNCH(linesearch_kernel, B, 256, s, ls);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[3], s));
   }

@@ -101,7 +101,7 @@ class Oracle:
         return dict(A=A, B=B, b=b, Q=Q, R=R, q=q, r=r, C=Cm[:n], D=Dm[:n], e=e[:n], nc=n, cost=cost.value)
 
     def mpc_solve(self, N, t0, x0, ttimes, tstates, nev, ev, modes, warm=None, line_search=True, time_grid=None):
-        T, X, U, M, st = np.zeros(N + 1), np.zeros((N + 1, 30)), np.zeros((N, 30)), np.zeros(N + 1, dtype=np.int32), np.zeros(8)
+        T, X, U, M, st = np.zeros(N + 1), np.zeros((N + 1, 30)), np.zeros((N, 30)), np.zeros(N + 1, dtype=np.int32), np.zeros(abi.NSTATS)
         self.lib.qmo_mpc_solve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
         wx = p(np.ascontiguousarray(warm[0])) if warm else None

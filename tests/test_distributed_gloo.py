@@ -22,7 +22,7 @@ def _solve(itf, orc, lo, hi):
     tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
     nev, ev, md = S.trot_schedule(2.0, phase0=0.02)
     sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
-    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, 8))
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
     a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B))
     rbd = np.array([S.rbd_from_state(orc, x) for x in x0])
     out, st = np.zeros((B, 54)), np.zeros(B, dtype=np.int32)

@@ -28,7 +28,7 @@ def test_emu_lq_and_sqp_iteration(emu):
     sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
     assert np.abs(sol.input_weight() - orc.input_weight()).max() < 1e-13
     sol.enable_debug(True)
-    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, 8))
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
     a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B))
     sol.mpc(a)
     dt = itf.problem.settings.dt
@@ -105,7 +105,7 @@ def test_emu_mixed_modes_and_event_grid(emu):
     tgt = S.nominal_target(orc, itf.initial_state)
     tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
     sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
-    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, 8))
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
     a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), evp[None, :].copy(), mdp[None, :].copy(), oT, oX, oU, oM, oS, time_grid=grid[None, :].copy())
     sol.mpc(a)
     ref = orc.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, evp, mdp, time_grid=grid)
@@ -129,3 +129,41 @@ def test_emu_frontend(emu):
         rx, rt, rs, rl = orc.frontend(c["rbd"], c["time"], c["kind"], c["cmd"], c["last_ee"], yaw_last=c["yaw_last"], feet_height=c["feet"])
         assert np.abs(x0[i] - rx).max() <= 1e-12 * max(1.0, np.abs(rx).max()) and np.abs(ts[i] - rs).max() <= 1e-12 * max(1.0, np.abs(rs).max())
         assert np.abs(tt[i] - rt).max() <= 1e-12 * max(1.0, np.abs(rt).max()) and np.abs(le[i] - rl).max() <= 1e-15
+
+
+def test_emu_sqp_convergence_test_skips_converged_instances():
+    """sqp.sqpIteration = 5 with upstream's convergence test: one instance starts at the optimum's doorstep (warm start = a solved
+    trajectory) and stops on the primal-step criterion, the other runs on; statistics slots 8 / 9 carry the count and the reason."""
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    itf.problem.settings.sqp_iterations = 5
+    itf.problem.settings.delta_tol = 5.0
+    orc = S.Oracle(itf.problem)
+    B, N = 2, 8
+    x0 = S.perturbed_states(itf.initial_state, B, seed=9)
+    tgt = S.nominal_target(orc, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.03)
+    # warm start: instance 0 from an already converged trajectory, instance 1 cold (x_k = x0, weight compensation)
+    solved = orc.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
+    cold = orc.mpc_solve(N, 0.0, x0[1], tt[1], ts[1], nev, ev, md)
+    wx = np.stack([solved["X"], np.tile(x0[1], (N + 1, 1))]); wu = np.stack([solved["U"], cold["U"] * 0.0])
+    for k in range(N):
+        mode = orc.mode_at(ev[:nev], md[:nev + 1], k * itf.problem.settings.dt)
+        flags = [(mode >> (3 - c)) & 1 for c in range(4)]
+        for c in range(4):
+            if flags[c]:
+                wu[1, k, 3 * c + 2] = itf.robot_mass * 9.81 / sum(flags)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+    a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B),
+                     warm_x=wx, warm_u=wu)
+    sol.mpc(a)
+    counts = []
+    for i in range(B):
+        ref = orc.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md, warm=(wx[i], wu[i]))
+        assert oS[i][8] == ref["stats"][8] and oS[i][9] == ref["stats"][9], (oS[i][8:], ref["stats"][8:])
+        assert np.abs(oX[i] - ref["X"]).max() <= 1e-8 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(oU[i] - ref["U"]).max() <= 1e-8 * max(1.0, np.abs(ref["U"]).max())
+        counts.append((int(oS[i][8]), int(oS[i][9])))
+    assert counts[0][0] < counts[1][0] and counts[0][1] in (3, 4), counts   # the warm-started instance stopped earlier, on a tolerance

@@ -90,7 +90,7 @@ def test_frontend_mpc_wbc_chain_stays_on_device(interface, oracle):
     """estimate + command -> front end -> MPC (two-knot targets, EE slerp) -> policy -> WBC without leaving the GPU, against the same chain on the oracle."""
     import gpu_harness as G
     import torch
-    from qm_door_amd import api
+    from qm_door_amd import abi, api
     cs = [c for c in _cases(interface, oracle, 12, seed=9) if c["kind"] in (1, 3)][:4]
     for c in cs:
         c["time"] = 0.2
@@ -103,7 +103,7 @@ def test_frontend_mpc_wbc_chain_stays_on_device(interface, oracle):
     nev, ev, md = S.trot_schedule(2.0, phase0=0.25)
     sn = G.dev(np.full(B, nev, dtype=np.int32), torch.int32); se = G.dev(np.tile(ev, (B, 1)), f64); sm = G.dev(np.tile(md, (B, 1)), torch.int32)
     oT = torch.zeros((B, N + 1), dtype=f64, device="cuda"); oX = torch.zeros((B, N + 1, 30), dtype=f64, device="cuda"); oU = torch.zeros((B, N, 30), dtype=f64, device="cuda")
-    oM = torch.zeros((B, N + 1), dtype=torch.int32, device="cuda"); oS = torch.zeros((B, 8), dtype=f64, device="cuda")
+    oM = torch.zeros((B, N + 1), dtype=torch.int32, device="cuda"); oS = torch.zeros((B, abi.NSTATS), dtype=f64, device="cuda")
     sol = G.make_solver(interface, B, N)
     sol.frontend(sol.frontend_args(B, rbd, tm, kd, cmd, le, x0, tt, ts))
     margs = api.GpuSolver.mpc_args(B, N, x0, tt, ts, sn, se, sm, oT, oX, oU, oM, oS, t0=tm)

@@ -108,6 +108,7 @@ def test_three_sqp_iterations_match_oracle(oracle):
         assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
         assert np.allclose(r["stats"][i][:4], ref["stats"][:4], rtol=1e-6, atol=1e-9)
+        assert r["stats"][i][8] == ref["stats"][8] == 3 and r["stats"][i][9] == ref["stats"][9] == 1   # ran to the iteration limit
 
 
 def test_results_do_not_depend_on_leftover_memory(interface, oracle):
@@ -128,3 +129,33 @@ def test_results_do_not_depend_on_leftover_memory(interface, oracle):
         assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(w["out"]).all() and (r["stats"][:, 7] == 0).all()
     ref = oracle.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
     assert np.abs(r["X"][0] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+
+
+def test_sqp_convergence_test_per_instance(oracle):
+    """Upstream's SqpSolver::checkConvergence between iterations: converged instances are skipped by the remaining launches; the
+    statistics carry the iteration count and the reason (4 = primal step below deltaTol)."""
+    import gpu_harness as G
+    from qm_door_amd import api
+    itf = api.QMInterface()
+    itf.problem.settings.sqp_iterations = 6
+    itf.problem.settings.delta_tol = 5.0
+    orc = S.Oracle(itf.problem)
+    B, N = 8, 30
+    x0 = S.perturbed_states(itf.initial_state, B, seed=11)
+    x0[::2] = itf.initial_state + 0.1 * (x0[::2] - itf.initial_state)      # every other instance starts close to the nominal state
+    tgt = S.nominal_target(oracle, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.1)
+    sol = G.make_solver(itf, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.debug_poison()
+    sol.mpc(mb.args)
+    r = mb.results()
+    its = []
+    for i in range(B):
+        ref = orc.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert r["stats"][i][8] == ref["stats"][8] and r["stats"][i][9] == ref["stats"][9], (i, r["stats"][i][8:], ref["stats"][8:])
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        its.append(int(ref["stats"][8]))
+    assert len(set(its)) > 1 and min(its) < 6, its      # the instances really stop at different iterations
