@@ -256,7 +256,7 @@ void qmo_frontend(const qmgpu_problem* P, const double* rbd, double time, int ha
 
 double qmo_time_cycles(const qmgpu_problem* P, int count, int N, const double* x0s /*count x 30*/, int K, const double* ttimes, const double* tstates, int nEv,
                        const double* ev, const int32_t* modes, const double* rbds /*count x 55*/, int lineSearch) {
-  std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(8);
+  std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(QMGPU_NSTATS);
   std::vector<int32_t> md(N + 1);
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < count; ++i) {
@@ -276,7 +276,7 @@ double qmo_time_cycles_mt(const qmgpu_problem* P, int count, int N, const double
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; ++t)
     pool.emplace_back([=]() {
-      std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(8);
+      std::vector<double> T(N + 1), X((N + 1) * 30), U(N * 30), st(QMGPU_NSTATS);
       std::vector<int32_t> md(N + 1);
       for (int i = t; i < count; i += threads) {
         qmo_mpc_solve(P, N, 0.0, x0s + i * 30, nullptr, K, ttimes, tstates, nEv, ev, modes, nullptr, nullptr, lineSearch, T.data(), X.data(), U.data(), md.data(), st.data());

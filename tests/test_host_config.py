@@ -131,3 +131,22 @@ def test_time_grid_with_events(hip_lib):
     from qm_door_amd import abi
     buf = (abi.d * 8)(); nn = abi.i32(0)
     assert hip_lib.qmgpu_time_grid_with_events(0.0, 1.0, dt, 0, None, 7, C.byref(nn), buf) == abi.ERR_CAPACITY
+
+
+def test_bench_cpu_baseline_leg_runs(interface):
+    """bench.py's cpu_baseline helper (oracle timing over host threads) on a tiny budget: this leg only ever runs on the GPU box
+    otherwise, and a crash there would take the whole bench line with it."""
+    import importlib.util
+    import os
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = bench.HORIZON_N
+    try:
+        bench.HORIZON_N = 12      # a short horizon keeps this in seconds; buffers and call signatures are the same
+        sc = bench.build_scenario(interface, 4, 0)
+        out = bench.cpu_baseline(interface, sc, budget_s=0.5)
+    finally:
+        bench.HORIZON_N = saved
+    assert out["kind"] == "port" and out["unit"] == "cycles/s" and np.isfinite(out["value"]) and out["value"] > 0 and out["cores"] >= 1
