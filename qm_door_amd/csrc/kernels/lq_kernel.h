@@ -1,7 +1,8 @@
 // ad_node_kernel + lq_node_kernel -- per-node LQ approximation and constraint projection.  One wavefront per shooting node.
-// Two launches so that each half gets the occupancy it can use: the AD sweep needs registers but no LDS (two wavefronts per
-// SIMD hide each other's waits), the projection needs ~35 KiB of LDS per node.  The AD rows (17 KiB per node: tangent rows of the
-// RK2 increment, the constraint rows and the end-effector error) cross HBM once in between.
+// Two launches so that each half gets the occupancy it can use: the AD sweep is fp64-VALU bound and needs the whole register file
+// (one wavefront per SIMD, 36.5 KiB of LDS only for parking), the projection is latency bound and runs two wavefronts per SIMD
+// (19.7 KiB of LDS, 187 VGPRs).  The AD rows (17 KiB per node: tangent rows of the RK2 increment, the constraint rows and the
+// end-effector error) cross HBM once in between.
 //
 // Replaces, per node: QMPreComputation::request (QMPreComputation.cpp:50-89),
 // QMDynamicsAD::linearApproximation x2 for the RK2 stages (QMDynamicsAD.cpp:30-33), the quadratic approximation of the
@@ -9,12 +10,11 @@
 // equality constraints (QMInterface.cpp:123-131) and upstream ocs2_sqp's discretisation + QR constraint projection.
 //
 // Wave layout
-//   phase AD   lane l carries the tangent d/dx_l (l<30) or d/du_{l-30} (30<=l<60) through BOTH RK2 stages, so after the
-//              sweep lane l owns column l of [A_d | B_d] and of every constraint / EE-error Jacobian (du.h).
-//   phase LQ   lane c<30 owns column c of Q, R (symmetric) and of Px; lane 30 owns Pe; lane 31+j owns null-space column j
-//              of Pu.  All small GEMMs are "matrix in LDS (broadcast reads) x my column in registers", no cross-lane
-//              reductions; Householder vectors are applied column-wise the same way.
-// LDS per wave: B (7.0 KiB) + R (7.0 KiB) + [C D e] aliased with [Px Pe Pu] (11.7 KiB) + reflectors/R1/vectors (~7 KiB).
+//   ad_node   lane l carries the tangent d/dx_l (l<30) or d/du_{l-30} (30<=l<60) through BOTH RK2 stages, so after the sweep lane l
+//             owns column l of [A_d | B_d] and of every constraint / EE-error Jacobian (du.h); lane 60 carries the values.
+//   lq_node   lane c<30 owns entry c of the cost gradients and column c of [C | e]; the Householder QR of D_v^T keeps one column per
+//             lane in registers and broadcasts reflectors with v_readlane; every dense product runs on v_mfma_f64_16x16x4_f64 with
+//             operands read from LDS (or assembled in registers) in the lane layout of gpu_rt.h; results leave in accumulator layout.
 #pragma once
 #include "layout.h"
 #include "schedule_dev.h"
