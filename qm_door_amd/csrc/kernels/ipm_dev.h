@@ -28,7 +28,7 @@ struct IpmIo {
 
 // returns the iteration count; 60 = not converged
 template <int NP, int LDZ_, int LDK_>
-__device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool rowActive, int lane, double* vOut) {
+__device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool rowActive, double sigma0, int lane, double* vOut) {
   constexpr int TP = (NP + 15) / 16;           // 16-wide tiles per dimension
   constexpr int KS = 14;                       // k steps of 4 rows: 56 inequality rows
   const int l16 = lane & 15, h = lane >> 4;
@@ -45,7 +45,9 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   const double scale = fmax(1.0, allMax(fmax(rowActive ? fabs(fl) : 0.0, colOn ? fabs(gC) : 0.0)));
   const double nRowsTot = allSum(rowActive ? (own ? 2.0 : 1.0) : 0.0);
   double zc = 0.0, zcPrev = 0.0;
-  double v = 0.0, s1 = rowActive ? fmax(1.0, fl) : 1.0, l1 = 1.0, s2 = 1.0, l2 = 1.0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
+  // starting point: slacks max(sigma0, f), multipliers sigma0 -- 1 for the top level, 300 below it (the oracle's kLowerLevelStart: a unit start
+  // spends up to fifteen iterations of the lower levels on tiny steps)
+  double v = 0.0, s1 = rowActive ? fmax(sigma0, fl) : 1.0, l1 = sigma0, s2 = sigma0, l2 = sigma0;  // own rows: (s1,l1) constraint, (s2,l2) v >= 0
   double s1p = s1, l1p = l1, s2p = s2, l2p = l2, vp = v, nrdPrev = 0.0, muPrev = 0.0;
   // Active-set polish (same as the oracle's solveQpIpm): once the interior point has stopped, the active set is read off the final
   // iterate and three augmented-Lagrangian Newton steps on the equality-constrained QP run through the SAME loop body (K tiles,

@@ -567,9 +567,9 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     if (nRowsTot > 0.0) {
       IpmIo io{G, gs, DZ, fhat, K, wt, zs, red};
       double vRow;
-      if (n <= 8) it = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
-      else if (n <= 20) it = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
-      else it = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, lane, &vRow);
+      if (n <= 8) it = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
+      else if (n <= 20) it = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
+      else it = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
       QM_WAVE_SYNC();
     } else {
       // no inequality rows at all: z = -G^-1 g  (LDS Cholesky; never on the hot path of the reference's task sets)
