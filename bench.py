@@ -69,12 +69,16 @@ def cpu_baseline(itf, sc, budget_s=12.0):
     probe = orc.time_cycles(*args(1))
     n1 = int(max(2, min(BATCH_PER_GPU, 0.4 * budget_s / max(probe, 1e-3))))
     sec1 = orc.time_cycles(*args(n1))
+    n3 = int(max(2, min(BATCH_PER_GPU, 0.25 * budget_s * 2.5 / max(probe, 1e-3))))
+    sec3 = orc.time_cycles_node_threads(*args(n3), node_threads=3)     # the reference's own configuration: nThreads 3 over the nodes (task.info:78)
     threads = os.cpu_count() or 1
     nT = int(max(threads, min(BATCH_PER_GPU, 0.6 * budget_s * threads / max(probe, 1e-3))))
     secT = orc.time_cycles(*args(nT), threads=threads)
     return {"value": nT / secT, "unit": "cycles/s", "cores": threads, "kind": "port",
             "sample": f"{nT} of the {BATCH_PER_GPU} instances (same x0/target/gait, N={HORIZON_N}) over {threads} threads in {secT:.1f} s; one thread: "
-                      f"{n1 / sec1:.2f} cycles/s ({n1} instances, {sec1:.1f} s); own CPU restatement (g++ -O2), not OCS2"}
+                      f"{n1 / sec1:.2f} cycles/s ({n1} instances, {sec1:.1f} s); three threads over the nodes of one instance (task.info nThreads 3): "
+                      f"{n3 / sec3:.2f} cycles/s ({n3} instances, {sec3:.1f} s); own CPU restatement (g++ -O2), not OCS2",
+            "one_thread": n1 / sec1, "three_threads_over_nodes": n3 / sec3}
 
 
 def main():

@@ -267,6 +267,24 @@ double qmo_time_cycles(const qmgpu_problem* P, int count, int N, const double* x
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// One instance at a time with `nodeThreads` worker threads over the shooting nodes: the reference's own configuration (task.info:78 nThreads = 3),
+// SURVEY.md 8(d)'s second mode.  The WBC stays on the calling thread, as QMController::update runs it.
+double qmo_time_cycles_node_threads(const qmgpu_problem* P, int count, int N, const double* x0s, int K, const double* ttimes, const double* tstates, int nEv,
+                                    const double* ev, const int32_t* modes, const double* rbds, int lineSearch, int nodeThreads) {
+  std::vector<double> X((N + 1) * 30), U(N * 30), tg(N + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < count; ++i) {
+    Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+    pr.nodeThreads = nodeThreads;
+    for (int k = 0; k <= N; ++k) { tg[k] = k * P->settings.dt; for (int j = 0; j < 30; ++j) X[k * 30 + j] = x0s[i * 30 + j]; }
+    for (int k = 0; k < N; ++k) weightCompensatingInput(*P, pr.ms.modeAt(tg[k]), &U[k * 30]);
+    const SqpResult r = sqpIteration(pr, N, tg.data(), x0s + i * 30, X, U, lineSearch != 0);
+    double il[30] = {0}, out[54];
+    wbcUpdate(*P, 0, r.X.data(), r.U.data(), rbds + i * 55, pr.ms.modeAt(tg[0]), 0.002, 20.0, il, out);
+  }
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 // Same, instances spread over `threads` host threads (thread t takes instances t, t + threads, ...): the "all hardware threads
 // over instances" baseline of SURVEY.md 8(d).  Every solve is self-contained (thread_local scratch only).
 double qmo_time_cycles_mt(const qmgpu_problem* P, int count, int N, const double* x0s, int K, const double* ttimes, const double* tstates, int nEv, const double* ev,

@@ -7,6 +7,7 @@
 //     (RK2 sensitivity discretisation, dt-scaled cost, QR constraint projection, Riccati solve of the
 //     equality-free QP, filter line search).
 #pragma once
+#include <thread>
 #include "qmo_model.h"
 
 namespace qmo {
@@ -180,7 +181,16 @@ struct Problem {
   Mat Rw;  // R'
   ModeSchedule ms;
   Target tg;
+  int nodeThreads = 1;  // worker threads over the shooting nodes (task.info:78 nThreads = 3 in the reference); the results do not depend on it
 };
+
+// f(k) for k in [0, count), node k on thread k % threads (upstream's SqpSolver distributes the nodes over its thread pool the same way)
+template <class F> inline void forEachNode(int count, int threads, F&& f) {
+  if (threads <= 1) { for (int k = 0; k < count; ++k) f(k); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) pool.emplace_back([&, t]() { for (int k = t; k < count; k += threads) f(k); });
+  for (auto& th : pool) th.join();
+}
 
 // value of every node term at (t,x,u): cost (unscaled), equality constraint vector
 inline double nodeCost(const Problem& pr, double t, const double* x, const double* u, int mode, bool terminal, std::vector<double>* eq,
@@ -415,7 +425,7 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
                               bool lineSearch, std::vector<NodeLQ>* keepLQ = nullptr) {
   const qmgpu_settings& st = pr.P->settings;
   std::vector<NodeLQ> lq(N + 1);
-  for (int k = 0; k < N; ++k) { nodeLQ(pr, tgrid[k], tgrid[k + 1] - tgrid[k], &X[k * 30], &U[k * 30], &X[(k + 1) * 30], false, lq[k]); projectNode(lq[k]); }
+  forEachNode(N, pr.nodeThreads, [&](int k) { nodeLQ(pr, tgrid[k], tgrid[k + 1] - tgrid[k], &X[k * 30], &U[k * 30], &X[(k + 1) * 30], false, lq[k]); projectNode(lq[k]); });
   nodeLQ(pr, tgrid[N], 0.0, &X[N * 30], nullptr, nullptr, true, lq[N]);
 
   // ---- Riccati backward (the equality-free OCP-QP HPIPM solves with one factorisation)
@@ -458,7 +468,9 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
   auto performance = [&](const std::vector<double>& Xn, const std::vector<double>& Un, double& merit, double& viol) {
     double cost = 0, dyn = 0, eq = 0;
     for (int i = 0; i < 30; ++i) dyn += (x0[i] - Xn[i]) * (x0[i] - Xn[i]);  // initial-state gap
-    for (int k = 0; k < N; ++k) { const NodeMetrics m = nodeMetrics(pr, tgrid[k], tgrid[k + 1] - tgrid[k], &Xn[k * 30], &Un[k * 30], &Xn[(k + 1) * 30], false); cost += m.cost; dyn += m.dynViolationSSE; eq += m.eqViolationSSE; }
+    std::vector<NodeMetrics> nm(N);
+    forEachNode(N, pr.nodeThreads, [&](int k) { nm[k] = nodeMetrics(pr, tgrid[k], tgrid[k + 1] - tgrid[k], &Xn[k * 30], &Un[k * 30], &Xn[(k + 1) * 30], false); });
+    for (int k = 0; k < N; ++k) { cost += nm[k].cost; dyn += nm[k].dynViolationSSE; eq += nm[k].eqViolationSSE; }   // summed in node order: independent of the thread count
     cost += nodeMetrics(pr, tgrid[N], 0.0, &Xn[N * 30], nullptr, nullptr, true).cost;
     merit = cost; viol = std::sqrt(dyn + eq);
   };

@@ -161,6 +161,13 @@ class Oracle:
                               p(le), feet_height, arm_dist, start[0], start[1], start[2], p(x0), p(tt), p(ts))
         return x0, tt, ts, le
 
+    def time_cycles_node_threads(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, node_threads=3, line_search=True):
+        """Seconds for `count` MPC+WBC cycles, one instance at a time, `node_threads` workers over the shooting nodes (task.info:78)."""
+        f = self.lib.qmo_time_cycles_node_threads
+        f.restype = C.c_double
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        return f(C.byref(self.P), count, N, p(x0s), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), p(rbds), int(line_search), int(node_threads))
+
     def time_cycles(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, line_search=True, threads=1):
         """Seconds of wall clock for `count` MPC+WBC cycles on `threads` host threads (instances interleaved over the threads)."""
         self.lib.qmo_time_cycles_mt.restype = C.c_double
