@@ -70,10 +70,11 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // Recursive pass: placements, twists and bias accelerations (generalized accelerations: 0 for the base, qddj for joints).
-// All lanes execute it identically (wave-uniform); lane 0 publishes to LDS.
+// The five kinematic chains hanging off the base (four legs of three joints, the arm of six: checked in qmgpu_create) are walked side by
+// side, chain c in lane c; every lane publishes the bodies of its own chain to LDS, lane 0 the base as well.
 __device__ inline void bodyPass(const qmgpu_model& md, const double* q, const double* v, const double* qddj, double* body, double* dof, int lane) {
   double sz, cz, sy, cy, sx, cx;
-  sincos(q[3], &sz, &cz); sincos(q[4], &sy, &cy); sincos(q[5], &sx, &cx);
+  qmSinCos(q[3], sz, cz); qmSinCos(q[4], sy, cy); qmSinCos(q[5], sx, cx);
   double R0[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx, sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx, -sy, cy * sx, cy * cx};  // row major
   const double a3[3] = {0, 0, 1}, a4[3] = {-sz, cz, 0}, a5[3] = {cz * cy, sz * cy, -sy};
   double w0[3], al0[3], t1[3], t2[3], t3[3];
@@ -84,7 +85,7 @@ __device__ inline void bodyPass(const qmgpu_model& md, const double* q, const do
     for (int k = 0; k < 3; ++k) for (int i = 0; i < 3; ++i) { dof[k * 3 + i] = (i == k) ? 1.0 : 0.0; dof[72 + k * 3 + i] = 0.0; }
     for (int i = 0; i < 3; ++i) { dof[9 + i] = a3[i]; dof[12 + i] = a4[i]; dof[15 + i] = a5[i]; dof[72 + 9 + i] = p0[i]; dof[72 + 12 + i] = p0[i]; dof[72 + 15 + i] = p0[i]; }
   }
-  auto publish = [&](int b, const double* R, const double* p, const double* w, const double* al, const double* vo, const double* ao) {
+  auto publish = [&](int b, bool mine, const double* R, const double* p, const double* w, const double* al, const double* vo, const double* ao) {
     double c[3], RI[9], Iw[6];
     const double* cm = md.com[b];
     for (int i = 0; i < 3; ++i) c[i] = p[i] + R[i * 3] * cm[0] + R[i * 3 + 1] * cm[1] + R[i * 3 + 2] * cm[2];
@@ -93,18 +94,23 @@ __device__ inline void bodyPass(const qmgpu_model& md, const double* q, const do
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RI[i * 3 + j] = R[i * 3] * I[j] + R[i * 3 + 1] * I[3 + j] + R[i * 3 + 2] * I[6 + j];
     int e = 0;
     for (int i = 0; i < 3; ++i) for (int j = i; j < 3; ++j) Iw[e++] = RI[i * 3] * R[j * 3] + RI[i * 3 + 1] * R[j * 3 + 1] + RI[i * 3 + 2] * R[j * 3 + 2];
-    if (lane == 0) {
+    if (mine) {
       double* o = body + b * 33;
       for (int i = 0; i < 9; ++i) o[i] = R[i];
       for (int i = 0; i < 3; ++i) { o[9 + i] = p[i]; o[12 + i] = c[i]; o[21 + i] = w[i]; o[24 + i] = al[i]; o[27 + i] = vo[i]; o[30 + i] = ao[i]; }
       for (int i = 0; i < 6; ++i) o[15 + i] = Iw[i];
     }
   };
-  publish(0, R0, p0, w0, al0, vo0, ao0);
+  publish(0, lane == 0, R0, p0, w0, al0, vo0, ao0);
+  const int chain = lane < 5 ? lane : 4;                 // idle lanes shadow the arm chain (their results are not published)
+  const int first = chain < 4 ? 1 + 3 * chain : 13, len = chain < 4 ? 3 : 6;
   double R[9], p[3], w[3], al[3], vo[3], ao[3];
+  for (int i = 0; i < 9; ++i) R[i] = R0[i];
+  for (int i = 0; i < 3; ++i) { p[i] = p0[i]; w[i] = w0[i]; al[i] = al0[i]; vo[i] = vo0[i]; ao[i] = ao0[i]; }
 #pragma unroll 1
-  for (int b = 1; b < QMGPU_NB; ++b) {
-    if (md.parent[b] == 0) { for (int i = 0; i < 9; ++i) R[i] = R0[i]; for (int i = 0; i < 3; ++i) { p[i] = p0[i]; w[i] = w0[i]; al[i] = al0[i]; vo[i] = vo0[i]; ao[i] = ao0[i]; } }
+  for (int sIdx = 0; sIdx < 6; ++sIdx) {
+    const bool live = sIdx < len;
+    const int b = first + (live ? sIdx : len - 1);       // finished chains repeat their last joint without publishing
     const double* off = md.joint_offset[b];
     double ow[3], tmp[3], tmp2[3];
     for (int i = 0; i < 3; ++i) ow[i] = R[i * 3] * off[0] + R[i * 3 + 1] * off[1] + R[i * 3 + 2] * off[2];
@@ -115,17 +121,24 @@ __device__ inline void bodyPass(const qmgpu_model& md, const double* q, const do
     cross3(al, ow, tmp);
     for (int i = 0; i < 3; ++i) { ao[i] += tmp[i] + tmp2[i]; p[i] += ow[i]; }
     const int ax = md.axis[b];
-    double aw[3] = {R[ax], R[3 + ax], R[6 + ax]};
+    const double aw[3] = {ax == 0 ? R[0] : (ax == 1 ? R[1] : R[2]), ax == 0 ? R[3] : (ax == 1 ? R[4] : R[5]), ax == 0 ? R[6] : (ax == 1 ? R[7] : R[8])};
     const double qd = v[5 + b], qdd = qddj ? qddj[b - 1] : 0.0;
     double wj[3] = {aw[0] * qd, aw[1] * qd, aw[2] * qd};
     cross3(w, wj, tmp);
     for (int i = 0; i < 3; ++i) { al[i] += tmp[i] + aw[i] * qdd; w[i] += wj[i]; }
-    if (lane == 0) for (int i = 0; i < 3; ++i) { dof[(5 + b) * 3 + i] = aw[i]; dof[72 + (5 + b) * 3 + i] = p[i]; }
+    const bool mine = live && lane < 5;
+    if (mine) for (int i = 0; i < 3; ++i) { dof[(5 + b) * 3 + i] = aw[i]; dof[72 + (5 + b) * 3 + i] = p[i]; }
     double sn, cs;
-    sincos(q[5 + b], &sn, &cs);
-    const int bb = (ax + 1) % 3, cc = (ax + 2) % 3;
-    for (int i = 0; i < 3; ++i) { const double rb = R[i * 3 + bb], rc = R[i * 3 + cc]; R[i * 3 + bb] = cs * rb + sn * rc; R[i * 3 + cc] = cs * rc - sn * rb; }
-    publish(b, R, p, w, al, vo, ao);
+    qmSinCos(q[5 + b], sn, cs);
+    for (int i = 0; i < 3; ++i) {   // rotation about the body axis ax: columns (ax + 1) % 3 and (ax + 2) % 3 mix
+      const double r0 = R[i * 3], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+      const double rb = ax == 0 ? r1 : (ax == 1 ? r2 : r0), rc = ax == 0 ? r2 : (ax == 1 ? r0 : r1);
+      const double nb = cs * rb + sn * rc, nc = cs * rc - sn * rb;
+      R[i * 3] = ax == 0 ? r0 : (ax == 1 ? nc : nb);
+      R[i * 3 + 1] = ax == 0 ? nb : (ax == 1 ? r1 : nc);
+      R[i * 3 + 2] = ax == 0 ? nc : (ax == 1 ? nb : r2);
+    }
+    publish(b, mine, R, p, w, al, vo, ao);
   }
 }
 
