@@ -271,6 +271,21 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   }
   QM_WAVE_SYNC();
   // ---- S4: lane k = generalized velocity k: nle_k, column k of M, Jacobian columns
+  // The Jacobian column of every (body b, velocity i) pair at the body's centre of mass is formed ONCE (by lane i, into the LDS that Z / Z_new / A Z
+  // take over later) instead of by every lane for every pair: M[i][k] = sum_b J_bi^T diag(m_b, I_b) J_bk is then six multiply-adds per term.
+  double* JL = Z;   // [19][24][6] = 2736 doubles over Z, Z_new and the head of A Z (contiguous, all unused before the first level)
+  static_assert(W_ZN == W_Z + ND * LDZ && W_AZ == W_ZN + ND * LDZ && QMGPU_NB * NVV * 6 <= 2 * ND * LDZ + MAXR * LDZ, "Jacobian columns fit the Z / Z_new / A Z regions");
+  if (lane < NVV) {
+#pragma unroll 1
+    for (int b = 0; b < QMGPU_NB; ++b) {
+      if (!dofMoves(lane, b)) continue;
+      double lk[3], ak[3];
+      jacCol(dof, lane, b, body + b * 33 + 12, lk, ak);
+      double* d = JL + (b * NVV + lane) * 6;
+      d[0] = lk[0]; d[1] = lk[1]; d[2] = lk[2]; d[3] = ak[0]; d[4] = ak[1]; d[5] = ak[2];
+    }
+  }
+  QM_WAVE_SYNC();
   if (lane < NVV) {
     const int k = lane;
     double macc[NVV];
@@ -281,16 +296,18 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     for (int b = 0; b < QMGPU_NB; ++b) {
       if (!dofMoves(k, b)) continue;
       const double* o = body + b * 33;
-      double lk[3], ak[3], Fk[3], Nk[3];
-      jacCol(dof, k, b, o + 12, lk, ak);
+      const double* jk = JL + (b * NVV + k) * 6;
+      const double lk[3] = {jk[0], jk[1], jk[2]}, ak[3] = {jk[3], jk[4], jk[5]};
+      double Fk[3], Nk[3];
       h += dot3(lk, wr + b * 3) + dot3(ak, wr + 57 + b * 3);
       for (int i = 0; i < 3; ++i) Fk[i] = md.mass[b] * lk[i];
       symMul(o + 15, ak, Nk);
 #pragma unroll
       for (int i = 0; i < NVV; ++i) {
-        double li[3], ai[3];
-        jacCol(dof, i, b, o + 12, li, ai);
-        macc[i] += dot3(li, Fk) + dot3(ai, Nk);
+        if (dofMoves(i, b)) {   // wave uniform for the lanes of this iteration (b is per lane, but every live lane of a given b agrees)
+          const double* ji = JL + (b * NVV + i) * 6;
+          macc[i] += (ji[0] * Fk[0] + ji[1] * Fk[1] + ji[2] * Fk[2]) + (ji[3] * Nk[0] + ji[4] * Nk[1] + ji[5] * Nk[2]);
+        }
       }
     }
     nle[k] = h;
