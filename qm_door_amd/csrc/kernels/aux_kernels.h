@@ -83,25 +83,29 @@ __global__ void mpc_init_kernel(InitArgs a) {
 }
 
 // MPC_MRT_Interface::evaluatePolicy (call site QMController.cpp:134-142): linear interpolation of (X, U) at t_eval, planned mode
-// of the interval.  One thread per instance.
-__global__ void policy_eval_kernel(int batch, int N, const double* tgrid, const double* X, const double* U, const int* modes, const double* tEval, double* xOut,
-                                   double* uOut, int* modeOut) {
-  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+// of the interval.  One wavefront per instance: lanes 0..29 interpolate the state, lanes 32..61 the input (every lane locates the segment).
+__global__ void __launch_bounds__(64) policy_eval_kernel(int batch, int N, const double* tgrid, const double* X, const double* U, const int* modes, const double* tEval,
+                                                         double* xOut, double* uOut, int* modeOut) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
   if (inst >= batch) return;
   const double* tg = tgrid + size_t(inst) * (N + 1);
   const double t = tEval[inst];
   int idx; double alpha;
   timeSegment(tg, N + 1, t, idx, alpha);
-  const double* xl = X + (size_t(inst) * (N + 1) + idx) * 30;
-  for (int i = 0; i < 30; ++i) xOut[size_t(inst) * 30 + i] = alpha * xl[i] + (1.0 - alpha) * xl[30 + i];
-  // the input trajectory has N entries; upstream pads it by repeating the last input at the final time
-  const int iu0 = min(idx, N - 1), iu1 = min(idx + 1, N - 1);
-  const double* ul = U + (size_t(inst) * N + iu0) * 30; const double* ur = U + (size_t(inst) * N + iu1) * 30;
-  for (int i = 0; i < 30; ++i) uOut[size_t(inst) * 30 + i] = alpha * ul[i] + (1.0 - alpha) * ur[i];
-  // mode of the node interval containing t (lower_bound convention of the grid)
-  int k = 0;
-  while (k < N && tg[k + 1] < t) ++k;
-  modeOut[inst] = modes[size_t(inst) * (N + 1) + k];
+  if (lane < 30) {
+    const double* xl = X + (size_t(inst) * (N + 1) + idx) * 30;
+    xOut[size_t(inst) * 30 + lane] = alpha * xl[lane] + (1.0 - alpha) * xl[30 + lane];
+  } else if (lane >= 32 && lane < 62) {
+    // the input trajectory has N entries; upstream pads it by repeating the last input at the final time
+    const int i = lane - 32, iu0 = min(idx, N - 1), iu1 = min(idx + 1, N - 1);
+    const double* ul = U + (size_t(inst) * N + iu0) * 30; const double* ur = U + (size_t(inst) * N + iu1) * 30;
+    uOut[size_t(inst) * 30 + i] = alpha * ul[i] + (1.0 - alpha) * ur[i];
+  } else if (lane == 63) {
+    // mode of the node interval containing t (lower_bound convention of the grid)
+    int k = 0;
+    while (k < N && tg[k + 1] < t) ++k;
+    modeOut[inst] = modes[size_t(inst) * (N + 1) + k];
+  }
 }
 
 }  // namespace qmk

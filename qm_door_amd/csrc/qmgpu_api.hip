@@ -280,7 +280,7 @@ int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const doub
                             double* x_out, double* u_out, int32_t* mode_out) {
   if (!h || !t_grid || !X || !U || !modes || !t_eval || !x_out || !u_out || !mode_out || batch < 1 || num_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments");
   return guarded([&]() {
-    QM_LAUNCH(policy_eval_kernel, (batch + 63) / 64, 64, h->stream, batch, num_nodes, t_grid, X, U, modes, t_eval, x_out, u_out, mode_out);
+    QM_LAUNCH(policy_eval_kernel, batch, 64, h->stream, batch, num_nodes, t_grid, X, U, modes, t_eval, x_out, u_out, mode_out);
     HIP_CHECK(hipGetLastError());
   });
 }
@@ -313,7 +313,7 @@ int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t
     if (wbc->batch != mpc->batch) throw std::invalid_argument("MPC and WBC batch sizes differ");
     beginTiming(h);
     enqueueMpc(h, mpc);
-    QM_LAUNCH(policy_eval_kernel, (mpc->batch + 63) / 64, 64, h->stream, mpc->batch, mpc->num_nodes, mpc->out_t, mpc->out_x, mpc->out_u, mpc->out_mode, t_eval, h->dPolX, h->dPolU,
+    QM_LAUNCH(policy_eval_kernel, mpc->batch, 64, h->stream, mpc->batch, mpc->num_nodes, mpc->out_t, mpc->out_x, mpc->out_u, mpc->out_mode, t_eval, h->dPolX, h->dPolU,
               h->dPolMode);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
     qmgpu_wbc_args w = *wbc;
