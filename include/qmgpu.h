@@ -13,6 +13,8 @@
  *   qmgpu_mpc_solve_batch   <-> ocs2::MPC_BASE::run -> SqpSolver::runImpl, one SQP iteration
  *                               (object built at qm_controllers/src/QMController.cpp:288-289)
  *   qmgpu_policy_eval_batch <-> MPC_MRT_Interface::evaluatePolicy (QMController.cpp:134-142)
+ *   qmgpu_warm_start_batch  <-> upstream SqpSolver::runImpl's initial guess from the previous PrimalSolution
+ *                               (the solver object built at QMController.cpp:288-289 keeps it between runs)
  *   qmgpu_wbc_solve_batch   <-> qm::WbcBase::update / HierarchicalWbc::update
  *                               (qm_wbc/include/qm_wbc/WbcBase.h:31-34, qm_wbc/src/HierarchicalWbc.cpp:18-44)
  *   qmgpu_cycle_batch       <-> one QMController::update tick fed by one advanceMpc
@@ -190,6 +192,13 @@ int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args);
 int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const double* t_grid, const double* X,
                             const double* U, const int32_t* modes, const double* t_eval, double* x_out /*[batch][30]*/,
                             double* u_out /*[batch][30]*/, int32_t* mode_out /*[batch]*/);
+
+/* Initial guess of the next MPC call from the previous solution: (X, U) of the previous grid resampled (linear interpolation, end values held, as
+ * upstream's LinearInterpolation) on new_grid [batch][new_nodes + 1]; x[0] of each instance is overwritten with x0 when x0 != NULL.  The results
+ * are what qmgpu_mpc_args::warm_x / warm_u expect.  All device pointers; prev_* and warm_* must not alias. */
+int qmgpu_warm_start_batch(qmgpu_handle h, int batch, int prev_nodes, const double* prev_grid, const double* prev_X, const double* prev_U,
+                           int new_nodes, const double* new_grid, const double* x0 /*[batch][30] or NULL*/, double* warm_x /*[batch][new_nodes+1][30]*/,
+                           double* warm_u /*[batch][new_nodes][30]*/);
 
 typedef struct qmgpu_wbc_args {
   int32_t batch;

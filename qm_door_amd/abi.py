@@ -91,7 +91,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libqmgpu.so")
 
 # every symbol include/qmgpu.h declares
 SYMBOLS = [
-    "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_time_grid_with_events",
+    "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_time_grid_with_events", "qmgpu_warm_start_batch",
     "qmgpu_create", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
     "qmgpu_policy_eval_batch", "qmgpu_frontend_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
     "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_debug_poison", "qmgpu_kernel_ms_mean",
@@ -143,6 +143,7 @@ def load_library(path=None):
     lib.qmgpu_get_input_weight.argtypes = [C.c_void_p, C.POINTER(d)]
     lib.qmgpu_mpc_solve_batch.argtypes = [C.c_void_p, C.POINTER(MpcArgs)]
     lib.qmgpu_policy_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8
+    lib.qmgpu_warm_start_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.qmgpu_wbc_solve_batch.argtypes = [C.c_void_p, C.POINTER(WbcArgs)]
     lib.qmgpu_cycle_batch.argtypes = [C.c_void_p, C.POINTER(MpcArgs), C.c_void_p, C.POINTER(WbcArgs)]
     lib.qmgpu_debug_get_lq.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.POINTER(i32)]

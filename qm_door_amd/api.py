@@ -181,6 +181,11 @@ class GpuSolver:
         abi.check(self.lib, self.lib.qmgpu_policy_eval_batch(self.handle, batch, num_nodes, _ptr(t_grid), _ptr(X), _ptr(U), _ptr(modes), _ptr(t_eval),
                                                             _ptr(x_out), _ptr(u_out), _ptr(mode_out)))
 
+    def warm_start(self, batch, prev_nodes, prev_grid, prev_X, prev_U, new_nodes, new_grid, x0, warm_x, warm_u):
+        """Previous solution resampled on the new grid (the initial guess upstream's SqpSolver takes from its PrimalSolution)."""
+        abi.check(self.lib, self.lib.qmgpu_warm_start_batch(self.handle, batch, prev_nodes, _ptr(prev_grid), _ptr(prev_X), _ptr(prev_U), new_nodes, _ptr(new_grid),
+                                                           _ptr(x0), _ptr(warm_x), _ptr(warm_u)))
+
     def debug_lq(self, instance, node):
         A, B, Q, R = (np.zeros((30, 30)) for _ in range(4))
         b, q, r = (np.zeros(30) for _ in range(3))

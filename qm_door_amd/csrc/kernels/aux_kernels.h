@@ -82,6 +82,29 @@ __global__ void mpc_init_kernel(InitArgs a) {
   }
 }
 
+// Warm start of the next solve: the previous solution resampled on the new grid.  One workgroup per instance, one new node per wavefront
+// pass (lanes 0..29 the state, 32..61 the input); the input trajectory has one entry less than the grid and holds its last value.
+__global__ void __launch_bounds__(256) warm_start_kernel(int batch, int Np, const double* gridP, const double* Xp, const double* Up, int Nn, const double* gridN,
+                                                         const double* x0, double* warmX, double* warmU) {
+  const int inst = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (inst >= batch) return;
+  const double* tg = gridP + size_t(inst) * (Np + 1);
+  for (int k = wave; k <= Nn; k += nw) {
+    const double t = gridN[size_t(inst) * (Nn + 1) + k];
+    int idx; double alpha;
+    timeSegment(tg, Np + 1, t, idx, alpha);
+    if (lane < 30) {
+      const double* xl = Xp + (size_t(inst) * (Np + 1) + idx) * 30;
+      const double v = alpha * xl[lane] + (1.0 - alpha) * xl[30 + lane];
+      warmX[(size_t(inst) * (Nn + 1) + k) * 30 + lane] = (k == 0 && x0) ? x0[size_t(inst) * 30 + lane] : v;
+    } else if (lane >= 32 && lane < 62 && k < Nn) {
+      const int i = lane - 32, iu0 = min(idx, Np - 1), iu1 = min(idx + 1, Np - 1);
+      const double* ul = Up + (size_t(inst) * Np + iu0) * 30; const double* ur = Up + (size_t(inst) * Np + iu1) * 30;
+      warmU[(size_t(inst) * Nn + k) * 30 + i] = alpha * ul[i] + (1.0 - alpha) * ur[i];
+    }
+  }
+}
+
 // MPC_MRT_Interface::evaluatePolicy (call site QMController.cpp:134-142): linear interpolation of (X, U) at t_eval, planned mode
 // of the interval.  One wavefront per instance: lanes 0..29 interpolate the state, lanes 32..61 the input (every lane locates the segment).
 __global__ void __launch_bounds__(64) policy_eval_kernel(int batch, int N, const double* tgrid, const double* X, const double* U, const int* modes, const double* tEval,

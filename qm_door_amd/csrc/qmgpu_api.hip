@@ -306,6 +306,17 @@ int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args) {
   });
 }
 
+int qmgpu_warm_start_batch(qmgpu_handle h, int batch, int prev_nodes, const double* prev_grid, const double* prev_X, const double* prev_U, int new_nodes,
+                           const double* new_grid, const double* x0, double* warm_x, double* warm_u) {
+  if (!h || !prev_grid || !prev_X || !prev_U || !new_grid || !warm_x || !warm_u || batch < 1 || prev_nodes < 1 || new_nodes < 1)
+    return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad warm-start arguments");
+  if (warm_x == prev_X || warm_u == prev_U) return setError(QMGPU_ERR_INVALID_ARGUMENT, "warm-start outputs must not alias the previous solution");
+  return guarded([&]() {
+    QM_LAUNCH(warm_start_kernel, batch, 256, h->stream, batch, prev_nodes, prev_grid, prev_X, prev_U, new_nodes, new_grid, x0, warm_x, warm_u);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
 int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t_eval, qmgpu_wbc_args* wbc) {
   if (!h || !t_eval || !wbc) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
   return guarded([&]() {

@@ -167,3 +167,27 @@ def test_emu_sqp_convergence_test_skips_converged_instances():
         assert np.abs(oU[i] - ref["U"]).max() <= 1e-8 * max(1.0, np.abs(ref["U"]).max())
         counts.append((int(oS[i][8]), int(oS[i][9])))
     assert counts[0][0] < counts[1][0] and counts[0][1] in (3, 4), counts   # the warm-started instance stopped earlier, on a tolerance
+
+
+def test_emu_warm_start_resamples_the_previous_solution(emu):
+    """qmgpu_warm_start_batch: previous (grid, X, U) -> initial guess on a shifted / non-uniform grid, against numpy interpolation."""
+    itf, orc = emu
+    rng = np.random.default_rng(3)
+    B, Np, Nn = 2, 9, 12
+    gp = np.cumsum(np.concatenate([np.zeros((B, 1)), rng.uniform(0.01, 0.02, (B, Np))], axis=1), axis=1)
+    Xp = rng.normal(size=(B, Np + 1, 30)); Up = rng.normal(size=(B, Np, 30))
+    gn = 0.013 + np.cumsum(np.concatenate([np.zeros((B, 1)), rng.uniform(0.008, 0.02, (B, Nn))], axis=1), axis=1)   # starts later, ends past the old horizon
+    x0 = rng.normal(size=(B, 30))
+    wx, wu = np.zeros((B, Nn + 1, 30)), np.zeros((B, Nn, 30))
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=Nn)
+    sol.warm_start(B, Np, gp, Xp, Up, Nn, gn, x0, wx, wu)
+    for b in range(B):
+        tu = gp[b][:-1]                                    # input k holds on [t_k, t_{k+1}); the last value is kept to the end
+        for i in range(30):
+            ex = np.interp(gn[b], gp[b], Xp[b][:, i]); ex[0] = x0[b][i]
+            # inputs: interpolation between entries k and k + 1 over [t_k, t_{k+1}], the last entry beyond t_{N-1} (upstream pads U with its last value)
+            eu = np.interp(gn[b][:-1], np.append(tu, gp[b][-1]), np.append(Up[b][:, i], Up[b][-1, i]))
+            assert np.abs(wx[b][:, i] - ex).max() <= 1e-12 and np.abs(wu[b][:, i] - eu).max() <= 1e-12
+    # the result is accepted as a warm start
+    tgt = S.nominal_target(orc, itf.initial_state)
+    assert sol.lib.qmgpu_warm_start_batch(sol.handle, B, Np, None, None, None, Nn, None, None, None, None) == 1

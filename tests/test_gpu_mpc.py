@@ -159,3 +159,41 @@ def test_sqp_convergence_test_per_instance(oracle):
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
         its.append(int(ref["stats"][8]))
     assert len(set(its)) > 1 and min(its) < 6, its      # the instances really stop at different iterations
+
+
+def test_receding_horizon_cycles_with_device_warm_start(interface, oracle):
+    """Three MPC cycles of a receding horizon: the previous solution is resampled on the shifted grid by qmgpu_warm_start_batch (what upstream's
+    SqpSolver does with its PrimalSolution) and nothing but the new initial state is computed on the host."""
+    import torch
+    import gpu_harness as G
+    B, N = 3, 30
+    dt = interface.problem.settings.dt
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, B, N, seed=12)
+    sol = G.make_solver(interface, B, N)
+    sn, se, sm = np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1))
+    mb = G.MpcBatch(x0, tt, ts, sn, se, sm, N)
+    sol.mpc(mb.args)
+    prev = mb.results()
+    ref = [oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md) for i in range(B)]
+    t0 = 0.0
+    for cycle in range(1, 3):
+        t0 += 2 * dt
+        grid = t0 + dt * np.arange(N + 1)
+        x0n = np.stack([np.array([np.interp(t0, prev["T"][i], prev["X"][i][:, c]) for c in range(30)]) for i in range(B)])   # perfect tracking
+        wx = torch.zeros((B, N + 1, 30), dtype=torch.float64, device="cuda"); wu = torch.zeros((B, N, 30), dtype=torch.float64, device="cuda")
+        sol.warm_start(B, N, mb.oT, mb.oX, mb.oU, N, G.dev(np.tile(grid, (B, 1)), torch.float64), G.dev(x0n, torch.float64), wx, wu)
+        nb = G.MpcBatch(x0n, tt, ts, sn, se, sm, N, t0=np.full(B, t0), warm=(wx.cpu().numpy(), wu.cpu().numpy()))
+        sol.mpc(nb.args)
+        cur = nb.results()
+        for i in range(B):
+            # the oracle gets the same initial guess, resampled on the host from ITS OWN previous solution
+            tu = np.append(ref[i]["T"][:-1], ref[i]["T"][-1])
+            rwx = np.stack([np.interp(grid, ref[i]["T"], ref[i]["X"][:, c]) for c in range(30)], axis=1); rwx[0] = x0n[i]
+            rwu = np.stack([np.interp(grid[:-1], tu, np.append(ref[i]["U"][:, c], ref[i]["U"][-1, c])) for c in range(30)], axis=1)
+            r = oracle.mpc_solve(N, t0, x0n[i], tt[i], ts[i], nev, ev, md, warm=(rwx, rwu))
+            assert np.array_equal(cur["mode"][i], r["mode"])
+            assert np.abs(cur["X"][i] - r["X"]).max() <= 1e-6 * max(1.0, np.abs(r["X"]).max()), (cycle, i)
+            assert np.abs(cur["U"][i] - r["U"]).max() <= 1e-6 * max(1.0, np.abs(r["U"]).max()), (cycle, i)
+            assert r["stats"][1] < ref[i]["stats"][1] or cycle > 1            # the warm start begins closer to feasibility than the cold start did
+            ref[i] = r
+        mb, prev = nb, cur
