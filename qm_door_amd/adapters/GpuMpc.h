@@ -57,7 +57,8 @@ class GpuSqpSolver final : public ocs2::SolverBase {
     const int N = static_cast<int>(grid.size()) - 1;
     if (N > maxNodes_) throw std::runtime_error("[GpuSqpSolver] horizon exceeds the capacity given to qmgpu_create");
     // 2. target trajectories (37-dim states, QmTargetTrajectoriesPublisher_node.cpp:76-78) and mode schedule -> device
-    // 3. warm start: previous primal solution interpolated on the new grid, initializer beyond its end (upstream SqpSolver)
+    // 3. warm start: previous primal solution resampled on the new grid (upstream SqpSolver) -- qmgpu_warm_start_batch does it on the device
+    //    from the previous call's out_t / out_x / out_u, which stay resident between runs
     // 4. qmgpu_mpc_solve_batch(batch = 1), qmgpu_synchronize, copy X / U back into primal_ (useFeedbackPolicy false: task.info:90)
     // The staging code is mechanical (hipMemcpy of the arrays named in qmgpu_mpc_args) and is spelled out in INTEGRATION.md.
     stageAndSolve(grid, initState, modeSchedule);
