@@ -80,6 +80,9 @@ __device__ __forceinline__ double qmAllMin(double v, double* scratch) { (void)sc
 #define QM_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 // scheduling fence: keeps the compiler from hoisting a long run of v_readlane broadcasts (two SGPRs each) ahead of their uses
 #define QM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a per-lane integer the optimiser cannot see through: values derived from it (the sixty lane == k ? 1 : 0 seeds of the AD sweep) are not
+// hoisted out of the loop it is refreshed in
+__device__ __forceinline__ int qmOpaqueLane(int v) { asm volatile("" : "+v"(v)); return v; }
 #define QM_POISON_LDS(ptr, count)   // host emulation only: fills LDS with NaN at kernel start
 #define QM_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmemBytes, stream, __VA_ARGS__)

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   int nc = 0;
 #pragma unroll 1
   for (int stage = 0; stage < (terminal ? 1 : 2); ++stage) {
-    const DuIn in{x, u, lane, stage ? dt : 0.0, k1p};
+    const DuIn in{x, u, qmOpaqueLane(lane), stage ? dt : 0.0, k1p};
     Du f[12];
     BaseMotion<Du> bm;
     const Du p0x = in.sx(6), p0y = in.sx(7), p0z = in.sx(8);   // base position (only the first stage uses it: EE error, swing height)
