@@ -39,6 +39,7 @@ void qmo_centroidal_matrix(const qmgpu_problem* P, const double* q, double* A /*
 void qmo_input_weight(const qmgpu_problem* P, double* R) { inputWeight(*P).to(R); }
 
 int qmo_mode_at(int nEv, const double* ev, const int32_t* modes, double t) { ModeSchedule ms{nEv, ev, modes}; return ms.modeAt(t); }
+int qmo_node_mode_at(int nEv, const double* ev, const int32_t* modes, double t) { ModeSchedule ms{nEv, ev, modes}; return ms.nodeModeAt(t); }
 
 void qmo_swing_reference(const qmgpu_problem* P, int nEv, const double* ev, const int32_t* modes, double t, double* zpos4, double* zvel4) {
   ModeSchedule ms{nEv, ev, modes};
@@ -79,7 +80,7 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
   for (int i = 0; i < 30; ++i) X[i] = x0[i];
   for (int k = 0; k < N; ++k) {
     if (warmU) for (int i = 0; i < 30; ++i) U[k * 30 + i] = warmU[k * 30 + i];
-    else weightCompensatingInput(*P, pr.ms.modeAt(tg[k]), &U[k * 30]);
+    else weightCompensatingInput(*P, pr.ms.nodeModeAt(tg[k]), &U[k * 30]);
   }
   // sqp.sqpIteration iterations at most (task.info:77, 1 in the reference's configuration), each warm-started from the previous
   // iterate, with upstream's convergence test (SqpSolver::checkConvergence) after every one.
@@ -90,7 +91,7 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
     r = sqpIteration(pr, N, tg.data(), x0, X, U, lineSearch != 0);
     ++iterations; convergence = sqpConvergence(P->settings, it, r);
   }
-  for (int k = 0; k <= N; ++k) { outT[k] = tg[k]; outMode[k] = pr.ms.modeAt(tg[k]); }
+  for (int k = 0; k <= N; ++k) { outT[k] = tg[k]; outMode[k] = pr.ms.nodeModeAt(tg[k]); }
   std::copy(r.X.begin(), r.X.end(), outX);
   std::copy(r.U.begin(), r.U.end(), outU);
   if (stats) { stats[0] = r.merit0; stats[1] = r.viol0; stats[2] = r.merit1; stats[3] = r.viol1; stats[4] = r.alpha; stats[5] = r.stepType; stats[6] = r.armijo; stats[7] = r.status; stats[8] = iterations; stats[9] = convergence; }
@@ -277,10 +278,10 @@ double qmo_time_cycles_node_threads(const qmgpu_problem* P, int count, int N, co
     Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
     pr.nodeThreads = nodeThreads;
     for (int k = 0; k <= N; ++k) { tg[k] = k * P->settings.dt; for (int j = 0; j < 30; ++j) X[k * 30 + j] = x0s[i * 30 + j]; }
-    for (int k = 0; k < N; ++k) weightCompensatingInput(*P, pr.ms.modeAt(tg[k]), &U[k * 30]);
+    for (int k = 0; k < N; ++k) weightCompensatingInput(*P, pr.ms.nodeModeAt(tg[k]), &U[k * 30]);
     const SqpResult r = sqpIteration(pr, N, tg.data(), x0s + i * 30, X, U, lineSearch != 0);
     double il[30] = {0}, out[54];
-    wbcUpdate(*P, 0, r.X.data(), r.U.data(), rbds + i * 55, pr.ms.modeAt(tg[0]), 0.002, 20.0, il, out);
+    wbcUpdate(*P, 0, r.X.data(), r.U.data(), rbds + i * 55, pr.ms.nodeModeAt(tg[0]), 0.002, 20.0, il, out);
   }
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }

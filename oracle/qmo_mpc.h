@@ -25,6 +25,10 @@ struct ModeSchedule {
   // upstream ModeSchedule::modeAtTime -> lookup::findIndexInTimeArray == std::lower_bound
   int phaseAt(double t) const { int i = 0; while (i < numEvents && eventTimes[i] < t) ++i; return i; }
   int modeAt(double t) const { return modes[phaseAt(t)]; }
+  // shooting nodes: a node on an event time is upstream's PostEvent node (interval start = t + weakEpsilon) and takes the
+  // mode that starts there (std::upper_bound)
+  int nodePhaseAt(double t) const { int i = 0; while (i < numEvents && eventTimes[i] <= t) ++i; return i; }
+  int nodeModeAt(double t) const { return modes[nodePhaseAt(t)]; }
 };
 
 // upstream ocs2_legged_robot CubicSpline (normalised-time Hermite cubic)
@@ -46,7 +50,7 @@ struct CubicSpline {
 // Settings: task.info:24-31.  Returns z position / z velocity reference of foot `leg` at time t.
 inline void swingReference(const qmgpu_settings& st, const ModeSchedule& ms, int leg, double t, double* zpos, double* zvel) {
   const int numPhases = ms.numEvents + 1;
-  const int p = ms.phaseAt(t);
+  const int p = ms.nodePhaseAt(t);
   auto inContact = [&](int phase) { bool f[4]; modeToContactFlags(ms.modes[phase], f); return f[leg]; };
   if (inContact(p)) { *zpos = 0.0; *zvel = 0.0; return; }
   int startIdx = -1;
@@ -233,7 +237,7 @@ inline double nodeCost(const Problem& pr, double t, const double* x, const doubl
     double zp, zv;
     for (int c = 0; c < 4; ++c) {
       if (!fl[c]) for (int a = 0; a < 3; ++a) eq->push_back(u[3 * c + a]);                // zeroForce  (QMInterface.cpp:123-124)
-      if (fl[c]) for (int a = 0; a < 3; ++a) eq->push_back(aux.footVel[c][a]);            // zeroVelocity (QMInterface.cpp:126,324-339)
+      if (fl[c]) for (int a = 0; a < 3; ++a) eq->push_back(aux.footVel[c][a] + (a == 2 ? st.position_error_gain * aux.footPos[c][2] : 0.0));   // zeroVelocity (QMInterface.cpp:126,324-339; Ax(2,2) = positionErrorGain)
       if (!fl[c]) {                                                                      // normalVelocity (QMPreComputation.cpp:56-66)
         swingReference(st, pr.ms, c, t, &zp, &zv);
         eq->push_back(aux.footVel[c][2] - zv + st.position_error_gain * (aux.footPos[c][2] - zp));
@@ -254,7 +258,7 @@ inline void rk2Step(const qmgpu_problem& P, double dt, const double* x, const do
 
 inline NodeMetrics nodeMetrics(const Problem& pr, double t, double dt, const double* x, const double* u, const double* xnext, bool terminal) {
   NodeMetrics m;
-  const int mode = pr.ms.modeAt(t);
+  const int mode = pr.ms.nodeModeAt(t);
   static thread_local double f[30];
   FlowAux<double> aux;
   double uz[30] = {0};
@@ -274,7 +278,7 @@ inline NodeMetrics nodeMetrics(const Problem& pr, double t, double dt, const dou
 inline void nodeLQ(const Problem& pr, double t, double dt, const double* x, const double* u, const double* xnext, bool terminal, NodeLQ& o) {
   const qmgpu_problem& P = *pr.P;
   const qmgpu_settings& st = P.settings;
-  const int mode = pr.ms.modeAt(t);
+  const int mode = pr.ms.nodeModeAt(t);
   bool fl[4]; modeToContactFlags(mode, fl);
   double xref[30], eePosRef[3], eeQuatRef[4];
   referenceAt(pr.tg, t, xref, eePosRef, eeQuatRef);
@@ -343,7 +347,7 @@ inline void nodeLQ(const Problem& pr, double t, double dt, const double* x, cons
   auto pushDual = [&](const D60& h) { std::vector<double> c(30), d(30); for (int i = 0; i < 30; ++i) { c[i] = h.d[i]; d[i] = h.d[30 + i]; } rowsC.push_back(c); rowsD.push_back(d); ev.push_back(h.v); };
   for (int c = 0; c < 4; ++c) {
     if (!fl[c]) for (int a = 0; a < 3; ++a) pushDual(ud[3 * c + a]);
-    if (fl[c]) for (int a = 0; a < 3; ++a) pushDual(aux.footVel[c][a]);
+    if (fl[c]) for (int a = 0; a < 3; ++a) pushDual(a == 2 ? aux.footVel[c][2] + st.position_error_gain * aux.footPos[c][2] : aux.footVel[c][a]);
     if (!fl[c]) { double zp, zv; swingReference(st, pr.ms, c, t, &zp, &zv); pushDual(aux.footVel[c][2] - D60(zv) + st.position_error_gain * (aux.footPos[c][2] - D60(zp))); }
   }
   o.nc = int(ev.size());

@@ -315,9 +315,14 @@ int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, dou
   if (!(period > 0.0)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "gait period must be positive");
   std::vector<double> ev;
   std::vector<int> md;
-  // first cycle start: latest t_phase0 + k*period that is <= t_begin (keeps the schedule short), but never before t_phase0
+  // first tiled cycle: the one BEFORE the cycle that contains t_begin (so that a swing phase straddling the template boundary keeps
+  // its real lift-off time, as upstream GaitSchedule keeps the preceding modes), but never before t_phase0: STANCE only precedes
+  // t_phase0 itself
   double start = t_phase0;
-  if (t_begin > t_phase0) start = t_phase0 + std::floor((t_begin - t_phase0) / period) * period;
+  if (t_begin > t_phase0) {
+    const double cycles = std::floor((t_begin - t_phase0) / period);
+    start = t_phase0 + (cycles >= 1.0 ? cycles - 1.0 : 0.0) * period;
+  }
   md.push_back(15);  // STANCE
   ev.push_back(start);
   double t = start;

@@ -72,7 +72,7 @@ __global__ void mpc_init_kernel(InitArgs a) {
         const double* su = a.warmU + (size_t(inst) * a.N + k) * 30;
         for (int i = 0; i < 30; ++i) u[i] = su[i];
       } else {
-        const int mode = sched.modes[phaseAt(sched, t)];
+        const int mode = sched.modes[nodePhaseAt(sched, t)];
         int n = 0;
         for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
         for (int i = 0; i < 30; ++i) u[i] = 0.0;

@@ -41,7 +41,7 @@ __device__ inline void nodePerformance(const qmgpu_problem& P, const double* Rw,
                                        bool terminal, const double* x, const double* u, const double* xnext, double& cost, double& dyn, double& eq) {
   const qmgpu_model& md = P.model;
   const qmgpu_settings& st = P.settings;
-  const int phase = phaseAt(sched, t);
+  const int phase = nodePhaseAt(sched, t);
   const int mode = sched.modes[phase];
   double eePosRef[3], eeQuatRef[4];
   eeReference(tTimes, tStates, K, t, eePosRef, eeQuatRef);
@@ -75,7 +75,7 @@ __device__ inline void nodePerformance(const qmgpu_problem& P, const double* Rw,
         for (int cc = 0; cc < 4; ++cc) {
           const Vec3<double> r = feet.r(cc);
           const Vec3<double> vf = bm.dp + cross(bm.omega, r) + feet.v(cc);
-          if (contactOf(mode, cc)) eq += vf.x * vf.x + vf.y * vf.y + vf.z * vf.z;
+          if (contactOf(mode, cc)) { const double hz = vf.z + st.position_error_gain * (x[8] + r.z); eq += vf.x * vf.x + vf.y * vf.y + hz * hz; }
           else {
             double zp, zv;
             swingReference(st, sched, cc, t, phase, zp, zv);

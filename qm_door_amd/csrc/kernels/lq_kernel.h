@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
   QM_WAVE_SYNC();
   const double* x = xu; const double* u = xu + 32;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
-  const int phase = phaseAt(sched, t);
+  const int phase = nodePhaseAt(sched, t);
   const int mode = sched.modes[phase];
   const double* tTimes = a.targetTimes + size_t(inst) * a.K;
   const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
           const Vec3<Du> vf = bm.dp + cross(bm.omega, r) + vj;
           auto putC = [&](int row, Du h) { putRow(AD_CD, row, h); };
           if (contact) {  // zeroVelocity (QMInterface.cpp:126, 324-339)
-            putC(nc, vf.x); putC(nc + 1, vf.y); putC(nc + 2, vf.z);
+            putC(nc, vf.x); putC(nc + 1, vf.y); putC(nc + 2, vf.z + st.position_error_gain * (p0z + r.z));   // Ax(2,2) = positionErrorGain
             nc += 3;
           } else {  // zeroForce (QMInterface.cpp:123-124) then normalVelocity (QMPreComputation.cpp:56-66)
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // chains of dependent scalar loads.  They live in region X and are dead before the QR publishes its factors there.
   double* x = lds + L_XU; double* u = x + 32; double* xnext = x + 64; double* xref = x + 96;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
-  const int phase = phaseAt(sched, t);
+  const int phase = nodePhaseAt(sched, t);
   const int mode = sched.modes[phase];
   const double* tTimes = a.targetTimes + size_t(inst) * a.K;
   const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;

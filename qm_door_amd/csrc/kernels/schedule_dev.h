@@ -16,11 +16,18 @@ struct Schedule {
   const int* modes;          // [MAX_EVENTS+1]
 };
 
-// std::lower_bound on the event times (upstream lookup::findIndexInTimeArray): an event time itself still belongs
-// to the phase before it.
+// Continuous-time lookup (policy evaluation): std::lower_bound on the event times (upstream ModeSchedule::modeAtTime ->
+// lookup::findIndexInTimeArray): an event time itself still belongs to the phase before it.
 __device__ __forceinline__ int phaseAt(const Schedule& s, double t) {
   int i = 0;
   while (i < s.numEvents && s.eventTimes[i] < t) ++i;
+  return i;
+}
+// Mode lookup of a SHOOTING NODE: a node placed exactly on an event time is upstream's PostEvent node (evaluated at
+// t + weakEpsilon by ocs2_sqp's getIntervalStart), so it takes the mode that STARTS there: std::upper_bound.
+__device__ __forceinline__ int nodePhaseAt(const Schedule& s, double t) {
+  int i = 0;
+  while (i < s.numEvents && s.eventTimes[i] <= t) ++i;
   return i;
 }
 __device__ __forceinline__ bool contactOf(int mode, int leg) { return (mode >> (3 - leg)) & 1; }

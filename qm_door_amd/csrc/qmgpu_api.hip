@@ -32,6 +32,20 @@ using namespace qmk;
     if (e_ != hipSuccess) throw HipFailure(std::string(#expr) + " failed: " + hipGetErrorString(e_));         \
   } while (0)
 
+// Every entry point runs on the device its handle was created for and leaves the caller's current device as it found it (a
+// process may hold handles on several GPUs).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) HIP_CHECK(hipSetDevice(device));
+    else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct qmgpu_context {
   int device = 0, maxBatch = 0, maxNodes = 0;
   hipStream_t ownStream = nullptr, stream = nullptr;
@@ -91,8 +105,9 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw NoDevice("no HIP device visible; qm_door_amd has no CPU execution path");
     if (device < 0 || device >= count) throw NoDevice("HIP device index out of range");
-    HIP_CHECK(hipSetDevice(device));
+    DeviceGuard onDevice(device);
     ctx = new qmgpu_context();
+    for (auto& set : ctx->ring) for (auto& e : set) e = nullptr;
     ctx->device = device; ctx->maxBatch = max_batch; ctx->maxNodes = max_nodes; ctx->hostProblem = *problem;
     HIP_CHECK(hipStreamCreate(&ctx->ownStream));
     ctx->stream = ctx->ownStream;
@@ -130,7 +145,15 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
   });
   if (st != QMGPU_OK) {
-    if (ctx) { for (void* p : ctx->allocations) hipFree(p); delete ctx; }
+    if (ctx) {   // nothing of a failed create survives: device memory, events, stream
+      int prev = -1;
+      const bool sw = hipGetDevice(&prev) == hipSuccess && prev != ctx->device && hipSetDevice(ctx->device) == hipSuccess;
+      for (void* p : ctx->allocations) hipFree(p);
+      for (auto& set : ctx->ring) for (auto& e : set) if (e) hipEventDestroy(e);
+      if (ctx->ownStream) hipStreamDestroy(ctx->ownStream);
+      if (sw) hipSetDevice(prev);
+      delete ctx;
+    }
     return st;
   }
   *out = ctx;
@@ -139,10 +162,13 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
 
 int qmgpu_destroy(qmgpu_handle h) {
   if (!h) return QMGPU_OK;
+  int prev = -1;
+  const bool sw = hipGetDevice(&prev) == hipSuccess && prev != h->device && hipSetDevice(h->device) == hipSuccess;
   hipStreamSynchronize(h->stream);
   for (void* p : h->allocations) hipFree(p);
   for (auto& set : h->ring) for (auto& e : set) if (e) hipEventDestroy(e);
   if (h->ownStream) hipStreamDestroy(h->ownStream);
+  if (sw) hipSetDevice(prev);
   delete h;
   return QMGPU_OK;
 }
@@ -155,12 +181,12 @@ int qmgpu_set_stream(qmgpu_handle h, void* hip_stream) {
 
 int qmgpu_synchronize(qmgpu_handle h) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() { HIP_CHECK(hipStreamSynchronize(h->stream)); });
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); });
 }
 
 int qmgpu_get_input_weight(qmgpu_handle h, double* R_host) {
   if (!h || !R_host) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
-  return guarded([&]() { HIP_CHECK(hipStreamSynchronize(h->stream)); HIP_CHECK(hipMemcpy(R_host, h->dRw, 900 * sizeof(double), hipMemcpyDeviceToHost)); });
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); HIP_CHECK(hipMemcpy(R_host, h->dRw, 900 * sizeof(double), hipMemcpyDeviceToHost)); });
 }
 
 int qmgpu_enable_timing(qmgpu_handle h, int enable) {
@@ -181,7 +207,7 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(int doubles, double* si
 
 int qmgpu_debug_poison(qmgpu_handle h) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     for (auto& sc : h->scratch) HIP_CHECK(hipMemsetAsync(sc.first, 0xFF, sc.second, h->stream));
     constexpr int kDoubles = 160 * 1024 / 8;
     HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(lds_poison_kernel, kDoubles * 8));
@@ -192,7 +218,7 @@ int qmgpu_debug_poison(qmgpu_handle h) {
 
 int qmgpu_enable_debug(qmgpu_handle h, int enable) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     if (enable && !h->dDebug) h->dDebug = h->alloc<double>(size_t(h->maxBatch) * (h->maxNodes + 1) * DBG_DOUBLES);
     h->debugLq = enable != 0;
   });
@@ -273,13 +299,13 @@ static void readTiming(qmgpu_handle h, long call, double* ms6) {
 }
 
 int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args) {
-  return guarded([&]() { checkMpcArgs(h, args); beginTiming(h); enqueueMpc(h, args); finishTiming(h, true, false); });
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); checkMpcArgs(h, args); beginTiming(h); enqueueMpc(h, args); finishTiming(h, true, false); });
 }
 
 int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const double* t_grid, const double* X, const double* U, const int32_t* modes, const double* t_eval,
                             double* x_out, double* u_out, int32_t* mode_out) {
   if (!h || !t_grid || !X || !U || !modes || !t_eval || !x_out || !u_out || !mode_out || batch < 1 || num_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     QM_LAUNCH(policy_eval_kernel, batch, 64, h->stream, batch, num_nodes, t_grid, X, U, modes, t_eval, x_out, u_out, mode_out);
     HIP_CHECK(hipGetLastError());
   });
@@ -288,7 +314,7 @@ int qmgpu_policy_eval_batch(qmgpu_handle h, int batch, int num_nodes, const doub
 int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* a) {
   if (!h || !a || a->batch < 1 || !a->rbd_measured || !a->time || !a->command_kind || !a->command || !a->last_ee_target || !a->x0 || !a->target_times || !a->target_states)
     return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad front-end arguments");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     FrontendArgs fa{h->dP, *a};
     QM_LAUNCH(frontend_kernel, (a->batch + 63) / 64, 64, h->stream, fa);
     HIP_CHECK(hipGetLastError());
@@ -297,7 +323,7 @@ int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* a) {
 
 int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     beginTiming(h);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
     enqueueWbc(h, args);
@@ -311,7 +337,7 @@ int qmgpu_warm_start_batch(qmgpu_handle h, int batch, int prev_nodes, const doub
   if (!h || !prev_grid || !prev_X || !prev_U || !new_grid || !warm_x || !warm_u || batch < 1 || prev_nodes < 1 || new_nodes < 1)
     return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad warm-start arguments");
   if (warm_x == prev_X || warm_u == prev_U) return setError(QMGPU_ERR_INVALID_ARGUMENT, "warm-start outputs must not alias the previous solution");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     QM_LAUNCH(warm_start_kernel, batch, 256, h->stream, batch, prev_nodes, prev_grid, prev_X, prev_U, new_nodes, new_grid, x0, warm_x, warm_u);
     HIP_CHECK(hipGetLastError());
   });
@@ -319,7 +345,7 @@ int qmgpu_warm_start_batch(qmgpu_handle h, int batch, int prev_nodes, const doub
 
 int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t_eval, qmgpu_wbc_args* wbc) {
   if (!h || !t_eval || !wbc) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     checkMpcArgs(h, mpc);
     if (wbc->batch != mpc->batch) throw std::invalid_argument("MPC and WBC batch sizes differ");
     beginTiming(h);
@@ -338,7 +364,7 @@ int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t
 int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double* B, double* b, double* Q, double* R, double* q, double* r, double* C, double* D, double* e,
                        int32_t* nc) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     if (!h->debugLq || !h->dDebug) throw std::invalid_argument("call qmgpu_enable_debug(h, 1) before the solve");
     if (instance < 0 || instance >= h->lastBatch || node < 0 || node > h->lastN) throw std::invalid_argument("instance / node out of range");
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -356,7 +382,7 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
 
 int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms6) {
   if (!h || !ms6) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
     readTiming(h, h->callCount - 1, ms6);
   });
@@ -364,7 +390,7 @@ int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms6) {
 
 int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6) {
   if (!h || !ms6 || last_calls < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad argument");
-  return guarded([&]() {
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
     const long n = std::min<long>(std::min<long>(last_calls, h->callCount), qmgpu_context::kRing);
     double acc[6] = {0, 0, 0, 0, 0, 0};

@@ -80,6 +80,12 @@ class Oracle:
         self.lib.qmo_mode_at.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
         return self.lib.qmo_mode_at(len(ev), p(ev), p(modes), t)
 
+    def node_mode_at(self, ev, modes, t):
+        """mode of a shooting node at time t (a node on an event time takes the post-event mode)"""
+        ev = np.ascontiguousarray(ev, dtype=np.float64); modes = np.ascontiguousarray(modes, dtype=np.int32)
+        self.lib.qmo_node_mode_at.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
+        return self.lib.qmo_node_mode_at(len(ev), p(ev), p(modes), t)
+
     def swing_reference(self, nev, ev, modes, t):
         zp, zv = np.zeros(4), np.zeros(4)
         self.lib.qmo_swing_reference.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]

@@ -35,7 +35,7 @@ def test_emu_lq_and_sqp_iteration(emu):
     for inst in range(B):
         for k in (0, 3, N):
             g = sol.debug_lq(inst, k)
-            mode = orc.mode_at(ev[:nev], md[:nev + 1], k * dt)
+            mode = orc.node_mode_at(ev[:nev], md[:nev + 1], k * dt)
             flags = [(mode >> (3 - c)) & 1 for c in range(4)]
             u = np.zeros(30)
             for c in range(4):
@@ -149,7 +149,7 @@ def test_emu_sqp_convergence_test_skips_converged_instances():
     cold = orc.mpc_solve(N, 0.0, x0[1], tt[1], ts[1], nev, ev, md)
     wx = np.stack([solved["X"], np.tile(x0[1], (N + 1, 1))]); wu = np.stack([solved["U"], cold["U"] * 0.0])
     for k in range(N):
-        mode = orc.mode_at(ev[:nev], md[:nev + 1], k * itf.problem.settings.dt)
+        mode = orc.node_mode_at(ev[:nev], md[:nev + 1], k * itf.problem.settings.dt)
         flags = [(mode >> (3 - c)) & 1 for c in range(4)]
         for c in range(4):
             if flags[c]:

@@ -43,7 +43,7 @@ def test_finite_converged_and_modes_bit_exact(solved, interface, oracle):
     assert (r["stats"][:, 7] == 0).all() and (r["status"] == 0).all()
     dt = interface.problem.settings.dt
     assert np.array_equal(r["T"], np.tile(np.arange(N + 1) * dt, (B, 1)))
-    modes = np.array([oracle.mode_at(ev[:nev], md[:nev + 1], k * dt) for k in range(N + 1)], dtype=np.int32)
+    modes = np.array([oracle.node_mode_at(ev[:nev], md[:nev + 1], k * dt) for k in range(N + 1)], dtype=np.int32)
     assert np.array_equal(r["mode"], np.tile(modes, (B, 1)))
     assert np.array_equal(r["X"][:, 0], solved["x0"])      # the initial state is never moved
 

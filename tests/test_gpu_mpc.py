@@ -30,7 +30,7 @@ def test_lq_blocks_match_oracle(interface, oracle):
     for inst in range(B):
         for k in (0, 2, 3, N):
             g = sol.debug_lq(inst, k)
-            mode = oracle.mode_at(ev[:nev], md[:nev + 1], k * dt)
+            mode = oracle.node_mode_at(ev[:nev], md[:nev + 1], k * dt)
             flags = [(mode >> (3 - c)) & 1 for c in range(4)]
             u = np.zeros(30)
             for c in range(4):
@@ -81,6 +81,8 @@ def test_event_aligned_grid_matches_oracle(interface, oracle):
     for i in range(B):
         ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md, time_grid=grid)
         assert np.array_equal(r["T"][i], grid) and np.array_equal(r["mode"][i], ref["mode"])
+        k = int(np.argmin(np.abs(grid - ev[0])))                # the node ON the first switch carries the post-event mode
+        assert grid[k] == ev[0] and r["mode"][i][k] == md[1] and r["mode"][i][k - 1] == md[0]
         assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
 

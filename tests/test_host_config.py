@@ -109,6 +109,18 @@ def test_tile_gait(hip_lib):
     g = gs.template("trot")
     nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
     assert hip_lib.qmgpu_tile_gait(C.byref(g), 0.0, 0.0, 100.0, C.byref(nn), e, m) == abi.ERR_CAPACITY
+    # a horizon that starts inside a later cycle keeps the real modes of the cycle before it (no artificial STANCE at the cycle
+    # start): STANCE only precedes t_phase0, and the tiling starts one full period before the cycle containing t_begin
+    n3, ev3, md3 = gs.mode_schedule("trot", 0.0, 1.5, 2.0)               # t_begin in the third cycle [1.4, 2.1)
+    assert md3[0] == 15 and np.isclose(ev3[0], 0.7) and list(md3[1:5]) == [9, 6, 9, 6] and np.allclose(ev3[1:4], [1.05, 1.4, 1.75])
+    # a swing phase that straddles the template boundary keeps its lift-off time: template RF_LH | LF_RH | RF_LH merges across cycles
+    g2 = abi.Gait(); g2.num_modes = 3
+    for i, mm in enumerate([6, 9, 6]): g2.modes[i] = mm
+    for i, tt in enumerate([0.0, 0.2, 0.5, 0.7]): g2.switching_times[i] = tt
+    assert hip_lib.qmgpu_tile_gait(C.byref(g2), 0.0, 1.45, 1.9, C.byref(nn), e, m) == 0
+    evs, mds = np.array(e[:nn.value]), list(m[:nn.value + 1])
+    # cycle starts: 0.7, 1.4, 2.1; the RF_LH phase [1.2, 1.6) straddles 1.4 and is one phase with its start at 1.2
+    assert np.allclose(evs[:4], [0.7, 0.9, 1.2, 1.6]) and mds[:5] == [15, 6, 9, 6, 9]
 
 
 def test_time_grid_with_events(hip_lib):

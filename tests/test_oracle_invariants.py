@@ -135,6 +135,26 @@ def test_mode_numbers_and_lookup(oracle):
     ev = np.array([0.35, 0.70]); md = np.array([9, 6, 15], dtype=np.int32)
     assert oracle.mode_at(ev, md, 0.0) == 9 and oracle.mode_at(ev, md, 0.35) == 9      # an event time still belongs to the phase before it
     assert oracle.mode_at(ev, md, 0.35 + 1e-12) == 6 and oracle.mode_at(ev, md, 0.70) == 6 and oracle.mode_at(ev, md, 5.0) == 15
+    # a SHOOTING NODE placed on an event time is upstream's PostEvent node: it takes the mode that starts there
+    assert oracle.node_mode_at(ev, md, 0.35) == 6 and oracle.node_mode_at(ev, md, 0.70) == 15 and oracle.node_mode_at(ev, md, 0.35 - 1e-12) == 9
+    assert oracle.node_mode_at(ev, md, 0.0) == 9 and oracle.node_mode_at(ev, md, 0.5) == 6
+
+
+def test_event_node_switches_constraint_rows(interface, oracle):
+    """On an event-aligned grid the node AT the switch carries the post-event mode: its equality rows are those of the new contact set."""
+    from qm_door_amd import api
+    dt = interface.problem.settings.dt
+    x_nom = interface.initial_state
+    tgt = S.nominal_target(oracle, x_nom)
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.04)
+    N, grid = api.time_grid_with_events(0.0, 0.3, dt, ev[:nev], lib=interface.lib)
+    r = oracle.mpc_solve(N, 0.0, x_nom, np.zeros(1), tgt[None, :].copy(), nev, ev, md, time_grid=grid, line_search=False)
+    k = int(np.argmin(np.abs(grid - ev[0])))
+    assert grid[k] == ev[0]
+    assert r["mode"][k - 1] == md[0] and r["mode"][k] == md[1] and md[0] != md[1]
+    nc = lambda m: sum(3 if (m >> (3 - c)) & 1 else 4 for c in range(4))
+    lq = oracle.lq_node(grid[k], grid[k + 1] - grid[k], r["X"][k], r["U"][k], r["X"][k + 1], False, nev, ev, md, np.zeros(1), tgt[None, :].copy())
+    assert lq["nc"] == nc(int(md[1]))
 
 
 def test_swing_spline_boundary_conditions(interface, oracle):
