@@ -160,6 +160,11 @@ int qmgpu_destroy(qmgpu_handle h);
 /* Use an externally owned HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
 int qmgpu_set_stream(qmgpu_handle h, void* hip_stream);
 int qmgpu_synchronize(qmgpu_handle h);
+/* Replace the settings behind a live handle (gains, weights, limits, barrier parameters; the model is fixed at create time):
+ * what the reference's dynamic_reconfigure callbacks do at run time (WbcBase::dynamicCallback, qm_wbc/src/WbcBase.cpp:74-121;
+ * QMController::dynamicCallback, qm_controllers/src/QMController.cpp:358-363).  Ordered on the handle's stream: calls enqueued
+ * afterwards see the new values; R' is recomputed. */
+int qmgpu_update_settings(qmgpu_handle h, const qmgpu_settings* settings);
 /* Leg-velocity-mapped input weight R' (30x30, row major) computed at create time (QMInterface.cpp:274-299). */
 int qmgpu_get_input_weight(qmgpu_handle h, double* R_host);
 

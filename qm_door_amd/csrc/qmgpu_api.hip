@@ -184,6 +184,18 @@ int qmgpu_synchronize(qmgpu_handle h) {
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); });
 }
 
+int qmgpu_update_settings(qmgpu_handle h, const qmgpu_settings* settings) {
+  if (!h || !settings) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
+  return guarded([&]() {
+    DeviceGuard onDevice(h->device);
+    HIP_CHECK(hipStreamSynchronize(h->stream));   // kernels in flight still read the old values through dP
+    h->hostProblem.settings = *settings;
+    HIP_CHECK(hipMemcpy(&h->dP->settings, &h->hostProblem.settings, sizeof(qmgpu_settings), hipMemcpyHostToDevice));
+    QM_LAUNCH(input_weight_kernel, 1, 64, h->stream, h->dP, h->dZeros, h->dRw);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
 int qmgpu_get_input_weight(qmgpu_handle h, double* R_host) {
   if (!h || !R_host) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); HIP_CHECK(hipMemcpy(R_host, h->dRw, 900 * sizeof(double), hipMemcpyDeviceToHost)); });

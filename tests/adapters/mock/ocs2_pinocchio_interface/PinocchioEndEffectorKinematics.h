@@ -1,0 +1,6 @@
+#pragma once
+namespace ocs2 {
+class PinocchioInterface {};
+class PinocchioEndEffectorKinematics {};
+struct CentroidalModelInfo {};
+}

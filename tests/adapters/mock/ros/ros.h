@@ -1,0 +1,19 @@
+// TEST INFRASTRUCTURE ONLY -- see ocs2_core/Types.h in this directory.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+namespace ros {
+class Publisher {};
+class NodeHandle {
+ public:
+  template <class M> Publisher advertise(const std::string& topic, unsigned queue) { advertised.push_back(topic); (void)queue; return Publisher(); }
+  std::vector<std::string> advertised;
+};
+namespace param {
+inline std::map<std::string, std::string>& store() { static std::map<std::string, std::string> s; return s; }
+inline bool get(const std::string& key, std::string& out) { auto it = store().find(key); if (it == store().end()) return false; out = it->second; return true; }
+}  // namespace param
+}  // namespace ros
+namespace ocs2_msgs { struct mpc_observation {}; }
+namespace qm_msgs { struct ee_state {}; }
