@@ -47,7 +47,7 @@ def test_config5_mixed_gaits_n200_batch1024(interface, oracle):
     tgt = S.nominal_target(oracle, x_nom)
     tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
     nev, ev, md = _mixed_schedule(N * dt + 0.2)
-    modes = np.array([oracle.mode_at(ev[:nev], md[:nev + 1], k * dt) for k in range(N + 1)], dtype=np.int32)
+    modes = np.array([oracle.node_mode_at(ev[:nev], md[:nev + 1], k * dt) for k in range(N + 1)], dtype=np.int32)
     assert {15, 9, 6, 0}.issubset(set(modes.tolist())) and len(set(modes.tolist())) >= 6      # stance, trot pair, FLY, three-leg phases
     sol = G.make_solver(interface, B, N)
     mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)

@@ -278,7 +278,7 @@ def test_riccati_step_equals_dense_kkt_solve(interface, oracle):
     # cold start (QMInitializer): x_k = x0, u_k = weight compensation of the node's mode
     lq = []
     for k in range(N + 1):
-        mode = oracle.mode_at(ev[:nev], md[:nev + 1], k * dt)
+        mode = oracle.node_mode_at(ev[:nev], md[:nev + 1], k * dt)
         flags = [(mode >> (3 - c)) & 1 for c in range(4)]
         u = np.zeros(30)
         for c in range(4):
