@@ -1,0 +1,295 @@
+// ad_node_kernel -- derivatives of the RK2 shooting map and of the state-input constraints, THREE shooting nodes per wavefront.
+//
+// Replaces, per node: QMDynamicsAD::linearApproximation for both RK2 stages
+// (qm_interface/src/dynamics/QMDynamicsAD.cpp:30-33, CppAD), QMPreComputation::request (QMPreComputation.cpp:50-89), the Jacobians of
+// the per-foot equality constraints (QMInterface.cpp:123-131) and of the end-effector error (EndEffectorConstraint.cpp:36-78), and
+// upstream ocs2_sqp's sensitivity discretisation  A_d = I + dt/2 (A1 + A2 (I + dt A1)),  B_d = dt/2 (B1 + A2 dt B1 + B2).
+//
+// Structure of the flow map f(x, u), x = [h/m (6); p (3); zyx (3); q_j (18)], u = [F (12); v_j (18)]:
+//   * f does not depend on the base position p at all (translation invariance);
+//   * f is LINEAR in the momentum h, the joint rates v_j and the contact forces F;
+//   * only the 21 configuration coordinates (zyx, q_j) enter non-linearly.
+// So a lane carries ONE configuration tangent through the tree sweep (Du, slot d) and, in the quantities that are linear in a
+// velocity-like argument, a second tangent (Du3, slot e) that only ever multiplies configuration values:
+//     lane direction dd in [0, 21):   slot d = d/d zyx_dd (dd < 3) or d/d q_{dd-3};
+//                                     slot e = d/d h_ang_dd (dd < 3) or d/d v_{j, dd-3} in the kinematic rows,
+//                                              d/d F_{dd-6} (6 <= dd < 18) in the momentum-rate rows;
+//                                     the remaining columns (h_lin, p, the value itself) are closed forms written by lanes 0..5, 18.
+// 21 lanes cover all 60 columns of one node: a wavefront differentiates three nodes side by side (lanes 0..20, 21..41, 42..62) with
+// the instruction count one node used to take with sixty full tangents.  Both RK2 stages are differentiated at their own arguments
+// (partials only); the chain rule that the sixty-lane version carried through the second sweep is the product
+//     d k2 / d (x, u) = J2 + dt J2[:, 0:12] J1 + dt [0 | J2[:, q_j] -> v_j columns]
+// whose dense part runs on the fp64 matrix cores (12 x 12 x 64 per node).
+//
+// Output: the AD rows of lq_kernel.h (one 64-double row per differentiated scalar: entries < 60 the derivative along (x, u), entry
+// 60 the value) -- unchanged, lq_node_kernel does not know how they were produced.
+#pragma once
+#include "layout.h"
+#include "schedule_dev.h"
+#include "sweep_dev.h"
+
+namespace qmk {
+
+struct LqArgs {
+  const qmgpu_problem* P;
+  const double* Rw;          // R' [30][30]
+  int batch, N, K;
+  const double* tgrid;       // [batch][N+1]
+  const double* X;           // [batch][N+1][30] current iterate
+  const double* U;           // [batch][N][30]
+  const double* targetTimes; // [batch][K]
+  const double* targetStates;// [batch][K][37]
+  const int* schedNum;       // [batch]
+  const double* schedTimes;  // [batch][MAX_EVENTS]
+  const int* schedModes;     // [batch][MAX_EVENTS+1]
+  const double* zeros;       // >= 64 zeros
+  double* stages;            // [batch][N+1][STAGE_DOUBLES]
+  int* stageNc;              // [batch][N+1]
+  int* nodeMode;             // [batch][N+1]
+  double* metrics;           // [batch][N+1][NODE_METRICS]
+  double* debug;             // [batch][N+1][DBG_DOUBLES] or null
+  double* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
+  const int* done;           // [batch] instances whose SQP iterations have converged are skipped
+};
+
+// AD rows: one 64-double row per differentiated scalar; entry l < 60 = d/d(x,u)_l, entry 60 = the value itself
+constexpr int AD_PHI = 0;                    // [12] RK2 increment phi = dt/2 (k1 + k2) of the momentum / base-pose states
+constexpr int AD_CD = AD_PHI + 12 * 64;      // [16] equality constraint rows
+constexpr int AD_EE = AD_CD + 16 * 64;       // [6]  end-effector pose error
+constexpr int AD_DOUBLES = AD_EE + 6 * 64;   // 2176
+
+constexpr int AD_DIRS = 21;                  // configuration directions = lanes per node
+constexpr int AD_NODES = 3;                  // nodes per wavefront
+__host__ __device__ constexpr int adGridFor(int nodes) { return (nodes + AD_NODES - 1) / AD_NODES; }
+
+// Inputs of the sweep as seen by one lane: values from the node's x | u staged in LDS, seeds from the lane's direction.
+struct AdIn {
+  const double* x;    // this node's state (30) ...
+  const double* u;    // ... and input (30) in LDS
+  const double* xs;   // the twelve momentum / base-pose states the stage is evaluated at: x (first stage) or x + dt k1 (second)
+  int dd;             // direction 0..20
+  double dtS;         // 0 (first stage) or dt (second stage: q_j + dt v_j)
+  __device__ __forceinline__ Du3 hn(int i) const { return Du3(xs[i], 0.0, (i >= 3 && dd == i - 3) ? 1.0 : 0.0); }
+  __device__ __forceinline__ Du euler(int i) const { return Du(xs[9 + i], dd == i ? 1.0 : 0.0); }
+  __device__ __forceinline__ Du q(int j) const { return Du(fma(dtS, u[12 + j], x[12 + j]), dd == 3 + j ? 1.0 : 0.0); }
+  __device__ __forceinline__ Du3 qd(int j) const { return Du3(u[12 + j], 0.0, dd == 3 + j ? 1.0 : 0.0); }
+  __device__ __forceinline__ Vec3<Du3> force(int c) const {
+    return Vec3<Du3>(Du3(u[3 * c], 0.0, dd == 6 + 3 * c ? 1.0 : 0.0), Du3(u[3 * c + 1], 0.0, dd == 7 + 3 * c ? 1.0 : 0.0), Du3(u[3 * c + 2], 0.0, dd == 8 + 3 * c ? 1.0 : 0.0));
+  }
+};
+
+// LDS of one wavefront (doubles): 37 KiB, four wavefronts (one per SIMD: the sweep needs the whole register file) per CU
+constexpr int ADL_XU = 0;                              // [3][64]  x (0..29) | u (32..61) per node
+constexpr int ADL_X2 = ADL_XU + AD_NODES * 64;         // [3][12]  x + dt k1, momentum / base-pose part
+constexpr int ADL_A2 = ADL_X2 + AD_NODES * 12;         // [3][12][16] J2[:, 0:12] (operand of the chain-rule product), columns 12..15 zero
+constexpr int ADL_PARK = ADL_A2 + AD_NODES * 12 * 16;  // feet of the first stage [4][15][64]  /  J1 then J1 + J2 + ... [3][12][64]
+constexpr int AD_PARK_DOUBLES = 4 * 15 * 64;
+constexpr int AD_LDS_DOUBLES = ADL_PARK + AD_PARK_DOUBLES;
+static_assert(AD_NODES * 12 * 64 <= AD_PARK_DOUBLES, "the Jacobian rows reuse the parking area");
+static_assert(AD_LDS_DOUBLES * 8 <= 40960, "four wavefronts per CU");
+
+__global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs a) {
+  __shared__ double lds[AD_LDS_DOUBLES];
+  QM_POISON_LDS(lds, AD_LDS_DOUBLES);
+  const int lane = threadIdx.x;
+  const int l16 = lane & 15, h = lane >> 4;
+  const int grp = lane / AD_DIRS < AD_NODES ? lane / AD_DIRS : AD_NODES - 1;   // lane 63 shadows the last lane of node 2 (stores nothing)
+  const int dd = qmOpaqueLane(lane < AD_NODES * AD_DIRS ? lane - grp * AD_DIRS : AD_DIRS - 1);
+  const int total = a.batch * (a.N + 1);
+  const int gRaw = blockIdx.x * AD_NODES + grp;
+  const int gnode = gRaw < total ? gRaw : total - 1;
+  const int node = gnode % (a.N + 1), inst = gnode / (a.N + 1);
+  const bool live = lane < AD_NODES * AD_DIRS && gRaw < total && !a.done[inst];   // this lane's results reach HBM
+  const bool terminal = node == a.N;
+  const qmgpu_model& md = a.P->model;
+  const qmgpu_settings& st = a.P->settings;
+  // column of the AD row each of this lane's three values goes to
+  const int cD = 9 + dd;                                                                   // zyx / q_j
+  const int cV = dd < 3 ? 3 + dd : 39 + dd;                                                // h_ang / v_j
+  const int cC = dd < 3 ? dd : (dd < 6 ? 3 + dd : (dd < 18 ? 24 + dd : (dd == 18 ? 60 : 42 + dd)));   // h_lin | p | F | value | padding 61, 62
+  const bool isF = dd >= 6 && dd < 18, isVal = dd == 18;
+
+  double* ad = a.adrows + size_t(gnode) * AD_DOUBLES;
+  double* xu = lds + ADL_XU + grp * 64;
+  double* x2 = lds + ADL_X2 + grp * 12;
+  double* A2 = lds + ADL_A2 + grp * 192;
+  double* park = lds + ADL_PARK + lane;                 // lane-private columns while the feet wait for the base twist
+  double* L1 = lds + ADL_PARK + grp * 768;              // [12][64] Jacobian rows of this node
+
+  const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
+  const double t = tg[node];
+  const double dt = terminal ? 0.0 : tg[node + 1] - t;
+  {  // x | u of the three nodes: lanes dd load 30 + 30 values of their node
+    const double* xG = a.X + size_t(gnode) * 30;
+    const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+    for (int i = dd; i < 30; i += AD_DIRS) { xu[i] = xG[i]; xu[32 + i] = uG[i]; }
+  }
+  QM_WAVE_SYNC();
+  const double* x = xu; const double* u = xu + 32;
+  const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
+  const int phase = nodePhaseAt(sched, t);
+  const int mode = sched.modes[phase];
+  double eePosRef[3], eeQuatRef[4];
+  eeReference(a.targetTimes + size_t(inst) * a.K, a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET, a.K, t, eePosRef, eeQuatRef);
+
+  // one row of the AD format: the lane's configuration slot, its velocity / force slot and its closed-form column
+  const bool owner = lane < AD_NODES * AD_DIRS;   // lane 63 computes along with the others but owns no column
+  auto putRow = [&](double* dst, int row, double dval, double vval, double cval) {
+    double* r = dst + row * 64;
+    if (owner) { r[cD] = dval; r[cV] = vval; r[cC] = cval; }
+  };
+  auto putGlobal = [&](int base, int row, double dval, double vval, double cval) { if (live) putRow(ad + base, row, dval, vval, cval); };
+
+  int nc = 0;
+#pragma unroll 1
+  for (int stage = 0; stage < 2; ++stage) {
+    const AdIn in{x, u, stage ? x2 : x, dd, stage ? dt : 0.0};
+    FlowOut<Du, Du3, Du3> f;
+    BaseMotion2<Du, Du3> bm;
+    centroidalSweep2<Du, Du3, Du3>(
+        md, st.gravity, in,
+        [&](int c, Vec3<Du> r, Vec3<Du3> v) {
+          if (stage == 0) {
+            double* p = park + (c * 15) * 64;
+            p[0] = r.x.v; p[64] = r.x.d; p[128] = r.y.v; p[192] = r.y.d; p[256] = r.z.v; p[320] = r.z.d;
+            p[384] = v.x.v; p[448] = v.x.d; p[512] = v.x.e; p[576] = v.y.v; p[640] = v.y.d; p[704] = v.y.e; p[768] = v.z.v; p[832] = v.z.d; p[896] = v.z.e;
+          }
+        },
+        [&](Vec3<Du> r, const Mat3<Du>& R) {
+          if (stage == 0) {  // end-effector pose error (EndEffectorConstraint.cpp:36-78): no velocity / force dependence, d/dp = identity
+            Du qee[4];
+            matrixToQuaternion(R, qee);
+            const Vec3<Du> od = quaternionDistance(qee, eeQuatRef);
+            const Du hq[6] = {x[6] + r.x - eePosRef[0], x[7] + r.y - eePosRef[1], x[8] + r.z - eePosRef[2], od.x, od.y, od.z};
+#pragma unroll
+            for (int q = 0; q < 6; ++q) putGlobal(AD_EE, q, hq[q].d, 0.0, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0 : 0.0));
+          }
+        },
+        f, bm);
+    if (stage == 0) {
+      // ---- equality constraints in the insertion order of QMInterface.cpp:116-131
+      if (!terminal) {
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+          const bool contact = contactOf(mode, c);
+          const double* p = park + (c * 15) * 64;
+          const Vec3<Du> r(Du(p[0], p[64]), Du(p[128], p[192]), Du(p[256], p[320]));
+          const Vec3<Du3> vj(Du3(p[384], p[448], p[512]), Du3(p[576], p[640], p[704]), Du3(p[768], p[832], p[896]));
+          const Vec3<Du3> vf = bm.dp + cross(bm.omega, r) + vj;
+          // velocity-type row: d/dh_lin = identity through dp; d/dp_z only through the position-error gain
+          auto putVel = [&](int row, Du3 hv, int axisIdx, double gainZ) {
+            putGlobal(AD_CD, row, hv.d, hv.e, isVal ? hv.v : (dd == axisIdx ? 1.0 : (dd == 5 ? gainZ : 0.0)));
+          };
+          if (contact) {  // zeroVelocity (QMInterface.cpp:126, 324-339; Ax(2,2) = positionErrorGain)
+            putVel(nc, vf.x, 0, 0.0); putVel(nc + 1, vf.y, 1, 0.0);
+            putVel(nc + 2, vf.z + st.position_error_gain * (x[8] + r.z), 2, st.position_error_gain);
+            nc += 3;
+          } else {  // zeroForce (QMInterface.cpp:123-124) then normalVelocity (QMPreComputation.cpp:56-66)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) putGlobal(AD_CD, nc + q, 0.0, 0.0, isVal ? u[3 * c + q] : (dd == 6 + 3 * c + q ? 1.0 : 0.0));
+            double zp, zv;
+            swingReference(st, sched, c, t, phase, zp, zv);
+            putVel(nc + 3, vf.z - zv + st.position_error_gain * (x[8] + r.z - zp), 2, st.position_error_gain);
+            nc += 4;
+          }
+        }
+      }
+      QM_WAVE_SYNC();   // every lane has read its parked feet: the area becomes the Jacobian rows
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        putRow(L1, i, f.lin[i].d, 0.0, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0));
+        putRow(L1, 3 + i, f.ang[i].d, 0.0, isF ? f.ang[i].e : (isVal ? f.ang[i].v : 0.0));
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) putRow(L1, 6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0 : 0.0));
+      if (dd == 19) {   // the columns nobody owns: p (f does not depend on the base position) and padding 63
+#pragma unroll
+        for (int i = 0; i < 12; ++i) L1[i * 64 + 63] = 0.0;
+      }
+      if (dd == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { x2[i] = fma(dt, f.lin[i].v, x[i]); x2[3 + i] = fma(dt, f.ang[i].v, x[3 + i]); }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x2[6 + i] = fma(dt, f.kin[i].v, x[6 + i]);
+      }
+      QM_WAVE_SYNC();
+    } else {
+      // ---- second stage: J2[:, 0:12] as a matrix-core operand, the rest of J2 stays in registers until J1 has been multiplied
+      if (dd < 3) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const double dv = i < 3 ? f.lin[i].d : (i < 6 ? f.ang[i - 3].d : f.kin[i - 6].d);
+          const double vv = i < 6 ? 0.0 : f.kin[i - 6].e;
+          A2[i * 16 + dd] = (i >= 6 && i < 9 && i - 6 == dd) ? 1.0 : 0.0;   // d/dh_lin
+          A2[i * 16 + 3 + dd] = vv;                                          // d/dh_ang
+          A2[i * 16 + 6 + dd] = 0.0;                                         // d/dp
+          A2[i * 16 + 9 + dd] = dv;                                          // d/dzyx
+          A2[i * 16 + 12 + dd] = 0.0;
+        }
+      } else if (dd == 3) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) A2[i * 16 + 15] = 0.0;
+      }
+      QM_WAVE_SYNC();
+      // ---- chain rule on the matrix cores: acc[g][tn] = J2[:, 0:12] J1[:, 16 tn ..] for the three nodes
+      QmAcc acc[AD_NODES][4];
+#pragma unroll
+      for (int g = 0; g < AD_NODES; ++g) {
+        const double* A2g = lds + ADL_A2 + g * 192;
+        const double* L1g = lds + ADL_PARK + g * 768;
+        double av[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const double raw = A2g[(l16 < 12 ? l16 : 0) * 16 + 4 * ks + h]; av[ks] = l16 < 12 ? raw : 0.0; }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[g][tn][r] = 0.0;
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) qmMfma(acc[g][tn], av[ks], L1g[(4 * ks + h) * 64 + tn * 16 + l16], nullptr);
+        }
+      }
+      QM_WAVE_SYNC();   // J1 has been read by every lane: the slot owners add J2 (+ dt J2[:, q_j] into the v_j columns) in place
+      {
+        const double sh = dd >= 3 ? dt : 0.0;
+        auto addRow = [&](int row, double dval, double vval, double cval) {
+          double* r = L1 + row * 64;
+          if (owner) { r[cD] += dval; r[cV] += fma(sh, dval, vval); r[cC] += cval; }
+        };
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          addRow(i, f.lin[i].d, 0.0, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0));
+          addRow(3 + i, f.ang[i].d, 0.0, isF ? f.ang[i].e : (isVal ? f.ang[i].v : 0.0));
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) addRow(6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0 : 0.0));
+      }
+      QM_WAVE_SYNC();
+      // ---- phi = dt/2 (k1 + k2): rows leave in accumulator layout (4 rows x 128-byte runs per store instruction)
+#pragma unroll
+      for (int g = 0; g < AD_NODES; ++g) {
+        const int gR = blockIdx.x * AD_NODES + g;
+        const int gN = gR < total ? gR : total - 1;
+        const int nodeG = gN % (a.N + 1), instG = gN / (a.N + 1);
+        const bool termG = nodeG == a.N;
+        const bool liveG = gR < total && !a.done[instG];
+        const double dtG = termG ? 0.0 : a.tgrid[size_t(instG) * (a.N + 1) + nodeG + 1] - a.tgrid[size_t(instG) * (a.N + 1) + nodeG];
+        const double* L1g = lds + ADL_PARK + g * 768;
+        double* adG = a.adrows + size_t(gN) * AD_DOUBLES;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const int i = h + 4 * r, c = tn * 16 + l16;
+            const double s = L1g[i * 64 + c];
+            // terminal node: the slope itself (one stage); otherwise dt/2 (J1 + J2 + dt J2x J1), the value column without the product
+            const double v = termG ? 0.5 * s : 0.5 * dtG * (c < 60 ? fma(dtG, acc[g][tn][r], s) : s);
+            if (liveG) adG[AD_PHI + i * 64 + c] = v;
+          }
+        }
+      }
+    }
+  }
+  if (live && dd == 0) { a.stageNc[gnode] = nc; a.nodeMode[gnode] = mode; }
+}
+
+}  // namespace qmk

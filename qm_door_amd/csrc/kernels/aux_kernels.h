@@ -7,21 +7,22 @@ namespace qmk {
 
 // R' = R_task with the 12x12 leg-velocity block replaced by J^T R_task J, J = feet Jacobian w.r.t. the leg joints at the
 // initial state (QMInterface::initializeInputCostWeight, QMInterface.cpp:274-299).  One wavefront; the Jacobian columns come
-// from the same lane-tangent sweep the LQ kernel uses (lane 42+j carries d/d(v_joint j)).
+// from the same structured sweep the LQ kernel uses (lane 3 + j carries d/d(v_joint j) in its velocity slot).
 __global__ void __launch_bounds__(64) input_weight_kernel(const qmgpu_problem* P, const double* zeros, double* Rw) {
   __shared__ double J[12 * 12];
   __shared__ double RJ[12 * 12];
   const int lane = threadIdx.x;
   const qmgpu_model& md = P->model;
-  const DuIn in{P->settings.initial_state, zeros, lane, 0.0, nullptr};   // dtS == 0: the parked first-stage slope is never read
-  Feet<Du> feet;
-  Du f[12];
-  BaseMotion<Du> bm;
-  centroidalSweep<Du>(md, P->settings.gravity, in, [&](int c, Vec3<Du> r, Vec3<Du> v) { feet.set(c, r, v); }, [&](Vec3<Du>, const Mat3<Du>&) {}, f, bm);
-  if (lane >= 42 && lane < 54) {
-    const int j = lane - 42;
-    for (int c = 0; c < 4; ++c) { const Vec3<Du> v = feet.v(c); J[(3 * c + 0) * 12 + j] = v.x.d; J[(3 * c + 1) * 12 + j] = v.y.d; J[(3 * c + 2) * 12 + j] = v.z.d; }
-  }
+  const int dd = lane < AD_DIRS ? lane : AD_DIRS - 1;
+  const AdIn in{P->settings.initial_state, zeros, P->settings.initial_state, dd, 0.0};
+  FlowOut<Du, Du3, Du3> f;
+  BaseMotion2<Du, Du3> bm;
+  centroidalSweep2<Du, Du3, Du3>(
+      md, P->settings.gravity, in,
+      [&](int c, Vec3<Du>, Vec3<Du3> v) {   // foot velocity caused by the joint rates: its velocity slot is the Jacobian column
+        if (lane >= 3 && lane < 15) { const int j = lane - 3; J[(3 * c + 0) * 12 + j] = v.x.e; J[(3 * c + 1) * 12 + j] = v.y.e; J[(3 * c + 2) * 12 + j] = v.z.e; }
+      },
+      [&](Vec3<Du>, const Mat3<Du>&) {}, f, bm);
   __syncthreads();
   const double* Rt = P->settings.R_task;
   for (int e = lane; e < 144; e += 64) {

@@ -35,6 +35,40 @@ __device__ __forceinline__ Du operator/(double a, Du b) { const double q = a / b
 __device__ __forceinline__ Du& operator+=(Du& a, Du b) { a.v += b.v; a.d += b.d; return a; }
 __device__ __forceinline__ Du& operator-=(Du& a, Du b) { a.v -= b.v; a.d -= b.d; return a; }
 
+// Velocity-type dual number for the structured Jacobian of ad_node_kernel.  The flow map is LINEAR in the joint velocities, the
+// momenta and the contact forces: only the 21 configuration directions (Euler angles, joint angles) need a tangent through the tree
+// sweep.  A quantity that depends on the configuration only is a Du (value, d = tangent along the lane's configuration direction); a
+// quantity that also depends linearly on a velocity-like argument (joint rates, momentum) is a Du3 whose third slot e carries the
+// tangent along the lane's VELOCITY direction -- that tangent only ever multiplies configuration VALUES, never configuration
+// tangents, so one lane differentiates along two directions at once for 5/3 of the arithmetic of one.  Du3 * Du3 is deliberately
+// not defined: a product of two velocity-type quantities would mean the map is not linear in them.
+struct Du3 {
+  double v, d, e;
+  __device__ __forceinline__ Du3() : v(0.0), d(0.0), e(0.0) {}
+  __device__ __forceinline__ Du3(double a) : v(a), d(0.0), e(0.0) {}  // NOLINT implicit
+  __device__ __forceinline__ Du3(Du a) : v(a.v), d(a.d), e(0.0) {}    // NOLINT implicit
+  __device__ __forceinline__ Du3(double a, double b, double c) : v(a), d(b), e(c) {}
+};
+__device__ __forceinline__ Du3 operator+(Du3 a, Du3 b) { return Du3(a.v + b.v, a.d + b.d, a.e + b.e); }
+__device__ __forceinline__ Du3 operator-(Du3 a, Du3 b) { return Du3(a.v - b.v, a.d - b.d, a.e - b.e); }
+__device__ __forceinline__ Du3 operator-(Du3 a) { return Du3(-a.v, -a.d, -a.e); }
+__device__ __forceinline__ Du3 operator+(Du3 a, Du b) { return Du3(a.v + b.v, a.d + b.d, a.e); }
+__device__ __forceinline__ Du3 operator+(Du b, Du3 a) { return Du3(a.v + b.v, a.d + b.d, a.e); }
+__device__ __forceinline__ Du3 operator-(Du3 a, Du b) { return Du3(a.v - b.v, a.d - b.d, a.e); }
+__device__ __forceinline__ Du3 operator-(Du b, Du3 a) { return Du3(b.v - a.v, b.d - a.d, -a.e); }
+__device__ __forceinline__ Du3 operator+(Du3 a, double b) { return Du3(a.v + b, a.d, a.e); }
+__device__ __forceinline__ Du3 operator+(double b, Du3 a) { return Du3(a.v + b, a.d, a.e); }
+__device__ __forceinline__ Du3 operator-(Du3 a, double b) { return Du3(a.v - b, a.d, a.e); }
+__device__ __forceinline__ Du3 operator-(double b, Du3 a) { return Du3(b - a.v, -a.d, -a.e); }
+__device__ __forceinline__ Du3 operator*(Du a, Du3 b) { return Du3(a.v * b.v, fma(a.v, b.d, a.d * b.v), a.v * b.e); }
+__device__ __forceinline__ Du3 operator*(Du3 b, Du a) { return Du3(a.v * b.v, fma(a.v, b.d, a.d * b.v), a.v * b.e); }
+__device__ __forceinline__ Du3 operator*(double a, Du3 b) { return Du3(a * b.v, a * b.d, a * b.e); }
+__device__ __forceinline__ Du3 operator*(Du3 b, double a) { return Du3(a * b.v, a * b.d, a * b.e); }
+__device__ __forceinline__ Du3 operator/(Du3 a, Du b) { const double r = 1.0 / b.v, q = a.v * r; return Du3(q, (a.d - q * b.d) * r, a.e * r); }
+__device__ __forceinline__ Du3 operator/(Du3 a, double b) { const double r = 1.0 / b; return Du3(a.v * r, a.d * r, a.e * r); }
+__device__ __forceinline__ Du3& operator+=(Du3& a, Du3 b) { a.v += b.v; a.d += b.d; a.e += b.e; return a; }
+__device__ __forceinline__ double val(Du3 a) { return a.v; }
+
 // sin and cos of a joint / Euler angle (|a| of a few radians): two-term Cody-Waite reduction by pi/2 and the classic minimax
 // kernels on [-pi/4, pi/4] (coefficients of the public-domain fdlibm k_sin.c / k_cos.c).  ~35 fp64 instructions instead of the
 // ~170 of the general-range library sincos, error < 1 ulp for |a| < 1e5 -- 42 of them sit on every node's tree sweep.
@@ -62,33 +96,40 @@ __device__ __forceinline__ double fmaT(double a, double b, double c) { return fm
 __device__ __forceinline__ Du fmaT(Du a, Du b, Du c) { return Du(fma(a.v, b.v, c.v), fma(a.v, b.d, fma(a.d, b.v, c.d))); }
 __device__ __forceinline__ Du fmaT(double a, Du b, Du c) { return Du(fma(a, b.v, c.v), fma(a, b.d, c.d)); }
 
+// result types of mixed arithmetic (double / Du / Du3)
+template <class A, class B> using ProdT = decltype(A() * B());
+template <class A, class B> using SumT = decltype(A() + B());
+
 template <class T> struct Vec3 {
   T x, y, z;
   __device__ __forceinline__ Vec3() : x(0.0), y(0.0), z(0.0) {}
   __device__ __forceinline__ Vec3(T a, T b, T c) : x(a), y(b), z(c) {}
+  template <class U> __device__ __forceinline__ Vec3(const Vec3<U>& o) : x(o.x), y(o.y), z(o.z) {}   // NOLINT implicit promotion (double -> Du -> Du3)
 };
-template <class T> __device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return Vec3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
-template <class T> __device__ __forceinline__ Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return Vec3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
-template <class T> __device__ __forceinline__ Vec3<T> operator*(T s, Vec3<T> a) { return Vec3<T>(s * a.x, s * a.y, s * a.z); }
+template <class A, class B> __device__ __forceinline__ Vec3<SumT<A, B>> operator+(Vec3<A> a, Vec3<B> b) { return Vec3<SumT<A, B>>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class A, class B> __device__ __forceinline__ Vec3<SumT<A, B>> operator-(Vec3<A> a, Vec3<B> b) { return Vec3<SumT<A, B>>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> operator*(A s, Vec3<B> a) { return Vec3<ProdT<A, B>>(s * a.x, s * a.y, s * a.z); }
 template <class T> __device__ __forceinline__ Vec3<T> scale(double s, Vec3<T> a) { return Vec3<T>(s * a.x, s * a.y, s * a.z); }
-template <class T> __device__ __forceinline__ Vec3<T> cross(Vec3<T> a, Vec3<T> b) { return Vec3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-template <class T> __device__ __forceinline__ T dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> cross(Vec3<A> a, Vec3<B> b) {
+  return Vec3<ProdT<A, B>>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <class A, class B> __device__ __forceinline__ ProdT<A, B> dot(Vec3<A> a, Vec3<B> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // 3x3 matrix stored by columns (a joint rotation about a body axis only mixes two columns)
 template <class T> struct Mat3 {
   Vec3<T> c0, c1, c2;
 };
 template <class T> __device__ __forceinline__ Vec3<T> mul(const Mat3<T>& R, double x, double y, double z) { return scale(x, R.c0) + scale(y, R.c1) + scale(z, R.c2); }
-template <class T> __device__ __forceinline__ Vec3<T> mul(const Mat3<T>& R, Vec3<T> v) { return v.x * R.c0 + v.y * R.c1 + v.z * R.c2; }
-template <class T> __device__ __forceinline__ Vec3<T> mulT(const Mat3<T>& R, Vec3<T> v) { return Vec3<T>(dot(R.c0, v), dot(R.c1, v), dot(R.c2, v)); }
+template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> mul(const Mat3<A>& R, Vec3<B> v) { return v.x * R.c0 + v.y * R.c1 + v.z * R.c2; }
+template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> mulT(const Mat3<A>& R, Vec3<B> v) { return Vec3<ProdT<A, B>>(dot(R.c0, v), dot(R.c1, v), dot(R.c2, v)); }
 
 // symmetric 3x3: xx xy xz yy yz zz
 template <class T> struct Sym3 {
   T xx, xy, xz, yy, yz, zz;
   __device__ __forceinline__ Sym3() : xx(0.0), xy(0.0), xz(0.0), yy(0.0), yz(0.0), zz(0.0) {}
 };
-template <class T> __device__ __forceinline__ Vec3<T> mul(const Sym3<T>& S, Vec3<T> v) {
-  return Vec3<T>(S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z);
+template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> mul(const Sym3<A>& S, Vec3<B> v) {
+  return Vec3<ProdT<A, B>>(S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z);
 }
 
 }  // namespace qmk

@@ -1,70 +1,18 @@
-// ad_node_kernel + lq_node_kernel -- per-node LQ approximation and constraint projection.  One wavefront per shooting node.
-// Two launches so that each half gets the occupancy it can use: the AD sweep is fp64-VALU bound and needs the whole register file
-// (one wavefront per SIMD, 36.5 KiB of LDS only for parking), the projection is latency bound and runs two wavefronts per SIMD
-// (19.7 KiB of LDS, 187 VGPRs).  The AD rows (17 KiB per node: tangent rows of the RK2 increment, the constraint rows and the
-// end-effector error) cross HBM once in between.
+// lq_node_kernel -- per-node cost, constraint projection and projected stage record.  One wavefront per shooting node.
+// The derivative rows it consumes come from ad_node_kernel (ad_kernel.h): two launches so that each half gets the occupancy it can
+// use -- the AD sweep is fp64-VALU bound and needs the whole register file, the projection is latency bound and runs two wavefronts
+// per SIMD (19.7 KiB of LDS, 187 VGPRs).  The AD rows (17 KiB per node) cross HBM once in between.
 //
-// Replaces, per node: QMPreComputation::request (QMPreComputation.cpp:50-89),
-// QMDynamicsAD::linearApproximation x2 for the RK2 stages (QMDynamicsAD.cpp:30-33), the quadratic approximation of the
-// tracking cost / EE soft constraint / joint-limit and friction-cone barriers (QMInterface.cpp:99-121), the per-foot
-// equality constraints (QMInterface.cpp:123-131) and upstream ocs2_sqp's discretisation + QR constraint projection.
+// Replaces, per node: the quadratic approximation of the tracking cost / EE soft
+// constraint / joint-limit and friction-cone barriers (QMInterface.cpp:99-121) and upstream ocs2_sqp's QR constraint projection.
 //
-// Wave layout
-//   ad_node   lane l carries the tangent d/dx_l (l<30) or d/du_{l-30} (30<=l<60) through BOTH RK2 stages, so after the sweep lane l
-//             owns column l of [A_d | B_d] and of every constraint / EE-error Jacobian (du.h); lane 60 carries the values.
-//   lq_node   lane c<30 owns entry c of the cost gradients and column c of [C | e]; the Householder QR of D_v^T keeps one column per
-//             lane in registers and broadcasts reflectors with v_readlane; every dense product runs on v_mfma_f64_16x16x4_f64 with
-//             operands read from LDS (or assembled in registers) in the lane layout of gpu_rt.h; results leave in accumulator layout.
+// Wave layout: lane c<30 owns entry c of the cost gradients and column c of [C | e]; the Householder QR of D_v^T keeps one column per
+// lane in registers and broadcasts reflectors with v_readlane; every dense product runs on v_mfma_f64_16x16x4_f64 with operands
+// read from LDS (or assembled in registers) in the lane layout of gpu_rt.h; results leave in accumulator layout.
 #pragma once
-#include "layout.h"
-#include "schedule_dev.h"
-#include "sweep_dev.h"
+#include "ad_kernel.h"
 
 namespace qmk {
-
-struct LqArgs {
-  const qmgpu_problem* P;
-  const double* Rw;          // R' [30][30]
-  int batch, N, K;
-  const double* tgrid;       // [batch][N+1]
-  const double* X;           // [batch][N+1][30] current iterate
-  const double* U;           // [batch][N][30]
-  const double* targetTimes; // [batch][K]
-  const double* targetStates;// [batch][K][37]
-  const int* schedNum;       // [batch]
-  const double* schedTimes;  // [batch][MAX_EVENTS]
-  const int* schedModes;     // [batch][MAX_EVENTS+1]
-  const double* zeros;       // >= 64 zeros
-  double* stages;            // [batch][N+1][STAGE_DOUBLES]
-  int* stageNc;              // [batch][N+1]
-  int* nodeMode;             // [batch][N+1]
-  double* metrics;           // [batch][N+1][NODE_METRICS]
-  double* debug;             // [batch][N+1][DBG_DOUBLES] or null
-  double* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
-  const int* done;           // [batch] instances whose SQP iterations have converged are skipped
-};
-
-// AD rows: one 64-double row per differentiated scalar; entry l < 60 = d/d(x,u)_l, entry 60 = the value itself
-constexpr int AD_PHI = 0;                    // [12] RK2 increment phi = dt/2 (k1 + k2) of the momentum / base-pose states
-constexpr int AD_CD = AD_PHI + 12 * 64;      // [16] equality constraint rows
-constexpr int AD_EE = AD_CD + 16 * 64;       // [6]  end-effector pose error
-constexpr int AD_DOUBLES = AD_EE + 6 * 64;   // 2176
-
-struct DuIn {
-  const double* x;
-  const double* u;
-  int lane;
-  double dtS;
-  const double* k1p;  // first-stage slope parked in LDS (lane-private column): entry i = (k1p[2 i * 64], k1p[(2 i + 1) * 64]); unused while dtS == 0
-  __device__ __forceinline__ Du sx(int i) const { return Du(x[i], lane == i ? 1.0 : 0.0); }
-  __device__ __forceinline__ Du su(int i) const { return Du(u[i], lane == 30 + i ? 1.0 : 0.0); }
-  __device__ __forceinline__ Du k1(int i) const { return Du(k1p[(2 * i) * 64], k1p[(2 * i + 1) * 64]); }
-  __device__ __forceinline__ Du hn(int i) const { return dtS != 0.0 ? sx(i) + dtS * k1(i) : sx(i); }
-  __device__ __forceinline__ Du euler(int i) const { return dtS != 0.0 ? sx(9 + i) + dtS * k1(9 + i) : sx(9 + i); }
-  __device__ __forceinline__ Du q(int j) const { return sx(12 + j) + dtS * su(12 + j); }
-  __device__ __forceinline__ Du qd(int j) const { return su(12 + j); }
-  __device__ __forceinline__ Vec3<Du> force(int c) const { return Vec3<Du>(su(3 * c), su(3 * c + 1), su(3 * c + 2)); }
-};
 
 // LDS of lq_node_kernel (doubles): 19.7 KiB per node, eight nodes per CU = TWO wavefronts per SIMD.  The kernel is latency bound
 // (readlane chains, LDS round trips, dependent matrix-core accumulations): at one wavefront per SIMD it ran 1.10 ms per launch.
@@ -85,16 +33,10 @@ constexpr int L_PA = L_X + X_DOUBLES;        // rows 12..29 of Pall [18][PAW]  /
 constexpr int L_EEJ = L_PA + 18 * PAW;       // EE error Jacobian [6][32]
 constexpr int L_VEC = L_EEJ + 192;           // b[30] r[30] e[16] eeh[6] (+2) | fin[64] | pe[12] fb[36] ddp[6] ddv[6] (+4)
 constexpr int L_RED = L_VEC + 84 + 64 + 64;  // wavefront exchange scratch
-#ifdef QMGPU_HOST_EMULATION
-constexpr int RED_DOUBLES = 256;             // the emulated cross-lane primitives exchange through this scratch
-#else
 constexpr int RED_DOUBLES = 64;
-#endif
 constexpr int LQ_LDS_DOUBLES = L_RED + RED_DOUBLES;
 static_assert(16 * CDW <= 18 * PAW && 32 * LDQ + 16 * LDY <= X_DOUBLES && 2 * 32 * LDT <= X_DOUBLES && 32 * LDW <= X_DOUBLES, "aliases must fit");
-#ifndef QMGPU_HOST_EMULATION
 static_assert(LQ_LDS_DOUBLES * 8 <= 20480, "eight nodes per CU");
-#endif
 
 // Both kernels of this file run one wavefront per workgroup: LDS hand-offs between lanes need no hardware barrier (a wavefront's
 // LDS operations complete in issue order), only the compiler fence QM_WAVE_SYNC() -- and, unlike __syncthreads(), that does not
@@ -115,109 +57,6 @@ __device__ __forceinline__ double waveSum(double* red, int lane, double v) {
   for (int i = 0; i < 64; ++i) s += red[i];
   QM_WAVE_SYNC();
   return s;
-}
-
-// ---- kernel 1: both RK2 stages with lane tangents; rows go straight from registers to HBM (512-byte coalesced stores)
-__global__ void __launch_bounds__(64) ad_node_kernel(LqArgs a) {
-  const int lane = threadIdx.x;
-  const int node = blockIdx.x % (a.N + 1);
-  const int inst = blockIdx.x / (a.N + 1);
-  if (a.done[inst]) return;
-  const bool terminal = node == a.N;
-  const qmgpu_model& md = a.P->model;
-  const qmgpu_settings& st = a.P->settings;
-  double* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
-  auto putRow = [&](int base, int row, Du h) { ad[base + row * 64 + lane] = (lane == 60) ? h.v : h.d; };
-  // Foot positions / joint-induced velocities wait in LDS (lane-private columns, conflict free) until the base twist is known
-  // at the end of the sweep: 96 VGPRs less for the register allocator during the tree sweep.
-  __shared__ double park[4 * 12 * 64];
-  auto parkFoot = [&](int c, const Vec3<Du>& r, const Vec3<Du>& v) {
-    double* p = park + (c * 12) * 64 + lane;
-    p[0] = r.x.v; p[64] = r.x.d; p[128] = r.y.v; p[192] = r.y.d; p[256] = r.z.v; p[320] = r.z.d;
-    p[384] = v.x.v; p[448] = v.x.d; p[512] = v.y.v; p[576] = v.y.d; p[640] = v.z.v; p[704] = v.z.d;
-  };
-  auto loadFoot = [&](int c, Vec3<Du>& r, Vec3<Du>& v) {
-    const double* p = park + (c * 12) * 64 + lane;
-    r = Vec3<Du>(Du(p[0], p[64]), Du(p[128], p[192]), Du(p[256], p[320]));
-    v = Vec3<Du>(Du(p[384], p[448]), Du(p[512], p[576]), Du(p[640], p[704]));
-  };
-
-  const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
-  const double t = tg[node];
-  const double dt = terminal ? 0.0 : tg[node + 1] - t;
-  const double* xG = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
-  const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
-  __shared__ double xu[64];   // x | u staged once: the sweep reads them with wave-uniform indices
-  if (lane < 30) { xu[lane] = xG[lane]; xu[32 + lane] = uG[lane]; }
-  QM_WAVE_SYNC();
-  const double* x = xu; const double* u = xu + 32;
-  const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
-  const int phase = nodePhaseAt(sched, t);
-  const int mode = sched.modes[phase];
-  const double* tTimes = a.targetTimes + size_t(inst) * a.K;
-  const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
-  double eePosRef[3], eeQuatRef[4];
-  eeReference(tTimes, tStates, a.K, t, eePosRef, eeQuatRef);
-
-  // ================================================================== phase AD: both RK2 stages with lane tangents
-  __shared__ double parkK[24 * 64];   // first-stage slope k1 (12 dual numbers per lane), parked during the second sweep
-  double* k1p = parkK + lane;
-  int nc = 0;
-#pragma unroll 1
-  for (int stage = 0; stage < (terminal ? 1 : 2); ++stage) {
-    const DuIn in{x, u, qmOpaqueLane(lane), stage ? dt : 0.0, k1p};
-    Du f[12];
-    BaseMotion<Du> bm;
-    const Du p0x = in.sx(6), p0y = in.sx(7), p0z = in.sx(8);   // base position (only the first stage uses it: EE error, swing height)
-    centroidalSweep<Du>(
-        md, st.gravity, in, [&](int c, Vec3<Du> r, Vec3<Du> v) { parkFoot(c, r, v); },
-        [&](Vec3<Du> r, const Mat3<Du>& R) {
-          if (stage == 0) {  // end-effector pose error (EndEffectorConstraint.cpp:36-78), rows -> LDS
-            Du qee[4];
-            matrixToQuaternion(R, qee);
-            const Vec3<Du> od = quaternionDistance(qee, eeQuatRef);
-            const Du h[6] = {p0x + r.x - eePosRef[0], p0y + r.y - eePosRef[1], p0z + r.z - eePosRef[2], od.x, od.y, od.z};
-#pragma unroll
-            for (int q = 0; q < 6; ++q) putRow(AD_EE, q, h[q]);
-          }
-        },
-        f, bm);
-    if (stage == 0) {
-      // ---- equality constraints in the insertion order of QMInterface.cpp:116-131 -> rows [C | D | e] in LDS
-      if (!terminal) {
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-          const bool contact = contactOf(mode, c);
-          Vec3<Du> r, vj;
-          loadFoot(c, r, vj);
-          const Vec3<Du> vf = bm.dp + cross(bm.omega, r) + vj;
-          auto putC = [&](int row, Du h) { putRow(AD_CD, row, h); };
-          if (contact) {  // zeroVelocity (QMInterface.cpp:126, 324-339)
-            putC(nc, vf.x); putC(nc + 1, vf.y); putC(nc + 2, vf.z + st.position_error_gain * (p0z + r.z));   // Ax(2,2) = positionErrorGain
-            nc += 3;
-          } else {  // zeroForce (QMInterface.cpp:123-124) then normalVelocity (QMPreComputation.cpp:56-66)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) putC(nc + q, in.su(3 * c + q));
-            double zp, zv;
-            swingReference(st, sched, c, t, phase, zp, zv);
-            putC(nc + 3, vf.z - zv + st.position_error_gain * (p0z + r.z - zp));
-            nc += 4;
-          }
-        }
-      }
-      if (terminal) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) putRow(AD_PHI, i, f[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { k1p[(2 * i) * 64] = f[i].v; k1p[(2 * i + 1) * 64] = f[i].d; }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) putRow(AD_PHI, i, 0.5 * dt * (in.k1(i) + f[i]));   // phi = dt/2 (k1 + k2)
-    }
-  }
-  if (lane == 0) { a.stageNc[size_t(inst) * (a.N + 1) + node] = nc; a.nodeMode[size_t(inst) * (a.N + 1) + node] = mode; }
 }
 
 // ---- kernel 2: cost, projection, projected stage record

@@ -92,48 +92,74 @@ template <class T> __device__ __forceinline__ void baseRotation(T yaw, T pitch, 
   R.c2 = Vec3<T>(cz * sy * cx + sz * sx, sz * sy * cx - cz * sx, cy * cx);
 }
 
-template <class T> __device__ __forceinline__ Vec3<T> solveSym3(const Sym3<T>& S, Vec3<T> b) {
-  const T c00 = S.yy * S.zz - S.yz * S.yz;
-  const T c01 = S.yz * S.xz - S.xy * S.zz;
-  const T c02 = S.xy * S.yz - S.yy * S.xz;
-  const T det = S.xx * c00 + S.xy * c01 + S.xz * c02;
-  const T c11 = S.xx * S.zz - S.xz * S.xz;
-  const T c12 = S.xy * S.xz - S.xx * S.yz;
-  const T c22 = S.xx * S.yy - S.xy * S.xy;
-  const T id = 1.0 / det;
-  return Vec3<T>((c00 * b.x + c01 * b.y + c02 * b.z) * id, (c01 * b.x + c11 * b.y + c12 * b.z) * id, (c02 * b.x + c12 * b.y + c22 * b.z) * id);
+template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> solveSym3(const Sym3<A>& S, Vec3<B> b) {
+  const A c00 = S.yy * S.zz - S.yz * S.yz;
+  const A c01 = S.yz * S.xz - S.xy * S.zz;
+  const A c02 = S.xy * S.yz - S.yy * S.xz;
+  const A det = S.xx * c00 + S.xy * c01 + S.xz * c02;
+  const A c11 = S.xx * S.zz - S.xz * S.xz;
+  const A c12 = S.xy * S.xz - S.xx * S.yz;
+  const A c22 = S.xx * S.yy - S.xy * S.xy;
+  const A id = 1.0 / det;
+  return Vec3<ProdT<A, B>>((c00 * b.x + c01 * b.y + c02 * b.z) * id, (c01 * b.x + c11 * b.y + c12 * b.z) * id, (c02 * b.x + c12 * b.y + c22 * b.z) * id);
 }
 
 // Closes the sweep: given the accumulators, the normalized momentum hn (6), the summed contact force and its torque about
 // the base origin, produce f[0..11] = [d(h_lin/m), d(h_ang/m), dp_base, d(zyx)] and the base twist (dp, omega) + com.
-template <class T> struct BaseMotion {
-  Vec3<T> dp, omega, com;
+// Three scalar types (du.h): P for quantities that depend on the configuration only, V for quantities that are also linear in a
+// velocity-like argument (joint rates, momentum), F for the contact forces.  Plain evaluation: P = V = F = double.
+template <class P, class V> struct Accum2 {
+  Vec3<P> M1;
+  Vec3<V> hl, ha;
+  Sym3<P> Io;
 };
-template <class T>
-__device__ __forceinline__ void closeSweep(const qmgpu_model& md, double gravity, const Accum<T>& acc, const T hn[6], Vec3<T> fsum, Vec3<T> tsum, T sz, T cz, T sy, T cy,
-                                           T f[12], BaseMotion<T>& bm) {
+template <class P, class V> struct BaseMotion2 {
+  Vec3<V> dp, omega;
+  Vec3<P> com;
+};
+template <class P, class V, class F> struct FlowOut {
+  ProdT<double, F> lin[3];   // d(h_lin / m)
+  ProdT<P, F> ang[3];        // d(h_ang / m)
+  V kin[6];                  // base position rates, Euler ZYX rates
+};
+template <class P, class V, class F>
+__device__ __forceinline__ void closeSweep2(const qmgpu_model& md, double gravity, const Accum2<P, V>& acc, const V hn[6], Vec3<F> fsum, Vec3<ProdT<P, F>> tsum, P sz, P cz, P sy, P cy,
+                                            FlowOut<P, V, F>& f, BaseMotion2<P, V>& bm) {
   const double m = md.total_mass, im = 1.0 / md.total_mass;
-  const Vec3<T> cm = scale(im, acc.M1);
-  const T cc = dot(cm, cm);
-  Sym3<T> Ic;
+  const Vec3<P> cm = scale(im, acc.M1);
+  const P cc = dot(cm, cm);
+  Sym3<P> Ic;
   Ic.xx = acc.Io.xx - m * (cc - cm.x * cm.x);
   Ic.yy = acc.Io.yy - m * (cc - cm.y * cm.y);
   Ic.zz = acc.Io.zz - m * (cc - cm.z * cm.z);
   Ic.xy = acc.Io.xy + m * (cm.x * cm.y);
   Ic.xz = acc.Io.xz + m * (cm.x * cm.z);
   Ic.yz = acc.Io.yz + m * (cm.y * cm.z);
-  const Vec3<T> haC = acc.ha - cross(cm, acc.hl);
-  const Vec3<T> rhsL = Vec3<T>(m * hn[0], m * hn[1], m * hn[2]) - acc.hl;
-  const Vec3<T> rhsA = Vec3<T>(m * hn[3], m * hn[4], m * hn[5]) - haC;
-  const Vec3<T> om = solveSym3(Ic, rhsA);
-  const Vec3<T> dp = scale(im, rhsL) - cross(om, cm);
-  const T tmp = (cz * om.x + sz * om.y) / cy;
-  f[0] = im * fsum.x; f[1] = im * fsum.y; f[2] = im * fsum.z - gravity;
-  const Vec3<T> ta = scale(im, tsum - cross(cm, fsum));
-  f[3] = ta.x; f[4] = ta.y; f[5] = ta.z;
-  f[6] = dp.x; f[7] = dp.y; f[8] = dp.z;
-  f[9] = sy * tmp + om.z; f[10] = cz * om.y - sz * om.x; f[11] = tmp;
+  const Vec3<V> haC = acc.ha - cross(cm, acc.hl);
+  const Vec3<V> rhsL = Vec3<V>(m * hn[0], m * hn[1], m * hn[2]) - acc.hl;
+  const Vec3<V> rhsA = Vec3<V>(m * hn[3], m * hn[4], m * hn[5]) - haC;
+  const Vec3<V> om = solveSym3(Ic, rhsA);
+  const Vec3<V> dp = scale(im, rhsL) - cross(om, cm);
+  const V tmp = (cz * om.x + sz * om.y) / cy;
+  f.lin[0] = im * fsum.x; f.lin[1] = im * fsum.y; f.lin[2] = im * fsum.z - gravity;
+  const Vec3<ProdT<P, F>> ta = scale(im, tsum - cross(cm, fsum));
+  f.ang[0] = ta.x; f.ang[1] = ta.y; f.ang[2] = ta.z;
+  f.kin[0] = dp.x; f.kin[1] = dp.y; f.kin[2] = dp.z;
+  f.kin[3] = sy * tmp + om.z; f.kin[4] = cz * om.y - sz * om.x; f.kin[5] = tmp;
   bm.dp = dp; bm.omega = om; bm.com = cm;
+}
+template <class T> using BaseMotion = BaseMotion2<T, T>;
+template <class T>
+__device__ __forceinline__ void closeSweep(const qmgpu_model& md, double gravity, const Accum<T>& acc, const T hn[6], Vec3<T> fsum, Vec3<T> tsum, T sz, T cz, T sy, T cy,
+                                           T f[12], BaseMotion<T>& bm) {
+  Accum2<T, T> a2;
+  a2.M1 = acc.M1; a2.hl = acc.hl; a2.ha = acc.ha; a2.Io = acc.Io;
+  FlowOut<T, T, T> o;
+  closeSweep2<T, T, T>(md, gravity, a2, hn, fsum, tsum, sz, cz, sy, cy, o, bm);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { f[i] = o.lin[i]; f[3 + i] = o.ang[i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) f[6 + i] = o.kin[i];
 }
 
 // Eigen::Quaternion(Matrix3) (what ocs2::matrixToQuaternion forwards to); q = (x, y, z, w).  Branches on primal values only.

@@ -14,15 +14,17 @@ namespace qmk {
 // linear in the joint rates, so the momentum a joint contributes is just (composite inertia of its subtree) x (joint twist) -- no
 // forward velocity pass is needed: one backward pass per chain yields mass moments, inertia, joint-induced momentum and the
 // position / velocity (/ orientation) of the frame at the chain's tip, all in the frame of the chain's root and about its origin.
-template <class T> struct ChainAcc {
+// Scalar types as in model_dev.h: P = configuration-only quantities, V = quantities also linear in the joint rates / momenta.
+template <class P, class V> struct ChainAcc {
   double M;            // composite mass
-  Vec3<T> h;           // first moment  sum m c
-  Sym3<T> I;           // inertia about the current origin
-  Vec3<T> l, k;        // momentum caused by the joint rates of the subtree (k about the current origin)
-  Vec3<T> p, vf;       // tip frame: position, velocity caused by the joint rates
+  Vec3<P> h;           // first moment  sum m c
+  Sym3<P> I;           // inertia about the current origin
+  Vec3<V> l, k;        // momentum caused by the joint rates of the subtree (k about the current origin)
+  Vec3<P> p;           // tip frame: position
+  Vec3<V> vf;          // tip frame: velocity caused by the joint rates
 };
 
-template <class T> __device__ __forceinline__ void rotAxis(int axis, T cs, T sn, Vec3<T>& v) {
+template <class C, class T> __device__ __forceinline__ void rotAxis(int axis, C cs, C sn, Vec3<T>& v) {
   if (axis == 0) { const T a = v.y, b = v.z; v.y = cs * a - sn * b; v.z = sn * a + cs * b; }
   else if (axis == 1) { const T a = v.z, b = v.x; v.z = cs * a - sn * b; v.x = sn * a + cs * b; }
   else { const T a = v.x, b = v.y; v.x = cs * a - sn * b; v.y = sn * a + cs * b; }
@@ -54,11 +56,11 @@ template <class T> __device__ __forceinline__ void rotSym(int axis, T cs, T sn, 
 }
 
 // add body b (its own frame = the current frame) to the composite: constants only
-template <class T> __device__ __forceinline__ void addBody(const qmgpu_model& md, int b, ChainAcc<T>& c) {
+template <class P, class V> __device__ __forceinline__ void addBody(const qmgpu_model& md, int b, ChainAcc<P, V>& c) {
   const double m = md.mass[b], cx = md.com[b][0], cy = md.com[b][1], cz = md.com[b][2];
   const double* in = md.inertia[b];
   c.M += m;
-  c.h = c.h + Vec3<T>(T(m * cx), T(m * cy), T(m * cz));
+  c.h = c.h + Vec3<P>(P(m * cx), P(m * cy), P(m * cz));
   c.I.xx = c.I.xx + (in[0] + m * (cy * cy + cz * cz)); c.I.yy = c.I.yy + (in[3] + m * (cx * cx + cz * cz)); c.I.zz = c.I.zz + (in[5] + m * (cx * cx + cy * cy));
   c.I.xy = c.I.xy + (in[1] - m * cx * cy); c.I.xz = c.I.xz + (in[2] - m * cx * cz); c.I.yz = c.I.yz + (in[4] - m * cy * cz);
 }
@@ -69,26 +71,26 @@ template <class T> __device__ __forceinline__ void addBody(const qmgpu_model& md
 __device__ constexpr int LEG_AXIS[3] = {0, 1, 1};
 __device__ constexpr int ARM_AXIS[6] = {2, 1, 1, 1, 2, 0};
 
-template <class T, class RotExtra> __device__ __forceinline__ void crossJoint(const qmgpu_model& md, int b, int axis, T q, T qd, ChainAcc<T>& c, RotExtra&& rotExtra) {
+template <class P, class V, class RotExtra> __device__ __forceinline__ void crossJoint(const qmgpu_model& md, int b, int axis, P q, V qd, ChainAcc<P, V>& c, RotExtra&& rotExtra) {
   c.l = c.l + qd * axisCross(axis, c.h);
   c.k = c.k + qd * symColumn(axis, c.I);
   c.vf = c.vf + qd * axisCross(axis, c.p);
-  T sn, cs;
+  P sn, cs;
   sincosT(q, sn, cs);
   rotAxis(axis, cs, sn, c.h); rotAxis(axis, cs, sn, c.l); rotAxis(axis, cs, sn, c.k); rotAxis(axis, cs, sn, c.p); rotAxis(axis, cs, sn, c.vf);
   rotSym(axis, cs, sn, c.I);
   rotExtra(axis, cs, sn);
   const double ox = md.joint_offset[b][0], oy = md.joint_offset[b][1], oz = md.joint_offset[b][2], M = c.M;
   // k about the new origin, inertia about the new origin (uses h about the old one), then h and the tip position
-  c.k = c.k + Vec3<T>(oy * c.l.z - oz * c.l.y, oz * c.l.x - ox * c.l.z, ox * c.l.y - oy * c.l.x);
+  c.k = c.k + Vec3<V>(oy * c.l.z - oz * c.l.y, oz * c.l.x - ox * c.l.z, ox * c.l.y - oy * c.l.x);
   c.I.xx = c.I.xx + (2.0 * (oy * c.h.y + oz * c.h.z) + M * (oy * oy + oz * oz));
   c.I.yy = c.I.yy + (2.0 * (ox * c.h.x + oz * c.h.z) + M * (ox * ox + oz * oz));
   c.I.zz = c.I.zz + (2.0 * (ox * c.h.x + oy * c.h.y) + M * (ox * ox + oy * oy));
   c.I.xy = c.I.xy - ((ox * c.h.y + oy * c.h.x) + M * ox * oy);
   c.I.xz = c.I.xz - ((ox * c.h.z + oz * c.h.x) + M * ox * oz);
   c.I.yz = c.I.yz - ((oy * c.h.z + oz * c.h.y) + M * oy * oz);
-  c.h = c.h + Vec3<T>(T(M * ox), T(M * oy), T(M * oz));
-  c.p = c.p + Vec3<T>(T(ox), T(oy), T(oz));
+  c.h = c.h + Vec3<P>(P(M * ox), P(M * oy), P(M * oz));
+  c.p = c.p + Vec3<P>(P(ox), P(oy), P(oz));
 }
 
 template <class T> __device__ __forceinline__ Sym3<T> similarity(const Mat3<T>& R, const Sym3<T>& S) {  // R S R^T
@@ -105,66 +107,78 @@ template <class T> __device__ __forceinline__ Sym3<T> similarity(const Mat3<T>& 
   return W;
 }
 
-// In must provide: T hn(i) i<6 ; T euler(i) i<3 ; T q(j), T qd(j) j<18 (joint order) ; Vec3<T> force(c) c<4 (contact order)
+// In must provide: V hn(i) i<6 ; P euler(i) i<3 ; P q(j), V qd(j) j<18 (joint order) ; Vec3<F> force(c) c<4 (contact order)
 // onEE(r_ee_rel_base, R_ee) is called once, onFoot(c, r_rel_base, v_joint_only) four times (world axes, relative to the base origin).
-template <class T, class In, class FootFn, class EeFn>
-__device__ __forceinline__ void centroidalSweep(const qmgpu_model& md, double gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, T f[12], BaseMotion<T>& bm) {
-  T sz, cz, sy, cy;
-  Mat3<T> R0;
+template <class P, class V, class F, class In, class FootFn, class EeFn>
+__device__ __forceinline__ void centroidalSweep2(const qmgpu_model& md, double gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, FlowOut<P, V, F>& f, BaseMotion2<P, V>& bm) {
+  P sz, cz, sy, cy;
+  Mat3<P> R0;
   baseRotation(in.euler(0), in.euler(1), in.euler(2), R0, sz, cz, sy, cy);
   // totals in the base frame, about the base origin; start with the base body itself
-  ChainAcc<T> tot;
+  ChainAcc<P, V> tot;
   tot.M = 0.0;
   addBody(md, 0, tot);
-  auto absorb = [&](const ChainAcc<T>& c) {
+  auto absorb = [&](const ChainAcc<P, V>& c) {
     tot.M += c.M; tot.h = tot.h + c.h; tot.l = tot.l + c.l; tot.k = tot.k + c.k;
     tot.I.xx = tot.I.xx + c.I.xx; tot.I.xy = tot.I.xy + c.I.xy; tot.I.xz = tot.I.xz + c.I.xz; tot.I.yy = tot.I.yy + c.I.yy; tot.I.yz = tot.I.yz + c.I.yz; tot.I.zz = tot.I.zz + c.I.zz;
   };
   {  // arm: bodies 18 .. 13, tip = end-effector frame (its orientation is carried along)
-    ChainAcc<T> c;
+    ChainAcc<P, V> c;
     c.M = 0.0;
-    c.p = Vec3<T>(T(md.ee_offset[0]), T(md.ee_offset[1]), T(md.ee_offset[2]));
-    Mat3<T> Re;
-    Re.c0 = Vec3<T>(T(1.0), T(0.0), T(0.0)); Re.c1 = Vec3<T>(T(0.0), T(1.0), T(0.0)); Re.c2 = Vec3<T>(T(0.0), T(0.0), T(1.0));
+    c.p = Vec3<P>(P(md.ee_offset[0]), P(md.ee_offset[1]), P(md.ee_offset[2]));
+    Mat3<P> Re;
+    Re.c0 = Vec3<P>(P(1.0), P(0.0), P(0.0)); Re.c1 = Vec3<P>(P(0.0), P(1.0), P(0.0)); Re.c2 = Vec3<P>(P(0.0), P(0.0), P(1.0));
 #pragma unroll
     for (int a = 5; a >= 0; --a) {
       addBody(md, 13 + a, c);
-      crossJoint(md, 13 + a, ARM_AXIS[a], in.q(12 + a), in.qd(12 + a), c, [&](int axis, T cs, T sn) { rotAxis(axis, cs, sn, Re.c0); rotAxis(axis, cs, sn, Re.c1); rotAxis(axis, cs, sn, Re.c2); });
+      crossJoint(md, 13 + a, ARM_AXIS[a], in.q(12 + a), in.qd(12 + a), c, [&](int axis, P cs, P sn) { rotAxis(axis, cs, sn, Re.c0); rotAxis(axis, cs, sn, Re.c1); rotAxis(axis, cs, sn, Re.c2); });
     }
     absorb(c);
-    Mat3<T> Rw;
+    Mat3<P> Rw;
     Rw.c0 = mul(R0, Re.c0); Rw.c1 = mul(R0, Re.c1); Rw.c2 = mul(R0, Re.c2);
     onEE(mul(R0, c.p), Rw);
   }
-  Vec3<T> fsum, tsum;
+  Vec3<F> fsum;
+  Vec3<ProdT<P, F>> tsum;
 #pragma unroll 1
   for (int leg = 0; leg < 4; ++leg) {
     int cft = 0;
     for (int k = 1; k < 4; ++k) if (md.foot_body[k] == 3 + 3 * leg) cft = k;
-    ChainAcc<T> c;
+    ChainAcc<P, V> c;
     c.M = 0.0;
-    c.p = Vec3<T>(T(md.foot_offset[cft][0]), T(md.foot_offset[cft][1]), T(md.foot_offset[cft][2]));
+    c.p = Vec3<P>(P(md.foot_offset[cft][0]), P(md.foot_offset[cft][1]), P(md.foot_offset[cft][2]));
 #pragma unroll
     for (int j = 2; j >= 0; --j) {
       addBody(md, 1 + 3 * leg + j, c);
-      crossJoint(md, 1 + 3 * leg + j, LEG_AXIS[j], in.q(3 * leg + j), in.qd(3 * leg + j), c, [](int, T, T) {});
+      crossJoint(md, 1 + 3 * leg + j, LEG_AXIS[j], in.q(3 * leg + j), in.qd(3 * leg + j), c, [](int, P, P) {});
     }
     absorb(c);
-    const Vec3<T> r = mul(R0, c.p), v = mul(R0, c.vf);
-    const Vec3<T> F = in.force(cft);
-    fsum = fsum + F;
-    tsum = tsum + cross(r, F);
+    const Vec3<P> r = mul(R0, c.p);
+    const Vec3<V> v = mul(R0, c.vf);
+    const Vec3<F> Fc = in.force(cft);
+    fsum = fsum + Fc;
+    tsum = tsum + cross(r, Fc);
     onFoot(cft, r, v);
   }
-  Accum<T> acc;
+  Accum2<P, V> acc;
   acc.M1 = mul(R0, tot.h);
   acc.hl = mul(R0, tot.l);
   acc.ha = mul(R0, tot.k);
   acc.Io = similarity(R0, tot.I);
-  T hn[6];
+  V hn[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) hn[i] = in.hn(i);
-  closeSweep(md, gravity, acc, hn, fsum, tsum, sz, cz, sy, cy, f, bm);
+  closeSweep2<P, V, F>(md, gravity, acc, hn, fsum, tsum, sz, cz, sy, cy, f, bm);
+}
+// single scalar type (plain evaluation with T = double; T = Du differentiates along one direction per lane through everything)
+template <class T, class In, class FootFn, class EeFn>
+__device__ __forceinline__ void centroidalSweep(const qmgpu_model& md, double gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, T f[12], BaseMotion<T>& bm) {
+  FlowOut<T, T, T> o;
+  centroidalSweep2<T, T, T>(md, gravity, in, onFoot, onEE, o, bm);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { f[i] = o.lin[i]; f[3 + i] = o.ang[i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) f[6 + i] = o.kin[i];
 }
 
 // four feet held in named registers (a register array indexed by a runtime contact index would be demoted to scratch)

@@ -258,7 +258,7 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
     QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
     LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
               a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows, h->dDone};
-    QM_LAUNCH(ad_node_kernel, B * (N + 1), 64, s, la);
+    QM_LAUNCH(ad_node_kernel, adGridFor(B * (N + 1)), 64, s, la);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[6], s));
     QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));

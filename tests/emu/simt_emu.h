@@ -48,10 +48,15 @@ inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std:
 using std::acos; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::sqrt; using std::sin; using std::cos;
 using std::max; using std::min;
 
-// ---- wavefront exchange primitives.  `scratch` is >= 256 doubles of LDS private to the wavefront: two 128-double buffers used
-// alternately, so one barrier per exchange suffices (a lane can only be one exchange ahead of the slowest lane of its wavefront).
+// ---- wavefront exchange primitives.  The lanes of a wavefront exchange values through a buffer the EMULATION owns (one per
+// wavefront of the running workgroup: two 128-double halves used alternately, so one barrier per exchange suffices -- a lane can
+// only be one exchange ahead of the slowest lane of its wavefront).  The `scratch` argument of the primitives is ignored: product
+// kernels need no LDS for these operations (they are register / DPP / v_readlane instructions on the GPU).
 inline thread_local unsigned g_emuXchg = 0;
-inline double* emuXchgBuf(double* scratch) { return scratch + 128 * ((g_emuXchg++) & 1u); }
+constexpr int kEmuWaveScratch = 4096;
+inline std::vector<std::unique_ptr<double[]>> g_emuWaveScratch;
+inline double* emuWaveScratch() { return g_emuWaveScratch[(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) / 64].get(); }
+inline double* emuXchgBuf(double*) { return emuWaveScratch() + 128 * ((g_emuXchg++) & 1u); }
 
 inline double qmShflXor(double v, int mask, double* scratch) {
   const unsigned lane = threadIdx.x & 63u;
@@ -115,11 +120,11 @@ inline void qmMfma(QmAcc& c, double a, double b, double* scratch) {
   QM_WAVE_SYNC();
   emuMfmaTile(c, buf, buf + 64, lane);
 }
-// all upper-triangle tiles of one k step with a single exchange (own region behind the 256 doubles of the plain exchanges:
-// scratch >= 256 + 2 * TP * 128 doubles)
+// all upper-triangle tiles of one k step with a single exchange (own region behind the 256 doubles of the plain exchanges)
 template <int TP> inline void qmMfmaUpper(QmAcc* acc, const double* a, const double* b, double* scratch) {
   const unsigned lane = threadIdx.x & 63u;
-  double* buf = scratch + 256 + (TP * 128) * ((g_emuXchg++) & 1u);
+  (void)scratch;
+  double* buf = emuWaveScratch() + 256 + (TP * 128) * ((g_emuXchg++) & 1u);
   for (int t = 0; t < TP; ++t) { buf[t * 128 + lane] = a[t]; buf[t * 128 + 64 + lane] = b[t]; }
   QM_WAVE_SYNC();
   int t = 0;
@@ -134,6 +139,8 @@ template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
   std::barrier<> bar(nt);
   g_emuBarrier = &bar;
   g_emuWaveBarriers.clear();
+  g_emuWaveScratch.clear();
+  for (unsigned w = 0; w < (nt + 63) / 64; ++w) g_emuWaveScratch.emplace_back(new double[kEmuWaveScratch]);
   for (unsigned w = 0; w < (nt + 63) / 64; ++w) g_emuWaveBarriers.emplace_back(std::make_unique<std::barrier<>>(std::min(64u, nt - 64 * w)));
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; ++t)
@@ -159,6 +166,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 // device memory is not zeroed by the driver: the emulation fills it with 0xFF (NaN as double, -1 as int32) so that reads of scratch
 // that no kernel wrote show up in the results
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (*p) std::memset(*p, 0xFF, n ? n : 1); return *p ? 0 : 1; }
