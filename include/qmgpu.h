@@ -156,6 +156,13 @@ int qmgpu_time_grid_with_events(double t0, double tf, double dt, int32_t num_eve
 
 /* ---- device context ---------------------------------------------------------------------------- */
 int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, qmgpu_handle* out);
+/* Arithmetic type of the MPC kernels behind a handle.  QMGPU_F64 is the reference's (ocs2::scalar_t = double) and what qmgpu_create
+ * gives.  QMGPU_F32 runs the whole MPC chain (derivatives, projection, Riccati, line search) in IEEE fp32 on
+ * v_mfma_f32_16x16x4_f32 with fp32 scratch; every array of this interface stays fp64 and is converted on the device.  The WBC, the
+ * front end and the policy evaluation always run in fp64.  Exists for BASELINE.json configs[4] (fp32-vs-fp64 tolerance sweep,
+ * DESIGN.md section 5): fp32 results are NOT within the 1e-6 parity bar of the reference. */
+typedef enum qmgpu_dtype { QMGPU_F64 = 0, QMGPU_F32 = 1 } qmgpu_dtype;
+int qmgpu_create_ex(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, int dtype, qmgpu_handle* out);
 int qmgpu_destroy(qmgpu_handle h);
 /* Use an externally owned HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
 int qmgpu_set_stream(qmgpu_handle h, void* hip_stream);

@@ -83,11 +83,13 @@ def time_grid_with_events(t0, tf, dt, event_times, max_nodes=1024, lib=None):
 class GpuSolver:
     """Owns a qmgpu handle (device scratch + stream)."""
 
-    def __init__(self, interface, max_batch, max_nodes, device=0):
+    def __init__(self, interface, max_batch, max_nodes, device=0, dtype="f64"):
+        """dtype "f64" (the reference's arithmetic) or "f32" (MPC kernels in fp32, qmgpu_create_ex; the arrays stay fp64)."""
         self.lib = interface.lib
         self.interface = interface
         self.handle = C.c_void_p()
-        abi.check(self.lib, self.lib.qmgpu_create(C.byref(interface.problem), device, max_batch, max_nodes, C.byref(self.handle)))
+        self.dtype = dtype
+        abi.check(self.lib, self.lib.qmgpu_create_ex(C.byref(interface.problem), device, max_batch, max_nodes, {"f64": abi.F64, "f32": abi.F32}[dtype], C.byref(self.handle)))
 
     def close(self):
         if self.handle:

@@ -39,9 +39,13 @@ def build_library(force=False, verbose=False, extra_flags=()):
         return OUT
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    api_o, host_o = os.path.join(OBJ, "qmgpu_api.o"), os.path.join(OBJ, "host_config.o")
+    api_o, mpc32_o, host_o = os.path.join(OBJ, "qmgpu_api.o"), os.path.join(OBJ, "qmgpu_mpc32.o"), os.path.join(OBJ, "host_config.o")
+    hip_flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *extra_flags]
+    # the kernel sources are written in terms of `real` (kernels/real.h) and compiled twice: fp64 = every kernel + the C ABI,
+    # fp32 = the MPC kernels a second time in namespace qmk32
     cmds = [
-        [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *extra_flags, "-c", os.path.join(CSRC, "qmgpu_api.hip"), "-o", api_o],
+        [hipcc, *hip_flags, "-c", os.path.join(CSRC, "qmgpu_api.hip"), "-o", api_o],
+        [hipcc, *hip_flags, "-DQM_REAL=float", "-Dqmk=qmk32", "-c", os.path.join(CSRC, "qmgpu_mpc32.hip"), "-o", mpc32_o],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, "host", "host_config.cpp"), "-o", host_o],
     ]
     # Inside this repository the process already holds PyTorch's bundled HIP runtime, so link against that one first; a catkin
@@ -49,15 +53,22 @@ def build_library(force=False, verbose=False, extra_flags=()):
     override = os.environ.get("QMGPU_HIP_LIBDIR")
     tl = None if override else _torch_lib_dir()
     libdirs = [override] if override else (([tl] if tl else []) + ["/opt/rocm/lib"])
-    link = ["g++", "-shared", "-o", OUT, api_o, host_o]
+    link = ["g++", "-shared", "-o", OUT, api_o, mpc32_o, host_o]
     for d in libdirs:
         link += [f"-L{d}", f"-Wl,-rpath,{d}"]
     link += ["-lamdhip64", "-lstdc++", "-lm"]
     cmds.append(link)
-    for c in cmds:
+    procs = []
+    for c in cmds[:-1]:   # the three compilations are independent
         if verbose:
             print(" ".join(c), file=sys.stderr)
-        subprocess.check_call(c)
+        procs.append(subprocess.Popen(c))
+    for c, pr in zip(cmds, procs):
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, c)
+    if verbose:
+        print(" ".join(cmds[-1]), file=sys.stderr)
+    subprocess.check_call(cmds[-1])
     return OUT
 
 

@@ -31,24 +31,26 @@
 namespace qmk {
 
 struct LqArgs {
-  const qmgpu_problem* P;
-  const double* Rw;          // R' [30][30]
+  const ProblemR* P;
+  const real* Rw;          // R' [30][30]
   int batch, N, K;
-  const double* tgrid;       // [batch][N+1]
-  const double* X;           // [batch][N+1][30] current iterate
-  const double* U;           // [batch][N][30]
-  const double* targetTimes; // [batch][K]
-  const double* targetStates;// [batch][K][37]
+  const real* tgrid;       // [batch][N+1] node times, the step to the next node (0 at the terminal node) and the phase of the mode schedule
+  const real* dtgrid;      //              the node lies in -- all three formed by mpc_init_kernel from the fp64 times
+  const int* nodePhase;
+  const real* X;           // [batch][N+1][30] current iterate
+  const real* U;           // [batch][N][30]
+  const real* targetTimes; // [batch][K]
+  const real* targetStates;// [batch][K][37]
   const int* schedNum;       // [batch]
-  const double* schedTimes;  // [batch][MAX_EVENTS]
+  const real* schedTimes;  // [batch][MAX_EVENTS]
   const int* schedModes;     // [batch][MAX_EVENTS+1]
-  const double* zeros;       // >= 64 zeros
-  double* stages;            // [batch][N+1][STAGE_DOUBLES]
+  const real* zeros;       // >= 64 zeros
+  real* stages;            // [batch][N+1][STAGE_DOUBLES]
   int* stageNc;              // [batch][N+1]
   int* nodeMode;             // [batch][N+1]
-  double* metrics;           // [batch][N+1][NODE_METRICS]
-  double* debug;             // [batch][N+1][DBG_DOUBLES] or null
-  double* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
+  real* metrics;           // [batch][N+1][NODE_METRICS]
+  real* debug;             // [batch][N+1][DBG_DOUBLES] or null
+  real* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
   const int* done;           // [batch] instances whose SQP iterations have converged are skipped
 };
 
@@ -64,17 +66,17 @@ __host__ __device__ constexpr int adGridFor(int nodes) { return (nodes + AD_NODE
 
 // Inputs of the sweep as seen by one lane: values from the node's x | u staged in LDS, seeds from the lane's direction.
 struct AdIn {
-  const double* x;    // this node's state (30) ...
-  const double* u;    // ... and input (30) in LDS
-  const double* xs;   // the twelve momentum / base-pose states the stage is evaluated at: x (first stage) or x + dt k1 (second)
+  const real* x;    // this node's state (30) ...
+  const real* u;    // ... and input (30) in LDS
+  const real* xs;   // the twelve momentum / base-pose states the stage is evaluated at: x (first stage) or x + dt k1 (second)
   int dd;             // direction 0..20
-  double dtS;         // 0 (first stage) or dt (second stage: q_j + dt v_j)
-  __device__ __forceinline__ Du3 hn(int i) const { return Du3(xs[i], 0.0, (i >= 3 && dd == i - 3) ? 1.0 : 0.0); }
-  __device__ __forceinline__ Du euler(int i) const { return Du(xs[9 + i], dd == i ? 1.0 : 0.0); }
-  __device__ __forceinline__ Du q(int j) const { return Du(fma(dtS, u[12 + j], x[12 + j]), dd == 3 + j ? 1.0 : 0.0); }
-  __device__ __forceinline__ Du3 qd(int j) const { return Du3(u[12 + j], 0.0, dd == 3 + j ? 1.0 : 0.0); }
+  real dtS;         // 0 (first stage) or dt (second stage: q_j + dt v_j)
+  __device__ __forceinline__ Du3 hn(int i) const { return Du3(xs[i], 0.0_r, (i >= 3 && dd == i - 3) ? 1.0_r : 0.0_r); }
+  __device__ __forceinline__ Du euler(int i) const { return Du(xs[9 + i], dd == i ? 1.0_r : 0.0_r); }
+  __device__ __forceinline__ Du q(int j) const { return Du(fma(dtS, u[12 + j], x[12 + j]), dd == 3 + j ? 1.0_r : 0.0_r); }
+  __device__ __forceinline__ Du3 qd(int j) const { return Du3(u[12 + j], 0.0_r, dd == 3 + j ? 1.0_r : 0.0_r); }
   __device__ __forceinline__ Vec3<Du3> force(int c) const {
-    return Vec3<Du3>(Du3(u[3 * c], 0.0, dd == 6 + 3 * c ? 1.0 : 0.0), Du3(u[3 * c + 1], 0.0, dd == 7 + 3 * c ? 1.0 : 0.0), Du3(u[3 * c + 2], 0.0, dd == 8 + 3 * c ? 1.0 : 0.0));
+    return Vec3<Du3>(Du3(u[3 * c], 0.0_r, dd == 6 + 3 * c ? 1.0_r : 0.0_r), Du3(u[3 * c + 1], 0.0_r, dd == 7 + 3 * c ? 1.0_r : 0.0_r), Du3(u[3 * c + 2], 0.0_r, dd == 8 + 3 * c ? 1.0_r : 0.0_r));
   }
 };
 
@@ -86,13 +88,13 @@ constexpr int ADL_PARK = ADL_A2 + AD_NODES * 12 * 16;  // feet of the first stag
 constexpr int AD_PARK_DOUBLES = 4 * 15 * 64;
 constexpr int AD_LDS_DOUBLES = ADL_PARK + AD_PARK_DOUBLES;
 static_assert(AD_NODES * 12 * 64 <= AD_PARK_DOUBLES, "the Jacobian rows reuse the parking area");
-static_assert(AD_LDS_DOUBLES * 8 <= 40960, "four wavefronts per CU");
+static_assert(AD_LDS_DOUBLES * sizeof(real) <= 40960, "four wavefronts per CU");
 
 __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs a) {
-  __shared__ double lds[AD_LDS_DOUBLES];
+  __shared__ real lds[AD_LDS_DOUBLES];
   QM_POISON_LDS(lds, AD_LDS_DOUBLES);
   const int lane = threadIdx.x;
-  const int l16 = lane & 15, h = lane >> 4;
+  const int l16 = lane & 15, h = lane >> 4, la = qmARow(l16);   // la: the row of an A operand this lane supplies (gpu_rt.h)
   const int grp = lane / AD_DIRS < AD_NODES ? lane / AD_DIRS : AD_NODES - 1;   // lane 63 shadows the last lane of node 2 (stores nothing)
   const int dd = qmOpaqueLane(lane < AD_NODES * AD_DIRS ? lane - grp * AD_DIRS : AD_DIRS - 1);
   const int total = a.batch * (a.N + 1);
@@ -101,56 +103,56 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   const int node = gnode % (a.N + 1), inst = gnode / (a.N + 1);
   const bool live = lane < AD_NODES * AD_DIRS && gRaw < total && !a.done[inst];   // this lane's results reach HBM
   const bool terminal = node == a.N;
-  const qmgpu_model& md = a.P->model;
-  const qmgpu_settings& st = a.P->settings;
+  const ModelR& md = a.P->model;
+  const SettingsR& st = a.P->settings;
   // column of the AD row each of this lane's three values goes to
   const int cD = 9 + dd;                                                                   // zyx / q_j
   const int cV = dd < 3 ? 3 + dd : 39 + dd;                                                // h_ang / v_j
   const int cC = dd < 3 ? dd : (dd < 6 ? 3 + dd : (dd < 18 ? 24 + dd : (dd == 18 ? 60 : 42 + dd)));   // h_lin | p | F | value | padding 61, 62
   const bool isF = dd >= 6 && dd < 18, isVal = dd == 18;
 
-  double* ad = a.adrows + size_t(gnode) * AD_DOUBLES;
-  double* xu = lds + ADL_XU + grp * 64;
-  double* x2 = lds + ADL_X2 + grp * 12;
-  double* A2 = lds + ADL_A2 + grp * 192;
-  double* park = lds + ADL_PARK + lane;                 // lane-private columns while the feet wait for the base twist
-  double* L1 = lds + ADL_PARK + grp * 768;              // [12][64] Jacobian rows of this node
+  real* ad = a.adrows + size_t(gnode) * AD_DOUBLES;
+  real* xu = lds + ADL_XU + grp * 64;
+  real* x2 = lds + ADL_X2 + grp * 12;
+  real* A2 = lds + ADL_A2 + grp * 192;
+  real* park = lds + ADL_PARK + lane;                 // lane-private columns while the feet wait for the base twist
+  real* L1 = lds + ADL_PARK + grp * 768;              // [12][64] Jacobian rows of this node
 
-  const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
-  const double t = tg[node];
-  const double dt = terminal ? 0.0 : tg[node + 1] - t;
+  const real* tg = a.tgrid + size_t(inst) * (a.N + 1);
+  const real t = tg[node];
+  const real dt = a.dtgrid[gnode];
   {  // x | u of the three nodes: lanes dd load 30 + 30 values of their node
-    const double* xG = a.X + size_t(gnode) * 30;
-    const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+    const real* xG = a.X + size_t(gnode) * 30;
+    const real* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
     for (int i = dd; i < 30; i += AD_DIRS) { xu[i] = xG[i]; xu[32 + i] = uG[i]; }
   }
   QM_WAVE_SYNC();
-  const double* x = xu; const double* u = xu + 32;
+  const real* x = xu; const real* u = xu + 32;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
-  const int phase = nodePhaseAt(sched, t);
+  const int phase = a.nodePhase[gnode];
   const int mode = sched.modes[phase];
-  double eePosRef[3], eeQuatRef[4];
+  real eePosRef[3], eeQuatRef[4];
   eeReference(a.targetTimes + size_t(inst) * a.K, a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET, a.K, t, eePosRef, eeQuatRef);
 
   // one row of the AD format: the lane's configuration slot, its velocity / force slot and its closed-form column
   const bool owner = lane < AD_NODES * AD_DIRS;   // lane 63 computes along with the others but owns no column
-  auto putRow = [&](double* dst, int row, double dval, double vval, double cval) {
-    double* r = dst + row * 64;
+  auto putRow = [&](real* dst, int row, real dval, real vval, real cval) {
+    real* r = dst + row * 64;
     if (owner) { r[cD] = dval; r[cV] = vval; r[cC] = cval; }
   };
-  auto putGlobal = [&](int base, int row, double dval, double vval, double cval) { if (live) putRow(ad + base, row, dval, vval, cval); };
+  auto putGlobal = [&](int base, int row, real dval, real vval, real cval) { if (live) putRow(ad + base, row, dval, vval, cval); };
 
   int nc = 0;
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
-    const AdIn in{x, u, stage ? x2 : x, dd, stage ? dt : 0.0};
+    const AdIn in{x, u, stage ? x2 : x, dd, stage ? dt : 0.0_r};
     FlowOut<Du, Du3, Du3> f;
     BaseMotion2<Du, Du3> bm;
     centroidalSweep2<Du, Du3, Du3>(
         md, st.gravity, in,
         [&](int c, Vec3<Du> r, Vec3<Du3> v) {
           if (stage == 0) {
-            double* p = park + (c * 15) * 64;
+            real* p = park + (c * 15) * 64;
             p[0] = r.x.v; p[64] = r.x.d; p[128] = r.y.v; p[192] = r.y.d; p[256] = r.z.v; p[320] = r.z.d;
             p[384] = v.x.v; p[448] = v.x.d; p[512] = v.x.e; p[576] = v.y.v; p[640] = v.y.d; p[704] = v.y.e; p[768] = v.z.v; p[832] = v.z.d; p[896] = v.z.e;
           }
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
             const Vec3<Du> od = quaternionDistance(qee, eeQuatRef);
             const Du hq[6] = {x[6] + r.x - eePosRef[0], x[7] + r.y - eePosRef[1], x[8] + r.z - eePosRef[2], od.x, od.y, od.z};
 #pragma unroll
-            for (int q = 0; q < 6; ++q) putGlobal(AD_EE, q, hq[q].d, 0.0, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0 : 0.0));
+            for (int q = 0; q < 6; ++q) putGlobal(AD_EE, q, hq[q].d, 0.0_r, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0_r : 0.0_r));
           }
         },
         f, bm);
@@ -172,22 +174,22 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
           const bool contact = contactOf(mode, c);
-          const double* p = park + (c * 15) * 64;
+          const real* p = park + (c * 15) * 64;
           const Vec3<Du> r(Du(p[0], p[64]), Du(p[128], p[192]), Du(p[256], p[320]));
           const Vec3<Du3> vj(Du3(p[384], p[448], p[512]), Du3(p[576], p[640], p[704]), Du3(p[768], p[832], p[896]));
           const Vec3<Du3> vf = bm.dp + cross(bm.omega, r) + vj;
           // velocity-type row: d/dh_lin = identity through dp; d/dp_z only through the position-error gain
-          auto putVel = [&](int row, Du3 hv, int axisIdx, double gainZ) {
-            putGlobal(AD_CD, row, hv.d, hv.e, isVal ? hv.v : (dd == axisIdx ? 1.0 : (dd == 5 ? gainZ : 0.0)));
+          auto putVel = [&](int row, Du3 hv, int axisIdx, real gainZ) {
+            putGlobal(AD_CD, row, hv.d, hv.e, isVal ? hv.v : (dd == axisIdx ? 1.0_r : (dd == 5 ? gainZ : 0.0_r)));
           };
           if (contact) {  // zeroVelocity (QMInterface.cpp:126, 324-339; Ax(2,2) = positionErrorGain)
-            putVel(nc, vf.x, 0, 0.0); putVel(nc + 1, vf.y, 1, 0.0);
+            putVel(nc, vf.x, 0, 0.0_r); putVel(nc + 1, vf.y, 1, 0.0_r);
             putVel(nc + 2, vf.z + st.position_error_gain * (x[8] + r.z), 2, st.position_error_gain);
             nc += 3;
           } else {  // zeroForce (QMInterface.cpp:123-124) then normalVelocity (QMPreComputation.cpp:56-66)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) putGlobal(AD_CD, nc + q, 0.0, 0.0, isVal ? u[3 * c + q] : (dd == 6 + 3 * c + q ? 1.0 : 0.0));
-            double zp, zv;
+            for (int q = 0; q < 3; ++q) putGlobal(AD_CD, nc + q, 0.0_r, 0.0_r, isVal ? u[3 * c + q] : (dd == 6 + 3 * c + q ? 1.0_r : 0.0_r));
+            real zp, zv;
             swingReference(st, sched, c, t, phase, zp, zv);
             putVel(nc + 3, vf.z - zv + st.position_error_gain * (x[8] + r.z - zp), 2, st.position_error_gain);
             nc += 4;
@@ -197,14 +199,14 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
       QM_WAVE_SYNC();   // every lane has read its parked feet: the area becomes the Jacobian rows
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        putRow(L1, i, f.lin[i].d, 0.0, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0));
-        putRow(L1, 3 + i, f.ang[i].d, 0.0, isF ? f.ang[i].e : (isVal ? f.ang[i].v : 0.0));
+        putRow(L1, i, f.lin[i].d, 0.0_r, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0_r));
+        putRow(L1, 3 + i, f.ang[i].d, 0.0_r, isF ? f.ang[i].e : (isVal ? f.ang[i].v : 0.0_r));
       }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) putRow(L1, 6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0 : 0.0));
+      for (int i = 0; i < 6; ++i) putRow(L1, 6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0_r : 0.0_r));
       if (dd == 19) {   // the columns nobody owns: p (f does not depend on the base position) and padding 63
 #pragma unroll
-        for (int i = 0; i < 12; ++i) L1[i * 64 + 63] = 0.0;
+        for (int i = 0; i < 12; ++i) L1[i * 64 + 63] = 0.0_r;
       }
       if (dd == 0) {
 #pragma unroll
@@ -218,50 +220,50 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
       if (dd < 3) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-          const double dv = i < 3 ? f.lin[i].d : (i < 6 ? f.ang[i - 3].d : f.kin[i - 6].d);
-          const double vv = i < 6 ? 0.0 : f.kin[i - 6].e;
-          A2[i * 16 + dd] = (i >= 6 && i < 9 && i - 6 == dd) ? 1.0 : 0.0;   // d/dh_lin
+          const real dv = i < 3 ? f.lin[i].d : (i < 6 ? f.ang[i - 3].d : f.kin[i - 6].d);
+          const real vv = i < 6 ? 0.0_r : f.kin[i - 6].e;
+          A2[i * 16 + dd] = (i >= 6 && i < 9 && i - 6 == dd) ? 1.0_r : 0.0_r;   // d/dh_lin
           A2[i * 16 + 3 + dd] = vv;                                          // d/dh_ang
-          A2[i * 16 + 6 + dd] = 0.0;                                         // d/dp
+          A2[i * 16 + 6 + dd] = 0.0_r;                                         // d/dp
           A2[i * 16 + 9 + dd] = dv;                                          // d/dzyx
-          A2[i * 16 + 12 + dd] = 0.0;
+          A2[i * 16 + 12 + dd] = 0.0_r;
         }
       } else if (dd == 3) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) A2[i * 16 + 15] = 0.0;
+        for (int i = 0; i < 12; ++i) A2[i * 16 + 15] = 0.0_r;
       }
       QM_WAVE_SYNC();
       // ---- chain rule on the matrix cores: acc[g][tn] = J2[:, 0:12] J1[:, 16 tn ..] for the three nodes
       QmAcc acc[AD_NODES][4];
 #pragma unroll
       for (int g = 0; g < AD_NODES; ++g) {
-        const double* A2g = lds + ADL_A2 + g * 192;
-        const double* L1g = lds + ADL_PARK + g * 768;
-        double av[3];
+        const real* A2g = lds + ADL_A2 + g * 192;
+        const real* L1g = lds + ADL_PARK + g * 768;
+        real av[3];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) { const double raw = A2g[(l16 < 12 ? l16 : 0) * 16 + 4 * ks + h]; av[ks] = l16 < 12 ? raw : 0.0; }
+        for (int ks = 0; ks < 3; ++ks) { const real raw = A2g[(la < 12 ? la : 0) * 16 + 4 * ks + h]; av[ks] = la < 12 ? raw : 0.0_r; }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[g][tn][r] = 0.0;
+          for (int r = 0; r < 4; ++r) acc[g][tn][r] = 0.0_r;
 #pragma unroll
           for (int ks = 0; ks < 3; ++ks) qmMfma(acc[g][tn], av[ks], L1g[(4 * ks + h) * 64 + tn * 16 + l16], nullptr);
         }
       }
       QM_WAVE_SYNC();   // J1 has been read by every lane: the slot owners add J2 (+ dt J2[:, q_j] into the v_j columns) in place
       {
-        const double sh = dd >= 3 ? dt : 0.0;
-        auto addRow = [&](int row, double dval, double vval, double cval) {
-          double* r = L1 + row * 64;
+        const real sh = dd >= 3 ? dt : 0.0_r;
+        auto addRow = [&](int row, real dval, real vval, real cval) {
+          real* r = L1 + row * 64;
           if (owner) { r[cD] += dval; r[cV] += fma(sh, dval, vval); r[cC] += cval; }
         };
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          addRow(i, f.lin[i].d, 0.0, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0));
-          addRow(3 + i, f.ang[i].d, 0.0, isF ? f.ang[i].e : (isVal ? f.ang[i].v : 0.0));
+          addRow(i, f.lin[i].d, 0.0_r, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0_r));
+          addRow(3 + i, f.ang[i].d, 0.0_r, isF ? f.ang[i].e : (isVal ? f.ang[i].v : 0.0_r));
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) addRow(6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0 : 0.0));
+        for (int i = 0; i < 6; ++i) addRow(6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0_r : 0.0_r));
       }
       QM_WAVE_SYNC();
       // ---- phi = dt/2 (k1 + k2): rows leave in accumulator layout (4 rows x 128-byte runs per store instruction)
@@ -272,17 +274,17 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
         const int nodeG = gN % (a.N + 1), instG = gN / (a.N + 1);
         const bool termG = nodeG == a.N;
         const bool liveG = gR < total && !a.done[instG];
-        const double dtG = termG ? 0.0 : a.tgrid[size_t(instG) * (a.N + 1) + nodeG + 1] - a.tgrid[size_t(instG) * (a.N + 1) + nodeG];
-        const double* L1g = lds + ADL_PARK + g * 768;
-        double* adG = a.adrows + size_t(gN) * AD_DOUBLES;
+        const real dtG = a.dtgrid[gN];
+        const real* L1g = lds + ADL_PARK + g * 768;
+        real* adG = a.adrows + size_t(gN) * AD_DOUBLES;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
             const int i = h + 4 * r, c = tn * 16 + l16;
-            const double s = L1g[i * 64 + c];
+            const real s = L1g[i * 64 + c];
             // terminal node: the slope itself (one stage); otherwise dt/2 (J1 + J2 + dt J2x J1), the value column without the product
-            const double v = termG ? 0.5 * s : 0.5 * dtG * (c < 60 ? fma(dtG, acc[g][tn][r], s) : s);
+            const real v = termG ? 0.5_r * s : 0.5_r * dtG * (c < 60 ? fma(dtG, acc[g][tn][r], s) : s);
             if (liveG) adG[AD_PHI + i * 64 + c] = v;
           }
         }

@@ -36,24 +36,24 @@ constexpr int L_RED = L_VEC + 84 + 64 + 64;  // wavefront exchange scratch
 constexpr int RED_DOUBLES = 64;
 constexpr int LQ_LDS_DOUBLES = L_RED + RED_DOUBLES;
 static_assert(16 * CDW <= 18 * PAW && 32 * LDQ + 16 * LDY <= X_DOUBLES && 2 * 32 * LDT <= X_DOUBLES && 32 * LDW <= X_DOUBLES, "aliases must fit");
-static_assert(LQ_LDS_DOUBLES * 8 <= 20480, "eight nodes per CU");
+static_assert(LQ_LDS_DOUBLES * sizeof(real) <= 20480, "eight nodes per CU");
 
 // Both kernels of this file run one wavefront per workgroup: LDS hand-offs between lanes need no hardware barrier (a wavefront's
 // LDS operations complete in issue order), only the compiler fence QM_WAVE_SYNC() -- and, unlike __syncthreads(), that does not
 // wait for the global stores of the stage record that are still in flight.
 // dot product of a broadcast LDS row with a register vector, three independent FMA chains (one wavefront per SIMD: the fp64 FMA
 // latency is hidden by instruction-level parallelism only)
-__device__ __forceinline__ double dot30(const double* row, const double (&z)[30]) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+__device__ __forceinline__ real dot30(const real* row, const real (&z)[30]) {
+  real s0 = 0.0_r, s1 = 0.0_r, s2 = 0.0_r;
 #pragma unroll
   for (int i = 0; i < 30; i += 3) { s0 += row[i] * z[i]; s1 += row[i + 1] * z[i + 1]; s2 += row[i + 2] * z[i + 2]; }
   return s0 + s1 + s2;
 }
 
-__device__ __forceinline__ double waveSum(double* red, int lane, double v) {
+__device__ __forceinline__ real waveSum(real* red, int lane, real v) {
   red[lane] = v;
   QM_WAVE_SYNC();
-  double s = 0.0;
+  real s = 0.0_r;
   for (int i = 0; i < 64; ++i) s += red[i];
   QM_WAVE_SYNC();
   return s;
@@ -61,44 +61,44 @@ __device__ __forceinline__ double waveSum(double* red, int lane, double v) {
 
 // ---- kernel 2: cost, projection, projected stage record
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) lq_node_kernel(LqArgs a) {
-  __shared__ double lds[LQ_LDS_DOUBLES];
+  __shared__ real lds[LQ_LDS_DOUBLES];
   QM_POISON_LDS(lds, LQ_LDS_DOUBLES);
   const int lane = threadIdx.x;
-  const int l16 = lane & 15, h = lane >> 4;
+  const int l16 = lane & 15, h = lane >> 4, la = qmARow(l16);   // la: the row of an A operand this lane supplies (gpu_rt.h)
   const int node = blockIdx.x % (a.N + 1);
   const int inst = blockIdx.x / (a.N + 1);
   if (a.done[inst]) return;
   const bool terminal = node == a.N;
-  const qmgpu_model& md = a.P->model;
-  const qmgpu_settings& st = a.P->settings;
+  const ModelR& md = a.P->model;
+  const SettingsR& st = a.P->settings;
 
-  double* PA = lds + L_PA; double* CD = lds + L_PA;
-  double* AT = lds + L_AT; double* BT = lds + L_BT; double* WT = lds + L_WT;
-  double* EEJ = lds + L_EEJ; double* bv = lds + L_VEC; double* rv = bv + 30; double* ev = rv + 30; double* eeh = ev + 16;
-  double* fin = bv + 84; double* pev = fin + 64; double* fb = pev + 12; double* ddp = fb + 36; double* ddv = ddp + 6;
-  double* red = lds + L_RED;
+  real* PA = lds + L_PA; real* CD = lds + L_PA;
+  real* AT = lds + L_AT; real* BT = lds + L_BT; real* WT = lds + L_WT;
+  real* EEJ = lds + L_EEJ; real* bv = lds + L_VEC; real* rv = bv + 30; real* ev = rv + 30; real* eeh = ev + 16;
+  real* fin = bv + 84; real* pev = fin + 64; real* fb = pev + 12; real* ddp = fb + 36; real* ddv = ddp + 6;
+  real* red = lds + L_RED;
 
-  const double* tg = a.tgrid + size_t(inst) * (a.N + 1);
-  const double t = tg[node];
-  const double dt = terminal ? 0.0 : tg[node + 1] - t;
-  const double* xG = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
-  const double* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
+  const real* tg = a.tgrid + size_t(inst) * (a.N + 1);
+  const real t = tg[node];
+  const real dt = a.dtgrid[size_t(inst) * (a.N + 1) + node];
+  const real* xG = a.X + (size_t(inst) * (a.N + 1) + node) * 30;
+  const real* uG = terminal ? a.zeros : a.U + (size_t(inst) * a.N + node) * 30;
   // x, u, x_next and the reference state are read many times with wave-uniform indices: one vector load each into LDS instead of
   // chains of dependent scalar loads.  They live in region X and are dead before the QR publishes its factors there.
-  double* x = lds + L_XU; double* u = x + 32; double* xnext = x + 64; double* xref = x + 96;
+  real* x = lds + L_XU; real* u = x + 32; real* xnext = x + 64; real* xref = x + 96;
   const Schedule sched{a.schedNum[inst], a.schedTimes + size_t(inst) * QMGPU_MAX_EVENTS, a.schedModes + size_t(inst) * (QMGPU_MAX_EVENTS + 1)};
-  const int phase = nodePhaseAt(sched, t);
+  const int phase = a.nodePhase[size_t(inst) * (a.N + 1) + node];
   const int mode = sched.modes[phase];
-  const double* tTimes = a.targetTimes + size_t(inst) * a.K;
-  const double* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
-  const double muP = terminal ? st.ee_final_mu_position : st.ee_mu_position, muO = terminal ? st.ee_final_mu_orientation : st.ee_mu_orientation;
+  const real* tTimes = a.targetTimes + size_t(inst) * a.K;
+  const real* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
+  const real muP = terminal ? st.ee_final_mu_position : st.ee_mu_position, muO = terminal ? st.ee_final_mu_orientation : st.ee_mu_orientation;
 
   // ---- rows of the AD sweep (ad_node_kernel)
-  const double* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
+  const real* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
   int nc = 0;
   if (!terminal) for (int k = 0; k < 4; ++k) nc += contactOf(mode, k) ? 3 : 4;
   {
-    double cdv[NCMAX], eev[6];   // all global loads in flight before the first LDS store
+    real cdv[NCMAX], eev[6];   // all global loads in flight before the first LDS store
 #pragma unroll
     for (int r = 0; r < NCMAX; ++r) cdv[r] = ad[AD_CD + (r < nc ? r : 0) * 64 + lane];
 #pragma unroll
@@ -112,13 +112,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int q = 0; q < 6; ++q) { if (lane < 32) EEJ[q * 32 + lane] = eev[q]; else if (lane == 60) eeh[q] = eev[q]; }
   }
-  double phid[12], phiv[12];
+  real phid[12], phiv[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
 
-  double* rec = a.stages + (size_t(inst) * (a.N + 1) + node) * STAGE_DOUBLES;
-  double* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
-  int tIdx; double tAlpha;
+  real* rec = a.stages + (size_t(inst) * (a.N + 1) + node) * STAGE_DOUBLES;
+  real* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
+  int tIdx; real tAlpha;
   timeSegment(tTimes, a.K, t, tIdx, tAlpha);
   if (lane < 30) {
     x[lane] = xG[lane]; u[lane] = uG[lane]; xnext[lane] = terminal ? xG[lane] : xG[30 + lane];
@@ -126,32 +126,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   QM_WAVE_SYNC();
   const int c = lane;
-  double qc = 0.0, costPart = 0.0;
-  const double sc = terminal ? 1.0 : dt;  // intermediate costs are scaled by dt, the terminal cost is not
+  real qc = 0.0_r, costPart = 0.0_r;
+  const real sc = terminal ? 1.0_r : dt;  // intermediate costs are scaled by dt, the terminal cost is not
 
   // ---- state cost, gradient entry c (lanes < 30): tracking + EE soft constraint (Gauss-Newton) + arm joint position soft box.
   //      The Hessian is never formed column-wise: qEntry(i, j) below assembles single entries where they are needed.
   {
-    double dd = 0.0;
+    real dd = 0.0_r;
     if (c < 30) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) qc += (q < 3 ? muP : muO) * eeh[q] * EEJ[q * 32 + c];
-      if (c < 6) costPart += 0.5 * (c < 3 ? muP : muO) * eeh[c] * eeh[c];
+      if (c < 6) costPart += 0.5_r * (c < 3 ? muP : muO) * eeh[c] * eeh[c];
     }
     if (!terminal && c < 30) {
-      double Qdx0 = 0.0, Qdx1 = 0.0;
+      real Qdx0 = 0.0_r, Qdx1 = 0.0_r;
 #pragma unroll
       for (int i = 0; i < 30; i += 2) {
         Qdx0 += st.Q[i * 30 + c] * (x[i] - xref[i]);
         Qdx1 += st.Q[(i + 1) * 30 + c] * (x[i + 1] - xref[i + 1]);
       }
-      const double Qdx = Qdx0 + Qdx1;
+      const real Qdx = Qdx0 + Qdx1;
       qc += Qdx;
-      costPart += 0.5 * (x[c] - xref[c]) * Qdx;
+      costPart += 0.5_r * (x[c] - xref[c]) * Qdx;
       if (c >= 24) {  // arm joint position soft box (QMInterface.cpp:177-219)
         const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta};
-        const double lo = md.q_lower[c - 12], up = md.q_upper[c - 12];
-        const double hl = x[c] - lo, hu = up - x[c];
+        const real lo = md.q_lower[c - 12], up = md.q_upper[c - 12];
+        const real hl = x[c] - lo, hu = up - x[c];
         costPart += bp.value(hl) + bp.value(hu) - (bp.value(-lo) + bp.value(up));
         qc += bp.d1(hl) - bp.d1(hu);
         dd = bp.d2(hl) + bp.d2(hu);
@@ -164,29 +164,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // entry (i, j) of the state-cost Hessian (unscaled); i, j may be any lane-dependent indices < 32
   auto qEntry = [&](int i, int j) {
     const int ic = i < 30 ? i : 0, jc = j < 30 ? j : 0;
-    double v = terminal ? 0.0 : st.Q[ic * 30 + jc];
+    real v = terminal ? 0.0_r : st.Q[ic * 30 + jc];
 #pragma unroll
     for (int q = 0; q < 6; ++q) v += (q < 3 ? muP : muO) * EEJ[q * 32 + ic] * EEJ[q * 32 + jc];
-    const double dg = ddp[ic >= 24 ? ic - 24 : 0];
+    const real dg = ddp[ic >= 24 ? ic - 24 : 0];
     if (ic == jc && ic >= 24) v += dg;
-    return (i < 30 && j < 30) ? v : 0.0;
+    return (i < 30 && j < 30) ? v : 0.0_r;
   };
 
   if (terminal) {
     if (c < 30) {
 #pragma unroll 6
-      for (int i = 0; i < 30; ++i) { const double v = qEntry(i, c); rec[OFF_QT + i * 30 + c] = v; if (dbg) dbg[DBG_Q + i * 30 + c] = v; }
+      for (int i = 0; i < 30; ++i) { const real v = qEntry(i, c); rec[OFF_QT + i * 30 + c] = v; if (dbg) dbg[DBG_Q + i * 30 + c] = v; }
     }
-    const double nodeCost = waveSum(red, lane, costPart);
+    const real nodeCost = waveSum(red, lane, costPart);
     if (c < 30) { rec[OFF_qt + c] = qc; if (dbg) dbg[DBG_q + c] = qc; }
-    if (lane == 0) { double* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS; m[0] = nodeCost; m[1] = 0.0; m[2] = 0.0; m[3] = 0.0; }
+    if (lane == 0) { real* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS; m[0] = nodeCost; m[1] = 0.0_r; m[2] = 0.0_r; m[3] = 0.0_r; }
     return;
   }
 
   // ---- Jacobian of the RK2 map Phi = x + dt/2 (k1 + k2): rows 12.. are x_j + dt v_j exactly, so only the twelve momentum /
   //      base-pose rows of [A | B] are dense (phid).
   if (dbg && c < 60) {
-    for (int i = 0; i < 30; ++i) { const double v = i < 12 ? phid[i < 12 ? i : 0] + (c == i ? 1.0 : 0.0) : (c == i ? 1.0 : 0.0) + (c == 30 + i ? dt : 0.0); if (c < 30) dbg[DBG_A + i * 30 + c] = v; else dbg[DBG_B + i * 30 + (c - 30)] = v; }
+    for (int i = 0; i < 30; ++i) { const real v = i < 12 ? phid[i < 12 ? i : 0] + (c == i ? 1.0_r : 0.0_r) : (c == i ? 1.0_r : 0.0_r) + (c == 30 + i ? dt : 0.0_r); if (c < 30) dbg[DBG_A + i * 30 + c] = v; else dbg[DBG_B + i * 30 + (c - 30)] = v; }
   }
   if (lane == 0) {
     for (int i = 0; i < 12; ++i) bv[i] = x[i] + phiv[i] - xnext[i];
@@ -197,42 +197,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   {
     int nStance = 0;
     for (int k = 0; k < 4; ++k) nStance += contactOf(mode, k) ? 1 : 0;
-    const double fzNom = nStance > 0 ? md.total_mass * st.gravity / nStance : 0.0;
+    const real fzNom = nStance > 0 ? md.total_mass * st.gravity / nStance : 0.0_r;
     if (c < 30) {
-      double Rdu0 = 0.0, Rdu1 = 0.0;
+      real Rdu0 = 0.0_r, Rdu1 = 0.0_r;
 #pragma unroll
       for (int i = 0; i < 30; i += 2) {
-        const double un0 = (i < 12 && (i % 3) == 2 && contactOf(mode, i / 3)) ? fzNom : 0.0;
-        const double un1 = (i + 1 < 12 && ((i + 1) % 3) == 2 && contactOf(mode, (i + 1) / 3)) ? fzNom : 0.0;
+        const real un0 = (i < 12 && (i % 3) == 2 && contactOf(mode, i / 3)) ? fzNom : 0.0_r;
+        const real un1 = (i + 1 < 12 && ((i + 1) % 3) == 2 && contactOf(mode, (i + 1) / 3)) ? fzNom : 0.0_r;
         Rdu0 += a.Rw[i * 30 + c] * (u[i] - un0);
         Rdu1 += a.Rw[(i + 1) * 30 + c] * (u[i + 1] - un1);
       }
-      const double Rdu = Rdu0 + Rdu1;
-      const double unomc = (c < 12 && (c % 3) == 2 && contactOf(mode, c / 3)) ? fzNom : 0.0;
-      double rc = Rdu;
-      costPart += 0.5 * (u[c] - unomc) * Rdu;
+      const real Rdu = Rdu0 + Rdu1;
+      const real unomc = (c < 12 && (c % 3) == 2 && contactOf(mode, c / 3)) ? fzNom : 0.0_r;
+      real rc = Rdu;
+      costPart += 0.5_r * (u[c] - unomc) * Rdu;
       if (c >= 24) {  // arm joint velocity soft box (QMInterface.cpp:221-254)
         const Barrier bvel{st.joint_vel_barrier_mu, st.joint_vel_barrier_delta};
         const int i = c - 24;
-        const double vl = u[c] - st.arm_vel_lower[i], vu = st.arm_vel_upper[i] - u[c];
+        const real vl = u[c] - st.arm_vel_lower[i], vu = st.arm_vel_upper[i] - u[c];
         costPart += bvel.value(vl) + bvel.value(vu) - (bvel.value(-st.arm_vel_lower[i]) + bvel.value(st.arm_vel_upper[i]));
         rc += bvel.d1(vl) - bvel.d1(vu);
         ddv[i] = bvel.d2(vl) + bvel.d2(vu);
       }
       if (c < 12) {
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        real e0 = 0.0_r, e1 = 0.0_r, e2 = 0.0_r;
         if (contactOf(mode, c / 3)) {  // friction cone barrier (QMInterface.cpp:344-358), column c % 3 of its 3x3 block
           const Barrier bf{st.friction_barrier_mu, st.friction_barrier_delta};
           const int fo = 3 * (c / 3), ac = c % 3;
-          const double fx = u[fo], fy = u[fo + 1], fz = u[fo + 2];
-          const double F = sqrt(fx * fx + fy * fy + st.friction_regularization), F3 = F * F * F;
-          const double hh = st.friction_coefficient * fz - F;
-          const double gx = -fx / F, gy = -fy / F, gz = st.friction_coefficient;
-          const double hxx = -(fy * fy + st.friction_regularization) / F3 - st.friction_hessian_shift, hxy = fx * fy / F3;
-          const double hyy = -(fx * fx + st.friction_regularization) / F3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
-          const double gac = ac == 0 ? gx : (ac == 1 ? gy : gz);
-          const double h0 = ac == 0 ? hxx : (ac == 1 ? hxy : 0.0), h1 = ac == 0 ? hxy : (ac == 1 ? hyy : 0.0), h2 = ac == 2 ? hzz : 0.0;
-          const double p1 = bf.d1(hh), p2 = bf.d2(hh);
+          const real fx = u[fo], fy = u[fo + 1], fz = u[fo + 2];
+          const real F = sqrt(fx * fx + fy * fy + st.friction_regularization), F3 = F * F * F;
+          const real hh = st.friction_coefficient * fz - F;
+          const real gx = -fx / F, gy = -fy / F, gz = st.friction_coefficient;
+          const real hxx = -(fy * fy + st.friction_regularization) / F3 - st.friction_hessian_shift, hxy = fx * fy / F3;
+          const real hyy = -(fx * fx + st.friction_regularization) / F3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
+          const real gac = ac == 0 ? gx : (ac == 1 ? gy : gz);
+          const real h0 = ac == 0 ? hxx : (ac == 1 ? hxy : 0.0_r), h1 = ac == 0 ? hxy : (ac == 1 ? hyy : 0.0_r), h2 = ac == 2 ? hzz : 0.0_r;
+          const real p1 = bf.d1(hh), p2 = bf.d2(hh);
           if (ac == 0) costPart += bf.value(hh);
           rc += p1 * gac;
           e0 = p2 * gx * gac + p1 * h0; e1 = p2 * gy * gac + p1 * h1; e2 = p2 * gz * gac + p1 * h2;
@@ -248,13 +248,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // zero column 31; rows >= 30 are zero
   auto rEntry = [&](int k, int i) {
     const int kc = k < 30 ? k : 0, ic = i < 30 ? i : 0;
-    double v = a.Rw[kc * 30 + ic];
-    const double fbv = fb[(kc < 12 ? kc : 0) * 3 + ic % 3], dv = ddv[kc >= 24 ? kc - 24 : 0];
+    real v = a.Rw[kc * 30 + ic];
+    const real fbv = fb[(kc < 12 ? kc : 0) * 3 + ic % 3], dv = ddv[kc >= 24 ? kc - 24 : 0];
     if (kc < 12 && ic < 12 && kc / 3 == ic / 3) v += fbv;
     if (kc == ic && kc >= 24) v += dv;
     v *= dt;
-    const double rk = rv[kc];
-    return k < 30 ? (i < 30 ? v : (i == 30 ? rk : 0.0)) : 0.0;
+    const real rk = rv[kc];
+    return k < 30 ? (i < 30 ? v : (i == 30 ? rk : 0.0_r)) : 0.0_r;
   };
   if (dbg && c < 30) {
     for (int i = 0; i < 30; ++i) dbg[DBG_R + i * 30 + c] = rEntry(i, c);
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int r = 0; r < nc; ++r) { dbg[DBG_C + r * 30 + c] = ad[AD_CD + r * 64 + c]; dbg[DBG_D + r * 30 + c] = ad[AD_CD + r * 64 + 30 + c]; }
     if (c < nc) dbg[DBG_e + c] = ev[c];
   }
-  double dynSq = 0.0, eqSq = 0.0;   // lane 0: node metrics (x, u, ... leave LDS below)
+  real dynSq = 0.0_r, eqSq = 0.0_r;   // lane 0: node metrics (x, u, ... leave LDS below)
   if (lane == 0) {
     for (int i = 0; i < 30; ++i) dynSq += bv[i] * bv[i];
     for (int i = 0; i < nc; ++i) eqSq += ev[i] * ev[i];
@@ -310,9 +310,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // Pall operand of the matrix cores, element (k, j) with k = 4 ks + h (this lane's row of k step ks) and j = 16 tq + l16:
   // rows k < 12 (force inputs, k steps 0..2) are synthesised -- Pe = pinned swing force in column 30, a unit entry in the Pu column
   // of a free stance force --, rows 12..29 come from LDS, rows 30 and 31 are zero.
-  double peK[3]; int puK[3];
+  real peK[3]; int puK[3];
   {
-    double peForce = 0.0;   // pinned swing-foot forces: Pe = -e_f
+    real peForce = 0.0_r;   // pinned swing-foot forces: Pe = -e_f
 #pragma unroll
     for (int i = 0; i < 12; ++i) if (lane == i && frcRowOf[i] >= 0) peForce = -ev[frcRowOf[i] >= 0 ? frcRowOf[i] : 0];
     if (lane < 12) pev[lane] = peForce;
@@ -327,71 +327,72 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       puK[ks] = pu;
     }
   }
-  auto pallOp = [&](int ks, int tq) {
-    const int j = tq * 16 + l16;
-    if (ks < 3) return j == 30 ? peK[ks] : ((j >= 32 && j - 32 == puK[ks]) ? 1.0 : 0.0);
+  auto pallOpAt = [&](int ks, int j) {
+    if (ks < 3) return j == 30 ? peK[ks] : ((j >= 32 && j - 32 == puK[ks]) ? 1.0_r : 0.0_r);
     const int kk = 4 * ks + h;
-    const double raw = PA[((kk < 30 ? kk : 12) - 12) * PAW + (j < PAW ? j : 0)];
-    return (kk < 30 && j < PAW) ? raw : 0.0;
+    const real raw = PA[((kk < 30 ? kk : 12) - 12) * PAW + (j < PAW ? j : 0)];
+    return (kk < 30 && j < PAW) ? raw : 0.0_r;
   };
+  auto pallOp = [&](int ks, int tq) { return pallOpAt(ks, tq * 16 + l16); };    // as a B operand: column of Pall
+  auto pallOpT = [&](int ks, int tq) { return pallOpAt(ks, tq * 16 + la); };    // as an A operand (Pall^T): row of Pall^T
   {
     int myVr = 0;
 #pragma unroll
     for (int r = 0; r < NVMAX; ++r) if (lane == r) myVr = vrOf[r];
-    double ce[NVMAX];   // my column of [C_v | e_v] (lanes <= 30)
+    real ce[NVMAX];   // my column of [C_v | e_v] (lanes <= 30)
 #pragma unroll
     for (int r = 0; r < NVMAX; ++r) {
-      const double cv = CD[vrOf[r] * CDW + (lane < 30 ? lane : 0)], evr = ev[vrOf[r]];
-      ce[r] = (r < nv) ? (lane < 30 ? cv : (lane == 30 ? evr : 0.0)) : 0.0;
+      const real cv = CD[vrOf[r] * CDW + (lane < 30 ? lane : 0)], evr = ev[vrOf[r]];
+      ce[r] = (r < nv) ? (lane < 30 ? cv : (lane == 30 ? evr : 0.0_r)) : 0.0_r;
     }
-    double qcol[18];
+    real qcol[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
-      const double dv = CD[myVr * CDW + 30 + i];
-      qcol[i] = lane < 16 ? (lane < nv ? dv : 0.0) : ((lane < 34 && i == lane - 16) ? 1.0 : 0.0);
+      const real dv = CD[myVr * CDW + 30 + i];
+      qcol[i] = lane < 16 ? (lane < nv ? dv : 0.0_r) : ((lane < 34 && i == lane - 16) ? 1.0_r : 0.0_r);
     }
     QM_WAVE_SYNC();  // the [C D_v] region is free from here on (it becomes Pall); so is x | u | x_next | x_ref in region X
 #pragma unroll
     for (int k = 0; k < NVMAX; ++k) {
       if (k < nv) {
-        double v[18];
-        double n2a = 0.0, n2b = 0.0;
+        real v[18];
+        real n2a = 0.0_r, n2b = 0.0_r;
 #pragma unroll
         for (int i = k; i < 18; ++i) { v[i] = qmReadLane(qcol[i], k, red); if ((i - k) & 1) n2b += v[i] * v[i]; else n2a += v[i] * v[i]; }
-        const double dk = v[k], tail2 = (n2a + n2b) - dk * dk;
-        const double nrm = sqrt(n2a + n2b);
-        const double alpha = dk > 0.0 ? -nrm : nrm;
+        const real dk = v[k], tail2 = (n2a + n2b) - dk * dk;
+        const real nrm = sqrt(n2a + n2b);
+        const real alpha = dk > 0.0_r ? -nrm : nrm;
         v[k] = dk - alpha;
-        const double vn = tail2 + v[k] * v[k];
-        const double beta = vn > 0.0 ? 2.0 / vn : 0.0;
-        double sa = 0.0, sb = 0.0;
+        const real vn = tail2 + v[k] * v[k];
+        const real beta = vn > 0.0_r ? 2.0_r / vn : 0.0_r;
+        real sa = 0.0_r, sb = 0.0_r;
 #pragma unroll
         for (int i = k; i < 18; ++i) { if ((i - k) & 1) sb += v[i] * qcol[i]; else sa += v[i] * qcol[i]; }
-        const double sf = (sa + sb) * beta;
+        const real sf = (sa + sb) * beta;
 #pragma unroll
-        for (int i = k; i < 18; ++i) qcol[i] = (lane == k) ? (i == k ? alpha : 0.0) : qcol[i] - sf * v[i];
+        for (int i = k; i < 18; ++i) qcol[i] = (lane == k) ? (i == k ? alpha : 0.0_r) : qcol[i] - sf * v[i];
       }
     }
     // Y = R1^-T [C_v | e_v]: forward substitution, R1[k][i] (k <= i) lives in lane i, register k
-    double y[NVMAX];
+    real y[NVMAX];
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
-      double sacc = ce[i];
+      real sacc = ce[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) sacc -= qmReadLane(qcol[k], i, red) * y[k];
-      const double d = qmReadLane(qcol[i], i, red);
-      y[i] = (i < nv) ? sacc / d : 0.0;
+      const real d = qmReadLane(qcol[i], i, red);
+      y[i] = (i < nv) ? sacc / d : 0.0_r;
     }
     // publish Y (rows k < 16, my column) and Q_v (lane 16 + c holds row c; rows 18..31 cleared) in region X
-    double* Ym = lds + L_YM;
-    double* Qs = lds + L_QS;
+    real* Ym = lds + L_YM;
+    real* Qs = lds + L_QS;
     if (lane < 32) {
 #pragma unroll
-      for (int k = 0; k < NCMAX; ++k) Ym[k * LDY + lane] = (k < NVMAX && lane <= 30) ? y[k < NVMAX ? k : 0] : 0.0;
+      for (int k = 0; k < NCMAX; ++k) Ym[k * LDY + lane] = (k < NVMAX && lane <= 30) ? y[k < NVMAX ? k : 0] : 0.0_r;
     }
     if (lane >= 16 && lane < 48) {
 #pragma unroll
-      for (int r = 0; r < 18; ++r) Qs[(lane - 16) * LDQ + r] = lane < 34 ? qcol[r] : 0.0;
+      for (int r = 0; r < 18; ++r) Qs[(lane - 16) * LDQ + r] = lane < 34 ? qcol[r] : 0.0_r;
     }
     QM_WAVE_SYNC();
     // [Px | Pe] rows 12..29 = -Q_v1 Y on the matrix cores (K = 16 >= nv; rows of Y beyond nv are zero)
@@ -399,12 +400,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pc[t4][r] = 0.0;
+      for (int r = 0; r < 4; ++r) pc[t4][r] = 0.0_r;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kk = 4 * ks + h;
-      const double a0 = -Qs[l16 * LDQ + kk], a1 = -Qs[(16 + l16) * LDQ + kk];
-      const double b0 = Ym[kk * LDY + l16], b1 = Ym[kk * LDY + 16 + l16];
+      const real a0 = -Qs[la * LDQ + kk], a1 = -Qs[(16 + la) * LDQ + kk];
+      const real b0 = Ym[kk * LDY + l16], b1 = Ym[kk * LDY + 16 + l16];
       qmMfma(pc[0], a0, b0, red); qmMfma(pc[1], a0, b1, red); qmMfma(pc[2], a1, b0, red); qmMfma(pc[3], a1, b1, red);
     }
     // Pall: rows 0..11 (forces): Px = 0, Pe = pinned swing forces, unit Pu columns for the free stance forces (record only);
@@ -412,9 +413,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (lane < PAW) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
-        const double pe = pev[i];
-        const double val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0 : 0.0);
-        if (lane < 30) rec[OFF_PX + i * 30 + lane] = 0.0;
+        const real pe = pev[i];
+        const real val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0_r : 0.0_r);
+        if (lane < 30) rec[OFF_PX + i * 30 + lane] = 0.0_r;
         else if (lane == 30) rec[OFF_PE + i] = pe;
         else if (lane >= 32 && lane < 32 + nt) rec[OFF_PU + i * MT + (lane - 32)] = val;
       }
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int r = 0; r < 4; ++r) {
         const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;   // i: joint-velocity input 12 + i
         if (i < 18) {
-          PA[i * PAW + j] = j <= 30 ? pc[t4][r] : 0.0;
+          PA[i * PAW + j] = j <= 30 ? pc[t4][r] : 0.0_r;
           if (j < 30) rec[OFF_PX + (12 + i) * 30 + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + 12 + i] = pc[t4][r];
         }
       }
@@ -434,9 +435,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const bool isQ2 = jj >= nStF && jj < nt;
 #pragma unroll
       for (int i = 0; i < 18; ++i) {
-        const double qv = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
-        PA[i * PAW + lane] = isQ2 ? qv : 0.0;
-        if (jj < nt) rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0;
+        const real qv = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
+        PA[i * PAW + lane] = isQ2 ? qv : 0.0_r;
+        if (jj < nt) rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0_r;
       }
     }
   }
@@ -445,17 +446,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
   for (int i = 12; i < 30; ++i) {
-    const double pv = PA[(i - 12) * PAW + (lane < PAW ? lane : 0)];
-    if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0 : 0.0) + dt * pv;
+    const real pv = PA[(i - 12) * PAW + (lane < PAW ? lane : 0)];
+    if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0_r : 0.0_r) + dt * pv;
     else if (isE) rec[OFF_bt + i] = bv[i] + dt * pv;
     else if (isU) rec[OFF_BT + i * MT + (lane - 32)] = dt * pv;
   }
   {  // transposed dense rows: At[j][i] = A[i][j], Bt[k][i] = B[i][k], i < 12 (columns 12..15 and rows 30,31 zero)
-    double* dst = (lane < 30) ? AT + lane * LDT : (lane < 60 ? BT + (lane - 30) * LDT : AT + 30 * LDT + (lane - 60) * LDT);
+    real* dst = (lane < 30) ? AT + lane * LDT : (lane < 60 ? BT + (lane - 30) * LDT : AT + 30 * LDT + (lane - 60) * LDT);
     const bool pad = lane >= 60;  // lanes 60..61 clear rows 30,31 of At; lanes 62..63 rows 30,31 of Bt
     if (lane >= 62) dst = BT + (30 + lane - 62) * LDT;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0 : 0.0) : 0.0;
+    for (int i = 0; i < 16; ++i) dst[i] = (!pad && i < 12) ? phid[i < 12 ? i : 0] + ((lane < 30 && lane == i) ? 1.0_r : 0.0_r) : 0.0_r;
   }
   QM_WAVE_SYNC();
 
@@ -469,13 +470,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = h + 4 * r, j = tn * 16 + l16;
-        const double av = AT[(j < 32 ? j : 0) * LDT + i], bb = bv[i < 30 ? i : 0];
-        c1[tn][r] = (i < 12) ? (j < 30 ? av : (j == 30 ? bb : 0.0)) : 0.0;
+        const real av = AT[(j < 32 ? j : 0) * LDT + i], bb = bv[i < 30 ? i : 0];
+        c1[tn][r] = (i < 12) ? (j < 30 ? av : (j == 30 ? bb : 0.0_r)) : 0.0_r;
       }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int kk = 4 * ks + h;
-      const double ab = BT[kk * LDT + l16];
+      const real ab = BT[kk * LDT + la];
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) { if (tn < nTn) qmMfma(c1[tn], ab, pallOp(ks, tn), red); }
     }
@@ -496,10 +497,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
   QM_WAVE_SYNC();   // every lane has consumed At / Bt: region X becomes the W tile
-  const double nodeCost = dt * waveSum(red, lane, costPart);
+  const real nodeCost = dt * waveSum(red, lane, costPart);
   if (lane == 0) {
-    double* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS;
-    m[0] = nodeCost; m[1] = dt * dynSq; m[2] = dt * eqSq; m[3] = 0.0;
+    real* m = a.metrics + (size_t(inst) * (a.N + 1) + node) * NODE_METRICS;
+    m[0] = nodeCost; m[1] = dt * dynSq; m[2] = dt * eqSq; m[3] = 0.0_r;
   }
   if (dbg && c < 30) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = sc * qEntry(i, c); dbg[DBG_q + c] = qc; }
 
@@ -509,18 +510,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   //   tn = 2, 3: tm = 2, 3 (R~; column 30 of tn = 1 carries Pu^T R Pe)
   // Row 30 of W is r^T Pall; together with row / column 30 of G it completes q~ and r~ (fin).
   {
-    fin[lane] = 0.0;
-    double r0[8], r1[8];   // R operand (symmetric: R[i][k] read as R[k][i]), shared by all tiles
+    fin[lane] = 0.0_r;
+    real r0[8], r1[8];   // R operand (symmetric: R[i][k] read as R[k][i]), shared by all tiles
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { const int kk = 4 * ks + h; r0[ks] = rEntry(kk, l16); r1[ks] = rEntry(kk, 16 + l16); }
+    for (int ks = 0; ks < 8; ++ks) { const int kk = 4 * ks + h; r0[ks] = rEntry(kk, la); r1[ks] = rEntry(kk, 16 + la); }
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       if (tn < nTn) {
         QmAcc wA, wB;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { wA[r] = 0.0; wB[r] = 0.0; }
+        for (int r = 0; r < 4; ++r) { wA[r] = 0.0_r; wB[r] = 0.0_r; }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { const double pb = pallOp(ks, tn); qmMfma(wA, r0[ks], pb, red); qmMfma(wB, r1[ks], pb, red); }
+        for (int ks = 0; ks < 8; ++ks) { const real pb = pallOp(ks, tn); qmMfma(wA, r0[ks], pb, red); qmMfma(wB, r1[ks], pb, red); }
         QM_WAVE_SYNC();   // the previous tile's readers are done
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int i = h + 4 * r; WT[i * LDW + l16] = wA[r]; WT[(16 + i) * LDW + l16] = wB[r]; }
@@ -532,14 +533,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) g[tm][r] = (tm < 2 && tn < 2) ? sc * qEntry(tm * 16 + h + 4 * r, tn * 16 + l16) : 0.0;
+          for (int r = 0; r < 4; ++r) g[tm][r] = (tm < 2 && tn < 2) ? sc * qEntry(tm * 16 + h + 4 * r, tn * 16 + l16) : 0.0_r;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           const int kk = 4 * ks + h;
-          const double wb = WT[kk * LDW + l16];
-          if (top) { qmMfma(g[0], pallOp(ks, 0), wb, red); qmMfma(g[1], pallOp(ks, 1), wb, red); }
-          qmMfma(g[2], pallOp(ks, 2), wb, red);
-          if (low3) qmMfma(g[3], pallOp(ks, 3), wb, red);
+          const real wb = WT[kk * LDW + l16];
+          if (top) { qmMfma(g[0], pallOpT(ks, 0), wb, red); qmMfma(g[1], pallOpT(ks, 1), wb, red); }
+          qmMfma(g[2], pallOpT(ks, 2), wb, red);
+          if (low3) qmMfma(g[3], pallOpT(ks, 3), wb, red);
         }
         const int j = tn * 16 + l16;
 #pragma unroll
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = tm * 16 + h + 4 * r;
-              const double v = g[tm][r];
+              const real v = g[tm][r];
               if (i < 30) {
                 if (j < 30) rec[OFF_QT + i * 30 + j] = v;
               } else if (i == 30) {

@@ -15,7 +15,7 @@
 //     qmgpu_create), so only the current chain state lives in registers.
 // Templated on the scalar: T = Du (lane-tangent forward mode, see du.h) or T = double.
 #pragma once
-#include "../../../include/qmgpu.h"
+#include "problem_r.h"
 #include "du.h"
 
 namespace qmk {
@@ -29,13 +29,13 @@ template <class T> struct Accum {
   Sym3<T> Io;
 };
 
-template <class T> __device__ __forceinline__ void accumulateBody(const qmgpu_model& md, int b, const ChainState<T>& s, Accum<T>& acc) {
-  const double m = md.mass[b];
+template <class T> __device__ __forceinline__ void accumulateBody(const ModelR& md, int b, const ChainState<T>& s, Accum<T>& acc) {
+  const real m = md.mass[b];
   const Vec3<T> lc = mul(s.R, md.com[b][0], md.com[b][1], md.com[b][2]);
   const Vec3<T> c = s.r + lc;
   const Vec3<T> vc = s.vo + cross(s.w, lc);
   // world inertia about the body com: R I R^T
-  const double ixx = md.inertia[b][0], ixy = md.inertia[b][1], ixz = md.inertia[b][2], iyy = md.inertia[b][3], iyz = md.inertia[b][4], izz = md.inertia[b][5];
+  const real ixx = md.inertia[b][0], ixy = md.inertia[b][1], ixz = md.inertia[b][2], iyy = md.inertia[b][3], iyz = md.inertia[b][4], izz = md.inertia[b][5];
   const Vec3<T> a0 = scale(ixx, s.R.c0) + scale(ixy, s.R.c1) + scale(ixz, s.R.c2);  // (R I) column 0
   const Vec3<T> a1 = scale(ixy, s.R.c0) + scale(iyy, s.R.c1) + scale(iyz, s.R.c2);
   const Vec3<T> a2 = scale(ixz, s.R.c0) + scale(iyz, s.R.c1) + scale(izz, s.R.c2);
@@ -60,7 +60,7 @@ template <class T> __device__ __forceinline__ void accumulateBody(const qmgpu_mo
 }
 
 // Advance the chain state from the parent of body b to body b (joint angle q, joint rate qd), then accumulate.
-template <class T> __device__ __forceinline__ void bodyStep(const qmgpu_model& md, int b, T q, T qd, ChainState<T>& s, Accum<T>& acc) {
+template <class T> __device__ __forceinline__ void bodyStep(const ModelR& md, int b, T q, T qd, ChainState<T>& s, Accum<T>& acc) {
   const Vec3<T> off = mul(s.R, md.joint_offset[b][0], md.joint_offset[b][1], md.joint_offset[b][2]);
   s.vo = s.vo + cross(s.w, off);
   s.r = s.r + off;
@@ -87,7 +87,7 @@ template <class T> __device__ __forceinline__ void bodyStep(const qmgpu_model& m
 template <class T> __device__ __forceinline__ void baseRotation(T yaw, T pitch, T roll, Mat3<T>& R, T& sz, T& cz, T& sy, T& cy) {
   T sx, cx;
   sincosT(yaw, sz, cz); sincosT(pitch, sy, cy); sincosT(roll, sx, cx);
-  R.c0 = Vec3<T>(cz * cy, sz * cy, T(0.0) - sy);
+  R.c0 = Vec3<T>(cz * cy, sz * cy, T(0.0_r) - sy);
   R.c1 = Vec3<T>(cz * sy * sx - sz * cx, sz * sy * sx + cz * cx, cy * sx);
   R.c2 = Vec3<T>(cz * sy * cx + sz * sx, sz * sy * cx - cz * sx, cy * cx);
 }
@@ -100,7 +100,7 @@ template <class A, class B> __device__ __forceinline__ Vec3<ProdT<A, B>> solveSy
   const A c11 = S.xx * S.zz - S.xz * S.xz;
   const A c12 = S.xy * S.xz - S.xx * S.yz;
   const A c22 = S.xx * S.yy - S.xy * S.xy;
-  const A id = 1.0 / det;
+  const A id = 1.0_r / det;
   return Vec3<ProdT<A, B>>((c00 * b.x + c01 * b.y + c02 * b.z) * id, (c01 * b.x + c11 * b.y + c12 * b.z) * id, (c02 * b.x + c12 * b.y + c22 * b.z) * id);
 }
 
@@ -118,14 +118,14 @@ template <class P, class V> struct BaseMotion2 {
   Vec3<P> com;
 };
 template <class P, class V, class F> struct FlowOut {
-  ProdT<double, F> lin[3];   // d(h_lin / m)
+  ProdT<real, F> lin[3];   // d(h_lin / m)
   ProdT<P, F> ang[3];        // d(h_ang / m)
   V kin[6];                  // base position rates, Euler ZYX rates
 };
 template <class P, class V, class F>
-__device__ __forceinline__ void closeSweep2(const qmgpu_model& md, double gravity, const Accum2<P, V>& acc, const V hn[6], Vec3<F> fsum, Vec3<ProdT<P, F>> tsum, P sz, P cz, P sy, P cy,
+__device__ __forceinline__ void closeSweep2(const ModelR& md, real gravity, const Accum2<P, V>& acc, const V hn[6], Vec3<F> fsum, Vec3<ProdT<P, F>> tsum, P sz, P cz, P sy, P cy,
                                             FlowOut<P, V, F>& f, BaseMotion2<P, V>& bm) {
-  const double m = md.total_mass, im = 1.0 / md.total_mass;
+  const real m = md.total_mass, im = 1.0_r / md.total_mass;
   const Vec3<P> cm = scale(im, acc.M1);
   const P cc = dot(cm, cm);
   Sym3<P> Ic;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void closeSweep2(const qmgpu_model& md, double gravit
 }
 template <class T> using BaseMotion = BaseMotion2<T, T>;
 template <class T>
-__device__ __forceinline__ void closeSweep(const qmgpu_model& md, double gravity, const Accum<T>& acc, const T hn[6], Vec3<T> fsum, Vec3<T> tsum, T sz, T cz, T sy, T cy,
+__device__ __forceinline__ void closeSweep(const ModelR& md, real gravity, const Accum<T>& acc, const T hn[6], Vec3<T> fsum, Vec3<T> tsum, T sz, T cz, T sy, T cy,
                                            T f[12], BaseMotion<T>& bm) {
   Accum2<T, T> a2;
   a2.M1 = acc.M1; a2.hl = acc.hl; a2.ha = acc.ha; a2.Io = acc.Io;
@@ -167,28 +167,28 @@ template <class T> __device__ __forceinline__ void matrixToQuaternion(const Mat3
   // R(i,j): row i of column j
   const T r00 = R.c0.x, r10 = R.c0.y, r20 = R.c0.z, r01 = R.c1.x, r11 = R.c1.y, r21 = R.c1.z, r02 = R.c2.x, r12 = R.c2.y, r22 = R.c2.z;
   T t = r00 + r11 + r22;
-  if (val(t) > 0.0) {
-    t = sqrtT(t + 1.0);
-    q[3] = 0.5 * t;
-    t = 0.5 / t;
+  if (val(t) > 0.0_r) {
+    t = sqrtT(t + 1.0_r);
+    q[3] = 0.5_r * t;
+    t = 0.5_r / t;
     q[0] = (r21 - r12) * t; q[1] = (r02 - r20) * t; q[2] = (r10 - r01) * t;
   } else if (val(r00) >= val(r11) && val(r00) >= val(r22)) {  // i = 0, j = 1, k = 2
-    t = sqrtT(r00 - r11 - r22 + 1.0);
-    q[0] = 0.5 * t; t = 0.5 / t;
+    t = sqrtT(r00 - r11 - r22 + 1.0_r);
+    q[0] = 0.5_r * t; t = 0.5_r / t;
     q[3] = (r21 - r12) * t; q[1] = (r10 + r01) * t; q[2] = (r20 + r02) * t;
   } else if (val(r11) > val(r00) && val(r11) >= val(r22)) {  // i = 1, j = 2, k = 0
-    t = sqrtT(r11 - r22 - r00 + 1.0);
-    q[1] = 0.5 * t; t = 0.5 / t;
+    t = sqrtT(r11 - r22 - r00 + 1.0_r);
+    q[1] = 0.5_r * t; t = 0.5_r / t;
     q[3] = (r02 - r20) * t; q[2] = (r21 + r12) * t; q[0] = (r01 + r10) * t;
   } else {  // i = 2, j = 0, k = 1
-    t = sqrtT(r22 - r00 - r11 + 1.0);
-    q[2] = 0.5 * t; t = 0.5 / t;
+    t = sqrtT(r22 - r00 - r11 + 1.0_r);
+    q[2] = 0.5_r * t; t = 0.5_r / t;
     q[3] = (r10 - r01) * t; q[0] = (r02 + r20) * t; q[1] = (r12 + r21) * t;
   }
 }
 
 // ocs2::quaternionDistance(q, qRef) = q.w qRef.vec - qRef.w q.vec + q.vec x qRef.vec
-template <class T> __device__ __forceinline__ Vec3<T> quaternionDistance(const T q[4], const double r[4]) {
+template <class T> __device__ __forceinline__ Vec3<T> quaternionDistance(const T q[4], const real r[4]) {
   const Vec3<T> qv(q[0], q[1], q[2]);
   const Vec3<T> c(q[1] * r[2] - q[2] * r[1], q[2] * r[0] - q[0] * r[2], q[0] * r[1] - q[1] * r[0]);
   return Vec3<T>(q[3] * r[0] - r[3] * qv.x + c.x, q[3] * r[1] - r[3] * qv.y + c.y, q[3] * r[2] - r[3] * qv.z + c.z);

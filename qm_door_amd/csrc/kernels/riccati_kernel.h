@@ -27,14 +27,14 @@ namespace qmk {
 
 struct RiccatiArgs {
   int batch, N;
-  const double* stages;   // [batch][N+1][STAGE_DOUBLES]
+  const real* stages;   // [batch][N+1][STAGE_DOUBLES]
   const int* stageNc;     // [batch][N+1]
-  const double* x0;       // [batch][30]
-  const double* X;        // [batch][N+1][30]
-  double* gains;          // [batch][N][GAIN_DOUBLES]
-  double* dX;             // [batch][N+1][30]
-  double* dU;             // [batch][N][30]
-  double* instStats;      // [batch][4]: armijo descent metric, status, -, -
+  const real* x0;       // [batch][30]
+  const real* X;        // [batch][N+1][30]
+  real* gains;          // [batch][N][GAIN_DOUBLES]
+  real* dX;             // [batch][N+1][30]
+  real* dU;             // [batch][N][30]
+  real* instStats;      // [batch][4]: armijo descent metric, status, -, -
   const int* done;        // [batch] converged instances are skipped
 };
 
@@ -54,7 +54,7 @@ constexpr int R_LIT = R_LI + 20 * LDS_W;          // L^-T row major [20][LDS_LT]
 constexpr int R_VEC = R_LIT + 20 * LDS_LT + 4;    // dx[32] dut[32]
 constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][256]; armijo reduction
 constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 256;
-constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * 8;  // ~105 KiB (dynamic LDS)
+constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * int(sizeof(real));  // ~105 KiB (dynamic LDS)
 static_assert(2 * STG_F <= RICCATI_LDS_DOUBLES, "forward-sweep staging fits");
 
 // Register-staged HBM -> LDS copy for a whole workgroup: issue() puts PF 16-byte loads per thread in flight, commit() drains
@@ -66,14 +66,14 @@ template <int PF, int NTHR> struct StagePrefetch {
   static_assert(PF <= 13, "add members");
   QmD2 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12;
 #define QM_PF_FOR_EACH(X) X(0, v0) X(1, v1) X(2, v2) X(3, v3) X(4, v4) X(5, v5) X(6, v6) X(7, v7) X(8, v8) X(9, v9) X(10, v10) X(11, v11) X(12, v12)
-  __device__ __forceinline__ void issue(const double* src, int n, int tid) {
+  __device__ __forceinline__ void issue(const real* src, int n, int tid) {
     const QmD2* s2 = reinterpret_cast<const QmD2*>(src);
     const int n2 = n >> 1;
 #define QM_PF_ISSUE(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; V = s2[idx < n2 ? idx : tid]; }
     QM_PF_FOR_EACH(QM_PF_ISSUE)
 #undef QM_PF_ISSUE
   }
-  __device__ __forceinline__ void commit(double* dst, int n, int tid) const {
+  __device__ __forceinline__ void commit(real* dst, int n, int tid) const {
     QmD2* d2 = reinterpret_cast<QmD2*>(dst);
     const int n2 = n >> 1;
 #define QM_PF_COMMIT(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (idx < n2) d2[idx] = V; }
@@ -95,26 +95,26 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   constexpr int PFH = (FWD_HEAD / 2 + NTHR - 1) / NTHR, PFT = (FWD_TAIL / 2 + NTHR - 1) / NTHR;
   constexpr int PFG = (GAIN_DOUBLES / 2 + NTHR - 1) / NTHR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l16 = lane & 15, h = lane >> 4;   // MFMA operand coordinates of this lane
+  const int l16 = lane & 15, h = lane >> 4, la = qmARow(l16);   // MFMA operand coordinates of this lane; la: row of an A operand (gpu_rt.h)
   const int inst = blockIdx.x;
   if (a.done[inst]) return;   // workgroup uniform
   const int N = a.N;
-  double* S = lds + R_S; double* sv = lds + R_SV; double* Y = lds + R_Y; double* T = lds + R_T;
-  double* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)
-  double* W = lds + R_W; double* LI = lds + R_LI; double* LIT = lds + R_LIT; double* dxv = lds + R_VEC; double* dut = dxv + 32;
-  double* scr = lds + R_SCR + wave * 256; double* red = lds + R_SCR;
-  const double* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
-  const double* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
+  real* S = lds + R_S; real* sv = lds + R_SV; real* Y = lds + R_Y; real* T = lds + R_T;
+  real* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)
+  real* W = lds + R_W; real* LI = lds + R_LI; real* LIT = lds + R_LIT; real* dxv = lds + R_VEC; real* dut = dxv + 32;
+  real* scr = lds + R_SCR + wave * 256; real* red = lds + R_SCR;
+  const real* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
+  const real* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
   const int* ncI = a.stageNc + size_t(inst) * (N + 1);
   int status = 0;
 
   // ---- terminal value function S_N = Q_N, s_N = q_N (zero padded), and the first stage to process
   {
-    const double* rec = stagesI + size_t(N) * STAGE_DOUBLES;
-    for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0; }
-    if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0;
-    for (int e = tid; e < 2 * 20 * LDS_W + 20 * LDS_LT; e += NTHR) W[e] = 0.0;        // W, L^-1, L^-T (contiguous)
-    for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0;        // Y, T (contiguous)
+    const real* rec = stagesI + size_t(N) * STAGE_DOUBLES;
+    for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
+    if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0_r;
+    for (int e = tid; e < 2 * 20 * LDS_W + 20 * LDS_LT; e += NTHR) W[e] = 0.0_r;        // W, L^-1, L^-T (contiguous)
+    for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
     pf.commit(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_PX, tid);
@@ -123,8 +123,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
-    const double* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
-    double* stgNext = lds + R_STG + ((k + 1) & 1) * STG_B;    // buffer of stage k - 1
+    const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
+    real* stgNext = lds + R_STG + ((k + 1) & 1) * STG_B;    // buffer of stage k - 1
     const int nt = 30 - ncI[k];
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
@@ -139,14 +139,14 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       const bool mValid = jA || jb || jB;
       QmAcc c0, c1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const double s0 = sv[h + 4 * r], s1 = sv[16 + h + 4 * r]; c0[r] = jb ? s0 : 0.0; c1[r] = jb ? s1 : 0.0; }
-      double a0[8], a1[8], bv[8];   // all operands first (unconditional loads, selects afterwards): the LDS latency is paid once
+      for (int r = 0; r < 4; ++r) { const real s0 = sv[h + 4 * r], s1 = sv[16 + h + 4 * r]; c0[r] = jb ? s0 : 0.0_r; c1[r] = jb ? s1 : 0.0_r; }
+      real a0[8], a1[8], bv[8];   // all operands first (unconditional loads, selects afterwards): the LDS latency is paid once
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of S^T are zero: the clamped b operand is multiplied by 0
-        a0[ks] = S[kk * LDS_S + l16]; a1[ks] = S[kk * LDS_S + 16 + l16];  // S is symmetric: S[i][k] read as S[k][i]
-        const double raw = stg[mOff + kc * mStr];
-        bv[ks] = mValid ? raw : 0.0;
+        a0[ks] = S[kk * LDS_S + la]; a1[ks] = S[kk * LDS_S + 16 + la];  // S is symmetric: S[i][k] read as S[k][i]
+        const real raw = stg[mOff + kc * mStr];
+        bv[ks] = mValid ? raw : 0.0_r;
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
@@ -161,22 +161,22 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
         const int i0c = i0 < MT ? i0 : 0, i1c = i1 < MT ? i1 : 0;
         const int jcA = jA ? jc : 0, jcB = jB ? jc - 32 : 0;
-        const double p0 = stg[OFF_PT + i0c * 30 + jcA], q0 = stg[OFF_rt + i0c], w0 = stg[OFF_RT + i0c * MT + jcB];
-        const double p1 = stg[OFF_PT + i1c * 30 + jcA], q1 = stg[OFF_rt + i1c], w1 = stg[OFF_RT + i1c * MT + jcB];
-        const double v0 = jA ? p0 : (jb ? q0 : (jB ? w0 : 0.0));
-        const double v1 = jA ? p1 : (jb ? q1 : (jB ? w1 : 0.0));
-        c0[r] = i0 < nt ? v0 : 0.0;
-        c1[r] = i1 < nt ? v1 : 0.0;
+        const real p0 = stg[OFF_PT + i0c * 30 + jcA], q0 = stg[OFF_rt + i0c], w0 = stg[OFF_RT + i0c * MT + jcB];
+        const real p1 = stg[OFF_PT + i1c * 30 + jcA], q1 = stg[OFF_rt + i1c], w1 = stg[OFF_RT + i1c * MT + jcB];
+        const real v0 = jA ? p0 : (jb ? q0 : (jB ? w0 : 0.0_r));
+        const real v1 = jA ? p1 : (jb ? q1 : (jB ? w1 : 0.0_r));
+        c0[r] = i0 < nt ? v0 : 0.0_r;
+        c1[r] = i1 < nt ? v1 : 0.0_r;
       }
-      const bool a0ok = l16 < nt, a1ok = 16 + l16 < nt;
-      const int a1c = 16 + l16 < MT ? 16 + l16 : 0;
-      double a0[8], a1[8], bv[8];
+      const bool a0ok = la < nt, a1ok = 16 + la < nt;
+      const int a1c = 16 + la < MT ? 16 + la : 0;
+      real a0[8], a1[8], bv[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of Y are zero
         bv[ks] = Y[kk * LDS_Y + jc];
-        const double r0 = stg[OFF_BT + kc * MT + l16], r1 = stg[OFF_BT + kc * MT + a1c];   // B~^T[i][k] = B~[k][i]
-        a0[ks] = a0ok ? r0 : 0.0; a1[ks] = a1ok ? r1 : 0.0;
+        const real r0 = stg[OFF_BT + kc * MT + (la < MT ? la : 0)], r1 = stg[OFF_BT + kc * MT + a1c];   // B~^T[i][k] = B~[k][i]
+        a0[ks] = a0ok ? r0 : 0.0_r; a1[ks] = a1ok ? r1 : 0.0_r;
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); if (mtTiles == 2) qmMfma(c1, a1[ks], bv[ks], scr); }
@@ -188,20 +188,20 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     if (wave == 0) {
       const bool isH = lane < 32;
       const int c = isH ? lane : lane - 32;
-      double col[MT];
+      real col[MT];
 #pragma unroll
       for (int r = 0; r < MT; ++r) {
-        const double e = (r == c) ? 1.0 : 0.0;
-        const double hv = T[r * LDS_Y + 32 + (lane < MT ? lane : 0)];
+        const real e = (r == c) ? 1.0_r : 0.0_r;
+        const real hv = T[r * LDS_Y + 32 + (lane < MT ? lane : 0)];
         col[r] = (isH && lane < nt && r < nt) ? hv : e;
       }
       // steps j >= m~ meet identity columns (pivot 1, multipliers 0): no branch, one basic block.  The reciprocal square root of
       // pivot j + 1 is started right after row j + 1 has received its update, so its latency hides behind the remaining updates.
-      double inv;
+      real inv;
       {
-        const double piv = qmReadLane(col[0], 0, scr);
-        if (!(piv > 0.0)) status = 1;
-        inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+        const real piv = qmReadLane(col[0], 0, scr);
+        if (!(piv > 0.0_r)) status = 1;
+        inv = qmRsqrt(piv > 0.0_r ? piv : 1.0_r);
       }
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
@@ -209,16 +209,16 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const QmGather gj = qmGather(col[j], scr);
         if (j + 1 < MT) {
           col[j + 1] -= gj.get(j + 1) * col[j];
-          const double piv = qmReadLane(col[j + 1], j + 1, scr);
-          if (!(piv > 0.0)) status = 1;
-          inv = qmRsqrt(piv > 0.0 ? piv : 1.0);
+          const real piv = qmReadLane(col[j + 1], j + 1, scr);
+          if (!(piv > 0.0_r)) status = 1;
+          inv = qmRsqrt(piv > 0.0_r ? piv : 1.0_r);
         }
 #pragma unroll
         for (int r = j + 2; r < MT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= m~: identity columns)
       }
       if (!isH && c < 20) {
 #pragma unroll
-        for (int r = 0; r < MT; ++r) { const double v = (c < nt && r < nt) ? col[r] : 0.0; LI[r * LDS_W + c] = v; LIT[c * LDS_LT + r] = v; }
+        for (int r = 0; r < MT; ++r) { const real v = (c < nt && r < nt) ? col[r] : 0.0_r; LI[r * LDS_W + c] = v; LIT[c * LDS_LT + r] = v; }
       }
     }
     pf.commit(stgNext, OFF_PX, tid);   // stage k - 1 lands in the other buffer: wavefronts 1..3 do it while wavefront 0 factorises
@@ -228,10 +228,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     {
       QmAcc c;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) c[r] = 0.0;
-      double av[5], bw[5];
+      for (int r = 0; r < 4; ++r) c[r] = 0.0_r;
+      real av[5], bw[5];
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = LIT[kk * LDS_LT + tm * 16 + l16]; bw[ks] = T[kk * LDS_Y + tn * 16 + l16]; }   // L^-1[i][k] = L^-T[k][i]
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = LIT[kk * LDS_LT + tm * 16 + la]; bw[ks] = T[kk * LDS_Y + tn * 16 + l16]; }   // L^-1[i][k] = L^-T[k][i]
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
 #pragma unroll
@@ -242,19 +242,19 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     {
       QmAcc c;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) c[r] = 0.0;
-      double av[5], bw[5];
+      for (int r = 0; r < 4; ++r) c[r] = 0.0_r;
+      real av[5], bw[5];
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -LI[kk * LDS_W + tm * 16 + l16]; bw[ks] = W[kk * LDS_W + tn * 16 + l16]; }   // L^-T[i][k] = L^-1[k][i]
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -LI[kk * LDS_W + tm * 16 + la]; bw[ks] = W[kk * LDS_W + tn * 16 + l16]; }   // L^-T[i][k] = L^-1[k][i]
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
-      double* gain = a.gains + (size_t(inst) * N + k) * GAIN_DOUBLES;
+      real* gain = a.gains + (size_t(inst) * N + k) * GAIN_DOUBLES;
       const int j = tn * 16 + l16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
         if (i < MT) {
-          const double v = i < nt ? c[r] : 0.0;
+          const real v = i < nt ? c[r] : 0.0_r;
           if (j < 30) gain[OFF_KFB + i * 30 + j] = v;
           else if (j == 30) gain[OFF_kff + i] = v;
         }
@@ -267,18 +267,18 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r, ic = i < 30 ? i : 0;
-        const double v = j < 30 ? stg[OFF_QT + ic * 30 + j] : (j == 30 ? stg[OFF_qt + ic] : 0.0);
-        c[r] = i < 30 ? v : 0.0;
+        const real v = j < 30 ? stg[OFF_QT + ic * 30 + j] : (j == 30 ? stg[OFF_qt + ic] : 0.0_r);
+        c[r] = i < 30 ? v : 0.0_r;
       }
-      const int ai = tm * 16 + l16 < 30 ? tm * 16 + l16 : 29;   // rows 30,31 of the result are discarded
-      double av[13], bw[13];
+      const int ai = tm * 16 + la < 30 ? tm * 16 + la : 29;   // rows 30,31 of the result are discarded
+      real av[13], bw[13];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
         av[ks] = stg[OFF_AT + kc * 30 + ai]; bw[ks] = Y[kk * LDS_Y + j];   // A~^T[i][k] = A~[k][i]
       }
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[8 + ks] = -W[kk * LDS_W + tm * 16 + l16]; bw[8 + ks] = W[kk * LDS_W + j]; }
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[8 + ks] = -W[kk * LDS_W + tm * 16 + la]; bw[8 + ks] = W[kk * LDS_W + j]; }
 #pragma unroll
       for (int ks = 0; ks < 13; ++ks) qmMfma(c, av[ks], bw[ks], scr);
       // The raw result goes to a scratch square (T is dead; stride 34 makes both the row and the column walk conflict free), s' in
@@ -294,8 +294,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
-        const double up = TS[i * LDS_TS + j], lo = TS[j * LDS_TS + i];
-        if (i < 30 && j < 30) S[i * LDS_S + j] = 0.5 * (up + lo);
+        const real up = TS[i * LDS_TS + j], lo = TS[j * LDS_TS + i];
+        if (i < 30 && j < 30) S[i * LDS_S + j] = 0.5_r * (up + lo);
       }
     }
     QM_LDS_BARRIER();
@@ -317,14 +317,14 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
   if (tid < 30) dxv[tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
-  double armijo = 0.0;
+  real armijo = 0.0_r;
   __syncthreads();
 #pragma unroll 1
   for (int k = 0; k < N; ++k) {
     const int nt = 30 - ncI[k];
     const int kn = k + 1 < N ? k + 1 : k;
-    const double* stg = lds + R_STG + (k & 1) * STG_F; const double* gn = stg + STAGE_DOUBLES;
-    double* stgNext = lds + R_STG + ((k + 1) & 1) * STG_F;
+    const real* stg = lds + R_STG + (k & 1) * STG_F; const real* gn = stg + STAGE_DOUBLES;
+    real* stgNext = lds + R_STG + ((k + 1) & 1) * STG_F;
     StagePrefetch<PFH, NTHR> ph;
     StagePrefetch<PFT, NTHR> pt;
     StagePrefetch<PFG, NTHR> pg;
@@ -333,22 +333,22 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     pg.issue(gainsI + size_t(kn) * GAIN_DOUBLES, GAIN_DOUBLES, tid);
     if (wave == 0 && lane < 30) a.dX[(size_t(inst) * (N + 1) + k) * 30 + lane] = dxv[lane];
     if (wave == 0 && lane < nt) {
-      double s0 = gn[OFF_kff + lane], s1 = 0.0;
+      real s0 = gn[OFF_kff + lane], s1 = 0.0_r;
 #pragma unroll
       for (int c = 0; c < 30; c += 2) { s0 += gn[OFF_KFB + lane * 30 + c] * dxv[c]; s1 += gn[OFF_KFB + lane * 30 + c + 1] * dxv[c + 1]; }
       dut[lane] = s0 + s1;
     }
     QM_LDS_BARRIER();
-    double nx = 0.0;
+    real nx = 0.0_r;
     if (wave == 0 && lane < 30) {  // du = Pe + Px dx + Pu du~
-      double s0 = stg[OFF_PE + lane], s1 = 0.0;
+      real s0 = stg[OFF_PE + lane], s1 = 0.0_r;
 #pragma unroll
       for (int c = 0; c < 30; c += 2) { s0 += stg[OFF_PX + lane * 30 + c] * dxv[c]; s1 += stg[OFF_PX + lane * 30 + c + 1] * dxv[c + 1]; }
       for (int j = 0; j < nt; ++j) s0 += stg[OFF_PU + lane * MT + j] * dut[j];
       a.dU[(size_t(inst) * N + k) * 30 + lane] = s0 + s1;
     }
     if (wave == WX && lane < 30) {  // dx+ = A~ dx + B~ du~ + b~ ; armijo contribution q~ . dx
-      double s0 = stg[OFF_bt + lane], s1 = 0.0;
+      real s0 = stg[OFF_bt + lane], s1 = 0.0_r;
 #pragma unroll
       for (int c = 0; c < 30; c += 2) { s0 += stg[OFF_AT + lane * 30 + c] * dxv[c]; s1 += stg[OFF_AT + lane * 30 + c + 1] * dxv[c + 1]; }
       for (int j = 0; j < nt; ++j) s0 += stg[OFF_BT + lane * MT + j] * dut[j];
@@ -372,10 +372,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   if (wave == WX) red[lane] = armijo;
   __syncthreads();
   if (tid == 0) {
-    double s = 0.0;
+    real s = 0.0_r;
     for (int i = 0; i < 64; ++i) s += red[i];
     a.instStats[size_t(inst) * 4 + 0] = s;
-    a.instStats[size_t(inst) * 4 + 1] = double(status);
+    a.instStats[size_t(inst) * 4 + 1] = real(status);
   }
 }
 

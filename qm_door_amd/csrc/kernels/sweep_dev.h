@@ -16,7 +16,7 @@ namespace qmk {
 // position / velocity (/ orientation) of the frame at the chain's tip, all in the frame of the chain's root and about its origin.
 // Scalar types as in model_dev.h: P = configuration-only quantities, V = quantities also linear in the joint rates / momenta.
 template <class P, class V> struct ChainAcc {
-  double M;            // composite mass
+  real M;            // composite mass
   Vec3<P> h;           // first moment  sum m c
   Sym3<P> I;           // inertia about the current origin
   Vec3<V> l, k;        // momentum caused by the joint rates of the subtree (k about the current origin)
@@ -30,9 +30,9 @@ template <class C, class T> __device__ __forceinline__ void rotAxis(int axis, C 
   else { const T a = v.x, b = v.y; v.x = cs * a - sn * b; v.y = sn * a + cs * b; }
 }
 template <class T> __device__ __forceinline__ Vec3<T> axisCross(int axis, const Vec3<T>& v) {  // e_axis x v
-  if (axis == 0) return Vec3<T>(T(0.0), T(0.0) - v.z, v.y);
-  if (axis == 1) return Vec3<T>(v.z, T(0.0), T(0.0) - v.x);
-  return Vec3<T>(T(0.0) - v.y, v.x, T(0.0));
+  if (axis == 0) return Vec3<T>(T(0.0_r), T(0.0_r) - v.z, v.y);
+  if (axis == 1) return Vec3<T>(v.z, T(0.0_r), T(0.0_r) - v.x);
+  return Vec3<T>(T(0.0_r) - v.y, v.x, T(0.0_r));
 }
 template <class T> __device__ __forceinline__ Vec3<T> symColumn(int axis, const Sym3<T>& S) {
   if (axis == 0) return Vec3<T>(S.xx, S.xy, S.xz);
@@ -41,7 +41,7 @@ template <class T> __device__ __forceinline__ Vec3<T> symColumn(int axis, const 
 }
 // E S E^T for the rotation E about `axis`; (i, j) is the rotated plane, k the axis: entries II JJ IJ IK JK (KK unchanged)
 template <class T> __device__ __forceinline__ void rotPlane(T c2, T s2, T cs, T sn, T& II, T& JJ, T& IJ, T& IK, T& JK) {
-  const T d = 0.5 * (II - JJ), m = 0.5 * (II + JJ);
+  const T d = 0.5_r * (II - JJ), m = 0.5_r * (II + JJ);
   const T t = d * c2 - IJ * s2;
   const T nij = d * s2 + IJ * c2;
   II = m + t; JJ = m - t; IJ = nij;
@@ -49,16 +49,16 @@ template <class T> __device__ __forceinline__ void rotPlane(T c2, T s2, T cs, T 
   IK = cs * a - sn * b; JK = sn * a + cs * b;
 }
 template <class T> __device__ __forceinline__ void rotSym(int axis, T cs, T sn, Sym3<T>& S) {
-  const T c2 = cs * cs - sn * sn, s2 = 2.0 * (cs * sn);
+  const T c2 = cs * cs - sn * sn, s2 = 2.0_r * (cs * sn);
   if (axis == 0) rotPlane(c2, s2, cs, sn, S.yy, S.zz, S.yz, S.xy, S.xz);        // plane (y, z), axis x
   else if (axis == 1) rotPlane(c2, s2, cs, sn, S.zz, S.xx, S.xz, S.yz, S.xy);   // plane (z, x), axis y
   else rotPlane(c2, s2, cs, sn, S.xx, S.yy, S.xy, S.xz, S.yz);                  // plane (x, y), axis z
 }
 
 // add body b (its own frame = the current frame) to the composite: constants only
-template <class P, class V> __device__ __forceinline__ void addBody(const qmgpu_model& md, int b, ChainAcc<P, V>& c) {
-  const double m = md.mass[b], cx = md.com[b][0], cy = md.com[b][1], cz = md.com[b][2];
-  const double* in = md.inertia[b];
+template <class P, class V> __device__ __forceinline__ void addBody(const ModelR& md, int b, ChainAcc<P, V>& c) {
+  const real m = md.mass[b], cx = md.com[b][0], cy = md.com[b][1], cz = md.com[b][2];
+  const real* in = md.inertia[b];
   c.M += m;
   c.h = c.h + Vec3<P>(P(m * cx), P(m * cy), P(m * cz));
   c.I.xx = c.I.xx + (in[0] + m * (cy * cy + cz * cz)); c.I.yy = c.I.yy + (in[3] + m * (cx * cx + cz * cz)); c.I.zz = c.I.zz + (in[5] + m * (cx * cx + cy * cy));
@@ -71,7 +71,7 @@ template <class P, class V> __device__ __forceinline__ void addBody(const qmgpu_
 __device__ constexpr int LEG_AXIS[3] = {0, 1, 1};
 __device__ constexpr int ARM_AXIS[6] = {2, 1, 1, 1, 2, 0};
 
-template <class P, class V, class RotExtra> __device__ __forceinline__ void crossJoint(const qmgpu_model& md, int b, int axis, P q, V qd, ChainAcc<P, V>& c, RotExtra&& rotExtra) {
+template <class P, class V, class RotExtra> __device__ __forceinline__ void crossJoint(const ModelR& md, int b, int axis, P q, V qd, ChainAcc<P, V>& c, RotExtra&& rotExtra) {
   c.l = c.l + qd * axisCross(axis, c.h);
   c.k = c.k + qd * symColumn(axis, c.I);
   c.vf = c.vf + qd * axisCross(axis, c.p);
@@ -80,12 +80,12 @@ template <class P, class V, class RotExtra> __device__ __forceinline__ void cros
   rotAxis(axis, cs, sn, c.h); rotAxis(axis, cs, sn, c.l); rotAxis(axis, cs, sn, c.k); rotAxis(axis, cs, sn, c.p); rotAxis(axis, cs, sn, c.vf);
   rotSym(axis, cs, sn, c.I);
   rotExtra(axis, cs, sn);
-  const double ox = md.joint_offset[b][0], oy = md.joint_offset[b][1], oz = md.joint_offset[b][2], M = c.M;
+  const real ox = md.joint_offset[b][0], oy = md.joint_offset[b][1], oz = md.joint_offset[b][2], M = c.M;
   // k about the new origin, inertia about the new origin (uses h about the old one), then h and the tip position
   c.k = c.k + Vec3<V>(oy * c.l.z - oz * c.l.y, oz * c.l.x - ox * c.l.z, ox * c.l.y - oy * c.l.x);
-  c.I.xx = c.I.xx + (2.0 * (oy * c.h.y + oz * c.h.z) + M * (oy * oy + oz * oz));
-  c.I.yy = c.I.yy + (2.0 * (ox * c.h.x + oz * c.h.z) + M * (ox * ox + oz * oz));
-  c.I.zz = c.I.zz + (2.0 * (ox * c.h.x + oy * c.h.y) + M * (ox * ox + oy * oy));
+  c.I.xx = c.I.xx + (2.0_r * (oy * c.h.y + oz * c.h.z) + M * (oy * oy + oz * oz));
+  c.I.yy = c.I.yy + (2.0_r * (ox * c.h.x + oz * c.h.z) + M * (ox * ox + oz * oz));
+  c.I.zz = c.I.zz + (2.0_r * (ox * c.h.x + oy * c.h.y) + M * (ox * ox + oy * oy));
   c.I.xy = c.I.xy - ((ox * c.h.y + oy * c.h.x) + M * ox * oy);
   c.I.xz = c.I.xz - ((ox * c.h.z + oz * c.h.x) + M * ox * oz);
   c.I.yz = c.I.yz - ((oy * c.h.z + oz * c.h.y) + M * oy * oz);
@@ -110,13 +110,13 @@ template <class T> __device__ __forceinline__ Sym3<T> similarity(const Mat3<T>& 
 // In must provide: V hn(i) i<6 ; P euler(i) i<3 ; P q(j), V qd(j) j<18 (joint order) ; Vec3<F> force(c) c<4 (contact order)
 // onEE(r_ee_rel_base, R_ee) is called once, onFoot(c, r_rel_base, v_joint_only) four times (world axes, relative to the base origin).
 template <class P, class V, class F, class In, class FootFn, class EeFn>
-__device__ __forceinline__ void centroidalSweep2(const qmgpu_model& md, double gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, FlowOut<P, V, F>& f, BaseMotion2<P, V>& bm) {
+__device__ __forceinline__ void centroidalSweep2(const ModelR& md, real gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, FlowOut<P, V, F>& f, BaseMotion2<P, V>& bm) {
   P sz, cz, sy, cy;
   Mat3<P> R0;
   baseRotation(in.euler(0), in.euler(1), in.euler(2), R0, sz, cz, sy, cy);
   // totals in the base frame, about the base origin; start with the base body itself
   ChainAcc<P, V> tot;
-  tot.M = 0.0;
+  tot.M = 0.0_r;
   addBody(md, 0, tot);
   auto absorb = [&](const ChainAcc<P, V>& c) {
     tot.M += c.M; tot.h = tot.h + c.h; tot.l = tot.l + c.l; tot.k = tot.k + c.k;
@@ -124,10 +124,10 @@ __device__ __forceinline__ void centroidalSweep2(const qmgpu_model& md, double g
   };
   {  // arm: bodies 18 .. 13, tip = end-effector frame (its orientation is carried along)
     ChainAcc<P, V> c;
-    c.M = 0.0;
+    c.M = 0.0_r;
     c.p = Vec3<P>(P(md.ee_offset[0]), P(md.ee_offset[1]), P(md.ee_offset[2]));
     Mat3<P> Re;
-    Re.c0 = Vec3<P>(P(1.0), P(0.0), P(0.0)); Re.c1 = Vec3<P>(P(0.0), P(1.0), P(0.0)); Re.c2 = Vec3<P>(P(0.0), P(0.0), P(1.0));
+    Re.c0 = Vec3<P>(P(1.0_r), P(0.0_r), P(0.0_r)); Re.c1 = Vec3<P>(P(0.0_r), P(1.0_r), P(0.0_r)); Re.c2 = Vec3<P>(P(0.0_r), P(0.0_r), P(1.0_r));
 #pragma unroll
     for (int a = 5; a >= 0; --a) {
       addBody(md, 13 + a, c);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void centroidalSweep2(const qmgpu_model& md, double g
     int cft = 0;
     for (int k = 1; k < 4; ++k) if (md.foot_body[k] == 3 + 3 * leg) cft = k;
     ChainAcc<P, V> c;
-    c.M = 0.0;
+    c.M = 0.0_r;
     c.p = Vec3<P>(P(md.foot_offset[cft][0]), P(md.foot_offset[cft][1]), P(md.foot_offset[cft][2]));
 #pragma unroll
     for (int j = 2; j >= 0; --j) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void centroidalSweep2(const qmgpu_model& md, double g
 }
 // single scalar type (plain evaluation with T = double; T = Du differentiates along one direction per lane through everything)
 template <class T, class In, class FootFn, class EeFn>
-__device__ __forceinline__ void centroidalSweep(const qmgpu_model& md, double gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, T f[12], BaseMotion<T>& bm) {
+__device__ __forceinline__ void centroidalSweep(const ModelR& md, real gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, T f[12], BaseMotion<T>& bm) {
   FlowOut<T, T, T> o;
   centroidalSweep2<T, T, T>(md, gravity, in, onFoot, onEE, o, bm);
 #pragma unroll

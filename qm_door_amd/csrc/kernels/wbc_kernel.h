@@ -34,7 +34,6 @@ struct WbcArgs {
   double* inputLast; double* out; int* status;
 };
 
-constexpr int WBC_SCRATCH_DOUBLES = 8;  // (unused, kept for the context layout)
 constexpr int ND = 36, NVV = 24, MAXR = 22, MAXM = 56;
 constexpr int LDZ = 37, LDK = 37;
 // ---- LDS carve (doubles)

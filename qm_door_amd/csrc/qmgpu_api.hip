@@ -14,14 +14,10 @@
 
 #include "../../include/qmgpu.h"
 #include "host/host_error.h"
-#include "kernels/aux_kernels.h"
-#include "kernels/gpu_rt.h"
-#include "kernels/layout.h"
-#include "kernels/linesearch_kernel.h"
-#include "kernels/lq_kernel.h"
-#include "kernels/riccati_kernel.h"
+#include "kernels/mpc_pipeline.h"
 #include "kernels/wbc_kernel.h"
 #include "kernels/frontend_kernel.h"
+#include "mpc32.h"
 
 using namespace qmhost;
 using namespace qmk;
@@ -50,16 +46,13 @@ struct qmgpu_context {
   int device = 0, maxBatch = 0, maxNodes = 0;
   hipStream_t ownStream = nullptr, stream = nullptr;
   qmgpu_problem hostProblem;
-  // device buffers
-  qmgpu_problem* dP = nullptr;
-  double *dRw = nullptr, *dZeros = nullptr;
-  double *dTgrid = nullptr, *dX = nullptr, *dU = nullptr, *dStages = nullptr, *dAdRows = nullptr, *dMetrics = nullptr, *dGains = nullptr, *ddX = nullptr, *ddU = nullptr;
-  double *dXt = nullptr, *dUt = nullptr, *dInstStats = nullptr, *dDebug = nullptr;
-  int *dStageNc = nullptr, *dNodeMode = nullptr, *dDone = nullptr;
+  int dtype = QMGPU_F64;
+  // device buffers of the fp64 kernels (MPC scratch, model / settings, R'); the WBC and the front end always run in fp64
+  MpcBuffers m;
+  qmk32::Mpc32* m32 = nullptr;   // fp32 MPC path (dtype == QMGPU_F32): its own scratch, staging and launch chain (qmgpu_mpc32.hip)
   // policy evaluation outputs feeding the WBC inside qmgpu_cycle_batch
   double *dPolX = nullptr, *dPolU = nullptr;
   int* dPolMode = nullptr;
-  double* dWbcScratch = nullptr;
   std::vector<void*> allocations;
   bool timing = false, debugLq = false;
   // HIP-event ring: one set of 7 events per call while timing is enabled, read back without a per-call sync
@@ -97,7 +90,11 @@ static void checkTopology(const qmgpu_model& m) {
 extern "C" {
 
 int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, qmgpu_handle* out) {
-  if (!problem || !out || max_batch < 1 || max_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments to qmgpu_create");
+  return qmgpu_create_ex(problem, device, max_batch, max_nodes, QMGPU_F64, out);
+}
+
+int qmgpu_create_ex(const qmgpu_problem* problem, int device, int max_batch, int max_nodes, int dtype, qmgpu_handle* out) {
+  if (!problem || !out || max_batch < 1 || max_nodes < 1 || (dtype != QMGPU_F64 && dtype != QMGPU_F32)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments to qmgpu_create");
   *out = nullptr;
   qmgpu_context* ctx = nullptr;
   const int st = guarded([&]() {
@@ -108,40 +105,29 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
     DeviceGuard onDevice(device);
     ctx = new qmgpu_context();
     for (auto& set : ctx->ring) for (auto& e : set) e = nullptr;
-    ctx->device = device; ctx->maxBatch = max_batch; ctx->maxNodes = max_nodes; ctx->hostProblem = *problem;
+    ctx->device = device; ctx->maxBatch = max_batch; ctx->maxNodes = max_nodes; ctx->hostProblem = *problem; ctx->dtype = dtype;
     HIP_CHECK(hipStreamCreate(&ctx->ownStream));
     ctx->stream = ctx->ownStream;
     const size_t B = size_t(max_batch), N1 = size_t(max_nodes) + 1, N = size_t(max_nodes);
-    ctx->dP = ctx->alloc<qmgpu_problem>(1, false);
-    ctx->dRw = ctx->alloc<double>(900, false);
-    ctx->dZeros = ctx->alloc<double>(64, false);
-    ctx->dTgrid = ctx->alloc<double>(B * N1);
-    ctx->dX = ctx->alloc<double>(B * N1 * 30);
-    ctx->dU = ctx->alloc<double>(B * N * 30);
-    ctx->dStages = ctx->alloc<double>(B * N1 * STAGE_DOUBLES);
-    ctx->dAdRows = ctx->alloc<double>(B * N1 * AD_DOUBLES);
-    ctx->dMetrics = ctx->alloc<double>(B * N1 * NODE_METRICS);
-    ctx->dGains = ctx->alloc<double>(B * N * GAIN_DOUBLES);
-    ctx->ddX = ctx->alloc<double>(B * N1 * 30);
-    ctx->ddU = ctx->alloc<double>(B * N * 30);
-    ctx->dXt = ctx->alloc<double>(2 * B * N1 * 30);   // two trial steps are evaluated side by side (linesearch_kernel)
-    ctx->dUt = ctx->alloc<double>(2 * B * N * 30);
-    ctx->dInstStats = ctx->alloc<double>(B * 4);
-    ctx->dStageNc = ctx->alloc<int>(B * N1);
-    ctx->dNodeMode = ctx->alloc<int>(B * N1);
-    ctx->dDone = ctx->alloc<int>(B);
+    auto rawAlloc = [&](size_t count, size_t elem, bool scratch) { return static_cast<void*>(ctx->alloc<char>(count * elem, scratch)); };
+    // the fp32 handle keeps the fp64 model / settings / R' (the WBC and the front end read them) but not the fp64 MPC scratch
+    if (dtype == QMGPU_F64) allocateMpcBuffers(ctx->m, B, N, rawAlloc);
+    else { ctx->m.dP = ctx->alloc<qmgpu_problem>(1, false); ctx->m.dRw = ctx->alloc<double>(900, false); ctx->m.dZeros = ctx->alloc<double>(64, false); }
     ctx->dPolX = ctx->alloc<double>(B * 30);
     ctx->dPolU = ctx->alloc<double>(B * 30);
     ctx->dPolMode = ctx->alloc<int>(B);
-    ctx->dWbcScratch = ctx->alloc<double>(B * WBC_SCRATCH_DOUBLES);
-    HIP_CHECK(hipMemcpy(ctx->dP, problem, sizeof(qmgpu_problem), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemsetAsync(ctx->dZeros, 0, 64 * sizeof(double), ctx->stream));
+    HIP_CHECK(hipMemcpy(ctx->m.dP, problem, sizeof(qmgpu_problem), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemsetAsync(ctx->m.dZeros, 0, 64 * sizeof(double), ctx->stream));
     for (auto& set : ctx->ring) for (auto& e : set) HIP_CHECK(hipEventCreate(&e));
     ctx->ev = ctx->ring[0];
     HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(wbc_kernel, WBC_LDS_BYTES));
-    HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(riccati_kernel<RICCATI_WAVES>, RICCATI_LDS_BYTES));
-    QM_LAUNCH(input_weight_kernel, 1, 64, ctx->stream, ctx->dP, ctx->dZeros, ctx->dRw);
+    HIP_CHECK(prepareMpcKernels());
+    QM_LAUNCH(input_weight_kernel, 1, 64, ctx->stream, ctx->m.dP, ctx->m.dZeros, ctx->m.dRw);
     HIP_CHECK(hipGetLastError());
+    if (dtype == QMGPU_F32) {
+      ctx->m32 = qmk32::create(*problem, max_batch, max_nodes, ctx->stream, rawAlloc);
+      if (!ctx->m32) throw HipFailure("fp32 MPC path could not be created");
+    }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
   });
   if (st != QMGPU_OK) {
@@ -152,6 +138,7 @@ int qmgpu_create(const qmgpu_problem* problem, int device, int max_batch, int ma
       for (auto& set : ctx->ring) for (auto& e : set) if (e) hipEventDestroy(e);
       if (ctx->ownStream) hipStreamDestroy(ctx->ownStream);
       if (sw) hipSetDevice(prev);
+      qmk32::destroy(ctx->m32);
       delete ctx;
     }
     return st;
@@ -169,6 +156,7 @@ int qmgpu_destroy(qmgpu_handle h) {
   for (auto& set : h->ring) for (auto& e : set) if (e) hipEventDestroy(e);
   if (h->ownStream) hipStreamDestroy(h->ownStream);
   if (sw) hipSetDevice(prev);
+  qmk32::destroy(h->m32);
   delete h;
   return QMGPU_OK;
 }
@@ -190,15 +178,16 @@ int qmgpu_update_settings(qmgpu_handle h, const qmgpu_settings* settings) {
     DeviceGuard onDevice(h->device);
     HIP_CHECK(hipStreamSynchronize(h->stream));   // kernels in flight still read the old values through dP
     h->hostProblem.settings = *settings;
-    HIP_CHECK(hipMemcpy(&h->dP->settings, &h->hostProblem.settings, sizeof(qmgpu_settings), hipMemcpyHostToDevice));
-    QM_LAUNCH(input_weight_kernel, 1, 64, h->stream, h->dP, h->dZeros, h->dRw);
+    HIP_CHECK(hipMemcpy(&h->m.dP->settings, &h->hostProblem.settings, sizeof(qmgpu_settings), hipMemcpyHostToDevice));
+    QM_LAUNCH(input_weight_kernel, 1, 64, h->stream, h->m.dP, h->m.dZeros, h->m.dRw);
     HIP_CHECK(hipGetLastError());
+    if (h->m32 && !qmk32::updateProblem(h->m32, h->hostProblem, h->stream)) throw HipFailure("fp32 settings update failed");
   });
 }
 
 int qmgpu_get_input_weight(qmgpu_handle h, double* R_host) {
   if (!h || !R_host) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
-  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); HIP_CHECK(hipMemcpy(R_host, h->dRw, 900 * sizeof(double), hipMemcpyDeviceToHost)); });
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); HIP_CHECK(hipMemcpy(R_host, h->m.dRw, 900 * sizeof(double), hipMemcpyDeviceToHost)); });
 }
 
 int qmgpu_enable_timing(qmgpu_handle h, int enable) {
@@ -231,7 +220,8 @@ int qmgpu_debug_poison(qmgpu_handle h) {
 int qmgpu_enable_debug(qmgpu_handle h, int enable) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
-    if (enable && !h->dDebug) h->dDebug = h->alloc<double>(size_t(h->maxBatch) * (h->maxNodes + 1) * DBG_DOUBLES);
+    if (enable && h->dtype != QMGPU_F64) throw std::invalid_argument("the per-node LQ dump exists in the fp64 path only");
+    if (enable && !h->m.dDebug) h->m.dDebug = h->alloc<double>(size_t(h->maxBatch) * (h->maxNodes + 1) * DBG_DOUBLES);
     h->debugLq = enable != 0;
   });
 }
@@ -246,39 +236,24 @@ static void checkMpcArgs(qmgpu_handle h, const qmgpu_mpc_args* a) {
 }
 
 static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
-  const int B = a->batch, N = a->num_nodes;
-  hipStream_t s = h->stream;
-  if (h->timing) HIP_CHECK(hipEventRecord(h->ev[0], s));
-  // sqp.sqpIteration iterations (task.info:77; 1 in the reference's configuration): later iterations warm-start from the iterate the
-  // line search just wrote to the caller's output buffers.  After every iteration the line-search kernel applies upstream's convergence
-  // test per instance; the kernels of the following iterations return at once for the instances that have converged.
   const int iterations = h->hostProblem.settings.sqp_iterations > 1 ? h->hostProblem.settings.sqp_iterations : 1;
-  for (int it = 0; it < iterations; ++it) {
-    InitArgs ia{h->dP, B, N, a->t0, a->x0, a->time_grid, it == 0 ? a->warm_x : a->out_x, it == 0 ? a->warm_u : a->out_u, a->sched_num_events, a->sched_event_times, a->sched_modes, h->dTgrid, h->dX, h->dU, it, h->dDone};
-    QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
-    LqArgs la{h->dP, h->dRw, B, N, a->num_target_knots, h->dTgrid, h->dX, h->dU, a->target_times, a->target_states, a->sched_num_events, a->sched_event_times,
-              a->sched_modes, h->dZeros, h->dStages, h->dStageNc, h->dNodeMode, h->dMetrics, h->debugLq ? h->dDebug : nullptr, h->dAdRows, h->dDone};
-    QM_LAUNCH(ad_node_kernel, adGridFor(B * (N + 1)), 64, s, la);
-    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[6], s));
-    QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
-    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[1], s));
-    RiccatiArgs ra{B, N, h->dStages, h->dStageNc, a->x0, h->dX, h->dGains, h->ddX, h->ddU, h->dInstStats, h->dDone};
-    QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
-    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[2], s));
-    LsArgs ls{h->dP, h->dRw, B, N, a->num_target_knots, a->line_search, h->dTgrid, h->dX, h->dU, h->ddX, h->ddU, a->target_times, a->target_states, a->sched_num_events,
-              a->sched_event_times, a->sched_modes, h->dMetrics, h->dInstStats, h->dNodeMode, h->dXt, h->dUt, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats, it, h->dDone};
-    QM_LAUNCH(linesearch_kernel, B, 256, s, ls);
-    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[3], s));
+  hipEvent_t* ev = h->timing ? h->ev : nullptr;
+  if (h->dtype == QMGPU_F32) {
+    if (!qmk32::enqueue(h->m32, h->stream, a, h->hostProblem.settings.dt, iterations, ev)) throw HipFailure("fp32 MPC launch failed");
+  } else {
+    const MpcIo io{a->batch, a->num_nodes, a->num_target_knots, a->line_search, h->hostProblem.settings.dt, a->t0, a->time_grid, a->sched_event_times, a->x0, a->target_times,
+                   a->target_states, a->sched_num_events, a->sched_event_times, a->sched_modes, a->warm_x, a->warm_u, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
+    enqueueMpcKernels(h->stream, h->m, io, iterations, h->debugLq, ev);
   }
   HIP_CHECK(hipGetLastError());
-  h->lastBatch = B; h->lastN = N;
+  h->lastBatch = a->batch; h->lastN = a->num_nodes;
 }
 
 static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
   if (!w || w->batch < 1) throw std::invalid_argument("bad WBC arguments");
   if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
   if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
-  WbcArgs wa{h->dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status};
+  WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status};
   QM_LAUNCH_DYN(wbc_kernel, w->batch, 64, WBC_LDS_BYTES, h->stream, wa);
   HIP_CHECK(hipGetLastError());
 }
@@ -327,7 +302,7 @@ int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* a) {
   if (!h || !a || a->batch < 1 || !a->rbd_measured || !a->time || !a->command_kind || !a->command || !a->last_ee_target || !a->x0 || !a->target_times || !a->target_states)
     return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad front-end arguments");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
-    FrontendArgs fa{h->dP, *a};
+    FrontendArgs fa{h->m.dP, *a};
     QM_LAUNCH(frontend_kernel, (a->batch + 63) / 64, 64, h->stream, fa);
     HIP_CHECK(hipGetLastError());
   });
@@ -377,14 +352,14 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
                        int32_t* nc) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
-    if (!h->debugLq || !h->dDebug) throw std::invalid_argument("call qmgpu_enable_debug(h, 1) before the solve");
+    if (!h->debugLq || !h->m.dDebug) throw std::invalid_argument("call qmgpu_enable_debug(h, 1) before the solve");
     if (instance < 0 || instance >= h->lastBatch || node < 0 || node > h->lastN) throw std::invalid_argument("instance / node out of range");
     HIP_CHECK(hipStreamSynchronize(h->stream));
     std::vector<double> rec(DBG_DOUBLES);
     const size_t idx = size_t(instance) * (h->lastN + 1) + node;
-    HIP_CHECK(hipMemcpy(rec.data(), h->dDebug + idx * DBG_DOUBLES, DBG_DOUBLES * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(rec.data(), h->m.dDebug + idx * DBG_DOUBLES, DBG_DOUBLES * sizeof(double), hipMemcpyDeviceToHost));
     int ncv = 0;
-    HIP_CHECK(hipMemcpy(&ncv, h->dStageNc + idx, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&ncv, h->m.dStageNc + idx, sizeof(int), hipMemcpyDeviceToHost));
     auto cp = [&](double* dst, int off, int n) { if (dst) std::memcpy(dst, rec.data() + off, n * sizeof(double)); };
     cp(A, DBG_A, 900); cp(B, DBG_B, 900); cp(b, DBG_b, 30); cp(Q, DBG_Q, 900); cp(R, DBG_R, 900); cp(q, DBG_q, 30); cp(r, DBG_r, 30);
     cp(C, DBG_C, 16 * 30); cp(D, DBG_D, 16 * 30); cp(e, DBG_e, 16);

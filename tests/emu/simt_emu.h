@@ -133,6 +133,7 @@ template <int TP> inline void qmMfmaUpper(QmAcc* acc, const double* a, const dou
 }
 inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
+constexpr int qmARow(int p) { return p; }   // fp64 accumulator map: the rows of an A operand are fed in order (gpu_rt.h)
 
 template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
   const unsigned nt = block.x * block.y * block.z;

@@ -55,7 +55,7 @@ class WbcBatch:
         return dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), input_last=self.il.cpu().numpy())
 
 
-def make_solver(interface, max_batch, max_nodes):
-    s = api.GpuSolver(interface, max_batch, max_nodes, device=torch.cuda.current_device())
+def make_solver(interface, max_batch, max_nodes, dtype="f64"):
+    s = api.GpuSolver(interface, max_batch, max_nodes, device=torch.cuda.current_device(), dtype=dtype)
     s.set_stream(torch.cuda.current_stream().cuda_stream)
     return s

@@ -2,7 +2,7 @@
 
   config 3: batch 2048, randomised base pose + EE target (the 8-GPU weak-scaling workload, here all on one GPU)
   config 5: mixed gait schedule stance -> trot -> flying_trot -> static_walk (nc in {12, 14, 16, 13}, FLY nodes), N = 200, batch 1024,
-            fp64 only (the fp32 half of the sweep is not built)
+            in fp64 against the oracle, and the fp32-vs-fp64 sweep of the same batch (MPC kernels in fp32, qmgpu_create_ex)
 Sampled instances are compared with the oracle at the north_star tolerance; the whole batch must be finite, factorised and carry
 bit-exact mode tables.
 """
@@ -92,3 +92,31 @@ def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
         assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
         st, out, _ = oracle.wbc_update(ref["X"][0], ref["U"][0], rbd[i], int(ref["mode"][0]), 0.002, 20.0, np.zeros(30))
         assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
+
+
+def test_config5_fp32_vs_fp64_sweep(interface, oracle):
+    """BASELINE.json configs[4], second half: the same 1024 x 200-node mixed-gait batch with the MPC kernels in fp32 (v_mfma_f32_16x16x4_f32, fp32
+    scratch) next to the fp64 path; one MPC + policy evaluation + WBC cycle each.  Contact modes must be bit-exact (they are decided on the fp64
+    times in both builds); X, U and the WBC torques are held to STATED ||.||_inf-relative bounds per instance:
+        X, U   1e-4   (measured on MI355X: max 1.1e-5 / 9.3e-6, median 2.5e-6 -- DESIGN.md section 5)
+        tau    5e-4   (measured: max 4.1e-5, median 2.7e-6; the WBC itself runs in fp64 on either policy)
+    fp32 is a tolerance study, not a parity path: 1e-6 against the reference is only claimed for fp64."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fp32_sweep
+    out = fp32_sweep.run(1024, 200)
+    rep = fp32_sweep.report(out)
+    assert rep["finite_f32"] and rep["riccati_status_f32_all_zero"] and rep["modes_bit_exact"]
+    assert (out["f32"]["wbc"]["status"] == 0).all() and (out["f64"]["wbc"]["status"] == 0).all()
+    assert rep["X"]["max"] <= 1e-4 and rep["U"]["max"] <= 1e-4 and rep["tau"]["max"] <= 5e-4, rep
+    assert rep["X"]["max"] > 1e-9           # the two paths really are different arithmetic
+    # the fp64 leg of the same run is the parity path: sampled against the oracle at the north_star tolerance
+    from test_gpu_configs import _mixed_schedule
+    dt = interface.problem.settings.dt
+    x0 = S.perturbed_states(interface.initial_state, 1024, seed=3)
+    tgt = S.nominal_target(oracle, interface.initial_state)
+    nev, ev, md = _mixed_schedule(200 * dt + 0.2)
+    ref = oracle.mpc_solve(200, 0.0, x0[7], np.zeros(1), tgt[None, :].copy(), nev, ev, md)
+    r64 = out["f64"]["mpc"]
+    assert np.abs(r64["X"][7] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+    assert np.abs(r64["U"][7] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
