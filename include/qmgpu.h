@@ -114,6 +114,13 @@ typedef struct qmgpu_settings {
   double kp_arm_joint[6], kd_arm_joint[6];
   double kp_ee_linear[3], kd_ee_linear[3], kp_ee_angular[3], kd_ee_angular[3];
   double gravity; /* 9.81 */
+  /* Force tracking (BASELINE.json configs[3]; OWN FORMULATION -- the reference's force-tracking branch is not in the mounted tree,
+   * README.md:15,161,180 is all it says).  The arm end-effector touches a compliant environment (the door) anchored at p_env(t):
+   *     f_e(x, t) = -K_e (p_ee(x) - p_env(t))                              force ON the end-effector, world axes
+   * which (1) acts on the centroidal dynamics, d(h_lin)/dt += f_e, d(h_ang)/dt += (p_ee - p_com) x f_e, and (2) is held to a
+   * reference by the soft constraint  1/2 mu_f |f_e - f_ref(t)|^2  on the intermediate nodes.  K_e = 0 or a NULL
+   * qmgpu_mpc_args::ee_contact_ref switches both off (task.info keys forceTracking.stiffness / forceTracking.muForce). */
+  double ee_contact_stiffness, ee_force_mu;
 } qmgpu_settings;
 
 typedef struct qmgpu_problem {
@@ -196,6 +203,9 @@ typedef struct qmgpu_mpc_args {
   int32_t* out_mode;                   /* [batch][N+1] */
   double* out_stats;                   /* [batch][NSTATS]: merit0, violation0, merit1, violation1, alpha, step_type, armijo, status,
                                           SQP iterations performed, convergence (1 iteration limit, 2 step size, 3 metrics, 4 primal step) */
+  const double* ee_contact_ref;        /* [batch][K][6] or NULL: per target knot the end-effector force reference f_ref (3) and the anchor
+                                          p_env (3) of the compliant environment, interpolated linearly like the other references
+                                          (force tracking, see qmgpu_settings::ee_contact_stiffness) */
 } qmgpu_mpc_args;
 
 int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args);
@@ -224,6 +234,9 @@ typedef struct qmgpu_wbc_args {
   double* input_last;                  /* [batch][30] in/out: WbcBase::inputLast_ (WbcBase.cpp:224-225) */
   double* out;                         /* [batch][54] */
   int32_t* out_status;                 /* [batch] 0 = all three QPs converged; bit l set = level l hit the iteration cap */
+  const double* ee_force;              /* [batch][3] or NULL: external force on the arm end-effector (world axes, measured or from the contact
+                                          model); enters the equations of motion, the torque limits and the torque recovery as J_ee^T f_e
+                                          (force tracking, own formulation) */
 } qmgpu_wbc_args;
 
 int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args);

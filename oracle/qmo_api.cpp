@@ -10,7 +10,15 @@
 
 using namespace qmo;
 
+// force tracking (own formulation): contact reference [K][6] attached to every Target / end-effector force handed to every WBC update
+// built by the entry points below until cleared (null).  Set from the tests' thread before a call; not part of the timed baselines.
+static const double* g_contactRef = nullptr;
+static const double* g_wbcEeForce = nullptr;
+
 extern "C" {
+
+void qmo_set_ee_contact_ref(const double* ref /* [K][6] or null */) { g_contactRef = ref; }
+void qmo_set_wbc_ee_force(const double* f3 /* [3] or null */) { g_wbcEeForce = f3; }
 
 void qmo_flow_map(const qmgpu_problem* P, const double* x, const double* u, double* f) { flowMap<double>(P->model, P->settings.gravity, x, u, f); }
 
@@ -47,7 +55,7 @@ void qmo_swing_reference(const qmgpu_problem* P, int nEv, const double* ev, cons
 }
 
 void qmo_reference_at(int K, const double* times, const double* states, double t, double* xref, double* eePos, double* eeQuat) {
-  Target tg{K, times, states};
+  Target tg{K, times, states, nullptr};
   referenceAt(tg, t, xref, eePos, eeQuat);
 }
 
@@ -55,7 +63,7 @@ void qmo_reference_at(int K, const double* times, const double* states, double t
 void qmo_lq_node(const qmgpu_problem* P, double t, double dt, const double* x, const double* u, const double* xnext, int terminal, int nEv, const double* ev,
                  const int32_t* modes, int K, const double* ttimes, const double* tstates, double* A, double* B, double* b, double* Q, double* R, double* q,
                  double* r, double* C, double* D, double* e, int32_t* nc, double* cost) {
-  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, g_contactRef}};
   NodeLQ o;
   nodeLQ(pr, t, dt, x, u, xnext, terminal != 0, o);
   o.Q.to(Q);
@@ -72,7 +80,7 @@ void qmo_lq_node(const qmgpu_problem* P, double t, double dt, const double* x, c
 int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, const double* timeGrid, int K, const double* ttimes, const double* tstates,
                   int nEv, const double* ev, const int32_t* modes, const double* warmX, const double* warmU, int lineSearch, double* outT, double* outX,
                   double* outU, int32_t* outMode, double* stats) {
-  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, g_contactRef}};
   std::vector<double> tg(N + 1);
   for (int k = 0; k <= N; ++k) tg[k] = timeGrid ? timeGrid[k] : t0 + k * P->settings.dt;
   std::vector<double> X((N + 1) * 30), U(N * 30);
@@ -101,7 +109,7 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
 // performance index of a trajectory (merit, constraint violation)
 void qmo_performance(const qmgpu_problem* P, int N, const double* tgrid, const double* x0, const double* X, const double* U, int K, const double* ttimes,
                      const double* tstates, int nEv, const double* ev, const int32_t* modes, double* merit, double* viol) {
-  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, g_contactRef}};
   double cost = 0, dyn = 0, eq = 0;
   for (int i = 0; i < 30; ++i) dyn += (x0[i] - X[i]) * (x0[i] - X[i]);
   for (int k = 0; k < N; ++k) { const NodeMetrics m = nodeMetrics(pr, tgrid[k], tgrid[k + 1] - tgrid[k], X + k * 30, U + k * 30, X + (k + 1) * 30, false); cost += m.cost; dyn += m.dynViolationSSE; eq += m.eqViolationSSE; }
@@ -126,7 +134,7 @@ void qmo_wbc_model(const qmgpu_problem* P, const double* xDes, const double* uDe
 
 int qmo_wbc_update(const qmgpu_problem* P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
                    double* inputLast, double* out54) {
-  return wbcUpdate(*P, variant, xDes, uDes, rbd, mode, period, time, inputLast, out54);
+  return wbcUpdate(*P, variant, xDes, uDes, rbd, mode, period, time, inputLast, out54, nullptr, g_wbcEeForce);
 }
 
 // generic QP (row-major H n x n, D m x n) for KKT tests
@@ -275,7 +283,7 @@ double qmo_time_cycles_node_threads(const qmgpu_problem* P, int count, int N, co
   std::vector<double> X((N + 1) * 30), U(N * 30), tg(N + 1);
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < count; ++i) {
-    Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates}};
+    Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, g_contactRef}};
     pr.nodeThreads = nodeThreads;
     for (int k = 0; k <= N; ++k) { tg[k] = k * P->settings.dt; for (int j = 0; j < 30; ++j) X[k * 30 + j] = x0s[i * 30 + j]; }
     for (int k = 0; k < N; ++k) weightCompensatingInput(*P, pr.ms.nodeModeAt(tg[k]), &U[k * 30]);

@@ -161,6 +161,12 @@ template <class S> void baseVelocityFromMomentum(const qmgpu_model& md, const S 
 
 // Centroidal flow map (upstream PinocchioCentroidalDynamics::getValue, driven from
 // qm_interface/src/dynamics/QMDynamicsAD.cpp:22-26).  Optionally returns foot velocities / EE pose.
+// Force tracking (OWN FORMULATION, include/qmgpu.h qmgpu_settings::ee_contact_stiffness): the arm end-effector touches a compliant
+// environment anchored at env, f_e = -K (p_ee - env) acts on the centroidal dynamics.  The node-level functions of qmo_mpc.h set the
+// contact of the node they evaluate (thread local) before they call the flow map; K = 0 = no contact.
+struct EeContact { double K = 0.0; double env[3] = {0.0, 0.0, 0.0}; double fref[3] = {0.0, 0.0, 0.0}; };
+inline thread_local EeContact g_eeContact;
+
 template <class S> struct FlowAux {
   V3<S> footPos[NCT], footVel[NCT];
   V3<S> eePos;
@@ -179,6 +185,11 @@ template <class S> void flowMap(const qmgpu_model& md, double gravity, const S* 
     const V3<S> fc(u[3 * c], u[3 * c + 1], u[3 * c + 2]);
     fl = fl + im * fc;
     fa = fa + im * cross(k.foot[c] - k.comTotal, fc);
+  }
+  if (g_eeContact.K != 0.0) {
+    const V3<S> fe = S(-g_eeContact.K) * (k.ee - V3<S>(S(g_eeContact.env[0]), S(g_eeContact.env[1]), S(g_eeContact.env[2])));
+    fl = fl + im * fe;
+    fa = fa + im * cross(k.ee - k.comTotal, fe);
   }
   for (int a = 0; a < 3; ++a) { f[a] = fl[a]; f[3 + a] = fa[a]; }
   for (int a = 0; a < 6; ++a) f[6 + a] = vb[a];

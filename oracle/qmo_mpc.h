@@ -78,6 +78,7 @@ struct Target {
   int K = 0;
   const double* times = nullptr;   // [K]
   const double* states = nullptr;  // [K][37]
+  const double* contact = nullptr; // [K][6] or null: end-effector force reference (3) and environment anchor (3) per knot (force tracking)
 };
 // upstream LinearInterpolation::timeSegment: (index, alpha = weight of the LEFT knot)
 inline void timeSegment(const double* times, int K, double t, int* index, double* alpha) {
@@ -135,6 +136,24 @@ inline void weightCompensatingInput(const qmgpu_problem& P, int mode, double u[3
 
 // ------------------------------------------------------------------------------------------------ penalties
 // upstream RelaxedBarrierPenalty
+// end-effector contact of the node at time t (references interpolated linearly like every other one); installs it for the flow map
+// evaluations of the calling thread and removes it again at the end of the scope
+struct ContactScope {
+  ContactScope(const qmgpu_settings& st, const Target& tg, double t) {
+    EeContact c;
+    if (tg.contact && st.ee_contact_stiffness != 0.0) {
+      int idx; double alpha;
+      timeSegment(tg.times, tg.K, t, &idx, &alpha);
+      const double* lhs = tg.contact + size_t(idx) * 6;
+      const double* rhs = tg.K > 1 ? lhs + 6 : lhs;
+      c.K = st.ee_contact_stiffness;
+      for (int a = 0; a < 3; ++a) { c.fref[a] = alpha * lhs[a] + (1.0 - alpha) * rhs[a]; c.env[a] = alpha * lhs[3 + a] + (1.0 - alpha) * rhs[3 + a]; }
+    }
+    g_eeContact = c;
+  }
+  ~ContactScope() { g_eeContact = EeContact(); }
+};
+
 struct Barrier {
   double mu, delta;
   double value(double h) const { return h > delta ? -mu * std::log(h) : mu * (-std::log(delta) + 0.5 * ((h - 2.0 * delta) / delta) * ((h - 2.0 * delta) / delta) - 0.5); }
@@ -212,6 +231,8 @@ inline double nodeCost(const Problem& pr, double t, const double* x, const doubl
     for (int a = 0; a < 3; ++a) { const double hp = aux.eePos[a] - eePos[a]; cost += 0.5 * muP * hp * hp + 0.5 * muO * od[a] * od[a]; }
   }
   if (terminal) return cost;
+  if (g_eeContact.K != 0.0)   // end-effector force soft constraint 1/2 mu_f |f_e - f_ref|^2 (force tracking, own formulation)
+    for (int a = 0; a < 3; ++a) { const double hf = -g_eeContact.K * (aux.eePos[a] - g_eeContact.env[a]) - g_eeContact.fref[a]; cost += 0.5 * st.ee_force_mu * hf * hf; }
   bool fl[4]; modeToContactFlags(mode, fl);
   double unom[30]; weightCompensatingInput(*pr.P, mode, unom);
   Vec dx(30), du(30);
@@ -258,6 +279,8 @@ inline void rk2Step(const qmgpu_problem& P, double dt, const double* x, const do
 
 inline NodeMetrics nodeMetrics(const Problem& pr, double t, double dt, const double* x, const double* u, const double* xnext, bool terminal) {
   NodeMetrics m;
+  const ContactScope contact(pr.P->settings, pr.tg, terminal ? 1e300 : t);
+  if (terminal) g_eeContact = EeContact();   // the contact acts on the intermediate nodes only
   const int mode = pr.ms.nodeModeAt(t);
   static thread_local double f[30];
   FlowAux<double> aux;
@@ -282,6 +305,8 @@ inline void nodeLQ(const Problem& pr, double t, double dt, const double* x, cons
   bool fl[4]; modeToContactFlags(mode, fl);
   double xref[30], eePosRef[3], eeQuatRef[4];
   referenceAt(pr.tg, t, xref, eePosRef, eeQuatRef);
+  const ContactScope contact(st, pr.tg, t);
+  if (terminal) g_eeContact = EeContact();
 
   // ---- kinematic quantities with derivatives (dual numbers over [x;u])
   static thread_local D60 xd[30], ud[30], fd[30];
@@ -305,6 +330,13 @@ inline void nodeLQ(const Problem& pr, double t, double dt, const double* x, cons
     }
   }
   if (terminal) { o.nc = 0; return; }
+  if (g_eeContact.K != 0.0) {   // end-effector force soft constraint, Gauss-Newton (state only)
+    for (int a = 0; a < 3; ++a) {
+      const D60 h = (-g_eeContact.K) * (aux.eePos[a] - D60(g_eeContact.env[a])) - D60(g_eeContact.fref[a]);
+      o.cost += 0.5 * st.ee_force_mu * h.v * h.v;
+      for (int i = 0; i < 30; ++i) { o.q[i] += st.ee_force_mu * h.v * h.d[i]; for (int j = 0; j < 30; ++j) o.Q(i, j) += st.ee_force_mu * h.d[i] * h.d[j]; }
+    }
+  }
 
   // ---- tracking cost
   double unom[30]; weightCompensatingInput(P, mode, unom);

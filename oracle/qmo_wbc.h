@@ -130,7 +130,7 @@ inline void wbcUpdateMeasured(const qmgpu_problem& P, const double* rbd, WbcMode
   for (int a = 0; a < 3; ++a) { double sl = 0, sa = 0; for (int d = 0; d < NV; ++d) { sl += w.armJ(a, d) * w.vM[d]; sa += w.armJ(3 + a, d) * w.vM[d]; } w.eeVelM[a] = sl; w.eeAngVelM[a] = sa; }
 }
 
-inline void wbcUpdateDesired(const qmgpu_problem& P, const double* xDes, const double* uDes, double* inputLast, double period, WbcModel& w) {
+inline void wbcUpdateDesired(const qmgpu_problem& P, const double* xDes, const double* uDes, double* inputLast, double period, WbcModel& w, const double* eeForce = nullptr) {
   const qmgpu_model& md = P.model;
   w.qD = Vec(xDes + 6, xDes + 30);
   // v_des from the centroidal map (WbcBase.cpp:217-219)
@@ -159,6 +159,11 @@ inline void wbcUpdateDesired(const qmgpu_problem& P, const double* xDes, const d
   for (int c = 0; c < 4; ++c) {
     const V3<double> f(uDes[3 * c], uDes[3 * c + 1], uDes[3 * c + 2]);
     const V3<double> t = cross(k.foot[c] - k.comTotal, f);
+    for (int a = 0; a < 3; ++a) { rate[a] += f[a]; rate[3 + a] += t[a]; }
+  }
+  if (eeForce) {   // force tracking (own formulation): the external end-effector force is part of the desired momentum rate
+    const V3<double> f(eeForce[0], eeForce[1], eeForce[2]);
+    const V3<double> t = cross(k.ee - k.comTotal, f);
     for (int a = 0; a < 3; ++a) { rate[a] += f[a]; rate[3 + a] += t[a]; }
   }
   for (int a = 0; a < 6; ++a) {
@@ -521,10 +526,13 @@ struct HoQp {
 
 // HierarchicalWbc::update (variant 0) / HierarchicalMpcWbc::update (variant 1); returns [x(36); tau(18)]
 inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
-                     double* inputLast, double out[54], WbcModel* modelOut = nullptr) {
+                     double* inputLast, double out[54], WbcModel* modelOut = nullptr, const double* eeForce = nullptr) {
   WbcModel w;
   wbcUpdateMeasured(P, rbd, w);
-  wbcUpdateDesired(P, xDes, uDes, inputLast, period, w);
+  // force tracking (own formulation): M qdd + nle = S^T tau + Jc^T F + Jee^T f_e  <=>  nle <- nle - Jee^T f_e in the equations of
+  // motion task, the torque limits and the torque recovery
+  if (eeForce) for (int d = 0; d < NV; ++d) for (int a = 0; a < 3; ++a) w.nle[d] -= w.armJ(a, d) * eeForce[a];
+  wbcUpdateDesired(P, xDes, uDes, inputLast, period, w, eeForce);
   WbcTasks tk(P, w, mode);
   const Task task0 = tk.floatingBaseEom() + tk.torqueLimits() + tk.noContactMotion() + tk.frictionCone();
   Task task1, task2;

@@ -134,25 +134,26 @@ class GpuSolver:
 
     @staticmethod
     def mpc_args(batch, num_nodes, x0, target_times, target_states, sched_num, sched_times, sched_modes, out_t, out_x, out_u, out_mode, out_stats=None,
-                 t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True):
+                 t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True, ee_contact_ref=None):
         K = target_times.shape[-1] if target_times.ndim > 1 else 1
         a = abi.MpcArgs()
         a.batch, a.num_nodes, a.num_target_knots, a.line_search = batch, num_nodes, K, int(line_search)
         for name, val in (("t0", t0), ("x0", x0), ("time_grid", time_grid), ("target_times", target_times), ("target_states", target_states),
                           ("sched_num_events", sched_num), ("sched_event_times", sched_times), ("sched_modes", sched_modes), ("warm_x", warm_x),
-                          ("warm_u", warm_u), ("out_t", out_t), ("out_x", out_x), ("out_u", out_u), ("out_mode", out_mode), ("out_stats", out_stats)):
+                          ("warm_u", warm_u), ("out_t", out_t), ("out_x", out_x), ("out_u", out_u), ("out_mode", out_mode), ("out_stats", out_stats),
+                          ("ee_contact_ref", ee_contact_ref)):
             setattr(a, name, _ptr(val))
-        a._keep = (t0, x0, time_grid, target_times, target_states, sched_num, sched_times, sched_modes, warm_x, warm_u, out_t, out_x, out_u, out_mode, out_stats)
+        a._keep = (ee_contact_ref, t0, x0, time_grid, target_times, target_states, sched_num, sched_times, sched_modes, warm_x, warm_u, out_t, out_x, out_u, out_mode, out_stats)
         return a
 
     @staticmethod
-    def wbc_args(batch, rbd, period, time, input_last, out, out_status=None, state_desired=None, input_desired=None, mode=None, variant=0):
+    def wbc_args(batch, rbd, period, time, input_last, out, out_status=None, state_desired=None, input_desired=None, mode=None, variant=0, ee_force=None):
         a = abi.WbcArgs()
         a.batch, a.variant = batch, variant
         for name, val in (("state_desired", state_desired), ("input_desired", input_desired), ("rbd_measured", rbd), ("mode", mode), ("period", period),
-                          ("time", time), ("input_last", input_last), ("out", out), ("out_status", out_status)):
+                          ("time", time), ("input_last", input_last), ("out", out), ("out_status", out_status), ("ee_force", ee_force)):
             setattr(a, name, _ptr(val))
-        a._keep = (state_desired, input_desired, rbd, mode, period, time, input_last, out, out_status)
+        a._keep = (ee_force, state_desired, input_desired, rbd, mode, period, time, input_last, out, out_status)
         return a
 
     @staticmethod

@@ -217,6 +217,9 @@ static void loadSettings(const std::string& taskFile, const std::string& referen
   s.target_displacement_velocity = infoDoubleOr(ref, "targetDisplacementVelocity", 0.5);
   s.target_rotation_velocity = infoDoubleOr(ref, "targetRotationVelocity", 0.3);
   s.gravity = 9.81;
+  // force tracking (own formulation, include/qmgpu.h): absent in the reference's task.info -> off
+  s.ee_contact_stiffness = infoDoubleOr(task, "forceTracking.stiffness", 0.0);
+  s.ee_force_mu = infoDoubleOr(task, "forceTracking.muForce", 0.0);
   // WBC gains: defaults of qm_wbc/cfg/wbcWigeht.cfg:7-47, optionally overridden from an INFO block "wbc_gains"
   s.kp_swing = 350; s.kd_swing = 37; s.kp_base_height = 400; s.kd_base_height = 140; s.kp_base_linear = 400; s.kd_base_linear = 100;
   s.kp_base_angular = 400; s.kd_base_angular = 140;

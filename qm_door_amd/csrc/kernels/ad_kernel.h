@@ -52,6 +52,7 @@ struct LqArgs {
   real* debug;             // [batch][N+1][DBG_DOUBLES] or null
   real* adrows;            // [batch][N+1][AD_DOUBLES]: ad_node_kernel -> lq_node_kernel
   const int* done;           // [batch] instances whose SQP iterations have converged are skipped
+  const real* eeContact;     // [batch][K][6] or null: force tracking (qmgpu_mpc_args::ee_contact_ref)
 };
 
 // AD rows: one 64-double row per differentiated scalar; entry l < 60 = d/d(x,u)_l, entry 60 = the value itself
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   const int cD = 9 + dd;                                                                   // zyx / q_j
   const int cV = dd < 3 ? 3 + dd : 39 + dd;                                                // h_ang / v_j
   const int cC = dd < 3 ? dd : (dd < 6 ? 3 + dd : (dd < 18 ? 24 + dd : (dd == 18 ? 60 : 42 + dd)));   // h_lin | p | F | value | padding 61, 62
-  const bool isF = dd >= 6 && dd < 18, isVal = dd == 18;
+  const bool isF = dd >= 3 && dd < 18, isVal = dd == 18;   // lanes whose closed-form column is a force-type slot (p only matters with the EE contact)
 
   real* ad = a.adrows + size_t(gnode) * AD_DOUBLES;
   real* xu = lds + ADL_XU + grp * 64;
@@ -133,6 +134,9 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   const int mode = sched.modes[phase];
   real eePosRef[3], eeQuatRef[4];
   eeReference(a.targetTimes + size_t(inst) * a.K, a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET, a.K, t, eePosRef, eeQuatRef);
+  // force tracking (own formulation): compliant environment at the end-effector, f_e = -K_e (p_ee - p_env), intermediate nodes only
+  real Ke = 0.0_r, fRef[3] = {0.0_r, 0.0_r, 0.0_r}, pEnv[3] = {0.0_r, 0.0_r, 0.0_r};
+  if (a.eeContact && !terminal) { Ke = st.ee_contact_stiffness; eeContactReference(a.targetTimes + size_t(inst) * a.K, a.eeContact + size_t(inst) * a.K * 6, a.K, t, fRef, pEnv); }
 
   // one row of the AD format: the lane's configuration slot, its velocity / force slot and its closed-form column
   const bool owner = lane < AD_NODES * AD_DIRS;   // lane 63 computes along with the others but owns no column
@@ -158,14 +162,23 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
           }
         },
         [&](Vec3<Du> r, const Mat3<Du>& R) {
+          // external force of the compliant contact: linear in the base position (force-type slot of lanes 3..5), configuration tangent -K dr
+          const real* xs = stage ? x2 : x;
+          const Vec3<Du3> fe(Du3(-Ke * (xs[6] + r.x.v - pEnv[0]), -Ke * r.x.d, dd == 3 ? -Ke : 0.0_r), Du3(-Ke * (xs[7] + r.y.v - pEnv[1]), -Ke * r.y.d, dd == 4 ? -Ke : 0.0_r),
+                             Du3(-Ke * (xs[8] + r.z.v - pEnv[2]), -Ke * r.z.d, dd == 5 ? -Ke : 0.0_r));
           if (stage == 0) {  // end-effector pose error (EndEffectorConstraint.cpp:36-78): no velocity / force dependence, d/dp = identity
             Du qee[4];
             matrixToQuaternion(R, qee);
             const Vec3<Du> od = quaternionDistance(qee, eeQuatRef);
             const Du hq[6] = {x[6] + r.x - eePosRef[0], x[7] + r.y - eePosRef[1], x[8] + r.z - eePosRef[2], od.x, od.y, od.z};
 #pragma unroll
-            for (int q = 0; q < 6; ++q) putGlobal(AD_EE, q, hq[q].d, 0.0_r, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0_r : 0.0_r));
+            for (int q = 0; q < 6; ++q) {
+              // padding column 61 of the three position rows carries the force error f_e - f_ref for lq_node_kernel's soft constraint
+              const real hf = q < 3 ? (q == 0 ? fe.x.v : (q == 1 ? fe.y.v : fe.z.v)) - fRef[q < 3 ? q : 0] : 0.0_r;
+              putGlobal(AD_EE, q, hq[q].d, 0.0_r, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0_r : ((q < 3 && dd == 19) ? hf : 0.0_r)));
+            }
           }
+          return fe;
         },
         f, bm);
     if (stage == 0) {
@@ -224,13 +237,15 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
           const real vv = i < 6 ? 0.0_r : f.kin[i - 6].e;
           A2[i * 16 + dd] = (i >= 6 && i < 9 && i - 6 == dd) ? 1.0_r : 0.0_r;   // d/dh_lin
           A2[i * 16 + 3 + dd] = vv;                                          // d/dh_ang
-          A2[i * 16 + 6 + dd] = 0.0_r;                                         // d/dp
           A2[i * 16 + 9 + dd] = dv;                                          // d/dzyx
           A2[i * 16 + 12 + dd] = 0.0_r;
         }
-      } else if (dd == 3) {
+      } else if (dd < 6) {   // d/dp: only the contact force of the force-tracking formulation depends on the base position
 #pragma unroll
-        for (int i = 0; i < 12; ++i) A2[i * 16 + 15] = 0.0_r;
+        for (int i = 0; i < 12; ++i) {
+          A2[i * 16 + 3 + dd] = i < 3 ? f.lin[i].e : (i < 6 ? f.ang[i - 3].e : 0.0_r);
+          if (dd == 3) A2[i * 16 + 15] = 0.0_r;
+        }
       }
       QM_WAVE_SYNC();
       // ---- chain rule on the matrix cores: acc[g][tn] = J2[:, 0:12] J1[:, 16 tn ..] for the three nodes

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(64) input_weight_kernel(const ProblemR* P, con
       [&](int c, Vec3<Du>, Vec3<Du3> v) {   // foot velocity caused by the joint rates: its velocity slot is the Jacobian column
         if (lane >= 3 && lane < 15) { const int j = lane - 3; J[(3 * c + 0) * 12 + j] = v.x.e; J[(3 * c + 1) * 12 + j] = v.y.e; J[(3 * c + 2) * 12 + j] = v.z.e; }
       },
-      [&](Vec3<Du>, const Mat3<Du>&) {}, f, bm);
+      [&](Vec3<Du>, const Mat3<Du>&) { return Vec3<Du3>(); }, f, bm);
   __syncthreads();
   const real* Rt = P->settings.R_task;
   for (int e = lane; e < 144; e += 64) {

@@ -15,6 +15,7 @@ struct LsArgs {
   const ProblemR* P;
   const real* Rw;
   int batch, N, K, lineSearch;
+  const real* eeContact;   // [batch][K][6] or null (force tracking)
   const real* tgrid; const real* dtgrid; const int* nodePhase;   // as in LqArgs
   const real* X; const real* U; const real* dX; const real* dU;
   const real* targetTimes; const real* targetStates;
@@ -38,13 +39,15 @@ struct DblIn {
 };
 
 // dt-scaled cost, dt*|defect|^2, dt*|eq|^2 of one node at (x, u, xnext)
-__device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const Schedule& sched, const real* tTimes, const real* tStates, int K, real t, real dt, int phase,
+__device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
                                        bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq) {
   const ModelR& md = P.model;
   const SettingsR& st = P.settings;
   const int mode = sched.modes[phase];
   real eePosRef[3], eeQuatRef[4];
   eeReference(tTimes, tStates, K, t, eePosRef, eeQuatRef);
+  real Ke = 0.0_r, fRef[3] = {0.0_r, 0.0_r, 0.0_r}, pEnv[3] = {0.0_r, 0.0_r, 0.0_r};   // force tracking (own formulation), intermediate nodes only
+  if (contact && !terminal) { Ke = st.ee_contact_stiffness; eeContactReference(tTimes, contact, K, t, fRef, pEnv); }
   real k1[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) k1[i] = 0.0_r;
@@ -60,7 +63,11 @@ __device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const 
     centroidalSweep<real>(
         md, st.gravity, in, [&](int cc, Vec3<real> r, Vec3<real> v) { feet.set(cc, r, v); },
         [&](Vec3<real> r, const Mat3<real>& R) {
+          const real sdt = stage ? dt : 0.0_r;
+          const Vec3<real> fe(-Ke * (x[6] + sdt * k1[6] + r.x - pEnv[0]), -Ke * (x[7] + sdt * k1[7] + r.y - pEnv[1]), -Ke * (x[8] + sdt * k1[8] + r.z - pEnv[2]));
           if (stage == 0) {
+            const real muF = Ke != 0.0_r ? st.ee_force_mu : 0.0_r;
+            c += 0.5_r * muF * ((fe.x - fRef[0]) * (fe.x - fRef[0]) + (fe.y - fRef[1]) * (fe.y - fRef[1]) + (fe.z - fRef[2]) * (fe.z - fRef[2]));
             real qee[4];
             matrixToQuaternion(R, qee);
             const Vec3<real> od = quaternionDistance(qee, eeQuatRef);
@@ -68,6 +75,7 @@ __device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const 
             const real hx = x[6] + r.x - eePosRef[0], hy = x[7] + r.y - eePosRef[1], hz = x[8] + r.z - eePosRef[2];
             c += 0.5_r * muP * (hx * hx + hy * hy + hz * hz) + 0.5_r * muO * (od.x * od.x + od.y * od.y + od.z * od.z);
           }
+          return fe;
         },
         f, bm);
     if (stage == 0) {
@@ -173,7 +181,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     for (int k = ltid; k <= N; k += half) {
       real c, d, e;
       const bool term = k == N;
-      nodePerformance(*a.P, a.Rw, sched, tTimes, tStates, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
+      nodePerformance(*a.P, a.Rw, sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
       cs += c; ds += d; es += e;
     }
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;

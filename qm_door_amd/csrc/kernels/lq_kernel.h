@@ -92,6 +92,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const real* tTimes = a.targetTimes + size_t(inst) * a.K;
   const real* tStates = a.targetStates + size_t(inst) * a.K * QMGPU_NTARGET;
   const real muP = terminal ? st.ee_final_mu_position : st.ee_mu_position, muO = terminal ? st.ee_final_mu_orientation : st.ee_mu_orientation;
+  // force tracking (own formulation): soft constraint 1/2 mu_f |f_e - f_ref|^2 with f_e = -K_e (p_ee - p_env): its Jacobian is -K_e times the
+  // position rows of the end-effector error, so it only changes the weights of those rows (Gauss-Newton) and adds to the gradient
+  const bool ftOn = a.eeContact && !terminal;
+  const real Ke = ftOn ? st.ee_contact_stiffness : 0.0_r, muF = ftOn ? st.ee_force_mu : 0.0_r;
 
   // ---- rows of the AD sweep (ad_node_kernel)
   const real* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
@@ -112,6 +116,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int q = 0; q < 6; ++q) { if (lane < 32) EEJ[q * 32 + lane] = eev[q]; else if (lane == 60) eeh[q] = eev[q]; }
   }
+  real hf[3];   // f_e - f_ref (column 61 of the position rows, ad_node_kernel)
+#pragma unroll
+  for (int q = 0; q < 3; ++q) hf[q] = ftOn ? ad[AD_EE + q * 64 + 61] : 0.0_r;
   real phid[12], phiv[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
@@ -135,8 +142,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     real dd = 0.0_r;
     if (c < 30) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) qc += (q < 3 ? muP : muO) * eeh[q] * EEJ[q * 32 + c];
+      for (int q = 0; q < 6; ++q) qc += ((q < 3 ? muP : muO) * eeh[q] - (q < 3 ? muF * Ke * hf[q < 3 ? q : 0] : 0.0_r)) * EEJ[q * 32 + c];
       if (c < 6) costPart += 0.5_r * (c < 3 ? muP : muO) * eeh[c] * eeh[c];
+      if (c < 3) costPart += 0.5_r * muF * hf[c] * hf[c];
     }
     if (!terminal && c < 30) {
       real Qdx0 = 0.0_r, Qdx1 = 0.0_r;
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int ic = i < 30 ? i : 0, jc = j < 30 ? j : 0;
     real v = terminal ? 0.0_r : st.Q[ic * 30 + jc];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) v += (q < 3 ? muP : muO) * EEJ[q * 32 + ic] * EEJ[q * 32 + jc];
+    for (int q = 0; q < 6; ++q) v += (q < 3 ? muP + muF * Ke * Ke : muO) * EEJ[q * 32 + ic] * EEJ[q * 32 + jc];
     const real dg = ddp[ic >= 24 ? ic - 24 : 0];
     if (ic == jc && ic >= 24) v += dg;
     return (i < 30 && j < 30) ? v : 0.0_r;

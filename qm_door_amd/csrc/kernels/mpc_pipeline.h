@@ -31,6 +31,7 @@ struct MpcIo {
   const int* schedNum; const real* schedTimes; const int* schedModes;
   const real *warmX, *warmU;
   real *outT, *outX, *outU; int* outMode; real* outStats;
+  const real* eeContact;                                // [batch][K][6] or null (force tracking)
 };
 
 // Alloc: callable (size_t count, size_t elemSize, bool scratch) -> void*
@@ -74,7 +75,7 @@ inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
                 m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, it, m.dDone};
     QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
     LqArgs la{m.dP, m.dRw, B, N, io.K, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, io.targetTimes, io.targetStates, io.schedNum, io.schedTimes,
-              io.schedModes, m.dZeros, m.dStages, m.dStageNc, m.dNodeMode, m.dMetrics, debugLq ? m.dDebug : nullptr, m.dAdRows, m.dDone};
+              io.schedModes, m.dZeros, m.dStages, m.dStageNc, m.dNodeMode, m.dMetrics, debugLq ? m.dDebug : nullptr, m.dAdRows, m.dDone, io.eeContact};
     QM_LAUNCH(ad_node_kernel, adGridFor(B * (N + 1)), 64, s, la);
     if (ev) (void)hipEventRecord(ev[6], s);
     QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
@@ -82,7 +83,7 @@ inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
     RiccatiArgs ra{B, N, m.dStages, m.dStageNc, io.x0, m.dX, m.dGains, m.ddX, m.ddU, m.dInstStats, m.dDone};
     QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
     if (ev) (void)hipEventRecord(ev[2], s);
-    LsArgs ls{m.dP, m.dRw, B, N, io.K, io.lineSearch, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, m.ddX, m.ddU, io.targetTimes, io.targetStates, io.schedNum,
+    LsArgs ls{m.dP, m.dRw, B, N, io.K, io.lineSearch, io.eeContact, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, m.ddX, m.ddU, io.targetTimes, io.targetStates, io.schedNum,
               io.schedTimes, io.schedModes, m.dMetrics, m.dInstStats, m.dNodeMode, m.dXt, m.dUt, io.outT, io.outX, io.outU, io.outMode, io.outStats, it, m.dDone};
     QM_LAUNCH(linesearch_kernel, B, 256, s, ls);
     if (ev) (void)hipEventRecord(ev[3], s);

@@ -92,6 +92,15 @@ __device__ inline void eeReference(const real* times, const real* states, int K,
   if (d < 0) s1 = -s1;
   for (int i = 0; i < 4; ++i) quat[i] = s0 * a[i] + s1 * b[i];
 }
+// Force tracking (own formulation, qmgpu_settings::ee_contact_stiffness): end-effector force reference and anchor of the compliant
+// environment at t, interpolated linearly between the target knots; contact [K][6] = f_ref (3), p_env (3)
+__device__ inline void eeContactReference(const real* times, const real* contact, int K, real t, real fref[3], real env[3]) {
+  int idx; real alpha;
+  timeSegment(times, K, t, idx, alpha);
+  const real* lhs = contact + size_t(idx) * 6;
+  const real* rhs = K > 1 ? lhs + 6 : lhs;
+  for (int i = 0; i < 3; ++i) { fref[i] = alpha * lhs[i] + (1.0_r - alpha) * rhs[i]; env[i] = alpha * lhs[3 + i] + (1.0_r - alpha) * rhs[3 + i]; }
+}
 // state reference component i (i < 30) at the segment already located
 __device__ __forceinline__ real xReference(const real* states, int K, int idx, real alpha, int i) {
   const real* lhs = states + size_t(idx) * QMGPU_NTARGET;

@@ -108,7 +108,8 @@ template <class T> __device__ __forceinline__ Sym3<T> similarity(const Mat3<T>& 
 }
 
 // In must provide: V hn(i) i<6 ; P euler(i) i<3 ; P q(j), V qd(j) j<18 (joint order) ; Vec3<F> force(c) c<4 (contact order)
-// onEE(r_ee_rel_base, R_ee) is called once, onFoot(c, r_rel_base, v_joint_only) four times (world axes, relative to the base origin).
+// onEE(r_ee_rel_base, R_ee) is called once and returns the external force acting on the end-effector (Vec3<F>, zero without force
+// tracking); onFoot(c, r_rel_base, v_joint_only) is called four times (world axes, relative to the base origin).
 template <class P, class V, class F, class In, class FootFn, class EeFn>
 __device__ __forceinline__ void centroidalSweep2(const ModelR& md, real gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, FlowOut<P, V, F>& f, BaseMotion2<P, V>& bm) {
   P sz, cz, sy, cy;
@@ -118,6 +119,8 @@ __device__ __forceinline__ void centroidalSweep2(const ModelR& md, real gravity,
   ChainAcc<P, V> tot;
   tot.M = 0.0_r;
   addBody(md, 0, tot);
+  Vec3<F> fsum;
+  Vec3<ProdT<P, F>> tsum;
   auto absorb = [&](const ChainAcc<P, V>& c) {
     tot.M += c.M; tot.h = tot.h + c.h; tot.l = tot.l + c.l; tot.k = tot.k + c.k;
     tot.I.xx = tot.I.xx + c.I.xx; tot.I.xy = tot.I.xy + c.I.xy; tot.I.xz = tot.I.xz + c.I.xz; tot.I.yy = tot.I.yy + c.I.yy; tot.I.yz = tot.I.yz + c.I.yz; tot.I.zz = tot.I.zz + c.I.zz;
@@ -136,10 +139,11 @@ __device__ __forceinline__ void centroidalSweep2(const ModelR& md, real gravity,
     absorb(c);
     Mat3<P> Rw;
     Rw.c0 = mul(R0, Re.c0); Rw.c1 = mul(R0, Re.c1); Rw.c2 = mul(R0, Re.c2);
-    onEE(mul(R0, c.p), Rw);
+    const Vec3<P> rEE = mul(R0, c.p);
+    const Vec3<F> fe = onEE(rEE, Rw);
+    fsum = fe;
+    tsum = cross(rEE, fe);
   }
-  Vec3<F> fsum;
-  Vec3<ProdT<P, F>> tsum;
 #pragma unroll 1
   for (int leg = 0; leg < 4; ++leg) {
     int cft = 0;

@@ -32,6 +32,7 @@ struct WbcArgs {
   int batch, variant;
   const double* xDes; const double* uDes; const double* rbd; const int* mode; const double* period; const double* time;
   double* inputLast; double* out; int* status;
+  const double* eeForce;   // [batch][3] or null: external force on the arm end-effector (force tracking, own formulation)
 };
 
 constexpr int ND = 36, NVV = 24, MAXR = 22, MAXM = 56;
@@ -222,6 +223,8 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   const int lane = threadIdx.x, inst = blockIdx.x;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
+  double fe[3] = {0.0, 0.0, 0.0};   // external force on the arm end-effector (force tracking; zero otherwise)
+  if (a.eeForce) for (int i = 0; i < 3; ++i) fe[i] = a.eeForce[size_t(inst) * 3 + i];
   double* in = lds + W_IN; double* rbd = in; double* xDes = in + 55; double* uDes = in + 85; double* il = in + 115;
   double* qM = lds + W_Q; double* vM = qM + 24; double* qD = qM + 48; double* vD = qM + 72;
   double* body = lds + W_BODY; double* dof = lds + W_DOF; double* wr = lds + W_WR; double* M = lds + W_M; double* nle = lds + W_NLE;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
         }
       }
     }
-    nle[k] = h;
+    const double nleRaw = h;
 #pragma unroll
     for (int i = 0; i < NVV; ++i) M[i * NVV + k] = macc[i];
     for (int c = 0; c < 4; ++c) {
@@ -324,6 +327,8 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
       pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
       jacCol(dof, k, md.ee_body, pos, lin, ang);
       for (int r = 0; r < 3; ++r) { Ja[r * NVV + k] = lin[r]; Ja[(3 + r) * NVV + k] = ang[r]; }
+      // M qdd + nle = S^T tau + Jc^T F + Jee^T f_e: the external end-effector force is folded into nle (equations of motion, torque limits, torque recovery)
+      nle[k] = nleRaw - (lin[0] * fe[0] + lin[1] * fe[1] + lin[2] * fe[2]);
     }
   }
   if (lane >= 32 && lane < 36) {  // feet: position, velocity, dJ v
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     const DblIn din{xDes, uDes, 0.0, k1z};
     double f[12];
     BaseMotion<double> bm;
-    centroidalSweep<double>(md, st.gravity, din, [&](int, Vec3<double>, Vec3<double>) {}, [&](Vec3<double>, const Mat3<double>&) {}, f, bm);
+    centroidalSweep<double>(md, st.gravity, din, [&](int, Vec3<double>, Vec3<double>) {}, [&](Vec3<double>, const Mat3<double>&) { return Vec3<double>(); }, f, bm);
     if (lane == 0) for (int i = 0; i < 6; ++i) vD[i] = f[6 + i];
   }
   QM_WAVE_SYNC();
@@ -385,6 +390,13 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
       pointKin(md, body, md.foot_body[c], md.foot_offset[c], pos, vel, acc);
       for (int i = 0; i < 3; ++i) { mi[MI_FOOTPD + 3 * c + i] = pos[i]; mi[MI_FOOTVD + 3 * c + i] = vel[i]; r[i] = pos[i] - ct[i]; rl[i] += uDes[3 * c + i]; }
       cross3(r, uDes + 3 * c, t);
+      for (int i = 0; i < 3; ++i) ra[i] += t[i];
+    }
+    {  // external end-effector force in the desired momentum rate (zero without force tracking)
+      double pos[3], vel[3], acc[3], t[3], r[3];
+      pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
+      for (int i = 0; i < 3; ++i) { r[i] = pos[i] - ct[i]; rl[i] += fe[i]; }
+      cross3(r, fe, t);
       for (int i = 0; i < 3; ++i) ra[i] += t[i];
     }
     // wdot = Ic^-1 ra ; euler acceleration = T^-1 wdot ; linear = rl/m - wdot x (c - p0)

@@ -242,7 +242,7 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
     if (!qmk32::enqueue(h->m32, h->stream, a, h->hostProblem.settings.dt, iterations, ev)) throw HipFailure("fp32 MPC launch failed");
   } else {
     const MpcIo io{a->batch, a->num_nodes, a->num_target_knots, a->line_search, h->hostProblem.settings.dt, a->t0, a->time_grid, a->sched_event_times, a->x0, a->target_times,
-                   a->target_states, a->sched_num_events, a->sched_event_times, a->sched_modes, a->warm_x, a->warm_u, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats};
+                   a->target_states, a->sched_num_events, a->sched_event_times, a->sched_modes, a->warm_x, a->warm_u, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats, a->ee_contact_ref};
     enqueueMpcKernels(h->stream, h->m, io, iterations, h->debugLq, ev);
   }
   HIP_CHECK(hipGetLastError());
@@ -253,7 +253,7 @@ static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
   if (!w || w->batch < 1) throw std::invalid_argument("bad WBC arguments");
   if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
   if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
-  WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status};
+  WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, w->ee_force};
   QM_LAUNCH_DYN(wbc_kernel, w->batch, 64, WBC_LDS_BYTES, h->stream, wa);
   HIP_CHECK(hipGetLastError());
 }

@@ -29,7 +29,7 @@ struct Mpc32 {
   MpcBuffers m;
   // fp32 staging of one call's arguments
   float *x0 = nullptr, *tgtT = nullptr, *tgtS = nullptr, *evT = nullptr, *warmX = nullptr, *warmU = nullptr;
-  float *outT = nullptr, *outX = nullptr, *outU = nullptr, *outStats = nullptr;
+  float *outT = nullptr, *outX = nullptr, *outU = nullptr, *outStats = nullptr, *contact = nullptr;
 };
 
 static bool uploadProblem(Mpc32* p, const qmgpu_problem& problem, hipStream_t stream) {
@@ -50,7 +50,7 @@ Mpc32* create(const qmgpu_problem& problem, int maxBatch, int maxNodes, hipStrea
   auto F = [&](size_t n) { return static_cast<float*>(alloc(n, sizeof(float), true)); };
   p->x0 = F(B * 30); p->tgtT = F(B * kMaxKnots32); p->tgtS = F(B * kMaxKnots32 * QMGPU_NTARGET); p->evT = F(B * QMGPU_MAX_EVENTS);
   p->warmX = F(B * N1 * 30); p->warmU = F(B * N * 30);
-  p->outT = F(B * N1); p->outX = F(B * N1 * 30); p->outU = F(B * N * 30); p->outStats = F(B * QMGPU_NSTATS);
+  p->outT = F(B * N1); p->outX = F(B * N1 * 30); p->outU = F(B * N * 30); p->outStats = F(B * QMGPU_NSTATS); p->contact = F(B * kMaxKnots32 * 6);
   if (hipMemsetAsync(p->m.dZeros, 0, 64 * sizeof(float), stream) != hipSuccess || prepareMpcKernels() != hipSuccess || !uploadProblem(p, problem, stream) ||
       hipStreamSynchronize(stream) != hipSuccess) {
     delete p;
@@ -82,6 +82,7 @@ bool enqueue(Mpc32* p, hipStream_t s, const qmgpu_mpc_args* a, double dtD, int i
   io.schedModes = a->sched_modes;
   io.warmX = narrow(a->warm_x, p->warmX, B * N1 * 30);
   io.warmU = narrow(a->warm_u, p->warmU, B * N * 30);
+  io.eeContact = narrow(a->ee_contact_ref, p->contact, B * K * 6);
   io.outT = p->outT; io.outX = p->outX; io.outU = p->outU; io.outMode = a->out_mode; io.outStats = a->out_stats ? p->outStats : nullptr;
   enqueueMpcKernels(s, p->m, io, iterations, false, ev);
   auto widen = [&](const float* src, double* dst, size_t n) { QM_LAUNCH(widen_kernel, unsigned((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, s, src, dst, n); };

@@ -80,6 +80,17 @@ class Oracle:
         self.lib.qmo_mode_at.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
         return self.lib.qmo_mode_at(len(ev), p(ev), p(modes), t)
 
+    def set_ee_contact_ref(self, ref):
+        """force tracking: contact reference [K][6] (f_ref, p_env per target knot) used by the following mpc / lq calls; None clears it"""
+        self._contact_ref = None if ref is None else np.ascontiguousarray(ref, dtype=np.float64)
+        self.lib.qmo_set_ee_contact_ref.argtypes = [C.c_void_p]
+        self.lib.qmo_set_ee_contact_ref(p(self._contact_ref))
+
+    def set_wbc_ee_force(self, f):
+        self._wbc_force = None if f is None else np.ascontiguousarray(f, dtype=np.float64)
+        self.lib.qmo_set_wbc_ee_force.argtypes = [C.c_void_p]
+        self.lib.qmo_set_wbc_ee_force(p(self._wbc_force))
+
     def node_mode_at(self, ev, modes, t):
         """mode of a shooting node at time t (a node on an event time takes the post-event mode)"""
         ev = np.ascontiguousarray(ev, dtype=np.float64); modes = np.ascontiguousarray(modes, dtype=np.int32)
@@ -224,3 +235,37 @@ def rbd_from_state(oracle, x, v=None):
     _, _, ee, eq, _ = oracle.kinematics(x, np.zeros(30))
     r[48:51] = ee; r[51:55] = eq
     return r
+
+
+# ------------------------------------------------------------------------------------------------ force tracking (BASELINE.json configs[3], own formulation)
+FT_STIFFNESS, FT_MU = 500.0, 0.02      # K_e [N/m], mu_f of the force soft constraint
+
+
+def door_opening_batch(oracle, x_nom, batch, seed=2, t_end=1.5, stiffness=FT_STIFFNESS):
+    """Door-opening reference for `batch` instances: the end-effector pushes 10 cm along a random horizontal direction n while the door
+    pushes back with a force that ramps from 0 to F in [5, 25] N; the base follows by 5 cm.  Two target knots (t = 0, t_end).
+    Returns x0 [B][30], target_times [B][2], target_states [B][2][37], contact [B][2][6] (f_ref, p_env per knot).
+    The anchor of the compliant environment is placed so that tracking the EE position exactly produces exactly f_ref."""
+    rng = np.random.default_rng(seed)
+    x0 = perturbed_states(x_nom, batch, seed=seed)
+    tgt = nominal_target(oracle, x_nom)
+    tt = np.tile(np.array([0.0, t_end]), (batch, 1))
+    ts = np.tile(tgt, (batch, 2, 1)).copy()
+    contact = np.zeros((batch, 2, 6))
+    psi = rng.uniform(-0.6, 0.6, batch)
+    force = rng.uniform(5.0, 25.0, batch)
+    for i in range(batch):
+        n = np.array([np.cos(psi[i]), np.sin(psi[i]), 0.0])
+        ts[i, 1, 30:33] += 0.10 * n
+        ts[i, 1, 6:9] += 0.05 * n
+        f1 = -force[i] * n                           # force ON the end-effector at the end of the push
+        contact[i, 0, 0:3] = 0.0; contact[i, 1, 0:3] = f1
+        for k in range(2):
+            contact[i, k, 3:6] = ts[i, k, 30:33] + contact[i, k, 0:3] / stiffness
+    return x0, tt, ts, contact
+
+
+def ee_contact_force(oracle, x, contact_knot, stiffness=FT_STIFFNESS):
+    """f_e = -K (p_ee(x) - p_env) of the contact model at state x for one knot [f_ref(3), p_env(3)]"""
+    _, _, ee, _, _ = oracle.kinematics(x, np.zeros(30))
+    return -stiffness * (ee - contact_knot[3:6])
