@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="single process: run the N > 1 code path (pack -> RCCL all_gather_into_tensor -> unpack) on a 1-rank nccl group and verify it")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +99,12 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:   # --force-collective without a launcher: a 1-rank group on the loopback address
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import gpu_harness as G
@@ -113,7 +119,7 @@ def main():
     t_eval = G.dev(np.zeros(B), torch.float64)
     # packed result gathered across ranks: X | U | wbc out | modes (qm_door_amd/sharding.py)
     from qm_door_amd import sharding
-    gathered = torch.zeros((world * B, sharding.pack_len(N)), dtype=torch.float64, device="cuda") if world > 1 else None
+    gathered = torch.zeros((world * B, sharding.pack_len(N)), dtype=torch.float64, device="cuda") if collective else None
 
     # The gather of step k runs on RCCL's stream while step k + 1 computes: its completion is only awaited (by the compute stream, not the
     # host) right before the next gather is enqueued, and once more before the closing synchronisation -- every gather is inside the timed
@@ -122,7 +128,7 @@ def main():
 
     def step():
         sol.cycle(mb.args, t_eval, wb.args)
-        if world > 1:
+        if collective:
             packed = sharding.pack(mb.oX, mb.oU, wb.out, mb.oM)
             if inflight["work"] is not None:
                 inflight["work"].wait()
@@ -138,7 +144,7 @@ def main():
         step()
     drain()
     sol.enable_timing(True)
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -146,18 +152,25 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = elapsed_rank
+    rank_values = [B * args.steps / elapsed_rank]
+    if collective:
+        tall = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([elapsed_rank], dtype=torch.float64, device="cuda"))
+        elapsed = max(float(t.item()) for t in tall)
+        rank_values = [B * args.steps / float(t.item()) for t in tall]
     kernel_ms = sol.kernel_ms_mean(args.steps)  # [ad, lq, riccati, linesearch, wbc, whole]
     sol.enable_timing(False)
 
     res = mb.results(); wres = wb.results()
     ok = bool(np.isfinite(res["X"]).all() and np.isfinite(wres["out"]).all() and (res["stats"][:, 7] == 0).all())
+    gather_ok = None
+    if collective:   # this rank's block of the gathered tensor is what it solved, bit for bit
+        gX, gU, gW, gM = sharding.unpack(gathered[rank * B:(rank + 1) * B].cpu().numpy(), N)
+        gather_ok = bool(np.array_equal(gX, res["X"]) and np.array_equal(gU, res["U"]) and np.array_equal(gW, wres["out"]) and np.array_equal(gM, res["mode"].astype(np.float64)))
 
     if rank == 0:
         names = ["ad_node_kernel", "lq_node_kernel", "riccati_kernel", "linesearch_kernel", "wbc_kernel"]
@@ -173,7 +186,7 @@ def main():
         roof_kernel = dom_name
         kms = kernel_ms[names.index(roof_kernel)]
         achieved = flops[roof_kernel] / (kms * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/, see its _how field)
+        traffic = None   # HBM bytes per launch of the roofline kernel: NOT measured in this run -- read from the committed rocprofv3 PMC passes of this same command
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             traffic = tr.get(roof_kernel, {}).get("bytes")
@@ -194,9 +207,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: batch=256 MPC instances per GPU, horizon N=100, dt=0.015, trot, 1 SQP iteration + filter line search + 3-level WBC",
                        "batch_per_gpu": B, "horizon_nodes": N, "gait": "trot", "seed": 0, "results_finite_and_converged": ok,
-                       "collective": "all_gather(X,U,tau,mode) over RCCL" if world > 1 else "none"},
+                       "collective": "all_gather(X,U,tau,mode) over RCCL" if collective else "none",
+                       "per_rank_value": rank_values, "gathered_bytes_per_step": int(world * B * sharding.pack_len(N) * 8) if collective else 0,
+                       "gather_matches_local_results": gather_ok},
             "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": f"profiles/{TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)",
                          "note": "algorithmic dense-contraction FLOPs of SURVEY.md 8(d) per launch / HIP-event kernel time; fp64 matrix peak is the public spec; "
                                  "the path is latency bound, not MFMA bound (DESIGN.md)",
                          "kernel_ms": dict(zip(names + ["whole_call"], kernel_ms)),
@@ -206,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(itf, sc)
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 
