@@ -22,6 +22,34 @@ void qmo_set_wbc_ee_force(const double* f3 /* [3] or null */) { g_wbcEeForce = f
 
 void qmo_flow_map(const qmgpu_problem* P, const double* x, const double* u, double* f) { flowMap<double>(P->model, P->settings.gravity, x, u, f); }
 
+// max |difference| between the two derivative routes of the oracle (Dual<60> through everything vs 21 dual directions + closed-form
+// linear columns) over the flow map and every auxiliary quantity the LQ approximation differentiates
+double qmo_structured_vs_dual60(const qmgpu_problem* P, const double* x, const double* u) {
+  static thread_local D60m xd[30], ud[30], fa[30], fb[30];
+  for (int i = 0; i < 30; ++i) { xd[i] = D60m(x[i]); xd[i].d[i] = 1.0; ud[i] = D60m(u[i]); ud[i].d[30 + i] = 1.0; }
+  FlowAux<D60m> aa, ab;
+  flowMap<D60m>(P->model, P->settings.gravity, xd, ud, fa, &aa);
+  flowMapStructured(P->model, P->settings.gravity, x, u, fb, &ab);
+  double worst = 0.0;
+  auto cmp = [&](const D60m& p, const D60m& q) { worst = std::max(worst, std::fabs(p.v - q.v)); for (int i = 0; i < 60; ++i) worst = std::max(worst, std::fabs(p.d[i] - q.d[i])); };
+  for (int i = 0; i < 30; ++i) cmp(fa[i], fb[i]);
+  for (int c = 0; c < 4; ++c) for (int a = 0; a < 3; ++a) { cmp(aa.footPos[c][a], ab.footPos[c][a]); cmp(aa.footVel[c][a], ab.footVel[c][a]); }
+  for (int a = 0; a < 3; ++a) { cmp(aa.eePos[a], ab.eePos[a]); for (int b = 0; b < 3; ++b) cmp(aa.eeRot.m[a][b], ab.eeRot.m[a][b]); }
+  return worst;
+}
+void qmo_set_flow_contact(double K, const double* env3) { g_eeContact = EeContact(); g_eeContact.K = K; if (env3) for (int a = 0; a < 3; ++a) g_eeContact.env[a] = env3[a]; }
+
+// thread-seconds spent per phase (all threads) since the last call: LQ + projection, Riccati, line search, WBC model, WBC QPs
+// (timing-grade build only; zeros in the checker build)
+void qmo_time_split(double* out5) { std::lock_guard<std::mutex> lock(g_phaseMutex); for (int i = 0; i < PH_COUNT; ++i) { out5[i] = g_phaseSeconds[i]; g_phaseSeconds[i] = 0.0; } }
+int qmo_is_fast_build(void) {
+#ifdef QMO_FAST
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 void qmo_flow_map_lin(const qmgpu_problem* P, const double* x, const double* u, double* f, double* A, double* B) {
   Mat Am, Bm;
   flowMapLinearization(*P, x, u, f, Am, Bm);

@@ -12,11 +12,33 @@
 #pragma once
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace qmo {
+
+// ------------------------------------------------------------------------------------------------ phase timers (timing-grade build only)
+// Where a cycle's time goes on the CPU: LQ approximation + projection, Riccati, line search, WBC model,
+// WBC QPs.  Thread-seconds summed over all threads, read and cleared by qmo_time_split.
+enum Phase { PH_LQ = 0, PH_RICCATI, PH_LINESEARCH, PH_WBC_MODEL, PH_WBC_QP, PH_COUNT };
+inline double g_phaseSeconds[PH_COUNT] = {0, 0, 0, 0, 0};   // summed over all threads (a handful of additions per cycle)
+inline std::mutex g_phaseMutex;
+struct PhaseTimer {
+#ifdef QMO_FAST
+  int ph; std::chrono::steady_clock::time_point t0;
+  explicit PhaseTimer(int p) : ph(p), t0(std::chrono::steady_clock::now()) {}
+  ~PhaseTimer() {
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lock(g_phaseMutex);
+    g_phaseSeconds[ph] += s;
+  }
+#else
+  explicit PhaseTimer(int) {}
+#endif
+};
 
 // ------------------------------------------------------------------------------------------------ dual numbers
 template <int N>

@@ -242,3 +242,113 @@ template <class S> V3<S> quaternionDistance(const S q[4], const double qRef[4]) 
 }
 
 }  // namespace qmo
+
+namespace qmo {
+
+// ------------------------------------------------------------------------------------------------ structured derivatives (timing-grade build)
+// The same flow map and auxiliary kinematics as flowMap<Dual<60>>, by a second route: the map is LINEAR in the momentum, the joint
+// rates and the contact forces and does not depend on the base position, so only the 21 configuration coordinates (zyx, q_j) are
+// carried as dual directions; the 39 remaining columns are closed forms in VALUES the evaluation already holds (A_b^-1, A_j, the
+// point Jacobians, (p_i - p_com) x).  tests/test_oracle_invariants.py checks that both routes give the same 60 columns; the
+// -O3 -march=native baseline build (Makefile target fast) uses this one.
+using D21 = Dual<21>;
+using D60m = Dual<60>;
+
+inline D60m liftToD60(const D21& s, const double hn[6], const double p[3], const double F[12], const double vj[18]) {
+  D60m r(s.v);
+  for (int k = 0; k < 6; ++k) r.d[k] = hn ? hn[k] : 0.0;
+  for (int a = 0; a < 3; ++a) { r.d[6 + a] = p ? p[a] : 0.0; r.d[9 + a] = s.d[a]; }
+  for (int j = 0; j < 18; ++j) { r.d[12 + j] = s.d[3 + j]; r.d[42 + j] = vj ? vj[j] : 0.0; }
+  for (int i = 0; i < 12; ++i) r.d[30 + i] = F ? F[i] : 0.0;
+  return r;
+}
+
+inline void flowMapStructured(const qmgpu_model& md, double gravity, const double* x, const double* u, D60m* f, FlowAux<D60m>* aux) {
+  D21 q[NV];
+  for (int a = 0; a < 3; ++a) { q[a] = D21(x[6 + a]); q[3 + a] = D21(x[9 + a]); q[3 + a].d[a] = 1.0; }
+  for (int j = 0; j < NJ; ++j) { q[6 + j] = D21(x[12 + j]); q[6 + j].d[3 + j] = 1.0; }
+  Kin<D21> k;
+  forwardKinematics<D21>(md, q, k);
+  static thread_local D21 A[6][NV];
+  centroidalMomentumMatrix(md, k, A);
+  D21 hn[6], vj[NJ], vb[6];
+  for (int a = 0; a < 6; ++a) hn[a] = D21(x[a]);
+  for (int j = 0; j < NJ; ++j) vj[j] = D21(u[12 + j]);
+  baseVelocityFromMomentum(md, A, hn, vj, vb);
+  // value of A and the closed-form columns of the base velocity: d vb / d hn_k = m Ab^-1 e_k, d vb / d vj_j = -Ab^-1 Aj e_j
+  static thread_local double Av[6][NV];
+  for (int a = 0; a < 6; ++a) for (int d = 0; d < NV; ++d) Av[a][d] = A[a][d].v;
+  double vbHn[6][6], vbVj[6][NJ];
+  {
+    double e[6], zero18[NJ] = {0}, col[6], ev[NJ], zero6[6] = {0};
+    for (int kk = 0; kk < 6; ++kk) { for (int a = 0; a < 6; ++a) e[a] = a == kk ? 1.0 : 0.0; baseVelocityFromMomentum<double>(md, Av, e, zero18, col); for (int a = 0; a < 6; ++a) vbHn[a][kk] = col[a]; }
+    for (int j = 0; j < NJ; ++j) { for (int i = 0; i < NJ; ++i) ev[i] = i == j ? 1.0 : 0.0; baseVelocityFromMomentum<double>(md, Av, zero6, ev, col); for (int a = 0; a < 6; ++a) vbVj[a][j] = col[a]; }
+  }
+  const double im = 1.0 / md.total_mass;
+  // momentum rates
+  V3<D21> fl(D21(0.0), D21(0.0), D21(-gravity)), fa;
+  double flF[3][12] = {{0}}, faF[3][12] = {{0}}, flP[3][3] = {{0}}, faP[3][3] = {{0}};
+  for (int c = 0; c < NCT; ++c) {
+    const V3<D21> fc(D21(u[3 * c]), D21(u[3 * c + 1]), D21(u[3 * c + 2]));
+    const V3<D21> arm = k.foot[c] - k.comTotal;
+    fl = fl + D21(im) * fc;
+    fa = fa + D21(im) * cross(arm, fc);
+    for (int a = 0; a < 3; ++a) {
+      V3<double> e; e[a] = 1.0;
+      const V3<double> t = cross(V3<double>(arm.x.v, arm.y.v, arm.z.v), e);
+      flF[a][3 * c + a] = im;
+      for (int r = 0; r < 3; ++r) faF[r][3 * c + a] = im * t[r];
+    }
+  }
+  if (g_eeContact.K != 0.0) {   // force tracking: f_e = -K (p_ee - env), linear in the base position
+    const V3<D21> fe = D21(-g_eeContact.K) * (k.ee - V3<D21>(D21(g_eeContact.env[0]), D21(g_eeContact.env[1]), D21(g_eeContact.env[2])));
+    const V3<D21> arm = k.ee - k.comTotal;
+    fl = fl + D21(im) * fe;
+    fa = fa + D21(im) * cross(arm, fe);
+    for (int a = 0; a < 3; ++a) {
+      V3<double> e; e[a] = -g_eeContact.K;
+      const V3<double> t = cross(V3<double>(arm.x.v, arm.y.v, arm.z.v), e);
+      flP[a][a] = -g_eeContact.K * im;
+      for (int r = 0; r < 3; ++r) faP[r][a] = im * t[r];
+    }
+  }
+  for (int a = 0; a < 3; ++a) { f[a] = liftToD60(fl[a], nullptr, flP[a], flF[a], nullptr); f[3 + a] = liftToD60(fa[a], nullptr, faP[a], faF[a], nullptr); }
+  for (int a = 0; a < 6; ++a) f[6 + a] = liftToD60(vb[a], vbHn[a], nullptr, nullptr, vbVj[a]);
+  for (int j = 0; j < NJ; ++j) { f[12 + j] = D60m(u[12 + j]); f[12 + j].d[42 + j] = 1.0; }
+  if (aux) {
+    D21 v[NV];
+    for (int a = 0; a < 6; ++a) v[a] = vb[a];
+    for (int j = 0; j < NJ; ++j) v[6 + j] = vj[j];
+    const double pId[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int c = 0; c < NCT; ++c) {
+      V3<D21> vel;
+      double velHn[3][6] = {{0}}, velVj[3][NJ] = {{0}};
+      for (int d = 0; d < NV; ++d) {
+        V3<D21> lin, ang;
+        pointJacobianColumn(md, k, md.foot_body[c], k.foot[c], d, lin, ang);
+        vel = vel + v[d] * lin;
+        for (int r = 0; r < 3; ++r) {
+          const double l = lin[r].v;
+          if (d < 6) { for (int kk = 0; kk < 6; ++kk) velHn[r][kk] += l * vbHn[d][kk]; for (int j = 0; j < NJ; ++j) velVj[r][j] += l * vbVj[d][j]; }
+          else velVj[r][d - 6] += l;
+        }
+      }
+      for (int r = 0; r < 3; ++r) { aux->footPos[c][r] = liftToD60(k.foot[c][r], nullptr, pId[r], nullptr, nullptr); aux->footVel[c][r] = liftToD60(vel[r], velHn[r], nullptr, nullptr, velVj[r]); }
+    }
+    for (int r = 0; r < 3; ++r) aux->eePos[r] = liftToD60(k.ee[r], nullptr, pId[r], nullptr, nullptr);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) aux->eeRot.m[i][j] = liftToD60(k.Ree.m[i][j], nullptr, nullptr, nullptr, nullptr);
+  }
+}
+
+// the derivative route of this build: flowMap<Dual<60>> (checker) or the structured one (timing-grade, -DQMO_FAST)
+inline void flowMapD60(const qmgpu_model& md, double gravity, const D60m* xd, const D60m* ud, D60m* fd, FlowAux<D60m>* aux) {
+#ifdef QMO_FAST
+  double x[30], u[30];
+  for (int i = 0; i < 30; ++i) { x[i] = xd[i].v; u[i] = ud[i].v; }
+  flowMapStructured(md, gravity, x, u, fd, aux);
+#else
+  flowMap<D60m>(md, gravity, xd, ud, fd, aux);
+#endif
+}
+
+}  // namespace qmo

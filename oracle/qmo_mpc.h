@@ -7,6 +7,7 @@
 //     (RK2 sensitivity discretisation, dt-scaled cost, QR constraint projection, Riccati solve of the
 //     equality-free QP, filter line search).
 #pragma once
+#include <memory>
 #include <thread>
 #include "qmo_model.h"
 
@@ -165,7 +166,7 @@ struct Barrier {
 inline void flowMapLinearization(const qmgpu_problem& P, const double* x, const double* u, double* f, Mat& A, Mat& B) {
   static thread_local D60 xd[30], ud[30], fd[30];
   for (int i = 0; i < 30; ++i) { xd[i] = D60(x[i]); xd[i].d[i] = 1.0; ud[i] = D60(u[i]); ud[i].d[30 + i] = 1.0; }
-  flowMap<D60>(P.model, P.settings.gravity, xd, ud, fd);
+  flowMapD60(P.model, P.settings.gravity, xd, ud, fd, nullptr);
   A = Mat(30, 30); B = Mat(30, 30);
   for (int i = 0; i < 30; ++i) { f[i] = fd[i].v; for (int j = 0; j < 30; ++j) { A(i, j) = fd[i].d[j]; B(i, j) = fd[i].d[30 + j]; } }
 }
@@ -312,7 +313,7 @@ inline void nodeLQ(const Problem& pr, double t, double dt, const double* x, cons
   static thread_local D60 xd[30], ud[30], fd[30];
   for (int i = 0; i < 30; ++i) { xd[i] = D60(x[i]); xd[i].d[i] = 1.0; ud[i] = D60(terminal ? 0.0 : u[i]); ud[i].d[30 + i] = 1.0; }
   FlowAux<D60> aux;
-  flowMap<D60>(P.model, st.gravity, xd, ud, fd, &aux);
+  flowMapD60(P.model, st.gravity, xd, ud, fd, &aux);
 
   o.Q = Mat(30, 30); o.q = Vec(30, 0.0); o.R = Mat(30, 30); o.r = Vec(30, 0.0); o.Pm = Mat(30, 30);
   o.cost = 0.0;
@@ -389,8 +390,9 @@ inline void nodeLQ(const Problem& pr, double t, double dt, const double* x, cons
   // ---- dynamics: upstream rk2SensitivityDiscretization
   {
     double k1[30], k2[30], x2[30];
-    Mat A1, B1, A2, B2;
-    flowMapLinearization(P, x, u, k1, A1, B1);
+    Mat A1(30, 30), B1(30, 30), A2, B2;
+    // first stage: the evaluation at (x, u) above already carries all sixty directions
+    for (int i = 0; i < 30; ++i) { k1[i] = fd[i].v; for (int j = 0; j < 30; ++j) { A1(i, j) = fd[i].d[j]; B1(i, j) = fd[i].d[30 + j]; } }
     for (int i = 0; i < 30; ++i) x2[i] = x[i] + dt * k1[i];
     flowMapLinearization(P, x2, u, k2, A2, B2);
     B2 = B2 + dt * (A2 * B1);
@@ -461,9 +463,11 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
                               bool lineSearch, std::vector<NodeLQ>* keepLQ = nullptr) {
   const qmgpu_settings& st = pr.P->settings;
   std::vector<NodeLQ> lq(N + 1);
+  std::unique_ptr<PhaseTimer> phase(new PhaseTimer(PH_LQ));
   forEachNode(N, pr.nodeThreads, [&](int k) { nodeLQ(pr, tgrid[k], tgrid[k + 1] - tgrid[k], &X[k * 30], &U[k * 30], &X[(k + 1) * 30], false, lq[k]); projectNode(lq[k]); });
   nodeLQ(pr, tgrid[N], 0.0, &X[N * 30], nullptr, nullptr, true, lq[N]);
 
+  phase.reset(); phase.reset(new PhaseTimer(PH_RICCATI));
   // ---- Riccati backward (the equality-free OCP-QP HPIPM solves with one factorisation)
   std::vector<Mat> Kfb(N); std::vector<Vec> kff(N);
   Mat S = lq[N].Q; Vec s = lq[N].q;
@@ -500,6 +504,7 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
   for (int i = 0; i < 30; ++i) dX[N * 30 + i] = dx[i];
   armijo += dot(lq[N].q, dx);
 
+  phase.reset(); phase.reset(new PhaseTimer(PH_LINESEARCH));
   // ---- performance of the baseline and filter line search (upstream FilterLinesearch::acceptStep, SqpSolver::takeStep)
   auto performance = [&](const std::vector<double>& Xn, const std::vector<double>& Un, double& merit, double& viol) {
     double cost = 0, dyn = 0, eq = 0;

@@ -528,6 +528,7 @@ struct HoQp {
 inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
                      double* inputLast, double out[54], WbcModel* modelOut = nullptr, const double* eeForce = nullptr) {
   WbcModel w;
+  std::unique_ptr<PhaseTimer> phase(new PhaseTimer(PH_WBC_MODEL));
   wbcUpdateMeasured(P, rbd, w);
   // force tracking (own formulation): M qdd + nle = S^T tau + Jc^T F + Jee^T f_e  <=>  nle <- nle - Jee^T f_e in the equations of
   // motion task, the torque limits and the torque recovery
@@ -543,6 +544,7 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
     task1 = tk.baseHeight() + tk.baseAngular() + tk.baseLinear() + tk.swingLeg() * 100.0;
     task2 = tk.contactForce(uDes);
   }
+  phase.reset(); phase.reset(new PhaseTimer(PH_WBC_QP));
   HoQp h0(task0, nullptr);
   HoQp h1(task1, &h0);
   Vec x;

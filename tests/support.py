@@ -18,6 +18,7 @@ from qm_door_amd import abi  # noqa: E402
 
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libqm_oracle.so")
+ORACLE_FAST_LIB = os.path.join(ORACLE_DIR, "libqm_oracle_fast.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "build", "libqmgpu_emu.so")
 
@@ -44,9 +45,10 @@ def p(a):
 
 
 class Oracle:
-    def __init__(self, problem):
+    def __init__(self, problem, fast=False):
+        """fast=True: the timing-grade build of the same sources (oracle/Makefile: -O3, structured derivatives, phase timers)"""
         build_oracle()
-        self.lib = C.CDLL(ORACLE_LIB)
+        self.lib = C.CDLL(ORACLE_FAST_LIB if fast else ORACLE_LIB)
         self.P = problem
         self.lib.qmo_time_cycles.restype = C.c_double
 
@@ -79,6 +81,22 @@ class Oracle:
         ev = np.ascontiguousarray(ev, dtype=np.float64); modes = np.ascontiguousarray(modes, dtype=np.int32)
         self.lib.qmo_mode_at.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
         return self.lib.qmo_mode_at(len(ev), p(ev), p(modes), t)
+
+    def structured_vs_dual60(self, x, u, contact_stiffness=0.0, env=None):
+        """max |difference| of the oracle's two derivative routes at (x, u), optionally with the force-tracking contact on"""
+        self.lib.qmo_set_flow_contact.argtypes = [C.c_double, C.c_void_p]
+        self.lib.qmo_set_flow_contact(contact_stiffness, p(None if env is None else np.ascontiguousarray(env, dtype=np.float64)))
+        self.lib.qmo_structured_vs_dual60.restype = C.c_double
+        self.lib.qmo_structured_vs_dual60.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        d = self.lib.qmo_structured_vs_dual60(C.byref(self.P), p(np.ascontiguousarray(x)), p(np.ascontiguousarray(u)))
+        self.lib.qmo_set_flow_contact(0.0, None)
+        return d
+
+    def time_split(self):
+        out = np.zeros(5)
+        self.lib.qmo_time_split.argtypes = [C.c_void_p]
+        self.lib.qmo_time_split(p(out))
+        return dict(zip(("lq", "riccati", "linesearch", "wbc_model", "wbc_qp"), out.tolist()))
 
     def set_ee_contact_ref(self, ref):
         """force tracking: contact reference [K][6] (f_ref, p_env per target knot) used by the following mpc / lq calls; None clears it"""

@@ -162,3 +162,4 @@ def test_bench_cpu_baseline_leg_runs(interface):
     finally:
         bench.HORIZON_N = saved
     assert out["kind"] == "port" and out["unit"] == "cycles/s" and np.isfinite(out["value"]) and out["value"] > 0 and out["cores"] >= 1
+    assert out["one_thread"] > 0 and out["three_threads_over_nodes"] > 0 and abs(sum(out["one_thread_split_percent"].values()) - 100.0) < 0.1

@@ -305,3 +305,38 @@ def test_riccati_step_equals_dense_kkt_solve(interface, oracle):
     U0 = np.array([u for _, u in lq[:N]])
     assert np.abs(r["X"] - (x0[None, :] + dX)).max() <= 1e-9 * max(1.0, np.abs(dX).max())
     assert np.abs(r["U"] - (U0 + dU)).max() <= 1e-8 * max(1.0, np.abs(dU).max())
+
+
+def test_two_derivative_routes_of_the_oracle_agree(interface, oracle):
+    """flowMap<Dual<60>> (every direction carried through the kinematics) against the structured route of the timing-grade build (21
+    configuration directions as dual numbers + closed-form columns for momentum / joint rates / forces / base position): all sixty columns of
+    the flow map, the foot positions / velocities and the end-effector pose, with and without the force-tracking contact."""
+    rng = np.random.default_rng(5)
+    x_nom, m = interface.initial_state, interface.robot_mass
+    for trial in range(4):
+        x = x_nom + rng.uniform(-1, 1, 30) * np.r_[np.full(6, 0.2), np.full(3, 0.3), np.full(3, 0.3), np.full(18, 0.3)]
+        u = np.r_[rng.uniform(-30, 30, 12), rng.uniform(-1, 1, 18)]; u[2::3][:4] += m * 9.81 / 4
+        assert oracle.structured_vs_dual60(x, u) <= 1e-11
+        assert oracle.structured_vs_dual60(x, u, contact_stiffness=500.0, env=rng.uniform(-1, 1, 3)) <= 1e-9
+
+
+def test_fast_oracle_build_reproduces_the_checker(interface, oracle):
+    """The -O3 structured-derivative build that bench.py times is the same algorithm: one MPC solve and one WBC update agree with the checker
+    build to round-off (the derivative route and the compiler's contraction of multiply-adds differ, nothing else)."""
+    fast = S.Oracle(interface.problem, fast=True)
+    assert fast.lib.qmo_is_fast_build() == 1 and oracle.lib.qmo_is_fast_build() == 0
+    x_nom = interface.initial_state
+    x0 = S.perturbed_states(x_nom, 1, seed=4)[0]
+    tgt = S.nominal_target(oracle, x_nom)
+    nev, ev, md = S.trot_schedule(1.0, phase0=0.04)
+    N = 20
+    a = oracle.mpc_solve(N, 0.0, x0, np.zeros(1), tgt[None, :].copy(), nev, ev, md)
+    b = fast.mpc_solve(N, 0.0, x0, np.zeros(1), tgt[None, :].copy(), nev, ev, md)
+    assert np.array_equal(a["mode"], b["mode"]) and a["stats"][4] == b["stats"][4]
+    assert np.abs(a["X"] - b["X"]).max() <= 1e-9 and np.abs(a["U"] - b["U"]).max() <= 1e-8 * max(1.0, np.abs(a["U"]).max())
+    rbd = S.rbd_from_state(oracle, x0)
+    _, oa, _ = oracle.wbc_update(a["X"][0], a["U"][0], rbd, int(a["mode"][0]), 0.002, 20.0, np.zeros(30))
+    _, ob, _ = fast.wbc_update(a["X"][0], a["U"][0], rbd, int(a["mode"][0]), 0.002, 20.0, np.zeros(30))
+    assert np.abs(oa - ob).max() <= 1e-7 * max(1.0, np.abs(oa).max())
+    split = fast.time_split()
+    assert split["lq"] > 0 and split["riccati"] > 0 and split["linesearch"] > 0 and split["wbc_qp"] > 0
