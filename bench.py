@@ -60,6 +60,26 @@ def build_scenario(itf, batch, seed):
     return dict(x0=x0, tt=tt, ts=ts, nev=nev, ev=ev, md=md, rbd=rbd)
 
 
+def usable_cpus():
+    """Host threads this process can actually keep busy: the affinity mask capped by the cgroup CPU quota (the GPU boxes of this pool
+    show 256 hardware threads and grant 16 CPUs' worth of time: cpu.max = 1600000 100000)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(np.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0]); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(np.ceil(q / p))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(itf, sc, budget_s=15.0):
     """The CPU restatement ("port": our own fp64 code, NOT the reference's OCS2 path, which cannot be built here) in its timing-grade
     build (oracle/Makefile target libqm_oracle_fast.so: -O3 -march=x86-64-v3, structured derivatives) on a bounded sample of the same
@@ -84,15 +104,15 @@ def cpu_baseline(itf, sc, budget_s=15.0):
     tot = sum(split.values()) or 1.0
     n3 = int(max(4, 0.25 * budget_s * 2.3 / max(probe, 1e-3)))
     sec3 = orc.time_cycles_node_threads(*args(n3), node_threads=3)
-    threads = os.cpu_count() or 1
-    nT = int(max(2 * threads, 0.4 * budget_s * 0.5 * threads / max(probe, 1e-3)))
+    threads = usable_cpus()
+    nT = int(max(2 * threads, 0.4 * budget_s * 0.7 * threads / max(probe, 1e-3)))
     secT = orc.time_cycles(*args(nT), threads=threads)
     one, three, allt = n1 / sec1, n3 / sec3, nT / secT
     return {"value": allt, "unit": "cycles/s", "cores": threads, "kind": "port",
-            "sample": f"{nT} cycles (the {BATCH_PER_GPU} instances of the bench, same x0/target/gait, N={HORIZON_N}, walked through repeatedly) over {threads} threads in "
+            "sample": f"{nT} cycles (the {BATCH_PER_GPU} instances of the bench, same x0/target/gait, N={HORIZON_N}, walked through repeatedly) over {threads} threads (= the CPUs this container may use: affinity mask capped by the cgroup quota) in "
                       f"{secT:.1f} s; one thread: {one:.2f} cycles/s ({n1} cycles, {sec1:.1f} s); three threads over the nodes of one instance (task.info nThreads 3): "
                       f"{three:.2f} cycles/s ({n3} cycles, {sec3:.1f} s); own CPU restatement, g++ -O3 -march=x86-64-v3, not OCS2",
-            "one_thread": one, "three_threads_over_nodes": three, "all_threads_over_instances": allt, "scaling_per_thread": allt / (one * threads),
+            "hardware_threads_visible": os.cpu_count(), "one_thread": one, "three_threads_over_nodes": three, "all_threads_over_instances": allt, "scaling_per_thread": allt / (one * threads),
             "one_thread_split_percent": {k: round(100.0 * v / tot, 2) for k, v in split.items()},
             "reference_design_rate_note": "the reference is configured for 100 MPC solves/s at 67 nodes with 3 threads (task.info:79,141,147: a configuration "
                                           "value, not a measurement); its CppAD-generated sparse straight-line derivative code is not reproducible here"}

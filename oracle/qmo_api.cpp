@@ -1,5 +1,7 @@
 // qmo_api.cpp -- TEST INFRASTRUCTURE ONLY.  extern "C" entry points of the CPU oracle for ctypes (tests/, smoke(),
 // bench.py cpu_baseline).  PARITY UNPINNED: see qmo_core.h.  The product (qm_door_amd/) never links or loads this.
+#include <malloc.h>
+
 #include <chrono>
 #include <cstdio>
 #include <memory>
@@ -327,6 +329,9 @@ double qmo_time_cycles_node_threads(const qmgpu_problem* P, int count, int N, co
 double qmo_time_cycles_mt(const qmgpu_problem* P, int count, int N, const double* x0s, int K, const double* ttimes, const double* tstates, int nEv, const double* ev,
                           const int32_t* modes, const double* rbds, int lineSearch, int threads) {
   if (threads < 1) threads = 1;
+  // Many threads of ONE process that return memory to the kernel (heap trims, munmap of large blocks) serialise on the process's address-space
+  // lock: keep what was allocated (the oracle's matrices are short-lived std::vector storage) -- measured on the 256-thread GPU host.
+  mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20);
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; ++t)
