@@ -100,3 +100,74 @@ def test_maximum_number_of_mode_switches(interface, oracle):
     assert np.array_equal(r["mode"][0], ref["mode"]) and len(set(ref["mode"].tolist())) == 3
     assert np.abs(r["X"][0] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
     assert np.abs(r["U"][0] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+
+
+def test_relaxed_barrier_quadratic_branches_and_distinct_target_knots(interface, oracle):
+    """The edge cases of the reference's soft constraints (QMInterface.cpp:177-259, 344-358) that nominal scenarios never reach, on the GPU:
+      * friction cone in the quadratic extension of the relaxed barrier (h = mu f_z - sqrt(f_x^2 + f_y^2 + reg) <= delta = 5: a stance foot that carries
+        a few newtons, and one pulling on the ground);
+      * arm joint positions within delta = 1e-3 of a URDF limit, exactly ON it and beyond it; arm joint velocities beyond their bounds;
+      * three DIFFERENT target knots (position lerp + a genuine quaternion slerp) straight through qmgpu_mpc_solve_batch.
+    The iterate comes in as a warm start, so the LQ blocks are formed exactly there; blocks and the resulting step are compared with the oracle."""
+    import gpu_harness as G
+    B, N = 4, 12
+    dt = interface.problem.settings.dt
+    md_ = interface.problem.model
+    x_nom, m = interface.initial_state, interface.robot_mass
+    x0 = S.perturbed_states(x_nom, B, seed=9)
+    up = np.array([md_.q_upper[12 + i] for i in range(6)]); lo = np.array([md_.q_lower[12 + i] for i in range(6)])
+    x0[0, 24] = up[0] - 5e-4; x0[0, 25] = lo[1] + 2e-4           # inside the delta band
+    x0[1, 26] = up[2]; x0[1, 27] = lo[3]                         # exactly on the limits
+    x0[2, 24] = up[0] + 0.02; x0[2, 28] = lo[4] - 0.01           # beyond
+    tgt = S.nominal_target(oracle, x_nom)
+    # three distinct knots: base moves and yaws, the EE target moves and rotates about two different axes
+    K = 3
+    tt = np.tile(np.array([0.0, 0.08, 0.2]), (B, 1))
+    ts = np.tile(tgt, (B, K, 1)).copy()
+    ts[:, 1, 6] += 0.05; ts[:, 2, 6] += 0.12; ts[:, 2, 9] += 0.2
+    ts[:, 1, 30:33] += [0.03, -0.02, 0.04]; ts[:, 2, 30:33] += [0.08, 0.05, -0.03]
+    def quat(axis, ang):
+        a = np.asarray(axis, float); a /= np.linalg.norm(a)
+        return np.r_[a * np.sin(ang / 2), np.cos(ang / 2)]
+    ts[:, 1, 33:37] = quat([0, 1, 0.2], 0.5); ts[:, 2, 33:37] = quat([1, 0.3, 0], -0.8)
+    nev, ev, md = S.trot_schedule(N * dt + 1.0, phase0=0.05)
+    # warm start: states = x0 held, inputs with starved / pulling stance feet and arm rates beyond their bounds
+    X = np.repeat(x0[:, None, :], N + 1, axis=1)
+    U = np.zeros((B, N, 30))
+    for i in range(B):
+        for k in range(N):
+            mode = oracle.node_mode_at(ev[:nev], md[:nev + 1], k * dt)
+            flags = [(mode >> (3 - c)) & 1 for c in range(4)]
+            st = [c for c in range(4) if flags[c]]
+            for c in st:
+                U[i, k, 3 * c + 2] = m * 9.81 / len(st)
+            U[i, k, 3 * st[0] + 2] = 3.0 + i                    # h = 0.7 * 3 - 5 < delta: quadratic branch
+            U[i, k, 3 * st[0]] = 4.0
+            if i == 3:
+                U[i, k, 3 * st[-1] + 2] = -6.0                  # pulling on the ground: h < 0
+    al = np.array([interface.problem.settings.arm_vel_lower[i] for i in range(6)]); au = np.array([interface.problem.settings.arm_vel_upper[i] for i in range(6)])
+    U[0, :, 24] = au[0] + 0.05; U[1, :, 26] = al[2] - 0.2; U[2, :, 29] = au[5] - 4e-4
+    sol = G.make_solver(interface, B, N)
+    sol.enable_debug(True)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N, warm=(X, U))
+    sol.mpc(mb.args)
+    r = mb.results()
+    assert np.isfinite(r["X"]).all() and (r["stats"][:, 7] == 0).all()
+    for i in range(B):
+        for k in (0, 5, 9):
+            g = sol.debug_lq(i, k)
+            o = oracle.lq_node(k * dt, dt, X[i, k], U[i, k], X[i, k + 1], False, nev, ev, md, tt[i], ts[i])
+            for key in ("A", "B", "b", "Q", "R", "q", "r", "C", "D", "e"):
+                assert np.abs(g[key] - o[key]).max() <= 1e-10 * max(1.0, np.abs(o[key]).max()), (i, k, key)
+        g = sol.debug_lq(i, N)
+        o = oracle.lq_node(N * dt, 0.0, X[i, N], None, X[i, N], True, nev, ev, md, tt[i], ts[i])
+        assert np.abs(g["Q"] - o["Q"]).max() <= 1e-10 * max(1.0, np.abs(o["Q"]).max()) and np.abs(g["q"] - o["q"]).max() <= 1e-10 * max(1.0, np.abs(o["q"]).max())
+        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md, warm=(X[i], U[i]))
+        assert np.array_equal(r["mode"][i], ref["mode"]) and r["stats"][i][4] == ref["stats"][4]
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+    # the branches really were the quadratic ones: the barrier's second derivative equals mu / delta^2 there
+    st_ = interface.problem.settings
+    o = oracle.lq_node(0.0, dt, X[2, 0], U[2, 0], X[2, 1], False, nev, ev, md, tt[2], ts[2])
+    curv = st_.joint_pos_barrier_mu / st_.joint_pos_barrier_delta ** 2          # 1e5; the end-effector Gauss-Newton term adds a few hundred on top
+    assert curv <= o["Q"][24, 24] / dt <= curv + 2e3
