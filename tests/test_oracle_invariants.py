@@ -340,3 +340,26 @@ def test_fast_oracle_build_reproduces_the_checker(interface, oracle):
     assert np.abs(oa - ob).max() <= 1e-7 * max(1.0, np.abs(oa).max())
     split = fast.time_split()
     assert split["lq"] > 0 and split["riccati"] > 0 and split["linesearch"] > 0 and split["wbc_qp"] > 0
+
+
+def test_model_against_independent_fixture(interface, oracle):
+    """tests/golden/model_independent.npz (tests/golden/make_model_fixture.py): mass matrix as the Hessian of the kinetic energy, non-linear
+    effects from Lagrange's equations, centroidal momentum matrix from body momenta -- all built from an independent parse of the URDF and
+    complex-step differentiation of forward kinematics only.  Pins the oracle's rigid-body model AND the product's URDF loader (fixed-link
+    merging, frame offsets, joint order), which the oracle's inputs come through."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_independent.npz"))
+    assert abs(float(fx["total_mass"]) - interface.robot_mass) <= 1e-9
+    for k in range(fx["q"].shape[0]):
+        q, v = fx["q"][k], fx["v"][k]
+        x = np.r_[np.zeros(6), q]
+        rbd = np.zeros(55)
+        rbd[0:3] = q[3:6]; rbd[3:6] = q[0:3]; rbd[6:24] = q[6:]
+        rbd[24:27] = fx["omega_world"][k]; rbd[27:30] = v[0:3]; rbd[30:48] = v[6:]
+        mm = oracle.wbc_model(x, np.zeros(30), rbd, 0.002, np.zeros(30))
+        assert np.abs(mm["M"] - fx["M"][k]).max() <= 1e-10 * np.abs(fx["M"][k]).max()
+        assert np.abs(mm["nle"] - fx["nle"][k]).max() <= 1e-7 * max(1.0, np.abs(fx["nle"][k]).max())
+        A = oracle.centroidal_matrix(q)
+        assert np.abs(A - fx["AG"][k]).max() <= 1e-10 * np.abs(fx["AG"][k]).max()
+        fp, _, ee, _, com = oracle.kinematics(x, np.zeros(30))
+        assert np.abs(fp.reshape(4, 3) - fx["feet"][k]).max() <= 1e-12 and np.abs(ee - fx["ee"][k]).max() <= 1e-12 and np.abs(com - fx["com"][k]).max() <= 1e-12
