@@ -274,6 +274,17 @@ typedef struct qmgpu_frontend_args {
 
 int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* args);
 
+/* Gait front end on the device: the per-instance mode schedules of a batch from gait templates, instead of
+ * tiling them on the host (qmgpu_tile_gait) and shipping MAX_EVENTS times + modes per instance every cycle.  Replaces, for a batch of
+ * robots, what GaitTopicPublisher::gaitCommandCallback (qm_controllers/src/GaitTopicPublisher.cpp:31-44) + upstream GaitReceiver /
+ * GaitSchedule::tileModeSequenceTemplate do for one: instance i runs template gait_index[i] of `templates` (host array, copied), first
+ * cycle at t_phase0[i] (STANCE before it), tiled over [t_begin[i], t_end[i]], default STANCE after the last tiled cycle.  The outputs are
+ * bit-identical to qmgpu_tile_gait and plug straight into qmgpu_mpc_args::sched_*.  status[i] = QMGPU_ERR_CAPACITY (and a pure STANCE
+ * schedule) when the schedule needs more than QMGPU_MAX_EVENTS events.  All pointers except `templates` are device pointers. */
+int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templates, int num_templates, const int32_t* gait_index, const double* t_phase0,
+                              const double* t_begin, const double* t_end, int32_t* sched_num_events /*[batch]*/, double* sched_event_times /*[batch][MAX_EVENTS]*/,
+                              int32_t* sched_modes /*[batch][MAX_EVENTS+1]*/, int32_t* status /*[batch] or NULL*/);
+
 /* Diagnostics used by the parity tests: per-node LQ blocks of the last qmgpu_mpc_solve_batch
  * (before projection: A B b | Q R q r | C D e ; nc rows valid).  Host pointers, any may be NULL. */
 int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double* B, double* b, double* Q, double* R,

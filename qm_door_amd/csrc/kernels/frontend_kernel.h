@@ -131,4 +131,62 @@ __global__ void __launch_bounds__(64) frontend_kernel(FrontendArgs fa) {
   for (int k = 0; k < 37; ++k) { ts[k] = s0[k]; ts[37 + k] = s1[k]; }
 }
 
+// ---- gait front end: one thread per instance tiles its template exactly as host_config.cpp: qmgpu_tile_gait does (same operations in the same
+// order, multiply-add contraction off, so the event times are bit-identical to the host's)
+struct GaitArgs {
+  int batch, numTemplates;
+  const qmgpu_gait* templates;   // device copy
+  const int* gaitIndex; const double* tPhase0; const double* tBegin; const double* tEnd;
+  int* numEvents; double* eventTimes; int* modes; int* status;
+};
+__global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.batch) return;
+  double* ev = a.eventTimes + size_t(i) * QMGPU_MAX_EVENTS;
+  int* md = a.modes + size_t(i) * (QMGPU_MAX_EVENTS + 1);
+  auto stanceOnly = [&](int st) {
+    a.numEvents[i] = 0;
+    for (int k = 0; k < QMGPU_MAX_EVENTS; ++k) ev[k] = 1e300;
+    for (int k = 0; k <= QMGPU_MAX_EVENTS; ++k) md[k] = 15;
+    if (a.status) a.status[i] = st;
+  };
+  const int gi = a.gaitIndex[i];
+  if (gi < 0 || gi >= a.numTemplates) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
+  const qmgpu_gait& g = a.templates[gi];
+  const double period = g.switching_times[g.num_modes] - g.switching_times[0];
+  if (g.num_modes < 1 || !(period > 0.0)) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
+  const double tPhase0 = a.tPhase0[i], tBegin = a.tBegin[i], tEnd = a.tEnd[i];
+  double start = tPhase0;
+  if (tBegin > tPhase0) {
+    const double cycles = floor((tBegin - tPhase0) / period);
+    start = tPhase0 + (cycles >= 1.0 ? cycles - 1.0 : 0.0) * period;
+  }
+  // events are produced in order and merged on the fly: an event whose mode equals the last kept mode disappears
+  int n = 0, lastMode = 15;
+  bool overflow = false;
+  auto push = [&](double t, int modeAfter) {
+    if (modeAfter == lastMode) return;
+    if (n < QMGPU_MAX_EVENTS) { ev[n] = t; md[n + 1] = modeAfter; }
+    else overflow = true;
+    ++n; lastMode = modeAfter;
+  };
+  md[0] = 15;
+  double t = start;
+  double evTime = start;
+  while (t < tEnd && !overflow) {
+    for (int m = 0; m < g.num_modes; ++m) {
+      push(evTime, g.modes[m]);
+      t += g.switching_times[m + 1] - g.switching_times[m];
+      evTime = t;
+    }
+  }
+  push(evTime, 15);   // default final phase
+  if (overflow) { stanceOnly(QMGPU_ERR_CAPACITY); return; }
+  a.numEvents[i] = n;
+  for (int k = n; k < QMGPU_MAX_EVENTS; ++k) ev[k] = 1e300;
+  for (int k = n + 1; k <= QMGPU_MAX_EVENTS; ++k) md[k] = 15;
+  if (a.status) a.status[i] = QMGPU_OK;
+}
+
 }  // namespace qmk

@@ -53,6 +53,7 @@ struct qmgpu_context {
   // policy evaluation outputs feeding the WBC inside qmgpu_cycle_batch
   double *dPolX = nullptr, *dPolU = nullptr;
   int* dPolMode = nullptr;
+  qmgpu_gait* dGaits = nullptr;   // gait templates of the last qmgpu_gait_schedule_batch call
   std::vector<void*> allocations;
   bool timing = false, debugLq = false;
   // HIP-event ring: one set of 7 events per call while timing is enabled, read back without a per-call sync
@@ -304,6 +305,21 @@ int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* a) {
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
     FrontendArgs fa{h->m.dP, *a};
     QM_LAUNCH(frontend_kernel, (a->batch + 63) / 64, 64, h->stream, fa);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templates, int num_templates, const int32_t* gait_index, const double* t_phase0,
+                              const double* t_begin, const double* t_end, int32_t* sched_num_events, double* sched_event_times, int32_t* sched_modes, int32_t* status) {
+  if (!h || batch < 1 || !templates || num_templates < 1 || num_templates > 64 || !gait_index || !t_phase0 || !t_begin || !t_end || !sched_num_events || !sched_event_times || !sched_modes)
+    return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad gait schedule arguments");
+  return guarded([&]() {
+    DeviceGuard onDevice(h->device);
+    if (!h->dGaits) h->dGaits = h->alloc<qmgpu_gait>(64, false);
+    HIP_CHECK(hipMemcpyAsync(h->dGaits, templates, sizeof(qmgpu_gait) * num_templates, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));   // `templates` is the caller's (pageable) host memory: nothing is retained after return
+    GaitArgs ga{batch, num_templates, h->dGaits, gait_index, t_phase0, t_begin, t_end, sched_num_events, sched_event_times, sched_modes, status};
+    QM_LAUNCH(gait_schedule_kernel, (batch + 63) / 64, 64, h->stream, ga);
     HIP_CHECK(hipGetLastError());
   });
 }

@@ -1,0 +1,88 @@
+"""Gait front end on the device (qmgpu_gait_schedule_batch): per-instance mode schedules tiled from gait.info templates by a
+kernel, bit-identical to the host tiler qmgpu_tile_gait (what upstream GaitSchedule does with the template GaitTopicPublisher.cpp:31-44 publishes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import support as S
+from qm_door_amd import abi, api
+
+GAITS = ["stance", "trot", "standing_trot", "flying_trot", "pace", "standing_pace", "dynamic_walk", "static_walk", "amble", "lindyhop", "skipping", "pawup"]
+
+
+def _cases(lib, batch, seed):
+    gs = api.GaitSchedule(lib=lib)
+    names = []
+    for g in GAITS:
+        try:
+            gs.template(g); names.append(g)
+        except abi.QmGpuError:
+            pass
+    assert len(names) >= 6
+    templates = [gs.template(g) for g in names]
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, len(names), batch).astype(np.int32)
+    t_phase0 = np.round(rng.uniform(0.0, 3.0, batch), 3)
+    t_begin = t_phase0 + rng.uniform(-1.0, 6.0, batch)
+    t_begin[::7] = t_phase0[::7]                                    # horizon starting exactly on the first cycle
+    t_end = t_begin + rng.uniform(0.5, 3.0, batch)
+    t_end[::11] = t_begin[::11] + 30.0                              # too long for MAX_EVENTS with the fast gaits: capacity status
+    return gs, names, templates, idx, t_phase0, t_begin, t_end
+
+
+def _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st):
+    over = 0
+    for i in range(len(idx)):
+        g = gs.template(names[idx[i]])
+        nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
+        rc = gs.lib.qmgpu_tile_gait(C.byref(g), float(t_phase0[i]), float(t_begin[i]), float(t_end[i]), C.byref(nn), e, m)
+        if rc == abi.ERR_CAPACITY:
+            over += 1
+            assert st[i] == abi.ERR_CAPACITY and n[i] == 0 and (md[i] == 15).all()
+            continue
+        assert rc == 0 and st[i] == 0
+        assert n[i] == nn.value
+        assert np.array_equal(ev[i], np.array(e[:])), (i, names[idx[i]])       # bit-identical event times (padding 1e300 included)
+        assert np.array_equal(md[i], np.array(m[:], dtype=np.int32))
+    return over
+
+
+def test_emu_gait_schedule_matches_host_tiler():
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    B = 96
+    gs, names, templates, idx, t_phase0, t_begin, t_end = _cases(lib, B, 1)
+    sol = api.GpuSolver(itf, max_batch=4, max_nodes=4)
+    n, ev, md, st = np.zeros(B, dtype=np.int32), np.zeros((B, abi.MAX_EVENTS)), np.zeros((B, abi.MAX_EVENTS + 1), dtype=np.int32), np.zeros(B, dtype=np.int32)
+    sol.gait_schedule(templates, idx, t_phase0, t_begin, t_end, n, ev, md, st)
+    assert _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st) >= 1
+
+
+@pytest.mark.gpu
+def test_gpu_gait_schedule_matches_host_tiler_and_feeds_the_mpc(interface, oracle):
+    import torch
+    import gpu_harness as G
+    B = 512
+    gs, names, templates, idx, t_phase0, t_begin, t_end = _cases(interface.lib, B, 2)
+    sol = G.make_solver(interface, B, 20)
+    dn = torch.zeros(B, dtype=torch.int32, device="cuda"); dev_ = torch.zeros((B, abi.MAX_EVENTS), dtype=torch.float64, device="cuda")
+    dmd = torch.zeros((B, abi.MAX_EVENTS + 1), dtype=torch.int32, device="cuda"); dst = torch.zeros(B, dtype=torch.int32, device="cuda")
+    sol.gait_schedule(templates, G.dev(idx, torch.int32), G.dev(t_phase0, torch.float64), G.dev(t_begin, torch.float64), G.dev(t_end, torch.float64), dn, dev_, dmd, dst)
+    torch.cuda.synchronize()
+    n, ev, md, st = dn.cpu().numpy(), dev_.cpu().numpy(), dmd.cpu().numpy(), dst.cpu().numpy()
+    assert _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st) >= 1
+    # the device-made schedules go straight into the MPC call (no host round trip): compared with the oracle on the same schedule
+    N = 20
+    x0 = S.perturbed_states(interface.initial_state, B, seed=6)
+    tgt = S.nominal_target(oracle, interface.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    mb = G.MpcBatch(x0, tt, ts, n, ev, md, N, t0=t_begin)
+    mb.args.sched_num_events = dn.data_ptr(); mb.args.sched_event_times = dev_.data_ptr(); mb.args.sched_modes = dmd.data_ptr()
+    sol.mpc(mb.args)
+    r = mb.results()
+    assert np.isfinite(r["X"]).all()
+    for i in (0, 100, 511):
+        ref = oracle.mpc_solve(N, float(t_begin[i]), x0[i], tt[i], ts[i], int(n[i]), ev[i], md[i])
+        assert np.array_equal(r["mode"][i], ref["mode"])
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
