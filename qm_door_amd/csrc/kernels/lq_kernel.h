@@ -170,6 +170,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   QM_WAVE_SYNC();
   // entry (i, j) of the state-cost Hessian (unscaled); i, j may be any lane-dependent indices < 32
+  // the same without the end-effector Gauss-Newton term (tracking weight + joint-limit barrier): the matrix-core path adds J^T diag(mu) J itself
+  auto qBase = [&](int i, int j) {
+    const int ic = i < 30 ? i : 0, jc = j < 30 ? j : 0;
+    real v = terminal ? 0.0_r : st.Q[ic * 30 + jc];
+    const real dg = ddp[ic >= 24 ? ic - 24 : 0];
+    if (ic == jc && ic >= 24) v += dg;
+    return (i < 30 && j < 30) ? v : 0.0_r;
+  };
   auto qEntry = [&](int i, int j) {
     const int ic = i < 30 ? i : 0, jc = j < 30 ? j : 0;
     real v = terminal ? 0.0_r : st.Q[ic * 30 + jc];
@@ -541,7 +549,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) g[tm][r] = (tm < 2 && tn < 2) ? sc * qEntry(tm * 16 + h + 4 * r, tn * 16 + l16) : 0.0_r;
+          for (int r = 0; r < 4; ++r) g[tm][r] = (tm < 2 && tn < 2) ? sc * qBase(tm * 16 + h + 4 * r, tn * 16 + l16) : 0.0_r;
+        if (tn < 2) {   // + J_ee^T diag(mu) J_ee (Gauss-Newton term of the end-effector soft constraints) on the matrix cores: K = 6 error rows in two k steps
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int qq = 4 * ks + h;                      // error row this lane supplies
+            const bool on = qq < 6;
+            const real wq = on ? sc * (qq < 3 ? muP + muF * Ke * Ke : muO) : 0.0_r;
+            const real bj = on ? EEJ[(on ? qq : 0) * 32 + tn * 16 + l16] : 0.0_r;
+            const real a0 = on ? wq * EEJ[(on ? qq : 0) * 32 + la] : 0.0_r, a1 = on ? wq * EEJ[(on ? qq : 0) * 32 + 16 + la] : 0.0_r;
+            qmMfma(g[0], a0, bj, red); qmMfma(g[1], a1, bj, red);
+          }
+        }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           const int kk = 4 * ks + h;
