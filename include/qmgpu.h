@@ -121,6 +121,9 @@ typedef struct qmgpu_settings {
    * reference by the soft constraint  1/2 mu_f |f_e - f_ref(t)|^2  on the intermediate nodes.  K_e = 0 or a NULL
    * qmgpu_mpc_args::ee_contact_ref switches both off (task.info keys forceTracking.stiffness / forceTracking.muForce). */
   double ee_contact_stiffness, ee_force_mu;
+  /* DDP variant (qmgpu_mpc_args::algorithm = QMGPU_ALG_DDP): task.info ddp{} block (:34-72) -- lineSearch.minStepLength / maxStepLength,
+   * constraintPenaltyInitialValue */
+  double ddp_min_step, ddp_max_step, ddp_constraint_penalty;
 } qmgpu_settings;
 
 typedef struct qmgpu_problem {
@@ -206,7 +209,23 @@ typedef struct qmgpu_mpc_args {
   const double* ee_contact_ref;        /* [batch][K][6] or NULL: per target knot the end-effector force reference f_ref (3) and the anchor
                                           p_env (3) of the compliant environment, interpolated linearly like the other references
                                           (force tracking, see qmgpu_settings::ee_contact_stiffness) */
+  int32_t algorithm;                   /* QMGPU_ALG_SQP (0, the solver the reference instantiates) or QMGPU_ALG_DDP */
+  int32_t reserved1;
 } qmgpu_mpc_args;
+
+/* Solver variants of qmgpu_mpc_solve_batch.
+ *   QMGPU_ALG_SQP  multiple-shooting SQP: ocs2::SqpMpc, the object the reference builds (QMController.cpp:288-289, task.info:76-93).
+ *   QMGPU_ALG_DDP  single-shooting DDP of the family the task file's ddp{} block configures (task.info:34-72, parsed at QMInterface.cpp:70 but never
+ *                  instantiated by the reference): forward rollout of the nonlinear dynamics, LQ approximation along it,
+ *                  the same projected Riccati recursion, and a line search that rolls the feedback policy u = u_nom + alpha du_ff + K (x - x_nom) out
+ *                  for alpha = maxStepLength * 2^-i >= minStepLength, accepting the first whose merit (cost + constraintPenalty * dt |eq|^2) passes the
+ *                  Armijo test.  OWN RESTATEMENT with stated deviations from upstream's SLQ: the rollout uses the shooting grid's RK2 steps (not
+ *                  ODE45, task.info:129-137) and the backward pass is the discrete-time recursion (upstream's ILQR form, not the continuous-time
+ *                  Riccati ODE).  One iteration per call (ddp.maxNumIterations 1).  The nominal trajectory the LQ approximation is formed along is
+ *                  the warm start (warm_x, warm_u) as it is -- a previous solution's defects are part of the linearisation, as in Gauss-Newton
+ *                  multiple shooting -- or, without warm_x, the open-loop rollout of warm_u / the initializer's inputs from x0.
+ *                  out_stats: merit0, eq-violation0, merit1, eq-violation1, alpha (0 = no step accepted), trials evaluated, armijo, status. */
+enum { QMGPU_ALG_SQP = 0, QMGPU_ALG_DDP = 1 };
 
 int qmgpu_mpc_solve_batch(qmgpu_handle h, const qmgpu_mpc_args* args);
 

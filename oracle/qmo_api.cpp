@@ -136,6 +136,24 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
   return r.status;
 }
 
+// DDP variant (ddpIteration): warmU [N][30] or null -> the initializer's inputs; warmX [N+1][30] or null -> open-loop rollout of the inputs
+int qmo_ddp_solve(const qmgpu_problem* P, int N, double t0, const double* x0, const double* timeGrid, int K, const double* ttimes, const double* tstates,
+                  int nEv, const double* ev, const int32_t* modes, const double* warmX, const double* warmU, double* outT, double* outX, double* outU, int32_t* outMode,
+                  double* stats) {
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, g_contactRef}};
+  std::vector<double> tg(N + 1), U(N * 30);
+  for (int k = 0; k <= N; ++k) tg[k] = timeGrid ? timeGrid[k] : t0 + k * P->settings.dt;
+  for (int k = 0; k < N; ++k) {
+    if (warmU) for (int i = 0; i < 30; ++i) U[k * 30 + i] = warmU[k * 30 + i];
+    else weightCompensatingInput(*P, pr.ms.nodeModeAt(tg[k]), &U[k * 30]);
+  }
+  const DdpResult r = ddpIteration(pr, N, tg.data(), x0, U, warmX);
+  for (int k = 0; k <= N; ++k) { outT[k] = tg[k]; outMode[k] = pr.ms.nodeModeAt(tg[k]); }
+  std::copy(r.X.begin(), r.X.end(), outX); std::copy(r.U.begin(), r.U.end(), outU);
+  if (stats) { stats[0] = r.merit0; stats[1] = std::sqrt(r.eq0); stats[2] = r.merit1; stats[3] = std::sqrt(r.eq1); stats[4] = r.alpha; stats[5] = r.trials; stats[6] = r.armijo; stats[7] = r.status; stats[8] = 1; stats[9] = 1; }
+  return r.status;
+}
+
 // performance index of a trajectory (merit, constraint violation)
 void qmo_performance(const qmgpu_problem* P, int N, const double* tgrid, const double* x0, const double* X, const double* U, int K, const double* ttimes,
                      const double* tstates, int nEv, const double* ev, const int32_t* modes, double* merit, double* viol) {

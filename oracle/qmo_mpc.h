@@ -458,9 +458,13 @@ inline int sqpConvergence(const qmgpu_settings& st, int iteration, const SqpResu
   return 0;
 }
 
-// One SQP iteration over the grid tgrid[0..N]; X [(N+1)*30], U [N*30] hold the initial guess.
+// what the DDP variant takes from the LQ approximation + Riccati recursion of one iterate
+struct RiccatiExport { std::vector<NodeLQ> lq; std::vector<Mat> K; std::vector<Vec> k; double armijo = 0.0; int status = 0; };
+
+// One SQP iteration over the grid tgrid[0..N]; X [(N+1)*30], U [N*30] hold the initial guess.  With `riccatiOut` the function stops after the
+// Riccati recursion and hands back the projected stages and gains (no line search).
 inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, const double* x0, const std::vector<double>& X, const std::vector<double>& U,
-                              bool lineSearch, std::vector<NodeLQ>* keepLQ = nullptr) {
+                              bool lineSearch, std::vector<NodeLQ>* keepLQ = nullptr, RiccatiExport* riccatiOut = nullptr) {
   const qmgpu_settings& st = pr.P->settings;
   std::vector<NodeLQ> lq(N + 1);
   std::unique_ptr<PhaseTimer> phase(new PhaseTimer(PH_LQ));
@@ -479,7 +483,7 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
     const Vec Sb = S * n.bt;
     const Vec g = n.rt + tmul(n.Bt, s + Sb);
     Mat L = H;
-    if (!cholesky(L)) { SqpResult r; r.status = 1; r.X = X; r.U = U; return r; }
+    if (!cholesky(L)) { SqpResult r; r.status = 1; r.X = X; r.U = U; if (riccatiOut) riccatiOut->status = 1; return r; }
     Mat Kk = -1.0 * cholSolve(L, G);
     Vec kk = g; cholSolve(L, kk); kk = -1.0 * kk;
     const Mat AtS = T(n.At) * S;
@@ -503,6 +507,7 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
   }
   for (int i = 0; i < 30; ++i) dX[N * 30 + i] = dx[i];
   armijo += dot(lq[N].q, dx);
+  if (riccatiOut) { riccatiOut->lq = lq; riccatiOut->K = Kfb; riccatiOut->k = kff; riccatiOut->armijo = armijo; SqpResult r; r.armijo = armijo; r.X = X; r.U = U; return r; }
 
   phase.reset(); phase.reset(new PhaseTimer(PH_LINESEARCH));
   // ---- performance of the baseline and filter line search (upstream FilterLinesearch::acceptStep, SqpSolver::takeStep)
@@ -534,6 +539,56 @@ inline SqpResult sqpIteration(const Problem& pr, int N, const double* tgrid, con
   } while (alpha >= st.alpha_min);
   res.alpha = 0.0; res.stepType = 4; res.X = X; res.U = U; res.merit1 = res.merit0; res.viol1 = res.viol0;
   if (keepLQ) *keepLQ = lq;
+  return res;
+}
+
+// ------------------------------------------------------------------------------------------------ DDP variant
+// Single-shooting DDP of the family the reference's task file configures in ddp{} (task.info:34-72, never instantiated by the reference):
+// own restatement, see include/qmgpu.h QMGPU_ALG_DDP for the stated deviations from upstream's SLQ (RK2 rollout on the shooting grid,
+// discrete-time backward pass).
+struct DdpResult { std::vector<double> X, U; double merit0 = 0, eq0 = 0, merit1 = 0, eq1 = 0, alpha = 0, armijo = 0; int trials = 0, status = 0; };
+
+inline DdpResult ddpIteration(const Problem& pr, int N, const double* tgrid, const double* x0, const std::vector<double>& Uinit, const double* Xwarm = nullptr) {
+  const qmgpu_settings& st = pr.P->settings;
+  DdpResult res;
+  // 1. nominal trajectory: the warm start as it is (states and inputs of the previous solve; its defects are part of the linearisation, as in
+  //    Gauss-Newton multiple shooting), or the open-loop rollout of the given inputs from x0 when no states are given
+  std::vector<double> X((N + 1) * 30), U = Uinit;
+  for (int i = 0; i < 30; ++i) X[i] = x0[i];
+  if (Xwarm) { for (int k = 1; k <= N; ++k) for (int i = 0; i < 30; ++i) X[k * 30 + i] = Xwarm[k * 30 + i]; }
+  else for (int k = 0; k < N; ++k) { const ContactScope contact(st, pr.tg, tgrid[k]); rk2Step(*pr.P, tgrid[k + 1] - tgrid[k], &X[k * 30], &U[k * 30], &X[(k + 1) * 30]); }
+  // 2. LQ approximation along it + projected Riccati recursion
+  RiccatiExport rx;
+  sqpIteration(pr, N, tgrid, x0, X, U, false, nullptr, &rx);
+  res.armijo = rx.armijo; res.status = rx.status; res.X = X; res.U = U;
+  // merit of a trajectory: dt-scaled costs + penalty * dt (|eq|^2 + |defect|^2); a rolled-out trajectory has no defect, a warm start may
+  auto meritOf = [&](const std::vector<double>& Xn, const std::vector<double>& Un, double& eqOut) {
+    double cost = 0, eq = 0;
+    for (int k = 0; k < N; ++k) { const NodeMetrics m = nodeMetrics(pr, tgrid[k], tgrid[k + 1] - tgrid[k], &Xn[k * 30], &Un[k * 30], &Xn[(k + 1) * 30], false); cost += m.cost; eq += m.eqViolationSSE + m.dynViolationSSE; }
+    cost += nodeMetrics(pr, tgrid[N], 0.0, &Xn[N * 30], nullptr, nullptr, true).cost;
+    eqOut = eq;
+    return cost + st.ddp_constraint_penalty * eq;
+  };
+  res.merit0 = meritOf(X, U, res.eq0); res.merit1 = res.merit0; res.eq1 = res.eq0;
+  if (rx.status != 0) return res;
+  // 3. policy rollouts, first step length that passes the Armijo test
+  for (double alpha = st.ddp_max_step; alpha >= st.ddp_min_step && res.trials < 8; alpha *= 0.5) {
+    ++res.trials;
+    std::vector<double> Xn((N + 1) * 30), Un(N * 30);
+    for (int i = 0; i < 30; ++i) Xn[i] = x0[i];
+    for (int k = 0; k < N; ++k) {
+      const NodeLQ& n = rx.lq[k];
+      Vec dx(30); for (int i = 0; i < 30; ++i) dx[i] = Xn[k * 30 + i] - X[k * 30 + i];
+      const Vec dut = rx.K[k] * dx + alpha * rx.k[k];
+      const Vec du = alpha * n.Pe + n.Px * dx + n.Pu * dut;
+      for (int i = 0; i < 30; ++i) Un[k * 30 + i] = U[k * 30 + i] + du[i];
+      const ContactScope contact(st, pr.tg, tgrid[k]);
+      rk2Step(*pr.P, tgrid[k + 1] - tgrid[k], &Xn[k * 30], &Un[k * 30], &Xn[(k + 1) * 30]);
+    }
+    double eq1;
+    const double m1 = meritOf(Xn, Un, eq1);
+    if (m1 == m1 && m1 <= res.merit0 - st.armijo_factor * alpha * std::fabs(rx.armijo)) { res.alpha = alpha; res.merit1 = m1; res.eq1 = eq1; res.X = Xn; res.U = Un; return res; }
+  }
   return res;
 }
 

@@ -45,7 +45,7 @@ class Settings(C.Structure):
         ("wbc_friction_coefficient", d), ("kp_swing", d), ("kd_swing", d), ("kp_base_height", d), ("kd_base_height", d),
         ("kp_base_linear", d), ("kd_base_linear", d), ("kp_base_angular", d), ("kd_base_angular", d),
         ("kp_arm_joint", d * 6), ("kd_arm_joint", d * 6), ("kp_ee_linear", d * 3), ("kd_ee_linear", d * 3),
-        ("kp_ee_angular", d * 3), ("kd_ee_angular", d * 3), ("gravity", d), ("ee_contact_stiffness", d), ("ee_force_mu", d),
+        ("kp_ee_angular", d * 3), ("kd_ee_angular", d * 3), ("gravity", d), ("ee_contact_stiffness", d), ("ee_force_mu", d), ("ddp_min_step", d), ("ddp_max_step", d), ("ddp_constraint_penalty", d),
     ]
 
 
@@ -63,7 +63,7 @@ class MpcArgs(C.Structure):
         ("t0", C.c_void_p), ("x0", C.c_void_p), ("time_grid", C.c_void_p), ("target_times", C.c_void_p), ("target_states", C.c_void_p),
         ("sched_num_events", C.c_void_p), ("sched_event_times", C.c_void_p), ("sched_modes", C.c_void_p),
         ("warm_x", C.c_void_p), ("warm_u", C.c_void_p),
-        ("out_t", C.c_void_p), ("out_x", C.c_void_p), ("out_u", C.c_void_p), ("out_mode", C.c_void_p), ("out_stats", C.c_void_p), ("ee_contact_ref", C.c_void_p),
+        ("out_t", C.c_void_p), ("out_x", C.c_void_p), ("out_u", C.c_void_p), ("out_mode", C.c_void_p), ("out_stats", C.c_void_p), ("ee_contact_ref", C.c_void_p), ("algorithm", i32), ("reserved1", i32),
     ]
 
 

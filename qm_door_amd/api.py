@@ -134,10 +134,11 @@ class GpuSolver:
 
     @staticmethod
     def mpc_args(batch, num_nodes, x0, target_times, target_states, sched_num, sched_times, sched_modes, out_t, out_x, out_u, out_mode, out_stats=None,
-                 t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True, ee_contact_ref=None):
+                 t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True, ee_contact_ref=None, algorithm=0):
         K = target_times.shape[-1] if target_times.ndim > 1 else 1
         a = abi.MpcArgs()
         a.batch, a.num_nodes, a.num_target_knots, a.line_search = batch, num_nodes, K, int(line_search)
+        a.algorithm = int(algorithm)
         for name, val in (("t0", t0), ("x0", x0), ("time_grid", time_grid), ("target_times", target_times), ("target_states", target_states),
                           ("sched_num_events", sched_num), ("sched_event_times", sched_times), ("sched_modes", sched_modes), ("warm_x", warm_x),
                           ("warm_u", warm_u), ("out_t", out_t), ("out_x", out_x), ("out_u", out_u), ("out_mode", out_mode), ("out_stats", out_stats),

@@ -220,6 +220,10 @@ static void loadSettings(const std::string& taskFile, const std::string& referen
   // force tracking (own formulation, include/qmgpu.h): absent in the reference's task.info -> off
   s.ee_contact_stiffness = infoDoubleOr(task, "forceTracking.stiffness", 0.0);
   s.ee_force_mu = infoDoubleOr(task, "forceTracking.muForce", 0.0);
+  // ddp{} block (task.info:34-72): what the DDP variant of the solver uses of it
+  s.ddp_min_step = infoDoubleOr(task, "ddp.lineSearch.minStepLength", 1e-2);
+  s.ddp_max_step = infoDoubleOr(task, "ddp.lineSearch.maxStepLength", 1.0);
+  s.ddp_constraint_penalty = infoDoubleOr(task, "ddp.constraintPenaltyInitialValue", 20.0);
   // WBC gains: defaults of qm_wbc/cfg/wbcWigeht.cfg:7-47, optionally overridden from an INFO block "wbc_gains"
   s.kp_swing = 350; s.kd_swing = 37; s.kp_base_height = 400; s.kd_base_height = 140; s.kp_base_linear = 400; s.kd_base_linear = 100;
   s.kp_base_angular = 400; s.kd_base_angular = 140;

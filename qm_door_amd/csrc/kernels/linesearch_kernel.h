@@ -38,9 +38,10 @@ struct DblIn {
   __device__ __forceinline__ Vec3<real> force(int c) const { return Vec3<real>(u[3 * c], u[3 * c + 1], u[3 * c + 2]); }
 };
 
-// dt-scaled cost, dt*|defect|^2, dt*|eq|^2 of one node at (x, u, xnext)
+// dt-scaled cost, dt*|defect|^2, dt*|eq|^2 of one node at (x, u, xnext); xnOut (optional, 30): the RK2 image of (x, u), in which case xnext may be
+// null and the defect is not formed (rollouts of the DDP variant)
 __device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
-                                       bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq) {
+                                       bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq, real* xnOut = nullptr) {
   const ModelR& md = P.model;
   const SettingsR& st = P.settings;
   const int mode = sched.modes[phase];
@@ -100,8 +101,13 @@ __device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const 
     }
   }
   if (terminal) { cost = c; return; }
-  for (int i = 0; i < 12; ++i) { const real d = x[i] + phi[i] - xnext[i]; dyn += d * d; }
-  for (int j = 0; j < 18; ++j) { const real d = x[12 + j] + dt * u[12 + j] - xnext[12 + j]; dyn += d * d; }
+  if (xnOut) {
+    for (int i = 0; i < 12; ++i) xnOut[i] = x[i] + phi[i];
+    for (int j = 0; j < 18; ++j) xnOut[12 + j] = x[12 + j] + dt * u[12 + j];
+  } else {
+    for (int i = 0; i < 12; ++i) { const real d = x[i] + phi[i] - xnext[i]; dyn += d * d; }
+    for (int j = 0; j < 18; ++j) { const real d = x[12 + j] + dt * u[12 + j] - xnext[12 + j]; dyn += d * d; }
+  }
   // tracking cost
   int tIdx; real tAlpha;
   timeSegment(tTimes, K, t, tIdx, tAlpha);

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "aux_kernels.h"
+#include "ddp_kernel.h"
 #include "gpu_rt.h"
 #include "layout.h"
 #include "linesearch_kernel.h"
@@ -20,6 +21,7 @@ struct MpcBuffers {
   real *dTgrid = nullptr, *dDtgrid = nullptr, *dX = nullptr, *dU = nullptr, *dStages = nullptr, *dAdRows = nullptr, *dMetrics = nullptr, *dGains = nullptr, *ddX = nullptr, *ddU = nullptr;
   real *dXt = nullptr, *dUt = nullptr, *dInstStats = nullptr, *dDebug = nullptr;
   int *dStageNc = nullptr, *dNodeMode = nullptr, *dNodePhase = nullptr, *dDone = nullptr;
+  real *dDdpX = nullptr, *dDdpU = nullptr, *dDdpMerit = nullptr;   // DDP variant: trial trajectories / merits, allocated on first use
 };
 
 // the arguments of one call (qmgpu_mpc_args) as `real` device arrays
@@ -32,6 +34,7 @@ struct MpcIo {
   const real *warmX, *warmU;
   real *outT, *outX, *outU; int* outMode; real* outStats;
   const real* eeContact;                                // [batch][K][6] or null (force tracking)
+  int algorithm;                                        // QMGPU_ALG_SQP / QMGPU_ALG_DDP
 };
 
 // Alloc: callable (size_t count, size_t elemSize, bool scratch) -> void*
@@ -61,6 +64,13 @@ template <class Alloc> inline void allocateMpcBuffers(MpcBuffers& m, size_t B, s
   m.dDone = I(B);
 }
 
+template <class Alloc> inline void ensureDdpBuffers(MpcBuffers& m, size_t B, size_t N, Alloc&& alloc) {
+  if (m.dDdpX) return;
+  m.dDdpX = static_cast<real*>(alloc(size_t(DDP_MAX_TRIALS) * B * (N + 1) * 30, sizeof(real), true));
+  m.dDdpU = static_cast<real*>(alloc(size_t(DDP_MAX_TRIALS) * B * N * 30, sizeof(real), true));
+  m.dDdpMerit = static_cast<real*>(alloc(size_t(DDP_MAX_TRIALS) * B * 2, sizeof(real), true));
+}
+
 inline hipError_t prepareMpcKernels() { return QM_ALLOW_DYNAMIC_LDS(riccati_kernel<RICCATI_WAVES>, RICCATI_LDS_BYTES); }
 
 // events (optional, 7 entries as in qmgpu_api.hip): [0] start, [6] after ad_node, [1] after lq_node, [2] after riccati, [3] after the line search
@@ -88,6 +98,38 @@ inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
     QM_LAUNCH(linesearch_kernel, B, 256, s, ls);
     if (ev) (void)hipEventRecord(ev[3], s);
   }
+}
+
+// One DDP iteration (ddp_kernel.h): rollout -> LQ approximation along it -> Riccati -> policy rollouts for every step length -> selection.
+// `trials` = number of step lengths maxStep * 2^-i >= minStep (host side, <= DDP_MAX_TRIALS).
+inline void enqueueDdpKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& io, int trials, hipEvent_t* ev) {
+  const int B = io.batch, N = io.N;
+  if (ev) (void)hipEventRecord(ev[0], s);
+  InitArgs ia{m.dP, B, N, io.dtD, io.t0D, io.timeGridD, io.schedTimesD, io.x0, io.warmX, io.warmU, io.schedNum, io.schedModes, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, 0, m.dDone};
+  QM_LAUNCH(mpc_init_kernel, B, 128, s, ia);
+  DdpArgs ra{m.dP, m.dRw, B, N, io.K, 0, io.eeContact, m.dTgrid, m.dDtgrid, m.dNodePhase, io.x0, m.dX, m.dU, io.targetTimes, io.targetStates, io.schedNum, io.schedTimes, io.schedModes,
+             m.dStages, m.dStageNc, m.dGains, m.dX, m.dU, m.dDdpMerit};
+  if (!io.warmX) QM_LAUNCH(ddp_rollout_kernel, (B + 63) / 64, 64, s, ra);   // no warm states: the nominal trajectory is the open-loop rollout of the inputs
+  LqArgs la{m.dP, m.dRw, B, N, io.K, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, io.targetTimes, io.targetStates, io.schedNum, io.schedTimes,
+            io.schedModes, m.dZeros, m.dStages, m.dStageNc, m.dNodeMode, m.dMetrics, nullptr, m.dAdRows, m.dDone, io.eeContact};
+  QM_LAUNCH(ad_node_kernel, adGridFor(B * (N + 1)), 64, s, la);
+  if (ev) (void)hipEventRecord(ev[6], s);
+  QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
+  if (ev) (void)hipEventRecord(ev[1], s);
+  RiccatiArgs ri{B, N, m.dStages, m.dStageNc, io.x0, m.dX, m.dGains, m.ddX, m.ddU, m.dInstStats, m.dDone};
+  QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ri);
+  if (ev) (void)hipEventRecord(ev[2], s);
+  ra.trials = trials; ra.Xout = m.dDdpX; ra.Uout = m.dDdpU;
+  QM_LAUNCH(ddp_rollout_kernel, (B * trials + 63) / 64, 64, s, ra);
+  DdpSelectArgs sa{m.dP, B, N, trials, m.dTgrid, m.dNodeMode, m.dX, m.dU, m.dMetrics, m.dInstStats, m.dDdpX, m.dDdpU, m.dDdpMerit, io.outT, io.outX, io.outU, io.outMode, io.outStats, m.dDone};
+  QM_LAUNCH(ddp_select_kernel, B, 256, s, sa);
+  if (ev) (void)hipEventRecord(ev[3], s);
+}
+
+inline int ddpTrialCount(double minStep, double maxStep) {
+  int n = 0;
+  for (double a = maxStep; a >= minStep && n < DDP_MAX_TRIALS; a *= 0.5) ++n;
+  return n > 0 ? n : 1;
 }
 
 }  // namespace qmk

@@ -22,14 +22,14 @@ using RawAlloc = std::function<void*(size_t, size_t, bool)>;
 inline Mpc32* create(const qmgpu_problem&, int, int, hipStream_t, const RawAlloc&) { return nullptr; }
 inline void destroy(Mpc32*) {}
 inline bool updateProblem(Mpc32*, const qmgpu_problem&, hipStream_t) { return false; }
-inline bool enqueue(Mpc32*, hipStream_t, const qmgpu_mpc_args*, double, int, hipEvent_t*) { return false; }
+inline bool enqueue(Mpc32*, hipStream_t, const qmgpu_mpc_args*, double, int, int, hipEvent_t*) { return false; }
 #else
 Mpc32* create(const qmgpu_problem& problem, int maxBatch, int maxNodes, hipStream_t stream, const RawAlloc& alloc);
 void destroy(Mpc32* p);
 bool updateProblem(Mpc32* p, const qmgpu_problem& problem, hipStream_t stream);
 // One MPC call in fp32: the caller's fp64 device arrays are converted to fp32 staging, the kernel chain of kernels/mpc_pipeline.h
 // runs in fp32, the results are converted back into the caller's fp64 arrays.  ev: optional timing events (qmgpu_api.hip).
-bool enqueue(Mpc32* p, hipStream_t stream, const qmgpu_mpc_args* a, double dt, int iterations, hipEvent_t* ev);
+bool enqueue(Mpc32* p, hipStream_t stream, const qmgpu_mpc_args* a, double dt, int iterations, int ddpTrials, hipEvent_t* ev);
 #endif
 
 }  // namespace qmk32

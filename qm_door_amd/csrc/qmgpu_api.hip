@@ -110,7 +110,8 @@ int qmgpu_create_ex(const qmgpu_problem* problem, int device, int max_batch, int
     HIP_CHECK(hipStreamCreate(&ctx->ownStream));
     ctx->stream = ctx->ownStream;
     const size_t B = size_t(max_batch), N1 = size_t(max_nodes) + 1, N = size_t(max_nodes);
-    auto rawAlloc = [&](size_t count, size_t elem, bool scratch) { return static_cast<void*>(ctx->alloc<char>(count * elem, scratch)); };
+    qmgpu_context* const owner = ctx;   // by value: the fp32 path keeps this allocator for buffers it creates on first use
+    auto rawAlloc = [owner](size_t count, size_t elem, bool scratch) { return static_cast<void*>(owner->alloc<char>(count * elem, scratch)); };
     // the fp32 handle keeps the fp64 model / settings / R' (the WBC and the front end read them) but not the fp64 MPC scratch
     if (dtype == QMGPU_F64) allocateMpcBuffers(ctx->m, B, N, rawAlloc);
     else { ctx->m.dP = ctx->alloc<qmgpu_problem>(1, false); ctx->m.dRw = ctx->alloc<double>(900, false); ctx->m.dZeros = ctx->alloc<double>(64, false); }
@@ -239,11 +240,19 @@ static void checkMpcArgs(qmgpu_handle h, const qmgpu_mpc_args* a) {
 static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   const int iterations = h->hostProblem.settings.sqp_iterations > 1 ? h->hostProblem.settings.sqp_iterations : 1;
   hipEvent_t* ev = h->timing ? h->ev : nullptr;
+  if (a->algorithm != QMGPU_ALG_SQP && a->algorithm != QMGPU_ALG_DDP) throw std::invalid_argument("unknown qmgpu_mpc_args::algorithm");
+  const int trials = ddpTrialCount(h->hostProblem.settings.ddp_min_step, h->hostProblem.settings.ddp_max_step);
   if (h->dtype == QMGPU_F32) {
-    if (!qmk32::enqueue(h->m32, h->stream, a, h->hostProblem.settings.dt, iterations, ev)) throw HipFailure("fp32 MPC launch failed");
+    if (!qmk32::enqueue(h->m32, h->stream, a, h->hostProblem.settings.dt, iterations, trials, ev)) throw HipFailure("fp32 MPC launch failed");
+  } else if (a->algorithm == QMGPU_ALG_DDP) {
+    ensureDdpBuffers(h->m, size_t(h->maxBatch), size_t(h->maxNodes), [&](size_t count, size_t elem, bool scratch) { return static_cast<void*>(h->alloc<char>(count * elem, scratch)); });
+    const MpcIo io{a->batch, a->num_nodes, a->num_target_knots, a->line_search, h->hostProblem.settings.dt, a->t0, a->time_grid, a->sched_event_times, a->x0, a->target_times,
+                   a->target_states, a->sched_num_events, a->sched_event_times, a->sched_modes, a->warm_x, a->warm_u, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats, a->ee_contact_ref,
+                   a->algorithm};
+    enqueueDdpKernels(h->stream, h->m, io, trials, ev);
   } else {
     const MpcIo io{a->batch, a->num_nodes, a->num_target_knots, a->line_search, h->hostProblem.settings.dt, a->t0, a->time_grid, a->sched_event_times, a->x0, a->target_times,
-                   a->target_states, a->sched_num_events, a->sched_event_times, a->sched_modes, a->warm_x, a->warm_u, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats, a->ee_contact_ref};
+                   a->target_states, a->sched_num_events, a->sched_event_times, a->sched_modes, a->warm_x, a->warm_u, a->out_t, a->out_x, a->out_u, a->out_mode, a->out_stats, a->ee_contact_ref, a->algorithm};
     enqueueMpcKernels(h->stream, h->m, io, iterations, h->debugLq, ev);
   }
   HIP_CHECK(hipGetLastError());

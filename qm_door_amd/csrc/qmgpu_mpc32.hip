@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) widen_kernel(const float* src, double* ds
 
 struct Mpc32 {
   int maxBatch = 0, maxNodes = 0;
+  RawAlloc alloc;   // the handle's allocator (device memory stays on the handle's list)
   MpcBuffers m;
   // fp32 staging of one call's arguments
   float *x0 = nullptr, *tgtT = nullptr, *tgtS = nullptr, *evT = nullptr, *warmX = nullptr, *warmU = nullptr;
@@ -44,7 +45,7 @@ static bool uploadProblem(Mpc32* p, const qmgpu_problem& problem, hipStream_t st
 Mpc32* create(const qmgpu_problem& problem, int maxBatch, int maxNodes, hipStream_t stream, const RawAlloc& alloc) {
   Mpc32* p = new (std::nothrow) Mpc32();
   if (!p) return nullptr;
-  p->maxBatch = maxBatch; p->maxNodes = maxNodes;
+  p->maxBatch = maxBatch; p->maxNodes = maxNodes; p->alloc = alloc;
   const size_t B = size_t(maxBatch), N = size_t(maxNodes), N1 = N + 1;
   allocateMpcBuffers(p->m, B, N, alloc);
   auto F = [&](size_t n) { return static_cast<float*>(alloc(n, sizeof(float), true)); };
@@ -63,7 +64,7 @@ void destroy(Mpc32* p) { delete p; }
 
 bool updateProblem(Mpc32* p, const qmgpu_problem& problem, hipStream_t stream) { return p && uploadProblem(p, problem, stream); }
 
-bool enqueue(Mpc32* p, hipStream_t s, const qmgpu_mpc_args* a, double dtD, int iterations, hipEvent_t* ev) {
+bool enqueue(Mpc32* p, hipStream_t s, const qmgpu_mpc_args* a, double dtD, int iterations, int ddpTrials, hipEvent_t* ev) {
   if (!p || a->num_target_knots > kMaxKnots32) return false;
   const size_t B = size_t(a->batch), N = size_t(a->num_nodes), N1 = N + 1, K = size_t(a->num_target_knots);
   auto narrow = [&](const double* src, float* dst, size_t n) {
@@ -84,7 +85,13 @@ bool enqueue(Mpc32* p, hipStream_t s, const qmgpu_mpc_args* a, double dtD, int i
   io.warmU = narrow(a->warm_u, p->warmU, B * N * 30);
   io.eeContact = narrow(a->ee_contact_ref, p->contact, B * K * 6);
   io.outT = p->outT; io.outX = p->outX; io.outU = p->outU; io.outMode = a->out_mode; io.outStats = a->out_stats ? p->outStats : nullptr;
-  enqueueMpcKernels(s, p->m, io, iterations, false, ev);
+  io.algorithm = a->algorithm;
+  if (a->algorithm == QMGPU_ALG_DDP) {
+    ensureDdpBuffers(p->m, size_t(p->maxBatch), size_t(p->maxNodes), p->alloc);
+    enqueueDdpKernels(s, p->m, io, ddpTrials, ev);
+  } else {
+    enqueueMpcKernels(s, p->m, io, iterations, false, ev);
+  }
   auto widen = [&](const float* src, double* dst, size_t n) { QM_LAUNCH(widen_kernel, unsigned((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, s, src, dst, n); };
   widen(p->outT, a->out_t, B * N1);
   widen(p->outX, a->out_x, B * N1 * 30);

@@ -145,6 +145,24 @@ class Oracle:
                                     p(X), p(U), p(M), p(st))
         return dict(status=rc, T=T, X=X, U=U, mode=M, stats=st)
 
+    def performance(self, N, tgrid, x0, X, U, ttimes, tstates, nev, ev, modes):
+        """(merit, constraint violation) of a trajectory: sum of the dt-scaled costs, sqrt(dt |defects|^2 + dt |equalities|^2)"""
+        m, v = C.c_double(0), C.c_double(0)
+        self.lib.qmo_performance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+        self.lib.qmo_performance(C.byref(self.P), N, p(np.ascontiguousarray(tgrid)), p(x0), p(np.ascontiguousarray(X)), p(np.ascontiguousarray(U)), len(ttimes), p(ttimes),
+                                 p(tstates), nev, p(ev), p(modes), C.byref(m), C.byref(v))
+        return m.value, v.value
+
+    def ddp_solve(self, N, t0, x0, ttimes, tstates, nev, ev, modes, warm_u=None, time_grid=None, warm_x=None):
+        T, X, U, M, st = np.zeros(N + 1), np.zeros((N + 1, 30)), np.zeros((N, 30)), np.zeros(N + 1, dtype=np.int32), np.zeros(abi.NSTATS)
+        self.lib.qmo_ddp_solve.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p] + [C.c_void_p] * 5
+        wu = p(np.ascontiguousarray(warm_u)) if warm_u is not None else None
+        wx = p(np.ascontiguousarray(warm_x)) if warm_x is not None else None
+        rc = self.lib.qmo_ddp_solve(C.byref(self.P), N, t0, p(x0), p(time_grid), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), wx, wu, p(T), p(X), p(U), p(M), p(st))
+        return dict(status=rc, T=T, X=X, U=U, mode=M, stats=st)
+
     def wbc_update(self, x_des, u_des, rbd, mode, period, time, input_last, variant=0):
         out = np.zeros(54)
         il = np.array(input_last, dtype=np.float64)

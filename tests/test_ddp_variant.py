@@ -1,0 +1,104 @@
+"""DDP variant of the MPC solve (qmgpu_mpc_args::algorithm = QMGPU_ALG_DDP; SURVEY.md 8(f) rank 3, the ddp{} block of the task file,
+task.info:34-72): forward rollout, LQ approximation along it, the projected Riccati recursion, policy rollouts over the step lengths.
+Kernels against the oracle's own restatement of the same iteration (include/qmgpu.h states the deviations from upstream's SLQ)."""
+import numpy as np
+import pytest
+
+import support as S
+from qm_door_amd import abi, api
+
+
+def _scenario(itf, orc, B, N, seed):
+    x_nom = itf.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=seed)
+    tgt = S.nominal_target(orc, x_nom)
+    tgt2 = tgt.copy(); tgt2[6] += 0.08; tgt2[30] += 0.08
+    tt = np.tile(np.array([0.0, 0.5]), (B, 1)); ts = np.tile(np.stack([tgt, tgt2]), (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(N * itf.problem.settings.dt + 1.0, phase0=0.04)
+    return x0, tt, ts, nev, ev, md
+
+
+def _check(r, i, ref, tolx):
+    assert np.array_equal(r["mode"][i], ref["mode"])
+    assert r["stats"][i][4] == ref["stats"][4] and r["stats"][i][5] == ref["stats"][5] and r["stats"][i][7] == 0      # step length, trials evaluated, status
+    assert np.abs(r["X"][i] - ref["X"]).max() <= tolx * max(1.0, np.abs(ref["X"]).max())
+    assert np.abs(r["U"][i] - ref["U"]).max() <= tolx * max(1.0, np.abs(ref["U"]).max())
+    assert np.allclose(r["stats"][i][[0, 2]], ref["stats"][[0, 2]], rtol=1e-7)
+
+
+def test_oracle_ddp_iteration_properties(interface, oracle):
+    """The restatement itself: the accepted trajectory is dynamically feasible (it IS a rollout), starts at x0, lowers the merit, and the policy
+    reproduces the nominal trajectory when the feed-forward step is switched off (alpha -> 0 limit is the nominal rollout)."""
+    N = 16
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, 1, N, 3)
+    r = oracle.ddp_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
+    assert r["status"] == 0 and r["stats"][4] > 0 and r["stats"][2] < r["stats"][0]
+    assert np.array_equal(r["X"][0], x0[0])
+    dt = interface.problem.settings.dt
+    m, v = oracle.performance(N, np.arange(N + 1) * dt, x0[0], r["X"], r["U"], tt[0], ts[0], nev, ev, md)
+    # violation = sqrt(defects + equalities): the defect part of a rollout is round-off, so this is the equality part alone
+    assert abs(v - r["stats"][3]) <= 1e-9 * max(1.0, v)
+
+
+def test_emu_ddp_matches_oracle():
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    orc = S.Oracle(itf.problem)
+    B, N = 2, 8
+    x0, tt, ts, nev, ev, md = _scenario(itf, orc, B, N, 5)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+    a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B),
+                     algorithm=1)
+    sol.mpc(a)
+    r = dict(X=oX, U=oU, mode=oM, stats=oS)
+    for i in range(B):
+        _check(r, i, orc.ddp_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md), 1e-8)
+    # a second iteration seeded with the inputs of the first one: the solver keeps improving the merit
+    a2 = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT.copy(), oX.copy(), oU.copy(),
+                      oM.copy(), np.zeros((B, abi.NSTATS)), t0=np.zeros(B), warm_x=oX.copy(), warm_u=oU.copy(), algorithm=1)
+    sol.mpc(a2)
+    ref2 = orc.ddp_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md, warm_u=oU[0], warm_x=oX[0])
+    assert np.allclose(a2._keep[-1][0][[0, 2]], ref2["stats"][[0, 2]], rtol=1e-7) and ref2["stats"][0] <= oS[0][2] * (1 + 1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_ddp_matches_oracle_n100(interface, oracle):
+    import gpu_harness as G
+    B, N = 64, 100
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, B, N, 7)
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    mb.args.algorithm = 1
+    sol.mpc(mb.args)
+    r = mb.results()
+    # cold start: a 1.5 s open-loop rollout of the initializer's inputs from a perturbed state is a poor linearisation point -- single shooting
+    # accepts short steps or none there (which is why the reference runs the multiple-shooting SQP); kernels and oracle must agree on that too
+    assert np.isfinite(r["X"]).all() and (r["stats"][:, 7] == 0).all() and (r["stats"][:, 2] <= r["stats"][:, 0]).all()
+    for i in (0, 31, 63):
+        _check(r, i, oracle.ddp_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md), 1e-6)
+    # warm start, as in a receding-horizon loop: the inputs of an SQP solve of the same problem seed the rollout
+    ms = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
+    sol.mpc(ms.args)
+    rs = ms.results()
+    mw = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N, warm=(rs["X"], rs["U"]))
+    mw.args.algorithm = 1
+    sol.mpc(mw.args)
+    rw = mw.results()
+    assert (rw["stats"][:, 7] == 0).all() and (rw["stats"][:, 4] == 1.0).mean() > 0.9 and (rw["stats"][:, 2] < 0.5 * rw["stats"][:, 0]).mean() > 0.9
+    for i in (0, 31, 63):
+        _check(rw, i, oracle.ddp_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md, warm_u=rs["U"][i], warm_x=rs["X"][i]), 1e-6)
+    # the accepted trajectory is a rollout: dynamically feasible to round-off, unlike the SQP iterate it started from
+    dt = interface.problem.settings.dt
+    m_, v_ = oracle.performance(N, np.arange(N + 1) * dt, x0[0], rw["X"][0], rw["U"][0], tt[0], ts[0], nev, ev, md)
+    assert abs(v_ - rw["stats"][0][3]) <= 1e-6 * max(1.0, v_) and rw["stats"][0][3] < 0.2 * rs["stats"][0][3]
+    # the fp32 build runs the same chain (compared on the warm-started, well-conditioned case: an open-loop cold-start rollout of this unstable model
+    # amplifies a rounding difference beyond any bound)
+    sol32 = G.make_solver(interface, B, N, dtype="f32")
+    mw32 = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N, warm=(rs["X"], rs["U"]))
+    mw32.args.algorithm = 1
+    sol32.mpc(mw32.args)
+    r32 = mw32.results()
+    assert np.array_equal(r32["mode"], rw["mode"]) and np.isfinite(r32["X"]).all()
+    same = r32["stats"][:, 4] == rw["stats"][:, 4]
+    assert same.mean() > 0.9 and np.abs(r32["X"][same] - rw["X"][same]).max() <= 2e-3
