@@ -154,6 +154,11 @@ int qmgpu_mode_from_string(const char* name); /* "LF_RH" -> 9, unknown -> -1 */
  * (num_events event times, num_events + 1 modes). Returns QMGPU_ERR_CAPACITY if it does not fit. */
 int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, double t_end,
                     int32_t* num_events, double* event_times /*[MAX_EVENTS]*/, int32_t* modes /*[MAX_EVENTS+1]*/);
+/* The same for a gait command that arrives while mode `prev_mode` is running (upstream GaitSchedule::insertModeSequenceTemplate behind
+ * GaitReceiver, fed by GaitTopicPublisher.cpp:31-44): prev_mode until t_switch; unless prev_mode is STANCE or the template's first mode, a
+ * STANCE phase of transition_stance_time (model_settings.phaseTransitionStanceTime, task.info:11) is inserted before the first cycle. */
+int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transition_stance_time, double t_switch, double t_begin, double t_end,
+                      int32_t* num_events, double* event_times /*[MAX_EVENTS]*/, int32_t* modes /*[MAX_EVENTS+1]*/);
 
 /* Shooting grid over [t0, tf] the way upstream ocs2::timeDiscretizationWithEvents lays it out for the SQP solver built at
  * qm_controllers/src/QMController.cpp:288-289 (dt = task.info:79): steps of dt, every event time inside (t0, tf) becomes a
@@ -297,10 +302,12 @@ int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* args);
  * tiling them on the host (qmgpu_tile_gait) and shipping MAX_EVENTS times + modes per instance every cycle.  Replaces, for a batch of
  * robots, what GaitTopicPublisher::gaitCommandCallback (qm_controllers/src/GaitTopicPublisher.cpp:31-44) + upstream GaitReceiver /
  * GaitSchedule::tileModeSequenceTemplate do for one: instance i runs template gait_index[i] of `templates` (host array, copied), first
- * cycle at t_phase0[i] (STANCE before it), tiled over [t_begin[i], t_end[i]], default STANCE after the last tiled cycle.  The outputs are
- * bit-identical to qmgpu_tile_gait and plug straight into qmgpu_mpc_args::sched_*.  status[i] = QMGPU_ERR_CAPACITY (and a pure STANCE
+ * cycle at t_phase0[i] (prev_mode[i] before it -- STANCE when prev_mode is NULL -- with the phase-transition stance of qmgpu_switch_gait,
+ * settings.phase_transition_stance_time, where upstream inserts one), tiled over [t_begin[i], t_end[i]], default STANCE after the last tiled
+ * cycle.  The outputs are bit-identical to qmgpu_tile_gait / qmgpu_switch_gait and plug straight into qmgpu_mpc_args::sched_*.  status[i] = QMGPU_ERR_CAPACITY (and a pure STANCE
  * schedule) when the schedule needs more than QMGPU_MAX_EVENTS events.  All pointers except `templates` are device pointers. */
-int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templates, int num_templates, const int32_t* gait_index, const double* t_phase0,
+int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templates, int num_templates, const int32_t* gait_index,
+                              const int32_t* prev_mode /*[batch] or NULL*/, const double* t_phase0 /*[batch]: t_switch of qmgpu_switch_gait*/,
                               const double* t_begin, const double* t_end, int32_t* sched_num_events /*[batch]*/, double* sched_event_times /*[batch][MAX_EVENTS]*/,
                               int32_t* sched_modes /*[batch][MAX_EVENTS+1]*/, int32_t* status /*[batch] or NULL*/);
 

@@ -93,7 +93,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libqmgpu.so")
 F64, F32 = 0, 1   # qmgpu_dtype
 
 SYMBOLS = [
-    "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_time_grid_with_events", "qmgpu_warm_start_batch",
+    "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_switch_gait", "qmgpu_time_grid_with_events", "qmgpu_warm_start_batch",
     "qmgpu_create", "qmgpu_create_ex", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
     "qmgpu_policy_eval_batch", "qmgpu_frontend_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
     "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_debug_poison", "qmgpu_kernel_ms_mean", "qmgpu_update_settings", "qmgpu_gait_schedule_batch",

@@ -169,11 +169,11 @@ class GpuSolver:
         a._keep = (rbd, time, yaw_last, command_kind, command, last_ee_target, feet_height, x0, target_times, target_states)
         return a
 
-    def gait_schedule(self, templates, gait_index, t_phase0, t_begin, t_end, num_events, event_times, modes, status=None):
+    def gait_schedule(self, templates, gait_index, t_phase0, t_begin, t_end, num_events, event_times, modes, status=None, prev_mode=None):
         """Per-instance mode schedules on the device (qmgpu_gait_schedule_batch); `templates` is a list of abi.Gait."""
         arr = (abi.Gait * len(templates))(*templates)
         batch = int(gait_index.shape[0])
-        abi.check(self.lib, self.lib.qmgpu_gait_schedule_batch(self.handle, batch, arr, len(templates), _ptr(gait_index), _ptr(t_phase0), _ptr(t_begin), _ptr(t_end),
+        abi.check(self.lib, self.lib.qmgpu_gait_schedule_batch(self.handle, batch, arr, len(templates), _ptr(gait_index), _ptr(prev_mode), _ptr(t_phase0), _ptr(t_begin), _ptr(t_end),
                                                               _ptr(num_events), _ptr(event_times), _ptr(modes), _ptr(status)))
 
     def frontend(self, args):

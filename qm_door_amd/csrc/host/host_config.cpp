@@ -317,7 +317,17 @@ int qmgpu_load_gait(const char* gait_file, const char* gait_name, qmgpu_gait* ou
 // default final STANCE phase -- the shape upstream GaitSchedule::tileModeSequenceTemplate produces after the initial
 // STANCE schedule of reference.info:24-36 (loaded at QMInterface.cpp:455-480).
 int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, double t_end, int32_t* num_events, double* event_times, int32_t* modes) {
-  if (!gait || !num_events || !event_times || !modes || gait->num_modes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad gait");
+  return qmgpu_switch_gait(gait, 15, 0.0, t_phase0, t_begin, t_end, num_events, event_times, modes);
+}
+
+// A gait command arriving while another mode is running (GaitTopicPublisher.cpp:31-44 -> upstream GaitReceiver -> GaitSchedule::insertModeSequenceTemplate):
+// the running mode `prev_mode` lasts until t_switch; unless it is STANCE or equals the template's first mode, a STANCE phase of
+// `transition_stance_time` (model_settings.phaseTransitionStanceTime, task.info:11) is inserted; then the template is tiled.
+int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transition_stance_time, double t_switch, double t_begin, double t_end, int32_t* num_events,
+                      double* event_times, int32_t* modes) {
+  if (!gait || !num_events || !event_times || !modes || gait->num_modes < 1 || prev_mode < 0 || prev_mode > 15) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad gait");
+  const bool transition = prev_mode != 15 && prev_mode != gait->modes[0] && transition_stance_time > 0.0;
+  const double t_phase0 = transition ? t_switch + transition_stance_time : t_switch;
   const double period = gait->switching_times[gait->num_modes] - gait->switching_times[0];
   if (!(period > 0.0)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "gait period must be positive");
   std::vector<double> ev;
@@ -330,7 +340,9 @@ int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, dou
     const double cycles = std::floor((t_begin - t_phase0) / period);
     start = t_phase0 + (cycles >= 1.0 ? cycles - 1.0 : 0.0) * period;
   }
-  md.push_back(15);  // STANCE
+  md.push_back(prev_mode);   // the mode running before the switch (STANCE for a plain tiling)
+  if (transition && start == t_phase0) { ev.push_back(t_switch); md.push_back(15); }   // the inserted stance phase (only while the horizon still sees the switch)
+  else if (start > t_phase0) md.back() = 15;   // the horizon starts cycles after the switch: what precedes the first tiled cycle is never looked up
   ev.push_back(start);
   double t = start;
   while (t < t_end) {

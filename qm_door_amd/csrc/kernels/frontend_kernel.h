@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) frontend_kernel(FrontendArgs fa) {
 struct GaitArgs {
   int batch, numTemplates;
   const qmgpu_gait* templates;   // device copy
-  const int* gaitIndex; const double* tPhase0; const double* tBegin; const double* tEnd;
+  const int* gaitIndex; const int* prevMode; double transitionStance; const double* tPhase0; const double* tBegin; const double* tEnd;
   int* numEvents; double* eventTimes; int* modes; int* status;
 };
 __global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
@@ -156,14 +156,18 @@ __global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
   const qmgpu_gait& g = a.templates[gi];
   const double period = g.switching_times[g.num_modes] - g.switching_times[0];
   if (g.num_modes < 1 || !(period > 0.0)) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
-  const double tPhase0 = a.tPhase0[i], tBegin = a.tBegin[i], tEnd = a.tEnd[i];
+  const int prevMode = a.prevMode ? a.prevMode[i] : 15;
+  if (prevMode < 0 || prevMode > 15) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
+  const double tSwitch = a.tPhase0[i], tBegin = a.tBegin[i], tEnd = a.tEnd[i];
+  const bool transition = prevMode != 15 && prevMode != g.modes[0] && a.transitionStance > 0.0;
+  const double tPhase0 = transition ? tSwitch + a.transitionStance : tSwitch;
   double start = tPhase0;
   if (tBegin > tPhase0) {
     const double cycles = floor((tBegin - tPhase0) / period);
     start = tPhase0 + (cycles >= 1.0 ? cycles - 1.0 : 0.0) * period;
   }
   // events are produced in order and merged on the fly: an event whose mode equals the last kept mode disappears
-  int n = 0, lastMode = 15;
+  int n = 0, lastMode = (start > tPhase0) ? 15 : prevMode;
   bool overflow = false;
   auto push = [&](double t, int modeAfter) {
     if (modeAfter == lastMode) return;
@@ -171,7 +175,8 @@ __global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
     else overflow = true;
     ++n; lastMode = modeAfter;
   };
-  md[0] = 15;
+  md[0] = lastMode;
+  if (transition && start == tPhase0) push(tSwitch, 15);
   double t = start;
   double evTime = start;
   while (t < tEnd && !overflow) {

@@ -318,8 +318,8 @@ int qmgpu_frontend_batch(qmgpu_handle h, const qmgpu_frontend_args* a) {
   });
 }
 
-int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templates, int num_templates, const int32_t* gait_index, const double* t_phase0,
-                              const double* t_begin, const double* t_end, int32_t* sched_num_events, double* sched_event_times, int32_t* sched_modes, int32_t* status) {
+int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templates, int num_templates, const int32_t* gait_index, const int32_t* prev_mode,
+                              const double* t_phase0, const double* t_begin, const double* t_end, int32_t* sched_num_events, double* sched_event_times, int32_t* sched_modes, int32_t* status) {
   if (!h || batch < 1 || !templates || num_templates < 1 || num_templates > 64 || !gait_index || !t_phase0 || !t_begin || !t_end || !sched_num_events || !sched_event_times || !sched_modes)
     return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad gait schedule arguments");
   return guarded([&]() {
@@ -327,7 +327,7 @@ int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templ
     if (!h->dGaits) h->dGaits = h->alloc<qmgpu_gait>(64, false);
     HIP_CHECK(hipMemcpyAsync(h->dGaits, templates, sizeof(qmgpu_gait) * num_templates, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));   // `templates` is the caller's (pageable) host memory: nothing is retained after return
-    GaitArgs ga{batch, num_templates, h->dGaits, gait_index, t_phase0, t_begin, t_end, sched_num_events, sched_event_times, sched_modes, status};
+    GaitArgs ga{batch, num_templates, h->dGaits, gait_index, prev_mode, h->hostProblem.settings.phase_transition_stance_time, t_phase0, t_begin, t_end, sched_num_events, sched_event_times, sched_modes, status};
     QM_LAUNCH(gait_schedule_kernel, (batch + 63) / 64, 64, h->stream, ga);
     HIP_CHECK(hipGetLastError());
   });

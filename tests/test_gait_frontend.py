@@ -28,15 +28,17 @@ def _cases(lib, batch, seed):
     t_begin[::7] = t_phase0[::7]                                    # horizon starting exactly on the first cycle
     t_end = t_begin + rng.uniform(0.5, 3.0, batch)
     t_end[::11] = t_begin[::11] + 30.0                              # too long for MAX_EVENTS with the fast gaits: capacity status
-    return gs, names, templates, idx, t_phase0, t_begin, t_end
+    prev = rng.choice(np.array([15, 15, 9, 6, 10, 5, 13, 0], dtype=np.int32), batch)    # the mode running when the gait command arrives
+    return gs, names, templates, idx, t_phase0, t_begin, t_end, prev
 
 
-def _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st):
+def _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st, prev, transition):
     over = 0
+    gs.lib.qmgpu_switch_gait.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     for i in range(len(idx)):
         g = gs.template(names[idx[i]])
         nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
-        rc = gs.lib.qmgpu_tile_gait(C.byref(g), float(t_phase0[i]), float(t_begin[i]), float(t_end[i]), C.byref(nn), e, m)
+        rc = gs.lib.qmgpu_switch_gait(C.byref(g), int(prev[i]), transition, float(t_phase0[i]), float(t_begin[i]), float(t_end[i]), C.byref(nn), e, m)
         if rc == abi.ERR_CAPACITY:
             over += 1
             assert st[i] == abi.ERR_CAPACITY and n[i] == 0 and (md[i] == 15).all()
@@ -52,11 +54,35 @@ def test_emu_gait_schedule_matches_host_tiler():
     lib = abi.load_library(S.build_emu())
     itf = api.QMInterface(lib=lib)
     B = 96
-    gs, names, templates, idx, t_phase0, t_begin, t_end = _cases(lib, B, 1)
+    gs, names, templates, idx, t_phase0, t_begin, t_end, prev = _cases(lib, B, 1)
     sol = api.GpuSolver(itf, max_batch=4, max_nodes=4)
     n, ev, md, st = np.zeros(B, dtype=np.int32), np.zeros((B, abi.MAX_EVENTS)), np.zeros((B, abi.MAX_EVENTS + 1), dtype=np.int32), np.zeros(B, dtype=np.int32)
+    trans = itf.problem.settings.phase_transition_stance_time
+    assert trans > 0
+    sol.gait_schedule(templates, idx, t_phase0, t_begin, t_end, n, ev, md, st, prev_mode=prev)
+    assert _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st, prev, trans) >= 1
+    # without prev_mode: STANCE before the first cycle, i.e. the plain tiler
     sol.gait_schedule(templates, idx, t_phase0, t_begin, t_end, n, ev, md, st)
-    assert _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st) >= 1
+    _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st, np.full(B, 15), trans)
+
+
+def test_gait_switch_inserts_the_transition_stance():
+    """Hand-checked: a trot command arriving during RF_LH (6): STANCE for phaseTransitionStanceTime, then LF_RH / RF_LH cycles; arriving during
+    LF_RH (9, the template's first mode) or during STANCE: no transition phase (upstream GaitSchedule::insertModeSequenceTemplate)."""
+    lib = abi.load_library(S.build_emu())
+    gs = api.GaitSchedule(lib=lib)
+    g = gs.template("trot")
+    lib.qmgpu_switch_gait.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    def run(prev, tr=0.4):
+        nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
+        assert lib.qmgpu_switch_gait(C.byref(g), prev, tr, 1.0, 0.5, 2.0, C.byref(nn), e, m) == 0
+        return nn.value, np.array(e[:nn.value]), list(m[:nn.value + 1])
+    n, ev, md = run(6)
+    assert md[:4] == [6, 15, 9, 6] and np.allclose(ev[:3], [1.0, 1.4, 1.75])
+    n, ev, md = run(9)
+    assert md[:3] == [9, 6, 9] and np.allclose(ev[:2], [1.35, 1.7])            # merged with the running LF_RH phase
+    n, ev, md = run(15)
+    assert md[:3] == [15, 9, 6] and np.allclose(ev[:2], [1.0, 1.35])
 
 
 @pytest.mark.gpu
@@ -64,14 +90,15 @@ def test_gpu_gait_schedule_matches_host_tiler_and_feeds_the_mpc(interface, oracl
     import torch
     import gpu_harness as G
     B = 512
-    gs, names, templates, idx, t_phase0, t_begin, t_end = _cases(interface.lib, B, 2)
+    gs, names, templates, idx, t_phase0, t_begin, t_end, prev = _cases(interface.lib, B, 2)
     sol = G.make_solver(interface, B, 20)
     dn = torch.zeros(B, dtype=torch.int32, device="cuda"); dev_ = torch.zeros((B, abi.MAX_EVENTS), dtype=torch.float64, device="cuda")
     dmd = torch.zeros((B, abi.MAX_EVENTS + 1), dtype=torch.int32, device="cuda"); dst = torch.zeros(B, dtype=torch.int32, device="cuda")
-    sol.gait_schedule(templates, G.dev(idx, torch.int32), G.dev(t_phase0, torch.float64), G.dev(t_begin, torch.float64), G.dev(t_end, torch.float64), dn, dev_, dmd, dst)
+    sol.gait_schedule(templates, G.dev(idx, torch.int32), G.dev(t_phase0, torch.float64), G.dev(t_begin, torch.float64), G.dev(t_end, torch.float64), dn, dev_, dmd, dst,
+                      prev_mode=G.dev(prev, torch.int32))
     torch.cuda.synchronize()
     n, ev, md, st = dn.cpu().numpy(), dev_.cpu().numpy(), dmd.cpu().numpy(), dst.cpu().numpy()
-    assert _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st) >= 1
+    assert _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st, prev, interface.problem.settings.phase_transition_stance_time) >= 1
     # the device-made schedules go straight into the MPC call (no host round trip): compared with the oracle on the same schedule
     N = 20
     x0 = S.perturbed_states(interface.initial_state, B, seed=6)

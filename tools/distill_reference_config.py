@@ -138,7 +138,7 @@ def main():
                 wanted={"centroidalModelType", "model_settings", "swing_trajectory_config", "sqp", "mpc",
                         "initialState", "Q", "R", "endEffector", "finalEndEffector",
                         "frictionConeSoftConstraint", "jointPositionLimits", "jointVelocityLimits",
-                        "frictionConeTask"})
+                        "frictionConeTask", "ddp", "rollout"})
     distil_info(os.path.join(cfg, "reference.info"), os.path.join(OUT, "reference.info"))
     distil_info(os.path.join(cfg, "gait.info"), os.path.join(OUT, "gait.info"))
     distil_urdf(os.path.join(REF, "qm_description", "urdf", "quadruped_manipulator", "robot.urdf"),
