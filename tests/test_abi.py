@@ -54,3 +54,36 @@ def test_product_never_links_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "libqm_oracle" not in txt and "qmo_" not in txt, f
+
+
+def test_fp32_translation_unit_contains_no_fp64_arithmetic():
+    """qmgpu_mpc32.hip is the MPC kernel sources compiled with real = float: its arithmetic kernels must not contain a single fp64 instruction (a literal
+    without the _r suffix or a forgotten `double` would promote a whole expression).  fp64 is allowed where it is meant: the two conversion kernels at
+    the library boundary and mpc_init_kernel, which forms node times / steps / schedule phases from the caller's fp64 times."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, "mpc32.s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-DQM_REAL=float", "-Dqmk=qmk32", "--cuda-device-only", "-S",
+                               os.path.join(root, "qm_door_amd", "csrc", "qmgpu_mpc32.hip"), "-o", asm], stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+    kernels = {}
+    for m in re.finditer(r"^(_ZN5qmk32\w+):.*?\n(.*?)^\s*s_endpgm", text, re.M | re.S):
+        kernels[m.group(1)] = m.group(2)
+    assert len(kernels) >= 8
+    arithmetic = ("ad_node_kernel", "lq_node_kernel", "riccati_kernel", "linesearch_kernel", "ddp_rollout_kernel", "ddp_select_kernel", "input_weight_kernel")
+    seen = set()
+    for name, body in kernels.items():
+        f64 = re.findall(r"^\s*(v_\w*f64\w*)", body, re.M)
+        for k in arithmetic:
+            if k in name:
+                seen.add(k)
+                assert not f64, (name, sorted(set(f64)))
+    assert seen == set(arithmetic), seen
+    assert "v_mfma_f32_16x16x4_f32" in text and "v_mfma_f64" not in text

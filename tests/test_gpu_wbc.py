@@ -115,3 +115,30 @@ def test_wbc_stress_all_modes_converge(interface, oracle, variant):
     # Random (not MPC-consistent) desired states make some lowest-priority levels nearly degenerate LPs whose minimiser moves by 1e-2
     # when an inherited bound moves by 1e-5; the 1e-6 bar is asserted on the MPC-driven workloads (test_gpu_fullsize, test_gpu_configs).
     assert np.median(errs) <= 1e-8 and np.quantile(errs, 0.85) <= 1e-6 and max(errs) <= 1e-4, np.sort(errs)[-8:]
+
+
+def test_settings_update_and_dtype_handles(interface, oracle):
+    """qmgpu_update_settings (run-time gain changes, what the reference's dynamic_reconfigure callbacks do): the next WBC call uses the new gains and matches
+    the oracle evaluated with them; qmgpu_create_ex validates the dtype and an fp32 handle refuses the fp64-only LQ dump."""
+    import copy
+    import ctypes as C
+    import gpu_harness as G
+    from qm_door_amd import abi
+    c = _cases(interface, oracle, 0)[2]
+    sol = G.make_solver(interface, 1, 4)
+    def wbc():
+        wb = G.WbcBatch(c["rbd"][None], np.array([0.002]), np.array([c["t"]]), c["il"][None].copy(), c["xd"][None], c["u"][None], np.array([c["mode"]], dtype=np.int32), 0)
+        sol.wbc(wb.args)
+        return wb.results()["out"][0]
+    before = wbc()
+    P2 = type(interface.problem).from_buffer_copy(interface.problem)
+    P2.settings.kp_base_height *= 3.0; P2.settings.kd_swing *= 0.5
+    abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(P2.settings)))
+    after = wbc()
+    assert np.abs(after - before).max() > 1e-3
+    st, ref, _ = S.Oracle(P2).wbc_update(c["xd"], c["u"], c["rbd"], c["mode"], 0.002, c["t"], c["il"])
+    assert st == 0 and np.abs(after[36:] - ref[36:]).max() <= 1e-6 * max(1.0, np.abs(ref[36:]).max())
+    h = C.c_void_p()
+    assert interface.lib.qmgpu_create_ex(C.byref(interface.problem), 0, 1, 4, 7, C.byref(h)) == abi.ERR_INVALID_ARGUMENT
+    s32 = G.make_solver(interface, 1, 4, dtype="f32")
+    assert interface.lib.qmgpu_enable_debug(s32.handle, 1) == abi.ERR_INVALID_ARGUMENT
