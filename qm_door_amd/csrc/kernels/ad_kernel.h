@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[g][tn][r] = 0.0_r;
 #pragma unroll
-          for (int ks = 0; ks < 3; ++ks) qmMfma(acc[g][tn], av[ks], L1g[(4 * ks + h) * 64 + tn * 16 + l16], nullptr);
+          for (int ks = 0; ks < 3; ++ks) qmMfma(acc[g][tn], av[ks], L1g[(4 * ks + h) * 64 + tn * 16 + l16]);
         }
       }
       QM_WAVE_SYNC();   // J1 has been read by every lane: the slot owners add J2 (+ dt J2[:, q_j] into the v_j columns) in place

@@ -1,7 +1,9 @@
 // Interface between qmgpu_api.hip (fp64 build of the kernels, namespace qmk) and qmgpu_mpc32.hip (the MPC kernels built a second time
 // with real = float, namespace qmk32).  Plain declarations only: nothing here depends on the arithmetic type.
 #pragma once
-#ifndef QMGPU_HOST_EMULATION
+#ifdef QMGPU_HOST_EMULATION
+#include "kernels/gpu_rt.h"   // the emulation's stand-ins for hipStream_t / hipEvent_t
+#else
 #include <hip/hip_runtime_api.h>
 #endif
 
@@ -17,19 +19,11 @@ struct Mpc32;
 using RawAlloc = std::function<void*(size_t, size_t, bool)>;
 
 // nullptr on failure (HIP error); the object itself is host memory, its device buffers belong to the handle's allocation list
-#ifdef QMGPU_HOST_EMULATION
-// the host emulation of tests/emu covers the fp64 build only: an fp32 handle cannot be created there
-inline Mpc32* create(const qmgpu_problem&, int, int, hipStream_t, const RawAlloc&) { return nullptr; }
-inline void destroy(Mpc32*) {}
-inline bool updateProblem(Mpc32*, const qmgpu_problem&, hipStream_t) { return false; }
-inline bool enqueue(Mpc32*, hipStream_t, const qmgpu_mpc_args*, double, int, int, hipEvent_t*) { return false; }
-#else
 Mpc32* create(const qmgpu_problem& problem, int maxBatch, int maxNodes, hipStream_t stream, const RawAlloc& alloc);
 void destroy(Mpc32* p);
 bool updateProblem(Mpc32* p, const qmgpu_problem& problem, hipStream_t stream);
 // One MPC call in fp32: the caller's fp64 device arrays are converted to fp32 staging, the kernel chain of kernels/mpc_pipeline.h
 // runs in fp32, the results are converted back into the caller's fp64 arrays.  ev: optional timing events (qmgpu_api.hip).
 bool enqueue(Mpc32* p, hipStream_t stream, const qmgpu_mpc_args* a, double dt, int iterations, int ddpTrials, hipEvent_t* ev);
-#endif
 
 }  // namespace qmk32

@@ -31,7 +31,7 @@ inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one p
 #define QM_ONE_WAVE_PER_SIMD
 // LDS is not zeroed between workgroups on the GPU: the emulation poisons it so that a read of never-written LDS that reaches the
 // arithmetic (a zero-padded tile operand, say) turns the results into NaN instead of passing by luck
-#define QM_POISON_LDS(ptr, count) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < int(count); ++i_) (ptr)[i_] = std::numeric_limits<double>::quiet_NaN(); __syncthreads(); } while (0)
+#define QM_POISON_LDS(ptr, count) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < int(count); ++i_) (ptr)[i_] = std::numeric_limits<qmk::real>::quiet_NaN(); __syncthreads(); } while (0)
 inline int qmOpaqueLane(int v) { return v; }
 #define QM_SCHED_FENCE()
 #define QM_LDS_BARRIER() __syncthreads()
@@ -45,6 +45,8 @@ inline void __syncthreads() { g_emuBarrier->arrive_and_wait(); }
 // lanes of one wavefront run in lockstep on the GPU; the emulation needs a real rendezvous wherever a kernel relies on that
 #define QM_WAVE_SYNC() g_emuWaveBarriers[(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) / 64]->arrive_and_wait()
 inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
+inline float sinf(float a) { return std::sin(a); }
+inline float cosf(float a) { return std::cos(a); }
 using std::acos; using std::fabs; using std::fma; using std::fmax; using std::fmin; using std::log; using std::sqrt; using std::sin; using std::cos;
 using std::max; using std::min;
 
@@ -58,74 +60,77 @@ inline std::vector<std::unique_ptr<double[]>> g_emuWaveScratch;
 inline double* emuWaveScratch() { return g_emuWaveScratch[(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) / 64].get(); }
 inline double* emuXchgBuf(double*) { return emuWaveScratch() + 128 * ((g_emuXchg++) & 1u); }
 
-inline double qmShflXor(double v, int mask, double* scratch) {
+// The primitives are templates over the arithmetic type T (double for the fp64 build, float for the fp32 build of the MPC kernels); the
+// exchange buffers hold doubles either way (every float is exactly representable).
+template <class T> inline T qmShflXor(T v, int mask, T* scratch = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
-  double* buf = emuXchgBuf(scratch);
-  buf[lane] = v;
+  double* buf = emuXchgBuf(nullptr); (void)scratch;
+  buf[lane] = double(v);
   QM_WAVE_SYNC();
-  return buf[lane ^ unsigned(mask)];
+  return T(buf[lane ^ unsigned(mask)]);
 }
 
-inline double qmReadLane(double v, int src, double* scratch) {
+template <class T> inline T qmReadLane(T v, int src, T* scratch = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
-  double* buf = emuXchgBuf(scratch);
-  buf[lane] = v;
+  double* buf = emuXchgBuf(nullptr); (void)scratch;
+  buf[lane] = double(v);
   QM_WAVE_SYNC();
-  return buf[unsigned(src) & 63u];
+  return T(buf[unsigned(src) & 63u]);
 }
 
-struct QmGather {
-  double vals[64];
-  double get(int src) const { return vals[src & 63]; }
+template <class T> struct QmGatherT {
+  T vals[64];
+  T get(int src) const { return vals[src & 63]; }
 };
-inline QmGather qmGather(double v, double* scratch) {
+template <class T> inline QmGatherT<T> qmGather(T v, T* scratch = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
-  double* buf = emuXchgBuf(scratch);
-  buf[lane] = v;
+  double* buf = emuXchgBuf(nullptr); (void)scratch;
+  buf[lane] = double(v);
   QM_WAVE_SYNC();
-  QmGather g;
-  for (int i = 0; i < 64; ++i) g.vals[i] = buf[i];
+  QmGatherT<T> g;
+  for (int i = 0; i < 64; ++i) g.vals[i] = T(buf[i]);
   return g;
 }
-template <class Op> inline double emuButterfly(double v, double* scratch, Op op) {
+template <class T, class Op> inline T emuButterfly(T v, Op op) {
   const unsigned lane = threadIdx.x & 63u;
-  QmGather g = qmGather(v, scratch);
-  double cur[64], nxt[64];
+  QmGatherT<T> g = qmGather(v);
+  T cur[64], nxt[64];
   for (int i = 0; i < 64; ++i) cur[i] = g.vals[i];
   for (int m = 1; m <= 32; m <<= 1) { for (int i = 0; i < 64; ++i) nxt[i] = op(cur[i], cur[i ^ m]);   // same pairing order as the DPP butterfly of gpu_rt.h
     for (int i = 0; i < 64; ++i) cur[i] = nxt[i]; }
   return cur[lane];
 }
-inline double qmAllSum(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return a + b; }); }
-inline double qmAllMax(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return std::fmax(a, b); }); }
-inline double qmAllMin(double v, double* scratch) { return emuButterfly(v, scratch, [](double a, double b) { return std::fmin(a, b); }); }
+template <class T> inline T qmAllSum(T v, T* = nullptr) { return emuButterfly(v, [](T a, T b) { return a + b; }); }
+template <class T> inline T qmAllMax(T v, T* = nullptr) { return emuButterfly(v, [](T a, T b) { return std::fmax(a, b); }); }
+template <class T> inline T qmAllMin(T v, T* = nullptr) { return emuButterfly(v, [](T a, T b) { return std::fmin(a, b); }); }
 
-// v_mfma_f64_16x16x4_f64 on host threads: lane l supplies a = A[l % 16][l / 16], b = B[l / 16][l % 16]; register r of lane l is
-// C[l / 16 + 4 r][l % 16] (layout measured on gfx950, tools/probe_mfma.hip)
-struct QmD2 { double x, y; };
-struct QmAcc { double v[4]; double& operator[](int i) { return v[i]; } const double& operator[](int i) const { return v[i]; } };
-inline void emuMfmaTile(QmAcc& c, const double* A, const double* B, unsigned lane) {
+// 16x16x4 matrix-core instruction on host threads: lane l supplies a = A[l % 16][l / 16], b = B[l / 16][l % 16]; the accumulator maps of the
+// HARDWARE are emulated (measured on gfx950, tools/probe_mfma.hip; cdna4 ISA): register r of lane l is C[l / 16 + 4 r][l % 16] for fp64 and
+// C[4 (l / 16) + r][l % 16] for fp32 -- so the fp32 build's permutation of the A rows (qmARow, gpu_rt.h) is exercised on the CPU tier too.
+template <class T> struct QmAccT { T v[4]; T& operator[](int i) { return v[i]; } const T& operator[](int i) const { return v[i]; } };
+template <class T> struct QmD2T { T x, y; };
+template <class T> inline void emuMfmaTile(QmAccT<T>& c, const double* A, const double* B, unsigned lane) {
   const unsigned j = lane & 15u, h = lane >> 4;
   for (unsigned r = 0; r < 4; ++r) {
-    const unsigned i = h + 4 * r;
-    double acc = c.v[r];
-    for (unsigned k = 0; k < 4; ++k) acc += A[k * 16 + i] * B[k * 16 + j];
+    const unsigned i = sizeof(T) == 8 ? h + 4 * r : 4 * h + r;
+    T acc = c.v[r];
+    for (unsigned k = 0; k < 4; ++k) acc += T(A[k * 16 + i]) * T(B[k * 16 + j]);
     c.v[r] = acc;
   }
 }
-inline void qmMfma(QmAcc& c, double a, double b, double* scratch) {
+template <class T> inline void qmMfma(QmAccT<T>& c, T a, T b, T* scratch = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
-  double* buf = emuXchgBuf(scratch);
-  buf[lane] = a; buf[64 + lane] = b;
+  double* buf = emuXchgBuf(nullptr); (void)scratch;
+  buf[lane] = double(a); buf[64 + lane] = double(b);
   QM_WAVE_SYNC();
   emuMfmaTile(c, buf, buf + 64, lane);
 }
 // all upper-triangle tiles of one k step with a single exchange (own region behind the 256 doubles of the plain exchanges)
-template <int TP> inline void qmMfmaUpper(QmAcc* acc, const double* a, const double* b, double* scratch) {
+template <int TP, class T> inline void qmMfmaUpper(QmAccT<T>* acc, const T* a, const T* b, T* scratch = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
   (void)scratch;
   double* buf = emuWaveScratch() + 256 + (TP * 128) * ((g_emuXchg++) & 1u);
-  for (int t = 0; t < TP; ++t) { buf[t * 128 + lane] = a[t]; buf[t * 128 + 64 + lane] = b[t]; }
+  for (int t = 0; t < TP; ++t) { buf[t * 128 + lane] = double(a[t]); buf[t * 128 + 64 + lane] = double(b[t]); }
   QM_WAVE_SYNC();
   int t = 0;
   for (int ti = 0; ti < TP; ++ti)
@@ -133,7 +138,14 @@ template <int TP> inline void qmMfmaUpper(QmAcc* acc, const double* a, const dou
 }
 inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
-constexpr int qmARow(int p) { return p; }   // fp64 accumulator map: the rows of an A operand are fed in order (gpu_rt.h)
+inline float qmRsqrt(float x) { return 1.0f / std::sqrt(x); }
+namespace qmk {
+using QmAcc = QmAccT<real>;
+using QmD2 = QmD2T<real>;
+using QmGather = QmGatherT<real>;
+constexpr int qmARow(int p) { return sizeof(real) == 8 ? p : (p >> 2) + 4 * (p & 3); }   // as gpu_rt.h
+}  // namespace qmk
+using qmk::QmAcc; using qmk::QmD2; using qmk::QmGather; using qmk::qmARow;
 
 template <class F> void emuLaunch(F&& body, dim3 grid, dim3 block) {
   const unsigned nt = block.x * block.y * block.z;
@@ -187,5 +199,5 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define QM_LAUNCH(kernel, grid, block, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
-#define QM_DYNAMIC_LDS(name) static double name[20480]  /* 160 KiB, the CU's whole LDS */
+#define QM_DYNAMIC_LDS(name) static qmk::real name[20480]  /* the CU's whole LDS at fp64 */
 #define QM_ALLOW_DYNAMIC_LDS(kernel, bytes) 0

@@ -30,13 +30,22 @@ def build_oracle():
 
 def build_emu():
     """g++ build of the kernel sources against tests/emu/simt_emu.h (host threads instead of lanes)."""
-    srcs = [os.path.join(ROOT, "qm_door_amd", "csrc", "qmgpu_api.hip"), os.path.join(ROOT, "qm_door_amd", "csrc", "host", "host_config.cpp")]
-    deps = srcs + [os.path.join(ROOT, "qm_door_amd", "csrc", "kernels", f) for f in os.listdir(os.path.join(ROOT, "qm_door_amd", "csrc", "kernels"))]
+    csrc = os.path.join(ROOT, "qm_door_amd", "csrc")
+    srcs = [os.path.join(csrc, "qmgpu_api.hip"), os.path.join(csrc, "host", "host_config.cpp")]
+    deps = srcs + [os.path.join(csrc, "qmgpu_mpc32.hip"), os.path.join(csrc, "mpc32.h")] + [os.path.join(ROOT, "qm_door_amd", "csrc", "kernels", f) for f in os.listdir(os.path.join(ROOT, "qm_door_amd", "csrc", "kernels"))]
     deps += [os.path.join(EMU_DIR, "simt_emu.h"), os.path.join(ROOT, "include", "qmgpu.h")]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return EMU_LIB
     os.makedirs(os.path.dirname(EMU_LIB), exist_ok=True)
-    subprocess.check_call(["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-DQMGPU_HOST_EMULATION", "-I", EMU_DIR, "-x", "c++", *srcs, "-o", EMU_LIB, "-lpthread"])
+    # as the product: the kernel sources twice, fp64 (everything) and fp32 (the MPC chain in namespace qmk32)
+    base = ["g++", "-std=c++20", "-O2", "-fPIC", "-DQMGPU_HOST_EMULATION", "-I", EMU_DIR, "-x", "c++", "-c"]
+    objs = [os.path.join(os.path.dirname(EMU_LIB), n) for n in ("api.o", "host.o", "mpc32.o")]
+    procs = [subprocess.Popen(base + [srcs[0], "-o", objs[0]]), subprocess.Popen(base + [srcs[1], "-o", objs[1]]),
+             subprocess.Popen(base + ["-DQM_REAL=float", "-Dqmk=qmk32", os.path.join(csrc, "qmgpu_mpc32.hip"), "-o", objs[2]])]
+    for pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, "g++ (emulation build)")
+    subprocess.check_call(["g++", "-shared", "-o", EMU_LIB, *objs, "-lpthread"])
     return EMU_LIB
 
 

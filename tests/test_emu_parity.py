@@ -191,3 +191,35 @@ def test_emu_warm_start_resamples_the_previous_solution(emu):
     # the result is accepted as a warm start
     tgt = S.nominal_target(orc, itf.initial_state)
     assert sol.lib.qmgpu_warm_start_batch(sol.handle, B, Np, None, None, None, Nn, None, None, None, None) == 1
+
+
+def test_emu_fp32_build_of_the_mpc_chain(emu):
+    """The fp32 build (qmgpu_mpc32.hip: the same kernel sources with real = float, namespace qmk32) on the CPU tier.  The emulation reproduces the
+    hardware's fp32 accumulator map (row 4 (l / 16) + r instead of fp64's l / 16 + 4 r), so the permutation of the A-operand rows that keeps the kernels'
+    accumulator code unchanged is exercised here: a wrong row anywhere scrambles the projected stages.  SQP and DDP variants, against the fp64 build."""
+    itf, orc = emu
+    B, N = 2, 10
+    x_nom = itf.initial_state
+    x0 = S.perturbed_states(x_nom, B, seed=8)
+    tgt = S.nominal_target(orc, x_nom)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.045)         # a switch falls between nodes 3 and 4
+    out = {}
+    for dtype in ("f64", "f32"):
+        sol = api.GpuSolver(itf, max_batch=B, max_nodes=N, dtype=dtype)
+        for alg in (0, 1):
+            oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+            a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B),
+                             algorithm=alg)
+            sol.mpc(a)
+            out[dtype, alg] = (oT, oX, oU, oM, oS)
+        sol.close()
+    for alg in (0, 1):
+        T64, X64, U64, M64, S64 = out["f64", alg]
+        T32, X32, U32, M32, S32 = out["f32", alg]
+        assert np.array_equal(M64, M32) and np.array_equal(T64.astype(np.float32), T32.astype(np.float32))
+        assert (S32[:, 7] == 0).all() and np.array_equal(S64[:, 4], S32[:, 4])          # factorised; same step length accepted
+        assert 1e-9 < np.abs(X64 - X32).max() <= 2e-5 * max(1.0, np.abs(X64).max())
+        assert np.abs(U64 - U32).max() <= 2e-5 * max(1.0, np.abs(U64).max())
+    ref = orc.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
+    assert np.abs(out["f64", 0][1][0] - ref["X"]).max() <= 1e-8
