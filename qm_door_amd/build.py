@@ -33,7 +33,8 @@ def _sources():
     return deps
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
+def build_library(force=False, verbose=False, extra_flags=(), out=None, obj_dir=None):
+    OUT, OBJ = out or globals()["OUT"], obj_dir or globals()["OBJ"]
     deps = _sources() + [os.path.abspath(__file__)]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT

@@ -46,6 +46,17 @@ __device__ __forceinline__ void qmMfma(QmAccF& c, float a, float b, float* = nul
 __device__ __forceinline__ constexpr int qmARow(int p) { return sizeof(real) == 8 ? p : (p >> 2) + 4 * (p & 3); }
 __device__ __forceinline__ double qmRsqrt(double x) { return rsqrt(x); }
 __device__ __forceinline__ float qmRsqrt(float x) { return rsqrtf(x); }
+// 1 / sqrt(x) for a positive, normal x on a dependent chain: v_rsq_f64 (~2^-26) and one third-order correction -- the arithmetic of the
+// library routine without its scaling of denormals and its special-case selects (5 dependent instructions instead of 9)
+__device__ __forceinline__ double qmRsqrtPos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
+__device__ __forceinline__ float qmRsqrtPos(float x) { return __builtin_amdgcn_rsqf(x); }
+// keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
+// into the select that consumes it and pays the LDS latency once per branch)
+#define QM_KEEP(x) asm volatile("" : "+v"(x))
 // upper-triangle tile set of a symmetric product: acc[(ti,tj), ti <= tj] += A_ti B_tj for one k step of 4
 template <int TP> __device__ __forceinline__ void qmMfmaUpper(QmAcc* acc, const real* a, const real* b, real* = nullptr) {
   int t = 0;

@@ -15,5 +15,6 @@ using real = QM_REAL;
 constexpr real operator""_r(long double v) { return real(v); }
 constexpr real operator""_r(unsigned long long v) { return real(v); }
 // machine epsilon of the arithmetic type (upstream tests against std::numeric_limits<scalar_t>::epsilon())
+constexpr real REAL_PIVOT_MIN = sizeof(real) == 8 ? real(1e-200) : real(1e-30);   // a Cholesky pivot below this is a failed factorisation
 constexpr real REAL_EPS = sizeof(real) == 8 ? real(2.220446049250313e-16) : real(1.1920929e-07);
 }  // namespace qmk

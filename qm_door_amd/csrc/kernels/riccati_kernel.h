@@ -12,11 +12,12 @@
 //   M  = [A~ | b~ | 0 | B~ | 0]           30 x 64 view of the staged record (columns 0..29, 30, 32..32+m~-1)
 //   P1 Y  = S M  (+ s in column 30)        so Y = [S A~ | S b~ + s | . | S B~]
 //   P2 T  = B~^T Y + [P~ | r~ | . | R~]    so T = [G | g | . | H]
-//   P3 H  = L L^T and L^-1                 wavefront 0, one column of [H | I] per lane in registers, row operations with the
-//                                          multipliers broadcast by v_readlane (no LDS round trip on the dependent chain)
-//   P4 W  = L^-1 [G | g]
-//   P5 [K | k] = -L^-T W                   -> gains (HBM)
-//   P6 [S' | s'] = [Q~ | q~] + A~^T [S A~ | y] - W^T W
+//   P3 H  = L L^T,  W = L^-1 [G | g]       wavefront 0, one column of [H | G g] per lane in registers (49 lanes), row operations with the
+//                                          multipliers broadcast by v_readlane (no LDS round trip on the dependent chain): the H lanes end with
+//                                          L^T, the G lanes with W.  MEANWHILE wavefronts 1..3 -- which have nothing on the critical path --
+//                                          commit the next stage, form  [Q~ | q~] + A~^T [S A~ | y]  (P6a) and the gains of the PREVIOUS
+//                                          stage  [K | k] = -L^-T W  by back-substitution (they are only needed by the forward sweep)
+//   P6b [S' | s'] = P6a - W^T W,  symmetrised
 // Column 30 carries the affine terms (b~, y, g, k, s') through the same tiles as the matrices.  Zero padding: rows/columns
 // 30,31 of S, rows >= m~ of T / W / L^-1 are kept at exactly zero so that partial tiles need no predication on the k loops.
 #pragma once
@@ -39,8 +40,21 @@ struct RiccatiArgs {
 };
 
 constexpr int RICCATI_WAVES = 4;
+// Phase clock of the profiling build (tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING): s_memtime deltas of workgroup 0 summed per phase
+// and wavefront into a device symbol.  The product build compiles every QM_TICK to nothing.
+#ifdef QM_RICCATI_TIMING
+__device__ unsigned long long qmRiccatiTicks[4 * 16];
+// sums kept in (scalar) registers, written once at the end: a read-modify-write of global memory per tick costs ~300 cycles
+#define QM_TICK_DECL unsigned long long qmT = clock64(), qmTs[14] = {}
+#define QM_TICK(slot) do { const unsigned long long n_ = clock64(); qmTs[slot] += n_ - qmT; qmT = n_; } while (0)
+#define QM_TICK_FLUSH do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 14; ++i_) qmRiccatiTicks[(threadIdx.x >> 6) * 16 + i_] += qmTs[i_]; } while (0)
+#else
+#define QM_TICK_DECL
+#define QM_TICK(slot)
+#define QM_TICK_FLUSH
+#endif
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
-constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LT = 49;   // LDS_LT odd: lane c writes row c of L^-T without bank conflicts
+constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 20;
 constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
 constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
 constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
@@ -48,13 +62,14 @@ constexpr int R_Y = R_STG + 2 * STG_B;            // Y [32][LDS_Y]
 constexpr int R_T = R_Y + 32 * LDS_Y;             // T [32][LDS_Y]
 constexpr int R_S = R_T + 32 * LDS_Y;             // S [32][LDS_S]
 constexpr int R_SV = R_S + 32 * LDS_S;            // s [32]
-constexpr int R_W = R_SV + 32;                    // W [20][LDS_W]
-constexpr int R_LI = R_W + 20 * LDS_W;            // L^-1 row major [20][LDS_W]
-constexpr int R_LIT = R_LI + 20 * LDS_W;          // L^-T row major [20][LDS_LT]
-constexpr int R_VEC = R_LIT + 20 * LDS_LT + 4;    // dx[32] dut[32]
-constexpr int R_SCR = R_VEC + 64;                 // exchange scratch of the host emulation [4][256]; armijo reduction
-constexpr int RICCATI_LDS_DOUBLES = R_SCR + 4 * 256;
-constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * int(sizeof(real));  // ~105 KiB (dynamic LDS)
+constexpr int W_DOUBLES = 20 * LDS_W;             // W [20][LDS_W] of one stage
+constexpr int LT_DOUBLES = 20 * LDS_LL;            // L [20][LDS_LL] row major, strictly lower triangle; the diagonal slot holds 1 / L_cc
+constexpr int R_W = R_SV + 32;                    // W of the stage in flight and of the previous one (by stage parity): the gains of stage k + 1 are
+constexpr int R_LT = R_W + 2 * W_DOUBLES;         // formed while stage k factorises, from W / L^T of stage k + 1
+constexpr int R_VEC = R_LT + 2 * LT_DOUBLES;      // dx[32] dut[32]
+constexpr int R_SCR = R_VEC + 64;                 // armijo reduction [64]
+constexpr int RICCATI_LDS_DOUBLES = R_SCR + 64;
+constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * int(sizeof(real));  // ~125 KiB at fp64 (dynamic LDS)
 static_assert(2 * STG_F <= RICCATI_LDS_DOUBLES, "forward-sweep staging fits");
 
 // Register-staged HBM -> LDS copy for a whole workgroup: issue() puts PF 16-byte loads per thread in flight, commit() drains
@@ -83,6 +98,81 @@ template <int PF, int NTHR> struct StagePrefetch {
 #undef QM_PF_FOR_EACH
 };
 
+// P3: rows 0..NT-1 of [H | G g] (T, one column per lane: lanes < MT the columns of H, lanes MT..MT+30 those of [G | g]) -> L (row c written by
+// lane c, 1 / L_cc on the diagonal) and W = L^-1 [G | g].  nt <= NT is the number of real pivots; rows / columns nt..NT-1 are identity.
+template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T, real* W, real* LL, int nt, int lane, int& status, real* scr) {
+  const bool isH = lane < MT, isG = lane >= MT && lane < MT + 31;
+  const int c = isH ? lane : (isG ? lane - MT : 0);
+  real col[NT];
+#pragma unroll
+  for (int r = 0; r < NT; ++r) col[r] = T[r * LDS_Y + (isH ? 32 + c : c)];
+#pragma unroll
+  for (int r = 0; r < NT; ++r) QM_KEEP(col[r]);
+  const bool live = isH ? c < nt : isG;
+#pragma unroll
+  for (int r = 0; r < NT; ++r) {
+    const real e = (isH && r == c) ? 1.0_r : 0.0_r;
+    col[r] = (live && r < nt) ? col[r] : e;
+  }
+  // steps j >= nt meet identity columns (pivot 1, multipliers 0): no branch, one basic block.  The reciprocal square root of
+  // pivot j + 1 is started right after row j + 1 has received its update, so its latency hides behind the remaining updates.
+  real inv, mine = 1.0_r;
+  {
+    const real piv = qmReadLane(col[0], 0, scr);
+    const bool ok = piv > REAL_PIVOT_MIN;
+    if (!ok) status = 1;
+    inv = qmRsqrtPos(ok ? piv : 1.0_r);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    col[j] *= inv;                                     // row j of [L^T | W] / sqrt(pivot)
+    mine = c == j ? inv : mine;
+    const QmGather gj = qmGather(col[j], scr);
+    if (j + 1 < NT) {
+      col[j + 1] -= gj.get(j + 1) * col[j];
+      const real piv = qmReadLane(col[j + 1], j + 1, scr);
+      const bool ok = piv > REAL_PIVOT_MIN;
+      if (!ok) status = 1;
+      inv = qmRsqrtPos(ok ? piv : 1.0_r);
+    }
+#pragma unroll
+    for (int r = j + 2; r < NT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= nt: identity columns)
+  }
+  if (isH) {
+    // lane c holds column c of L^T = row c of L in col[0..c]; entries right of the diagonal are elimination residue and never read
+#pragma unroll
+    for (int r = 0; r < NT; ++r) if (r == c) col[r] = mine;
+#pragma unroll
+    for (int r = 0; r + 1 < NT; r += 2) { QmD2 v; v.x = col[r]; v.y = col[r + 1]; *reinterpret_cast<QmD2*>(LL + c * LDS_LL + r) = v; }
+    if (NT & 1) LL[c * LDS_LL + NT - 1] = col[NT - 1];
+  } else if (isG) {
+#pragma unroll
+    for (int r = 0; r < NT; ++r) W[r * LDS_W + c] = col[r];          // rows >= nt are exactly zero
+  }
+}
+
+// [K | k] = -L^-T W of one stage by back-substitution, one column of [K | k] per lane (31 lanes of one wavefront), in the axpy order:
+// the dependent chain is one multiply + one multiply-add per row, the other multiply-adds of a step are independent.
+__device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, int ntp, int lane, real* gain) {
+  real w[MT];
+#pragma unroll
+  for (int r = 0; r < MT; ++r) w[r] = Wp[r * LDS_W + lane];
+#pragma unroll
+  for (int q = MT - 1; q >= 0; --q) {
+    real lrow[MT];   // row q of L up to and including the diagonal slot (= 1 / L_qq), the same address in every lane
+#pragma unroll
+    for (int r = 0; r <= q; r += 2) { const QmD2 v = *reinterpret_cast<const QmD2*>(LLp + q * LDS_LL + r); lrow[r] = v.x; if (r + 1 < MT) lrow[r + 1] = v.y; }
+    w[q] *= lrow[q];
+#pragma unroll
+    for (int r = 0; r < q; ++r) w[r] -= lrow[r] * w[q];
+  }
+#pragma unroll
+  for (int r = 0; r < MT; ++r) {
+    const real v = r < ntp ? -w[r] : 0.0_r;
+    if (lane < 30) gain[OFF_KFB + r * 30 + lane] = v; else gain[OFF_kff + r] = v;
+  }
+}
+
 template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIMD riccati_kernel(RiccatiArgs a) {
   static_assert(NW == 4, "tile ownership below is written for four wavefronts");
   QM_DYNAMIC_LDS(lds);
@@ -101,8 +191,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const int N = a.N;
   real* S = lds + R_S; real* sv = lds + R_SV; real* Y = lds + R_Y; real* T = lds + R_T;
   real* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)
-  real* W = lds + R_W; real* LI = lds + R_LI; real* LIT = lds + R_LIT; real* dxv = lds + R_VEC; real* dut = dxv + 32;
-  real* scr = lds + R_SCR + wave * 256; real* red = lds + R_SCR;
+  real* dxv = lds + R_VEC; real* dut = dxv + 32;
+  real* scr = nullptr; real* red = lds + R_SCR;
   const real* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const real* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
   const int* ncI = a.stageNc + size_t(inst) * (N + 1);
@@ -113,197 +203,199 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const real* rec = stagesI + size_t(N) * STAGE_DOUBLES;
     for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
     if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0_r;
-    for (int e = tid; e < 2 * 20 * LDS_W + 20 * LDS_LT; e += NTHR) W[e] = 0.0_r;        // W, L^-1, L^-T (contiguous)
+    for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;        // W, L^T of both parities (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
     pf.commit(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_PX, tid);
   }
   __syncthreads();
+  QM_TICK_DECL;
 
+  int ncCur = ncI[N - 1], ncPrev = 0;   // constraint rows of stage k and of stage k + 1; the next one is loaded a stage ahead
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
     const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
     real* stgNext = lds + R_STG + ((k + 1) & 1) * STG_B;    // buffer of stage k - 1
-    const int nt = 30 - ncI[k];
+    const int nt = 30 - ncCur;
+    const int ncLoad = ncI[k > 0 ? k - 1 : 0];
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid);  // next stage's blocks, in flight during this stage
-    // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T
+    QM_TICK(0);
+    // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T.  Every product runs on two accumulators per tile
+    //      (even / odd k steps): a dependent v_mfma_f64 issues every 64 cycles, an independent one every 16.
     const int jc = wave * 16 + l16;          // my column of M / Y / T
     const bool jA = jc < 30, jb = jc == 30, jB = jc >= 32 && jc < 32 + nt;
     if (wave < nTiles) {
       const int mOff = jA ? OFF_AT + jc : (jb ? OFF_bt : (jB ? OFF_BT + (jc - 32) : 0));
       const int mStr = jA ? 30 : (jb ? 1 : (jB ? MT : 0));
       const bool mValid = jA || jb || jB;
-      QmAcc c0, c1;
+      QmAcc c0, c1, d0, d1;
+      real a0[8], a1[8], bv[8], s0[4], s1[4];   // all operands first (unconditional loads, selects afterwards): the LDS latency is paid once
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const real s0 = sv[h + 4 * r], s1 = sv[16 + h + 4 * r]; c0[r] = jb ? s0 : 0.0_r; c1[r] = jb ? s1 : 0.0_r; }
-      real a0[8], a1[8], bv[8];   // all operands first (unconditional loads, selects afterwards): the LDS latency is paid once
+      for (int r = 0; r < 4; ++r) { s0[r] = sv[h + 4 * r]; s1[r] = sv[16 + h + 4 * r]; }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of S^T are zero: the clamped b operand is multiplied by 0
         a0[ks] = S[kk * LDS_S + la]; a1[ks] = S[kk * LDS_S + 16 + la];  // S is symmetric: S[i][k] read as S[k][i]
-        const real raw = stg[mOff + kc * mStr];
-        bv[ks] = mValid ? raw : 0.0_r;
+        bv[ks] = stg[mOff + kc * mStr];
       }
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
+      for (int ks = 0; ks < 8; ++ks) QM_KEEP(bv[ks]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
+      for (int r = 0; r < 4; ++r) { QM_KEEP(s0[r]); QM_KEEP(s1[r]); c0[r] = jb ? s0[r] : 0.0_r; c1[r] = jb ? s1[r] : 0.0_r; d0[r] = 0.0_r; d1[r] = 0.0_r; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bv[ks] = mValid ? bv[ks] : 0.0_r;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks += 2) {
+        qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr);
+        qmMfma(d0, a0[ks + 1], bv[ks + 1], scr); qmMfma(d1, a1[ks + 1], bv[ks + 1], scr);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r] + d0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r] + d1[r]; }
     }
+    QM_TICK(1);
     QM_LDS_BARRIER();
+    QM_TICK(2);
     if (wave < nTiles) {
-      QmAcc c0, c1;
+      QmAcc c0, c1, d0, d1;
+      real p0[4], q0[4], w0[4], p1[4], q1[4], w1[4];
+      const int jcA = jA ? jc : 0, jcB = jB ? jc - 32 : 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
         const int i0c = i0 < MT ? i0 : 0, i1c = i1 < MT ? i1 : 0;
-        const int jcA = jA ? jc : 0, jcB = jB ? jc - 32 : 0;
-        const real p0 = stg[OFF_PT + i0c * 30 + jcA], q0 = stg[OFF_rt + i0c], w0 = stg[OFF_RT + i0c * MT + jcB];
-        const real p1 = stg[OFF_PT + i1c * 30 + jcA], q1 = stg[OFF_rt + i1c], w1 = stg[OFF_RT + i1c * MT + jcB];
-        const real v0 = jA ? p0 : (jb ? q0 : (jB ? w0 : 0.0_r));
-        const real v1 = jA ? p1 : (jb ? q1 : (jB ? w1 : 0.0_r));
-        c0[r] = i0 < nt ? v0 : 0.0_r;
-        c1[r] = i1 < nt ? v1 : 0.0_r;
+        p0[r] = stg[OFF_PT + i0c * 30 + jcA]; q0[r] = stg[OFF_rt + i0c]; w0[r] = stg[OFF_RT + i0c * MT + jcB];
+        p1[r] = stg[OFF_PT + i1c * 30 + jcA]; q1[r] = stg[OFF_rt + i1c]; w1[r] = stg[OFF_RT + i1c * MT + jcB];
       }
       const bool a0ok = la < nt, a1ok = 16 + la < nt;
-      const int a1c = 16 + la < MT ? 16 + la : 0;
+      const int a0c = la < MT ? la : 0, a1c = 16 + la < MT ? 16 + la : 0;
       real a0[8], a1[8], bv[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of Y are zero
         bv[ks] = Y[kk * LDS_Y + jc];
-        const real r0 = stg[OFF_BT + kc * MT + (la < MT ? la : 0)], r1 = stg[OFF_BT + kc * MT + a1c];   // B~^T[i][k] = B~[k][i]
-        a0[ks] = a0ok ? r0 : 0.0_r; a1[ks] = a1ok ? r1 : 0.0_r;
+        a0[ks] = stg[OFF_BT + kc * MT + a0c]; a1[ks] = stg[OFF_BT + kc * MT + a1c];   // B~^T[i][k] = B~[k][i]
       }
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); if (mtTiles == 2) qmMfma(c1, a1[ks], bv[ks], scr); }
+      for (int r = 0; r < 4; ++r) { QM_KEEP(p0[r]); QM_KEEP(q0[r]); QM_KEEP(w0[r]); QM_KEEP(p1[r]); QM_KEEP(q1[r]); QM_KEEP(w1[r]); }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r]; if (mtTiles == 2) T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
-    }
-    QM_LDS_BARRIER();
-    // ---- P3: H = L L^T and L^-1 by row operations on [H | I]; lane c < 32 holds column c of H, lane 32 + c column c of I
-    if (wave == 0) {
-      const bool isH = lane < 32;
-      const int c = isH ? lane : lane - 32;
-      real col[MT];
-#pragma unroll
-      for (int r = 0; r < MT; ++r) {
-        const real e = (r == c) ? 1.0_r : 0.0_r;
-        const real hv = T[r * LDS_Y + 32 + (lane < MT ? lane : 0)];
-        col[r] = (isH && lane < nt && r < nt) ? hv : e;
-      }
-      // steps j >= m~ meet identity columns (pivot 1, multipliers 0): no branch, one basic block.  The reciprocal square root of
-      // pivot j + 1 is started right after row j + 1 has received its update, so its latency hides behind the remaining updates.
-      real inv;
-      {
-        const real piv = qmReadLane(col[0], 0, scr);
-        if (!(piv > 0.0_r)) status = 1;
-        inv = qmRsqrt(piv > 0.0_r ? piv : 1.0_r);
-      }
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        col[j] *= inv;                                     // row j of [L^T | .] / sqrt(pivot)
-        const QmGather gj = qmGather(col[j], scr);
-        if (j + 1 < MT) {
-          col[j + 1] -= gj.get(j + 1) * col[j];
-          const real piv = qmReadLane(col[j + 1], j + 1, scr);
-          if (!(piv > 0.0_r)) status = 1;
-          inv = qmRsqrt(piv > 0.0_r ? piv : 1.0_r);
-        }
-#pragma unroll
-        for (int r = j + 2; r < MT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= m~: identity columns)
-      }
-      if (!isH && c < 20) {
-#pragma unroll
-        for (int r = 0; r < MT; ++r) { const real v = (c < nt && r < nt) ? col[r] : 0.0_r; LI[r * LDS_W + c] = v; LIT[c * LDS_LT + r] = v; }
-      }
-    }
-    pf.commit(stgNext, OFF_PX, tid);   // stage k - 1 lands in the other buffer: wavefronts 1..3 do it while wavefront 0 factorises
-    QM_LDS_BARRIER();
-    // ---- P4: W = L^-1 [G | g]: wavefront w owns tile (w >> 1, w & 1)
-    const int tm = wave >> 1, tn = wave & 1;
-    {
-      QmAcc c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[r] = 0.0_r;
-      real av[5], bw[5];
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = LIT[kk * LDS_LT + tm * 16 + la]; bw[ks] = T[kk * LDS_Y + tn * 16 + l16]; }   // L^-1[i][k] = L^-T[k][i]
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const int i = tm * 16 + h + 4 * r; if (i < 20) W[i * LDS_W + tn * 16 + l16] = c[r]; }
-    }
-    QM_LDS_BARRIER();
-    // ---- P5: [K | k] = -L^-T W -> gains
-    {
-      QmAcc c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[r] = 0.0_r;
-      real av[5], bw[5];
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -LI[kk * LDS_W + tm * 16 + la]; bw[ks] = W[kk * LDS_W + tn * 16 + l16]; }   // L^-T[i][k] = L^-1[k][i]
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) qmMfma(c, av[ks], bw[ks], scr);
-      real* gain = a.gains + (size_t(inst) * N + k) * GAIN_DOUBLES;
-      const int j = tn * 16 + l16;
+      for (int ks = 0; ks < 8; ++ks) { QM_KEEP(a0[ks]); QM_KEEP(a1[ks]); }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = tm * 16 + h + 4 * r;
-        if (i < MT) {
-          const real v = i < nt ? c[r] : 0.0_r;
-          if (j < 30) gain[OFF_KFB + i * 30 + j] = v;
-          else if (j == 30) gain[OFF_kff + i] = v;
+        const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
+        const real v0 = jA ? p0[r] : (jb ? q0[r] : (jB ? w0[r] : 0.0_r));
+        const real v1 = jA ? p1[r] : (jb ? q1[r] : (jB ? w1[r] : 0.0_r));
+        c0[r] = i0 < nt ? v0 : 0.0_r; c1[r] = i1 < nt ? v1 : 0.0_r; d0[r] = 0.0_r; d1[r] = 0.0_r;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { a0[ks] = a0ok ? a0[ks] : 0.0_r; a1[ks] = a1ok ? a1[ks] : 0.0_r; }
+      if (mtTiles == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+          qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr);
+          qmMfma(d0, a0[ks + 1], bv[ks + 1], scr); qmMfma(d1, a1[ks + 1], bv[ks + 1], scr);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r] + d0[r]; T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r] + d1[r]; }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(d0, a0[ks + 1], bv[ks + 1], scr); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(h + 4 * r) * LDS_Y + jc] = c0[r] + d0[r];
       }
     }
-    // ---- P6: [S' | s'] = [Q~ | q~] + A~^T [S A~ | y] - W^T W: wavefront w owns tile (w >> 1, w & 1) of the 32 x 32 result
-    {
-      const int j = tn * 16 + l16;
-      QmAcc c;
+    QM_TICK(3);
+    QM_LDS_BARRIER();
+    QM_TICK(4);
+    // ---- P3 on wavefront 0; P6a + deferred gains on wavefronts 1..3
+    real* W = lds + R_W + (k & 1) * W_DOUBLES;
+    real* LL = lds + R_LT + (k & 1) * LT_DOUBLES;
+    // S' is symmetric: only the tiles (0,0), (0,1) and (1,1) of the 32 x 32 update are formed, by wavefronts 1, 2, 3; the tile (1,0) is
+    // the mirror of (0,1).  Tile t = (t >> 1, t & 1).
+    const int myTile = wave == 1 ? 0 : (wave == 2 ? 1 : 3);
+    QmAcc c6, d6;
+    if (wave == 0) {
+      riccatiFactorise<MT>(T, W, LL, nt, lane, status, scr);
+    } else {
+      // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation)
+      const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
+      real qv[4], qq[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r, ic = i < 30 ? i : 0;
-        const real v = j < 30 ? stg[OFF_QT + ic * 30 + j] : (j == 30 ? stg[OFF_qt + ic] : 0.0_r);
-        c[r] = i < 30 ? v : 0.0_r;
+        qv[r] = stg[OFF_QT + ic * 30 + (j < 30 ? j : 0)]; qq[r] = stg[OFF_qt + ic];
       }
       const int ai = tm * 16 + la < 30 ? tm * 16 + la : 29;   // rows 30,31 of the result are discarded
-      real av[13], bw[13];
+      real av[8], bw[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
         av[ks] = stg[OFF_AT + kc * 30 + ai]; bw[ks] = Y[kk * LDS_Y + j];   // A~^T[i][k] = A~[k][i]
       }
 #pragma unroll
-      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[8 + ks] = -W[kk * LDS_W + tm * 16 + la]; bw[8 + ks] = W[kk * LDS_W + j]; }
-#pragma unroll
-      for (int ks = 0; ks < 13; ++ks) qmMfma(c, av[ks], bw[ks], scr);
-      // The raw result goes to a scratch square (T is dead; stride 34 makes both the row and the column walk conflict free), s' in
-      // place; after the barrier S = (C + C^T) / 2.  Without the symmetrisation the antisymmetric part of the rounding error is
-      // propagated by the OPEN-loop dynamics (it sees A~^T . A~ but not the cancelling G^T H^-1 G) and grows ~1.13x per stage.
-#pragma unroll
       for (int r = 0; r < 4; ++r) {
+        QM_KEEP(qv[r]); QM_KEEP(qq[r]);
         const int i = tm * 16 + h + 4 * r;
-        TS[i * LDS_TS + j] = c[r];
-        if (i < 30 && j == 30) sv[i] = c[r];
+        const real v = j < 30 ? qv[r] : (j == 30 ? qq[r] : 0.0_r);
+        c6[r] = i < 30 ? v : 0.0_r; d6[r] = 0.0_r;
       }
-      QM_LDS_BARRIER();
+#pragma unroll
+      for (int ks = 0; ks < 8; ks += 2) { qmMfma(c6, av[ks], bw[ks], scr); qmMfma(d6, av[ks + 1], bw[ks + 1], scr); }
+      // ---- gains of stage k + 1 (its W and L sit in the other parity's buffers)
+      if (wave == 3 && k + 1 < N && lane < 31)
+        riccatiGains(lds + R_W + ((k + 1) & 1) * W_DOUBLES, lds + R_LT + ((k + 1) & 1) * LT_DOUBLES, 30 - ncPrev, lane, a.gains + (size_t(inst) * N + k + 1) * GAIN_DOUBLES);
+    }
+    QM_TICK(5);
+    pf.commit(stgNext, OFF_PX, tid);   // stage k - 1 lands in the other buffer
+    QM_TICK(6);
+    QM_LDS_BARRIER();
+    QM_TICK(7);
+    // ---- P6b: - W^T W on the tiles' owners; the raw result goes to a scratch square (T is dead; stride 34 makes both the row and the
+    //      column walk conflict free), s' in place; after the barrier the diagonal tiles are symmetrised, S = (C + C^T) / 2, and the tile
+    //      (1,0) is copied from (0,1).  Without the symmetrisation the antisymmetric part of the rounding error is propagated by the
+    //      OPEN-loop dynamics (it sees A~^T . A~ but not the cancelling G^T H^-1 G) and grows ~1.13x per stage.
+    if (wave != 0) {
+      const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
+      real av[5], bw[5];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -W[kk * LDS_W + tm * 16 + la]; bw[ks] = W[kk * LDS_W + j]; }
+      qmMfma(c6, av[0], bw[0], scr); qmMfma(d6, av[1], bw[1], scr); qmMfma(c6, av[2], bw[2], scr); qmMfma(d6, av[3], bw[3], scr); qmMfma(c6, av[4], bw[4], scr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
-        const real up = TS[i * LDS_TS + j], lo = TS[j * LDS_TS + i];
+        const real v = c6[r] + d6[r];
+        TS[i * LDS_TS + j] = v;
+        if (i < 30 && j == 30) sv[i] = v;
+      }
+    }
+    QM_TICK(8);
+    QM_LDS_BARRIER();
+    QM_TICK(9);
+    {
+      const int tm = wave >> 1, tn = wave & 1, j = tn * 16 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tm * 16 + h + 4 * r;
+        const real up = TS[(wave == 2 ? j : i) * LDS_TS + (wave == 2 ? i : j)];     // the tile (1,0) reads its mirror image
+        const real lo = TS[(wave == 1 ? i : j) * LDS_TS + (wave == 1 ? j : i)];
         if (i < 30 && j < 30) S[i * LDS_S + j] = 0.5_r * (up + lo);
       }
     }
+    QM_TICK(10);
     QM_LDS_BARRIER();
+    QM_TICK(11);
+    ncPrev = ncCur; ncCur = ncLoad;
   }
+  // ---- gains of stage 0 (nobody factorises any more)
+  if (wave == 3 && lane < 31) riccatiGains(lds + R_W, lds + R_LT, 30 - ncPrev, lane, a.gains + size_t(inst) * N * GAIN_DOUBLES);
 
   // ================================================================== forward substitution
   // wavefront 0: du~ = K dx + k, du = Pe + Px dx + Pu du~ ; wavefront 1: dx+ = A~ dx + B~ du~ + b~ ; everybody prefetches
   constexpr int WX = 1 % NW;
+  QM_TICK(12);
   __syncthreads();   // full barrier: the gains written to HBM by every wavefront are read back by all of them below
   {
     StagePrefetch<PFH, NTHR> ph;
@@ -319,10 +411,12 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   if (tid < 30) dxv[tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
   real armijo = 0.0_r;
   __syncthreads();
+  int ncFwd = ncI[0];
 #pragma unroll 1
   for (int k = 0; k < N; ++k) {
-    const int nt = 30 - ncI[k];
+    const int nt = 30 - ncFwd;
     const int kn = k + 1 < N ? k + 1 : k;
+    ncFwd = ncI[kn];
     const real* stg = lds + R_STG + (k & 1) * STG_F; const real* gn = stg + STAGE_DOUBLES;
     real* stgNext = lds + R_STG + ((k + 1) & 1) * STG_F;
     StagePrefetch<PFH, NTHR> ph;
@@ -363,6 +457,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     pg.commit(stgNext + STAGE_DOUBLES, GAIN_DOUBLES, tid);
     QM_LDS_BARRIER();
   }
+  QM_TICK(13);
+  QM_TICK_FLUSH;
   if (wave == WX && lane < 30) {
     a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxv[lane];
     armijo += stagesI[size_t(N) * STAGE_DOUBLES + OFF_qt + lane] * dxv[lane];

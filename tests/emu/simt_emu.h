@@ -139,6 +139,9 @@ template <int TP, class T> inline void qmMfmaUpper(QmAccT<T>* acc, const T* a, c
 inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline float qmRsqrt(float x) { return 1.0f / std::sqrt(x); }
+inline double qmRsqrtPos(double x) { return 1.0 / std::sqrt(x); }
+inline float qmRsqrtPos(float x) { return 1.0f / std::sqrt(x); }
+#define QM_KEEP(x) (void)(x)
 namespace qmk {
 using QmAcc = QmAccT<real>;
 using QmD2 = QmD2T<real>;

@@ -1,0 +1,45 @@
+"""Phase clocks of riccati_kernel (profiling build, -DQM_RICCATI_TIMING): where the cycles of a backward stage go, per wavefront.
+
+  python tools/riccati_phase_probe.py --build      # here (hipcc): qm_door_amd/build/ticks/libqmgpu_ticks.so
+  python tools/riccati_phase_probe.py              # on the GPU box: runs the bench scenario, prints the s_memtime sums of workgroup 0
+The product library carries no clocks (QM_TICK compiles to nothing)."""
+import ctypes as C, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from qm_door_amd import abi, build
+LIB = os.path.join(ROOT, "qm_door_amd", "build", "ticks", "libqmgpu_ticks.so")
+SLOTS = ["issue", "P1", "bar1", "P2", "bar2", "P3|P6a+gains", "commit", "bar3", "P6b", "bar4", "symm", "bar5", "tail", "forward"]
+
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    print(build.build_library(force=True, extra_flags=("-DQM_RICCATI_TIMING",), out=LIB, obj_dir=os.path.dirname(LIB)))
+    sys.exit(0)
+
+abi.LIB_PATH = LIB
+import torch, bench, gpu_harness as G
+from qm_door_amd import api
+B, N = 256, 100
+itf = api.QMInterface()
+sc = bench.build_scenario(itf, B, seed=0)
+sol = G.make_solver(itf, B, N)
+mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int32), np.tile(sc["ev"], (B, 1)), np.tile(sc["md"], (B, 1)), N)
+for _ in range(3): sol.mpc(mb.args)
+lib = sol.lib
+lib.qmgpu_debug_riccati_ticks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+buf = (C.c_ulonglong * 64)()
+assert lib.qmgpu_debug_riccati_ticks(buf, 1) == 0
+sol.enable_timing(True)
+R = 10
+for _ in range(R): sol.mpc(mb.args)
+torch.cuda.synchronize()
+ms = sol.kernel_ms_mean(R)
+assert lib.qmgpu_debug_riccati_ticks(buf, 0) == 0
+t = np.array(buf[:], dtype=np.float64).reshape(4, 16) / R
+tot = t[0, :14].sum()
+print("riccati kernel ms (with clocks):", round(ms[2], 4), " ticks per launch, wavefront 0:", int(tot), " => ticks per ms:", round(tot / ms[2]))
+print("per backward stage (ticks / %d stages), by wavefront:" % N)
+for i, n in enumerate(SLOTS):
+    per = t[:, i] / (N if i < 12 else 1)
+    print("  %-14s" % n, "  ".join("%8.0f" % v for v in per))
+print(json.dumps({"kernel_ms": ms[2], "slots": SLOTS, "ticks": t[:, :14].tolist()}))

@@ -1,0 +1,139 @@
+// Stand-alone timing of the dense factorisation step of riccati_kernel (P3): one wavefront, [H | G g] (18 + 31 columns) from LDS,
+// variants of the multiplier broadcast and of the reciprocal square root.  Each variant is checked against a host Cholesky.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/_bin/ubench_p3 tools/ubench_p3.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+constexpr int MT = 18, NG = 31, LDS_Y = 80, LDS_W = 48, REPS = 50;
+__device__ __forceinline__ double rl(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double fastRsqrt(double x) {     // v_rsq_f64 + one third-order correction (what ocml does, minus the special cases)
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
+__device__ __forceinline__ long long tick(double& a) { long long t; asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a)); return t; }
+
+// V = 0: readlane multipliers + ocml rsqrt (the kernel today); 1: readlane + fast rsqrt; 2: LDS broadcast multipliers + fast rsqrt
+// NT = compile-time number of pivots (rows >= NT are identity)
+template <int V, int NT> __global__ void p3(const double* Tin, double* Wout, double* LTout, long long* ticks) {
+  __shared__ double T[32 * LDS_Y];
+  __shared__ double W[20 * LDS_W];
+  __shared__ double LT[20 * 20 + 20];
+  __shared__ __attribute__((aligned(16))) double rowb[2][32];
+  const int lane = threadIdx.x;
+  for (int e = lane; e < 32 * LDS_Y; e += 64) T[e] = Tin[e];
+  __syncthreads();
+  const bool isH = lane < MT, isG = lane >= MT && lane < MT + NG;
+  const int c = isH ? lane : (isG ? lane - MT : 0);
+  long long total = 0;
+  double keep = 0;
+  for (int rep = 0; rep < REPS; ++rep) {
+    double col[MT], hv[MT];
+    double dummy = keep;
+    const long long t0 = tick(dummy);
+#pragma unroll
+    for (int r = 0; r < NT; ++r) hv[r] = T[r * LDS_Y + (isH ? 32 + c : c)];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) asm volatile("" : "+v"(hv[r]));
+#pragma unroll
+    for (int r = 0; r < NT; ++r) col[r] = (isH ? c < NT : isG) ? hv[r] : ((isH && r == c) ? 1.0 : 0.0);
+    double inv, invd[MT];
+    {
+      const double piv = rl(col[0], 0);
+      inv = V == 0 ? rsqrt(piv > 0 ? piv : 1.0) : fastRsqrt(piv > 0 ? piv : 1.0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      col[j] *= inv; invd[j] = inv;
+      if constexpr (V == 2) {
+        if (j + 1 < NT) {
+          if (isH) rowb[j & 1][lane] = col[j];             // the scaled pivot row: multipliers of this step, by lane
+          col[j + 1] -= rl(col[j], j + 1) * col[j];
+          const double piv = rl(col[j + 1], j + 1);
+          inv = fastRsqrt(piv > 0 ? piv : 1.0);
+          // rows j + 2 .. NT - 1: multipliers from LDS, two per ds_read_b128 (same address in every lane)
+          const double2* rb = reinterpret_cast<const double2*>(&rowb[j & 1][0]);
+#pragma unroll
+          for (int r = (j + 2) & ~1; r < NT; r += 2) {
+            const double2 m = rb[r >> 1];
+            if (r >= j + 2) col[r] -= m.x * col[j];
+            if (r + 1 < NT) col[r + 1] -= m.y * col[j];
+          }
+        }
+      } else {
+        if (j + 1 < NT) {
+          col[j + 1] -= rl(col[j], j + 1) * col[j];
+          const double piv = rl(col[j + 1], j + 1);
+          inv = V == 0 ? rsqrt(piv > 0 ? piv : 1.0) : fastRsqrt(piv > 0 ? piv : 1.0);
+        }
+#pragma unroll
+        for (int r = j + 2; r < NT; ++r) col[r] -= rl(col[j], r) * col[j];
+      }
+    }
+    if (isH) {
+#pragma unroll
+      for (int r = 0; r < NT; ++r) LT[r * 20 + c] = col[r];
+      double mine = 1.0;
+#pragma unroll
+      for (int r = 0; r < NT; ++r) if (r == c) mine = invd[r];
+      LT[400 + c] = mine;
+    } else if (isG) {
+#pragma unroll
+      for (int r = 0; r < NT; ++r) W[r * LDS_W + c] = col[r];
+    }
+    double d2 = col[0];
+    const long long t1 = tick(d2);
+    total += t1 - t0; keep += d2 * 1e-300;
+    __syncthreads();
+  }
+  if (lane == 0) ticks[0] = total / REPS;
+  __syncthreads();
+  for (int e = lane; e < 20 * LDS_W; e += 64) Wout[e] = W[e];
+  for (int e = lane; e < 420; e += 64) LTout[e] = LT[e];
+  if (keep == 12345.0) Wout[0] = keep;
+}
+
+template <int V, int NT> void run(const char* name, const std::vector<double>& T, const std::vector<double>& Lref, const std::vector<double>& Wref, double* dT, double* dW, double* dL, long long* dt) {
+  for (int i = 0; i < 2; ++i) { hipLaunchKernelGGL((p3<V, NT>), dim3(1), dim3(64), 0, 0, dT, dW, dL, dt); (void)hipDeviceSynchronize(); }
+  std::vector<double> W(20 * LDS_W), L(420); long long t;
+  (void)hipMemcpy(W.data(), dW, W.size() * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(L.data(), dL, L.size() * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
+  double eL = 0, eW = 0;
+  for (int r = 0; r < NT; ++r) { for (int c = r; c < NT; ++c) eL = fmax(eL, fabs(L[r * 20 + c] - Lref[c * MT + r])); for (int c = 0; c < NG; ++c) eW = fmax(eW, fabs(W[r * LDS_W + c] - Wref[r * NG + c])); }
+  printf("%-44s NT=%2d  %6lld cycles   err L %.1e  W %.1e\n", name, NT, t, eL, eW);
+}
+
+int main() {
+  // SPD H (NT x NT leading block used), random G
+  std::vector<double> T(32 * LDS_Y, 0.0), H(MT * MT), G(MT * NG);
+  unsigned s = 12345; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return double(s >> 8) / (1 << 24) - 0.5; };
+  std::vector<double> A(MT * MT); for (auto& a : A) a = rnd();
+  for (int i = 0; i < MT; ++i) for (int j = 0; j < MT; ++j) { double v = i == j ? 2.0 : 0.0; for (int k = 0; k < MT; ++k) v += A[i * MT + k] * A[j * MT + k]; H[i * MT + j] = v; }
+  for (auto& g : G) g = rnd();
+  for (int r = 0; r < MT; ++r) { for (int c = 0; c < MT; ++c) T[r * LDS_Y + 32 + c] = H[r * MT + c]; for (int c = 0; c < NG; ++c) T[r * LDS_Y + c] = G[r * NG + c]; }
+  double *dT, *dW, *dL; long long* dt;
+  (void)hipMalloc(&dT, T.size() * 8); (void)hipMalloc(&dW, 20 * LDS_W * 8); (void)hipMalloc(&dL, 420 * 8); (void)hipMalloc(&dt, 8);
+  (void)hipMemcpy(dT, T.data(), T.size() * 8, hipMemcpyHostToDevice);
+  auto ref = [&](int NT, std::vector<double>& L, std::vector<double>& W) {
+    L.assign(MT * MT, 0.0); W.assign(MT * NG, 0.0);
+    for (int j = 0; j < NT; ++j) {
+      double d = H[j * MT + j]; for (int k = 0; k < j; ++k) d -= L[j * MT + k] * L[j * MT + k]; L[j * MT + j] = sqrt(d);
+      for (int i = j + 1; i < NT; ++i) { double v = H[i * MT + j]; for (int k = 0; k < j; ++k) v -= L[i * MT + k] * L[j * MT + k]; L[i * MT + j] = v / L[j * MT + j]; }
+    }
+    for (int c = 0; c < NG; ++c) for (int r = 0; r < NT; ++r) { double v = G[r * NG + c]; for (int k = 0; k < r; ++k) v -= L[r * MT + k] * W[k * NG + c]; W[r * NG + c] = v / L[r * MT + r]; }
+  };
+  std::vector<double> L, W;
+  ref(18, L, W);
+  run<0, 18>("readlane multipliers, ocml rsqrt", T, L, W, dT, dW, dL, dt);
+  run<1, 18>("readlane multipliers, rsq + one correction", T, L, W, dT, dW, dL, dt);
+  run<2, 18>("LDS broadcast multipliers, rsq + correction", T, L, W, dT, dW, dL, dt);
+  ref(16, L, W);
+  run<0, 16>("readlane multipliers, ocml rsqrt", T, L, W, dT, dW, dL, dt);
+  run<1, 16>("readlane multipliers, rsq + one correction", T, L, W, dT, dW, dL, dt);
+  run<2, 16>("LDS broadcast multipliers, rsq + correction", T, L, W, dT, dW, dL, dt);
+  ref(14, L, W);
+  run<2, 14>("LDS broadcast multipliers, rsq + correction", T, L, W, dT, dW, dL, dt);
+  return 0;
+}
