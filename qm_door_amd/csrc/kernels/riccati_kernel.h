@@ -179,6 +179,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   QM_POISON_LDS(lds, RICCATI_LDS_DOUBLES);
   constexpr int NTHR = NW * 64;
   constexpr int PFB = (OFF_PX / 2 + NTHR - 1) / NTHR;
+  constexpr int PFW = (OFF_PX / 2 + NTHR - 64 - 1) / (NTHR - 64);   // the same copy by three wavefronts
   // forward sweep: only A~ B~ (the head of the record) and b~ q~ r~ Px Pu Pe (its tail) are read; Q~ P~ R~ in between are not
   constexpr int FWD_HEAD = OFF_QT, FWD_TAIL0 = OFF_bt, FWD_TAIL = STAGE_DOUBLES - OFF_bt;
   static_assert(FWD_HEAD % 2 == 0 && FWD_TAIL0 % 2 == 0 && FWD_TAIL % 2 == 0, "16-byte units");
@@ -221,8 +222,6 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const int ncLoad = ncI[k > 0 ? k - 1 : 0];
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
-    StagePrefetch<PFB, NTHR> pf;
-    pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid);  // next stage's blocks, in flight during this stage
     QM_TICK(0);
     // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T.  Every product runs on two accumulators per tile
     //      (even / odd k steps): a dependent v_mfma_f64 issues every 64 cycles, an independent one every 16.
@@ -320,6 +319,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     if (wave == 0) {
       riccatiFactorise<MT>(T, W, LL, nt, lane, status, scr);
     } else {
+      // the next stage's blocks HBM -> registers -> LDS by the three wavefronts that are off the critical path here; the other
+      // staging buffer was last read before the final barrier of the previous stage
+      StagePrefetch<PFW, NTHR - 64> pf;
+      pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid - 64);
       // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation)
       const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
       real qv[4], qq[4];
@@ -347,9 +350,9 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       // ---- gains of stage k + 1 (its W and L sit in the other parity's buffers)
       if (wave == 3 && k + 1 < N && lane < 31)
         riccatiGains(lds + R_W + ((k + 1) & 1) * W_DOUBLES, lds + R_LT + ((k + 1) & 1) * LT_DOUBLES, 30 - ncPrev, lane, a.gains + (size_t(inst) * N + k + 1) * GAIN_DOUBLES);
+      pf.commit(stgNext, OFF_PX, tid - 64);   // stage k - 1 lands in the other buffer
     }
     QM_TICK(5);
-    pf.commit(stgNext, OFF_PX, tid);   // stage k - 1 lands in the other buffer
     QM_TICK(6);
     QM_LDS_BARRIER();
     QM_TICK(7);
@@ -363,27 +366,27 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -W[kk * LDS_W + tm * 16 + la]; bw[ks] = W[kk * LDS_W + j]; }
       qmMfma(c6, av[0], bw[0], scr); qmMfma(d6, av[1], bw[1], scr); qmMfma(c6, av[2], bw[2], scr); qmMfma(d6, av[3], bw[3], scr); qmMfma(c6, av[4], bw[4], scr);
+      real v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
-        const real v = c6[r] + d6[r];
-        TS[i * LDS_TS + j] = v;
-        if (i < 30 && j == 30) sv[i] = v;
+        v[r] = c6[r] + d6[r];
+        TS[i * LDS_TS + j] = v[r];
+        if (i < 30 && j == 30) sv[i] = v[r];
+      }
+      QM_WAVE_SYNC();   // the transposed read below meets this wavefront's own writes (LDS operations of one wavefront complete in order)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // diagonal tiles: S[i][j] = (C[i][j] + C[j][i]) / 2, both mine.  Tile (0,1): S[i][j] = C[i][j], and the lane also fills the element
+        // (i2, j2) = (16 + h + 4 r, l16) of the tile (1,0) with C[j2][i2].
+        const int i = tm * 16 + h + 4 * r, i2 = 16 + h + 4 * r;
+        const real m = TS[(wave == 2 ? l16 : j) * LDS_TS + (wave == 2 ? i2 : i)];
+        if (i < 30 && j < 30) S[i * LDS_S + j] = wave == 2 ? v[r] : 0.5_r * (v[r] + m);
+        if (wave == 2 && i2 < 30) S[i2 * LDS_S + l16] = m;
       }
     }
     QM_TICK(8);
-    QM_LDS_BARRIER();
     QM_TICK(9);
-    {
-      const int tm = wave >> 1, tn = wave & 1, j = tn * 16 + l16;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = tm * 16 + h + 4 * r;
-        const real up = TS[(wave == 2 ? j : i) * LDS_TS + (wave == 2 ? i : j)];     // the tile (1,0) reads its mirror image
-        const real lo = TS[(wave == 1 ? i : j) * LDS_TS + (wave == 1 ? j : i)];
-        if (i < 30 && j < 30) S[i * LDS_S + j] = 0.5_r * (up + lo);
-      }
-    }
     QM_TICK(10);
     QM_LDS_BARRIER();
     QM_TICK(11);
