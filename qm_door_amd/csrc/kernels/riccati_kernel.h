@@ -145,9 +145,13 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
 #pragma unroll
     for (int r = 0; r + 1 < NT; r += 2) { QmD2 v; v.x = col[r]; v.y = col[r + 1]; *reinterpret_cast<QmD2*>(LL + c * LDS_LL + r) = v; }
     if (NT & 1) LL[c * LDS_LL + NT - 1] = col[NT - 1];
+#pragma unroll
+    for (int r = NT; r < MT; ++r) LL[c * LDS_LL + r] = r == c ? 1.0_r : 0.0_r;   // identity rows / columns beyond the unrolled size
   } else if (isG) {
 #pragma unroll
     for (int r = 0; r < NT; ++r) W[r * LDS_W + c] = col[r];          // rows >= nt are exactly zero
+#pragma unroll
+    for (int r = NT; r < MT; ++r) W[r * LDS_W + c] = 0.0_r;          // (the buffer may hold a stage with more inputs)
   }
 }
 
@@ -166,11 +170,10 @@ __device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, in
 #pragma unroll
     for (int r = 0; r < q; ++r) w[r] -= lrow[r] * w[q];
   }
+  real* gp = gain + (lane < 30 ? OFF_KFB + lane : OFF_kff);     // column `lane` of K, or k
+  const int gs = lane < 30 ? 30 : 1;
 #pragma unroll
-  for (int r = 0; r < MT; ++r) {
-    const real v = r < ntp ? -w[r] : 0.0_r;
-    if (lane < 30) gain[OFF_KFB + r * 30 + lane] = v; else gain[OFF_kff + r] = v;
-  }
+  for (int r = 0; r < MT; ++r) gp[r * gs] = r < ntp ? -w[r] : 0.0_r;
 }
 
 template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIMD riccati_kernel(RiccatiArgs a) {
@@ -317,7 +320,13 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const int myTile = wave == 1 ? 0 : (wave == 2 ? 1 : 3);
     QmAcc c6, d6;
     if (wave == 0) {
-      riccatiFactorise<MT>(T, W, LL, nt, lane, status, scr);
+      // the elimination is unrolled for the stage's number of projected inputs: 18 stance, 17 three-leg support, 16 trot, 14 flight
+      switch (nt) {
+        case 16: riccatiFactorise<16>(T, W, LL, nt, lane, status, scr); break;
+        case 14: riccatiFactorise<14>(T, W, LL, nt, lane, status, scr); break;
+        case 17: riccatiFactorise<17>(T, W, LL, nt, lane, status, scr); break;
+        default: riccatiFactorise<MT>(T, W, LL, nt, lane, status, scr); break;
+      }
     } else {
       // the next stage's blocks HBM -> registers -> LDS by the three wavefronts that are off the critical path here; the other
       // staging buffer was last read before the final barrier of the previous stage
