@@ -40,7 +40,10 @@ struct DblIn {
 
 // dt-scaled cost, dt*|defect|^2, dt*|eq|^2 of one node at (x, u, xnext); xnOut (optional, 30): the RK2 image of (x, u), in which case xnext may be
 // null and the defect is not formed (rollouts of the DDP variant)
-__device__ inline void nodePerformance(const ProblemR& P, const real* Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
+// NOT inlined: with this body inlined into the 35 k-instruction line-search kernel of the fp32 build the compiler produced a binary whose
+// equality-violation sum read stale registers (2-3x too large, different from run to run; tests/test_gpu_configs.py pins both symptoms).
+// As a called function the body is compiled once, for linesearch_kernel and ddp_rollout_kernel alike.
+__device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, const real* Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
                                        bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq, real* xnOut = nullptr) {
   const ModelR& md = P.model;
   const SettingsR& st = P.settings;

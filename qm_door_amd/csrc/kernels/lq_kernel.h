@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const real val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0_r : 0.0_r);
         if (lane < 30) rec[OFF_PX + i * 30 + lane] = 0.0_r;
         else if (lane == 30) rec[OFF_PE + i] = pe;
-        else if (lane >= 32 && lane < 32 + nt) rec[OFF_PU + i * MT + (lane - 32)] = val;
+        else if (lane >= 32 && lane < 32 + MT) rec[OFF_PU + i * MT + (lane - 32)] = val;   // columns >= m~ are written as zeros (puColOf < m~)
       }
     }
 #pragma unroll
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int i = 0; i < 18; ++i) {
         const real qv = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
         PA[i * PAW + lane] = isQ2 ? qv : 0.0_r;
-        if (jj < nt) rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0_r;
+        rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0_r;                          // jj < MT = PAW - 32: zero padding included
       }
     }
   }
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const real pv = PA[(i - 12) * PAW + (lane < PAW ? lane : 0)];
     if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0_r : 0.0_r) + dt * pv;
     else if (isE) rec[OFF_bt + i] = bv[i] + dt * pv;
-    else if (isU) rec[OFF_BT + i * MT + (lane - 32)] = dt * pv;
+    else if (lane >= 32 && lane < 32 + MT) rec[OFF_BT + i * MT + (lane - 32)] = isU ? dt * pv : 0.0_r;   // columns >= m~: zero padding
   }
   {  // transposed dense rows: At[j][i] = A[i][j], Bt[k][i] = B[i][k], i < 12 (columns 12..15 and rows 30,31 zero)
     real* dst = (lane < 30) ? AT + lane * LDT : (lane < 60 ? BT + (lane - 30) * LDT : AT + 30 * LDT + (lane - 60) * LDT);
@@ -595,6 +595,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   QM_WAVE_SYNC();
   if (isX) rec[OFF_qt + lane] = qc + fin[lane];
   else if (isU) rec[OFF_rt + (lane - 32)] = fin[lane];
+  // zero padding of B~, Pu (above) and r~ beyond m~ columns: the forward sweep of riccati_kernel multiplies whole MT-wide rows
+  // (P~, R~ keep undefined padding: their consumer masks by m~)
+  if (nt < MT) {
+    if (lane >= 32 + nt && lane < 32 + MT) rec[OFF_rt + (lane - 32)] = 0.0_r;
+    if (lane < 48) { const int i = lane >> 2, jj = nt + (lane & 3); if (jj < MT) rec[OFF_BT + i * MT + jj] = 0.0_r; }        // rows 0..11 of B~
+  }
 }
 
 }  // namespace qmk

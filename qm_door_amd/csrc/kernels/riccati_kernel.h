@@ -43,11 +43,11 @@ constexpr int RICCATI_WAVES = 4;
 // Phase clock of the profiling build (tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING): s_memtime deltas of workgroup 0 summed per phase
 // and wavefront into a device symbol.  The product build compiles every QM_TICK to nothing.
 #ifdef QM_RICCATI_TIMING
-__device__ unsigned long long qmRiccatiTicks[4 * 16];
+__device__ unsigned long long qmRiccatiTicks[4 * 32];
 // sums kept in (scalar) registers, written once at the end: a read-modify-write of global memory per tick costs ~300 cycles
-#define QM_TICK_DECL unsigned long long qmT = clock64(), qmTs[14] = {}
+#define QM_TICK_DECL unsigned long long qmT = clock64(), qmTs[24] = {}
 #define QM_TICK(slot) do { const unsigned long long n_ = clock64(); qmTs[slot] += n_ - qmT; qmT = n_; } while (0)
-#define QM_TICK_FLUSH do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 14; ++i_) qmRiccatiTicks[(threadIdx.x >> 6) * 16 + i_] += qmTs[i_]; } while (0)
+#define QM_TICK_FLUSH do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 24; ++i_) qmRiccatiTicks[(threadIdx.x >> 6) * 32 + i_] += qmTs[i_]; } while (0)
 #else
 #define QM_TICK_DECL
 #define QM_TICK(slot)
@@ -66,11 +66,16 @@ constexpr int W_DOUBLES = 20 * LDS_W;             // W [20][LDS_W] of one stage
 constexpr int LT_DOUBLES = 20 * LDS_LL;            // L [20][LDS_LL] row major, strictly lower triangle; the diagonal slot holds 1 / L_cc
 constexpr int R_W = R_SV + 32;                    // W of the stage in flight and of the previous one (by stage parity): the gains of stage k + 1 are
 constexpr int R_LT = R_W + 2 * W_DOUBLES;         // formed while stage k factorises, from W / L^T of stage k + 1
-constexpr int R_VEC = R_LT + 2 * LT_DOUBLES;      // dx[32] dut[32]
-constexpr int R_SCR = R_VEC + 64;                 // armijo reduction [64]
+constexpr int R_KST = R_LT + 2 * LT_DOUBLES;        // the gains record [GAIN_DOUBLES] of two stages: formed here by one wavefront, copied to HBM by two others a stage later
+constexpr int R_BWD_END = R_KST + 2 * GAIN_DOUBLES;
+static_assert(R_KST % 2 == 0 && GAIN_DOUBLES % 2 == 0, "16-byte copies");
+// forward sweep (over everything above, dead by then): a ring of three staging buffers [3][STG_F], then the B-operand images of dx and du~
+constexpr int FWD_XV = 32, FWD_UV = 32;               // dx [30] and du~ [MT] of one stage (padded)
+constexpr int F_XV = 3 * STG_F, F_UV = F_XV + 3 * FWD_XV, R_FWD_END = F_UV + 3 * FWD_UV;
+constexpr int R_SCR = R_BWD_END > R_FWD_END ? R_BWD_END : R_FWD_END;   // armijo reduction [64]
 constexpr int RICCATI_LDS_DOUBLES = R_SCR + 64;
-constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * int(sizeof(real));  // ~125 KiB at fp64 (dynamic LDS)
-static_assert(2 * STG_F <= RICCATI_LDS_DOUBLES, "forward-sweep staging fits");
+constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * int(sizeof(real));  // ~145 KiB at fp64 (dynamic LDS)
+static_assert(RICCATI_LDS_DOUBLES <= 20480, "one CU's LDS at fp64");
 
 // Register-staged HBM -> LDS copy for a whole workgroup: issue() puts PF 16-byte loads per thread in flight, commit() drains
 // them into LDS.  Between the two the workgroup computes on the *current* stage, so the memory latency of the next stage is
@@ -157,7 +162,7 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
 
 // [K | k] = -L^-T W of one stage by back-substitution, one column of [K | k] per lane (31 lanes of one wavefront), in the axpy order:
 // the dependent chain is one multiply + one multiply-add per row, the other multiply-adds of a step are independent.
-__device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, int ntp, int lane, real* gain) {
+__device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, int ntp, int lane, real* kst) {
   real w[MT];
 #pragma unroll
   for (int r = 0; r < MT; ++r) w[r] = Wp[r * LDS_W + lane];
@@ -170,10 +175,23 @@ __device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, in
 #pragma unroll
     for (int r = 0; r < q; ++r) w[r] -= lrow[r] * w[q];
   }
-  real* gp = gain + (lane < 30 ? OFF_KFB + lane : OFF_kff);     // column `lane` of K, or k
-  const int gs = lane < 30 ? 30 : 1;
+  // into the LDS image of the record (immediate-offset ds_write, consecutive lanes consecutive addresses)
+  real* gp = kst + (lane < 30 ? OFF_KFB + lane : OFF_kff);
+  if (lane < 30) {
 #pragma unroll
-  for (int r = 0; r < MT; ++r) gp[r * gs] = r < ntp ? -w[r] : 0.0_r;
+    for (int r = 0; r < MT; ++r) gp[r * 30] = r < ntp ? -w[r] : 0.0_r;
+  } else {
+#pragma unroll
+    for (int r = 0; r < MT; ++r) gp[r] = r < ntp ? -w[r] : 0.0_r;
+  }
+}
+
+// LDS image of one gains record -> HBM by 128 threads (t in [0, 128)), 16 bytes per access
+__device__ __forceinline__ void riccatiGainsOut(const real* kst, real* gain, int t) {
+  const QmD2* src = reinterpret_cast<const QmD2*>(kst);
+  QmD2* dst = reinterpret_cast<QmD2*>(gain);
+#pragma unroll
+  for (int i = 0; i < (GAIN_DOUBLES / 2 + 127) / 128; ++i) { const int idx = t + 128 * i; if (idx < GAIN_DOUBLES / 2) dst[idx] = src[idx]; }
 }
 
 template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIMD riccati_kernel(RiccatiArgs a) {
@@ -195,7 +213,6 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const int N = a.N;
   real* S = lds + R_S; real* sv = lds + R_SV; real* Y = lds + R_Y; real* T = lds + R_T;
   real* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)
-  real* dxv = lds + R_VEC; real* dut = dxv + 32;
   real* scr = nullptr; real* red = lds + R_SCR;
   const real* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const real* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
@@ -207,7 +224,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const real* rec = stagesI + size_t(N) * STAGE_DOUBLES;
     for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
     if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0_r;
-    for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;        // W, L^T of both parities (contiguous)
+    for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES + 2 * GAIN_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;   // W, L, gains images of both parities (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
@@ -357,8 +374,13 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
       for (int ks = 0; ks < 8; ks += 2) { qmMfma(c6, av[ks], bw[ks], scr); qmMfma(d6, av[ks + 1], bw[ks + 1], scr); }
       // ---- gains of stage k + 1 (its W and L sit in the other parity's buffers)
-      if (wave == 3 && k + 1 < N && lane < 31)
-        riccatiGains(lds + R_W + ((k + 1) & 1) * W_DOUBLES, lds + R_LT + ((k + 1) & 1) * LT_DOUBLES, 30 - ncPrev, lane, a.gains + (size_t(inst) * N + k + 1) * GAIN_DOUBLES);
+      //      into the LDS image of their record; wavefronts 1 and 2 send the image finished a stage ago (stage k + 2) to HBM
+      if (wave == 3) {
+        if (k + 1 < N && lane < 31)
+          riccatiGains(lds + R_W + ((k + 1) & 1) * W_DOUBLES, lds + R_LT + ((k + 1) & 1) * LT_DOUBLES, 30 - ncPrev, lane, lds + R_KST + ((k + 1) & 1) * GAIN_DOUBLES);
+      } else if (k + 2 < N) {
+        riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, tid - 64);
+      }
       pf.commit(stgNext, OFF_PX, tid - 64);   // stage k - 1 lands in the other buffer
     }
     QM_TICK(5);
@@ -402,13 +424,24 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     ncPrev = ncCur; ncCur = ncLoad;
   }
   // ---- gains of stage 0 (nobody factorises any more)
-  if (wave == 3 && lane < 31) riccatiGains(lds + R_W, lds + R_LT, 30 - ncPrev, lane, a.gains + size_t(inst) * N * GAIN_DOUBLES);
+  if (wave == 3) { if (lane < 31) riccatiGains(lds + R_W, lds + R_LT, 30 - ncPrev, lane, lds + R_KST); }
+  else if (wave != 0 && N > 1) riccatiGainsOut(lds + R_KST + GAIN_DOUBLES, a.gains + (size_t(inst) * N + 1) * GAIN_DOUBLES, tid - 64);
+  QM_LDS_BARRIER();
+  if (wave == 1 || wave == 2) riccatiGainsOut(lds + R_KST, a.gains + size_t(inst) * N * GAIN_DOUBLES, tid - 64);
 
   // ================================================================== forward substitution
-  // wavefront 0: du~ = K dx + k, du = Pe + Px dx + Pu du~ ; wavefront 1: dx+ = A~ dx + B~ du~ + b~ ; everybody prefetches
-  constexpr int WX = 1 % NW;
+  // The recursion  du~ = K dx + k,  dx+ = A~ dx + B~ du~ + b~  runs on wavefront 0 alone (a v_mfma_f64 holds a SIMD's matrix pipe for 64
+  // cycles whatever its operands, so a matrix-vector product is cheaper as plain multiply-adds: each row's dot product is split over the
+  // two halves of the wavefront and joined by one v_permlane32_swap); the hand-off du~ -> second product and dx+ -> next stage goes
+  // through LDS inside the wavefront, and the workgroup meets at ONE barrier per stage.  Everything off the chain runs one stage behind
+  // on the other wavefronts, from a ring of three staging buffers: wavefront 1 forms du = Pe + Px dx + Pu du~, wavefront 2 stores dx and
+  // accumulates the Armijo slope q~.dx + r~.du~, and wavefronts 1..3 stream the next stage's blocks and gains HBM -> registers -> LDS.
+  // All MT columns of B~ / Pu / K are multiplied: the producers pad with zeros (lq_node_kernel; riccatiGains).
+  constexpr int XV = FWD_XV, UV = FWD_UV;
+  constexpr int NPF = NTHR - 128;   // wavefronts 2 and 3 stream the blocks
+  constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_TAIL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
   QM_TICK(12);
-  __syncthreads();   // full barrier: the gains written to HBM by every wavefront are read back by all of them below
+  __syncthreads();   // full barrier: the gains written to HBM by wavefront 3 are read back below
   {
     StagePrefetch<PFH, NTHR> ph;
     StagePrefetch<PFT, NTHR> pt;
@@ -416,68 +449,131 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     ph.issue(stagesI, FWD_HEAD, tid);
     pt.issue(stagesI + FWD_TAIL0, FWD_TAIL, tid);
     pg.issue(gainsI, GAIN_DOUBLES, tid);
+    for (int e = tid; e < 3 * XV + 3 * UV; e += NTHR) lds[F_XV + e] = 0.0_r;
     ph.commit(lds + R_STG, FWD_HEAD, tid);
     pt.commit(lds + R_STG + FWD_TAIL0, FWD_TAIL, tid);
     pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
-  if (tid < 30) dxv[tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
+  __syncthreads();
+  if (tid < 30) lds[F_XV + tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
   real armijo = 0.0_r;
   __syncthreads();
-  int ncFwd = ncI[0];
+  const bool upper = lane >= 32;            // second half of the wavefront: the second half of every dot product
+  const int rowl = lane & 31;               // row of a matrix-vector product handled by this lane
+  const int rK = rowl < MT ? rowl : 0, rX = rowl < 30 ? rowl : 0;
+  // the blocks of stage k + 1 are requested during iteration k - 1 and land in LDS during iteration k (an iteration is shorter than
+  // the HBM latency): the loads in flight live in registers of wavefronts 2 and 3 across the loop back-edge
+  StagePrefetch<PFH3, NPF> ph;
+  StagePrefetch<PFT3, NPF> pt;
+  StagePrefetch<PFG3, NPF> pg;
+  if (wave >= 2 && N > 1) {
+    ph.issue(stagesI + STAGE_DOUBLES, FWD_HEAD, tid - 128);
+    pt.issue(stagesI + STAGE_DOUBLES + FWD_TAIL0, FWD_TAIL, tid - 128);
+    pg.issue(gainsI + GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
+  }
 #pragma unroll 1
-  for (int k = 0; k < N; ++k) {
-    const int nt = 30 - ncFwd;
-    const int kn = k + 1 < N ? k + 1 : k;
-    ncFwd = ncI[kn];
-    const real* stg = lds + R_STG + (k & 1) * STG_F; const real* gn = stg + STAGE_DOUBLES;
-    real* stgNext = lds + R_STG + ((k + 1) & 1) * STG_F;
-    StagePrefetch<PFH, NTHR> ph;
-    StagePrefetch<PFT, NTHR> pt;
-    StagePrefetch<PFG, NTHR> pg;
-    ph.issue(stagesI + size_t(kn) * STAGE_DOUBLES, FWD_HEAD, tid);
-    pt.issue(stagesI + size_t(kn) * STAGE_DOUBLES + FWD_TAIL0, FWD_TAIL, tid);
-    pg.issue(gainsI + size_t(kn) * GAIN_DOUBLES, GAIN_DOUBLES, tid);
-    if (wave == 0 && lane < 30) a.dX[(size_t(inst) * (N + 1) + k) * 30 + lane] = dxv[lane];
-    if (wave == 0 && lane < nt) {
-      real s0 = gn[OFF_kff + lane], s1 = 0.0_r;
+  for (int k = 0; k <= N; ++k) {   // iteration k: the chain does stage k (k < N), the others finish stage k - 1 and stage the blocks of k + 1
+    const int sl = k % 3, slPrev = (k + 2) % 3, slNext = (k + 1) % 3;
+    QM_TICK(14);
+    if (wave == 0) {
+      if (k < N) {
+        const real* stg = lds + R_STG + sl * STG_F; const real* gn = stg + STAGE_DOUBLES;
+        const real* xv = lds + F_XV + sl * XV; real* uv = lds + F_UV + sl * UV; real* xvNext = lds + F_XV + slNext * XV;
+        // du~ = K dx + k: columns 0..14 on the lower half, 15..29 on the upper half
+        const real* Krow = gn + OFF_KFB + rK * 30 + (upper ? 15 : 0);
+        const real* xh = xv + (upper ? 15 : 0);
+        real s0 = upper ? 0.0_r : gn[OFF_kff + rK], s1 = 0.0_r;
 #pragma unroll
-      for (int c = 0; c < 30; c += 2) { s0 += gn[OFF_KFB + lane * 30 + c] * dxv[c]; s1 += gn[OFF_KFB + lane * 30 + c + 1] * dxv[c + 1]; }
-      dut[lane] = s0 + s1;
-    }
-    QM_LDS_BARRIER();
-    real nx = 0.0_r;
-    if (wave == 0 && lane < 30) {  // du = Pe + Px dx + Pu du~
-      real s0 = stg[OFF_PE + lane], s1 = 0.0_r;
+        for (int c = 0; c < 14; c += 2) { s0 += Krow[c] * xh[c]; s1 += Krow[c + 1] * xh[c + 1]; }
+        s0 += Krow[14] * xh[14];
+        // the part of dx+ that needs no du~: A~ columns 0..24 on the lower half, 25..29 and b~ on the upper half
+        const real* Arow = stg + OFF_AT + rX * 30;
+        real t0 = upper ? stg[OFF_bt + rX] : 0.0_r, t1 = 0.0_r;
+        if (!upper) {
 #pragma unroll
-      for (int c = 0; c < 30; c += 2) { s0 += stg[OFF_PX + lane * 30 + c] * dxv[c]; s1 += stg[OFF_PX + lane * 30 + c + 1] * dxv[c + 1]; }
-      for (int j = 0; j < nt; ++j) s0 += stg[OFF_PU + lane * MT + j] * dut[j];
-      a.dU[(size_t(inst) * N + k) * 30 + lane] = s0 + s1;
-    }
-    if (wave == WX && lane < 30) {  // dx+ = A~ dx + B~ du~ + b~ ; armijo contribution q~ . dx
-      real s0 = stg[OFF_bt + lane], s1 = 0.0_r;
+          for (int c = 0; c < 24; c += 2) { t0 += Arow[c] * xv[c]; t1 += Arow[c + 1] * xv[c + 1]; }
+          t0 += Arow[24] * xv[24];
+        } else {
 #pragma unroll
-      for (int c = 0; c < 30; c += 2) { s0 += stg[OFF_AT + lane * 30 + c] * dxv[c]; s1 += stg[OFF_AT + lane * 30 + c + 1] * dxv[c + 1]; }
-      for (int j = 0; j < nt; ++j) s0 += stg[OFF_BT + lane * MT + j] * dut[j];
-      nx = s0 + s1;
-      armijo += stg[OFF_qt + lane] * dxv[lane];
+          for (int c = 25; c < 30; ++c) t0 += Arow[c] * xv[c];
+        }
+        const real sd = s0 + s1;
+        const real du = sd + qmHalfXor32(sd, upper);
+        QM_TICK(15);
+        if (lane < MT) uv[lane] = du;
+        QM_WAVE_SYNC();
+        QM_TICK(16);
+        if (upper) {    // B~ du~ on the upper half (18 columns)
+          const real* Brow = stg + OFF_BT + rX * MT;
+#pragma unroll
+          for (int j = 0; j < MT; j += 2) { t0 += Brow[j] * uv[j]; t1 += Brow[j + 1] * uv[j + 1]; }
+        }
+        const real td = t0 + t1;
+        const real nx = td + qmHalfXor32(td, upper);
+        if (lane < 30) xvNext[lane] = nx;
+      }
+    } else {
+      QM_TICK(15);
+      if (wave >= 2) {
+        if (k + 1 < N) {
+          real* dst = lds + R_STG + slNext * STG_F;
+          ph.commit(dst, FWD_HEAD, tid - 128);
+          pt.commit(dst + FWD_TAIL0, FWD_TAIL, tid - 128);
+          pg.commit(dst + STAGE_DOUBLES, GAIN_DOUBLES, tid - 128);
+        }
+        if (k + 2 < N) {
+          ph.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES, FWD_HEAD, tid - 128);
+          pt.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES + FWD_TAIL0, FWD_TAIL, tid - 128);
+          pg.issue(gainsI + size_t(k + 2) * GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
+        }
+      }
+      QM_TICK(16);
+      if (k > 0) {
+        const int j = k - 1;
+        const real* stg = lds + R_STG + slPrev * STG_F;
+        const real* xv = lds + F_XV + slPrev * XV; const real* uv = lds + F_UV + slPrev * UV;
+        if (wave == 1) {   // du = Pe + Px dx + Pu du~: Px columns 0..24 on the lower half; Px 25..29, Pu and Pe on the upper half
+          const real* Prow = stg + OFF_PX + rX * 30;
+          real t0 = upper ? stg[OFF_PE + rX] : 0.0_r, t1 = 0.0_r;
+          if (!upper) {
+#pragma unroll
+            for (int c = 0; c < 24; c += 2) { t0 += Prow[c] * xv[c]; t1 += Prow[c + 1] * xv[c + 1]; }
+            t0 += Prow[24] * xv[24];
+          } else {
+            const real* Urow = stg + OFF_PU + rX * MT;
+#pragma unroll
+            for (int c = 25; c < 30; ++c) t0 += Prow[c] * xv[c];
+#pragma unroll
+            for (int q = 0; q < MT; q += 2) { t0 += Urow[q] * uv[q]; t1 += Urow[q + 1] * uv[q + 1]; }
+          }
+          const real td = t0 + t1;
+          const real duo = td + qmHalfXor32(td, upper);
+          if (lane < 30) a.dU[(size_t(inst) * N + j) * 30 + lane] = duo;
+        } else if (wave == 2) {   // dx out; Armijo slope q~ . dx + r~ . du~
+          if (lane < 30) {
+            const real dxl = xv[lane];
+            a.dX[(size_t(inst) * (N + 1) + j) * 30 + lane] = dxl;
+            armijo += stg[OFF_qt + lane] * dxl;
+          } else if (lane >= 32 && lane < 32 + MT) {
+            armijo += stg[OFF_rt + (lane - 32)] * uv[lane - 32];     // rows >= m~ of du~ and of r~ are zero
+          }
+        }
+      }
     }
-    if (wave == WX && lane >= 32 && lane < 32 + nt) armijo += stg[OFF_rt + (lane - 32)] * dut[lane - 32];
+    QM_TICK(17);
     QM_LDS_BARRIER();
-    if (wave == WX && lane < 30) dxv[lane] = nx;
-    ph.commit(stgNext, FWD_HEAD, tid);
-    pt.commit(stgNext + FWD_TAIL0, FWD_TAIL, tid);
-    pg.commit(stgNext + STAGE_DOUBLES, GAIN_DOUBLES, tid);
-    QM_LDS_BARRIER();
+    QM_TICK(18);
   }
   QM_TICK(13);
   QM_TICK_FLUSH;
-  if (wave == WX && lane < 30) {
-    a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxv[lane];
-    armijo += stagesI[size_t(N) * STAGE_DOUBLES + OFF_qt + lane] * dxv[lane];
+  if (wave == 2 && lane < 30) {   // terminal node: dx_N sits in slot N % 3
+    const real dxl = lds[F_XV + (N % 3) * XV + lane];
+    a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxl;
+    armijo += stagesI[size_t(N) * STAGE_DOUBLES + OFF_qt + lane] * dxl;
   }
-  // reduce armijo over the lanes of wavefront WX through LDS
+  // reduce armijo over the lanes of wavefront 2 through LDS
   __syncthreads();
-  if (wave == WX) red[lane] = armijo;
+  if (wave == 2) red[lane] = armijo;
   __syncthreads();
   if (tid == 0) {
     real s = 0.0_r;

@@ -70,6 +70,9 @@ template <class T> inline T qmShflXor(T v, int mask, T* scratch = nullptr) {
   return T(buf[lane ^ unsigned(mask)]);
 }
 
+template <class T> inline T qmHalfXor32(T v, bool) { return qmShflXor(v, 32); }   // v_permlane32_swap
+template <class T> inline T qmRowXor16(T v, bool) { return qmShflXor(v, 16); }    // v_permlane16_swap
+
 template <class T> inline T qmReadLane(T v, int src, T* scratch = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
   double* buf = emuXchgBuf(nullptr); (void)scratch;

@@ -97,8 +97,7 @@ def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
 def test_config5_fp32_vs_fp64_sweep(interface, oracle):
     """BASELINE.json configs[4], second half: the same 1024 x 200-node mixed-gait batch with the MPC kernels in fp32 (v_mfma_f32_16x16x4_f32, fp32
     scratch) next to the fp64 path; one MPC + policy evaluation + WBC cycle each.  Contact modes must be bit-exact (they are decided on the fp64
-    times in both builds); X, U and the WBC torques are held to STATED ||.||_inf-relative bounds per instance (instances that accepted the
-    same line-search step length in both builds; at most 0.5 % of the batch may differ there):
+    times in both builds); X, U and the WBC torques are held to STATED ||.||_inf-relative bounds per instance:
         X, U   1e-4   (measured on MI355X: max 0.9e-5 .. 1.1e-5 / 0.8e-5 .. 0.9e-5, median 2.5e-6 -- DESIGN.md section 5.1)
         tau    2e-3   (measured: 99th percentile 2.3e-5 .. 2.6e-5, median 2.7e-6, max 4e-5 .. 7.5e-4: the WBC runs in fp64 on either policy and is
                        piecewise linear in it -- an instance next to an active-set change amplifies the 1e-5 policy difference)
@@ -109,12 +108,11 @@ def test_config5_fp32_vs_fp64_sweep(interface, oracle):
     out = fp32_sweep.run(1024, 200)
     rep = fp32_sweep.report(out)
     assert rep["finite_f32"] and rep["riccati_status_f32_all_zero"] and rep["modes_bit_exact"]
+    assert rep["statistics_repeat_bit_for_bit"]        # merits / violations of three identical calls: a stray write into a neighbouring buffer shows here
     assert (out["f32"]["wbc"]["status"] == 0).all() and (out["f64"]["wbc"]["status"] == 0).all()
-    # The filter line search is a discrete decision: an instance whose merit sits on the acceptance threshold may take another step length
-    # in fp32 (then X, U differ by the step, not by rounding).  Those instances are counted and bounded; the rounding bounds hold on the rest.
-    assert rep["line_search_alpha_differs"] <= 0.005 * rep["batch"], rep
-    assert rep["X"]["max_same_step_length"] <= 1e-4 and rep["U"]["max_same_step_length"] <= 1e-4, rep
-    assert rep["tau"]["max_same_step_length"] <= 2e-3 and rep["tau"]["p99"] <= 1e-4, rep
+    assert max(rep["step_metrics_rel"].values()) <= 2e-4, rep      # merit and constraint violation before / after the step agree between the builds
+    assert rep["line_search_alpha_differs"] == 0, rep    # (a differing step length would show as an O(1) deviation below)
+    assert rep["X"]["max"] <= 1e-4 and rep["U"]["max"] <= 1e-4 and rep["tau"]["max"] <= 2e-3 and rep["tau"]["p99"] <= 1e-4, rep
     assert rep["X"]["max"] > 1e-9           # the two paths really are different arithmetic
     # the fp64 leg of the same run is the parity path: sampled against the oracle at the north_star tolerance
     from test_gpu_configs import _mixed_schedule

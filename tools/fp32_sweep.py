@@ -32,14 +32,15 @@ def run(batch, nodes, seed=3):
     for dtype in ("f64", "f32"):
         sol = G.make_solver(itf, batch, nodes, dtype=dtype)
         sol.enable_timing(True)
-        ms = []
+        ms, stats_reps = [], []
         for rep in range(3):
             mb = G.MpcBatch(x0, tt, ts, np.full(batch, nev, dtype=np.int32), np.tile(ev, (batch, 1)), np.tile(md, (batch, 1)), nodes)
             wb = G.WbcBatch(rbd, np.full(batch, 0.002), np.full(batch, 20.0), np.zeros((batch, 30)))
             sol.cycle(mb.args, G.dev(np.full(batch, 0.4 * dt), torch.float64), wb.args)
             torch.cuda.synchronize()
             ms.append(sol.last_kernel_ms())
-        out[dtype] = dict(mpc=mb.results(), wbc=wb.results(), ms=ms[-1])
+            stats_reps.append(mb.results()["stats"])
+        out[dtype] = dict(mpc=mb.results(), wbc=wb.results(), ms=ms[-1], repeatable=all(np.array_equal(stats_reps[0], r) for r in stats_reps[1:]))
         sol.close()
     return out
 
@@ -55,8 +56,11 @@ def report(out):
     same_alpha = a["mpc"]["stats"][:, 4] == b["mpc"]["stats"][:, 4]
     rep = {"finite_f32": bool(np.isfinite(b["mpc"]["X"]).all() and np.isfinite(b["mpc"]["U"]).all() and np.isfinite(b["wbc"]["out"]).all()),
            "modes_bit_exact": bool(np.array_equal(a["mpc"]["mode"], b["mpc"]["mode"])),
+           "statistics_repeat_bit_for_bit": bool(a["repeatable"] and b["repeatable"]),   # three identical calls per build
            "riccati_status_f32_all_zero": bool((b["mpc"]["stats"][:, 7] == 0).all()),
            "line_search_alpha_differs": int((~same_alpha).sum()), "batch": int(a["mpc"]["X"].shape[0]), "nodes": int(a["mpc"]["X"].shape[1] - 1)}
+    sa, sb = a["mpc"]["stats"], b["mpc"]["stats"]
+    rep["step_metrics_rel"] = {n: float((np.abs(sa[:, c] - sb[:, c]) / np.maximum(1e-12, np.abs(sa[:, c])))[same_alpha].max()) for c, n in ((0, "merit0"), (1, "violation0"), (2, "merit1"), (3, "violation1"))}
     for key, x, y in (("X", a["mpc"]["X"], b["mpc"]["X"]), ("U", a["mpc"]["U"], b["mpc"]["U"]), ("tau", a["wbc"]["out"][:, 36:], b["wbc"]["out"][:, 36:])):
         d = rel_inf(x, y)
         ds = rel_inf(x[same_alpha], y[same_alpha]) if same_alpha.any() else d

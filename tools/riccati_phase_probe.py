@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from qm_door_amd import abi, build
 LIB = os.path.join(ROOT, "qm_door_amd", "build", "ticks", "libqmgpu_ticks.so")
-SLOTS = ["issue", "P1", "bar1", "P2", "bar2", "P3|P6a+gains", "commit", "bar3", "P6b", "bar4", "symm", "bar5", "tail", "forward"]
+SLOTS = ["issue", "P1", "bar1", "P2", "bar2", "P3|P6a+gains", "commit", "bar3", "P6b", "bar4", "symm", "bar5", "tail", "fwd-tail", "F:top", "F:K.dx | issue", "F:sync | work", "F:B.du | commit", "F:barrier"]
 
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -27,7 +27,7 @@ mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int
 for _ in range(3): sol.mpc(mb.args)
 lib = sol.lib
 lib.qmgpu_debug_riccati_ticks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 assert lib.qmgpu_debug_riccati_ticks(buf, 1) == 0
 sol.enable_timing(True)
 R = 10
@@ -35,11 +35,11 @@ for _ in range(R): sol.mpc(mb.args)
 torch.cuda.synchronize()
 ms = sol.kernel_ms_mean(R)
 assert lib.qmgpu_debug_riccati_ticks(buf, 0) == 0
-t = np.array(buf[:], dtype=np.float64).reshape(4, 16) / R
-tot = t[0, :14].sum()
+t = np.array(buf[:], dtype=np.float64).reshape(4, 32) / R
+tot = t[0, :24].sum()
 print("riccati kernel ms (with clocks):", round(ms[2], 4), " ticks per launch, wavefront 0:", int(tot), " => ticks per ms:", round(tot / ms[2]))
 print("per backward stage (ticks / %d stages), by wavefront:" % N)
 for i, n in enumerate(SLOTS):
-    per = t[:, i] / (N if i < 12 else 1)
+    per = t[:, i] / (1 if i in (12, 13) else N)
     print("  %-14s" % n, "  ".join("%8.0f" % v for v in per))
-print(json.dumps({"kernel_ms": ms[2], "slots": SLOTS, "ticks": t[:, :14].tolist()}))
+print(json.dumps({"kernel_ms": ms[2], "slots": SLOTS, "ticks": t[:, :len(SLOTS)].tolist()}))
