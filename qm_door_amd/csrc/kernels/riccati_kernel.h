@@ -70,8 +70,8 @@ constexpr int R_KST = R_LT + 2 * LT_DOUBLES;        // the gains record [GAIN_DO
 constexpr int R_BWD_END = R_KST + 2 * GAIN_DOUBLES;
 static_assert(R_KST % 2 == 0 && GAIN_DOUBLES % 2 == 0, "16-byte copies");
 // forward sweep (over everything above, dead by then): a ring of three staging buffers [3][STG_F], then the B-operand images of dx and du~
-constexpr int FWD_XV = 32, FWD_UV = 32;               // dx [30] and du~ [MT] of one stage (padded)
-constexpr int F_XV = 3 * STG_F, F_UV = F_XV + 3 * FWD_XV, R_FWD_END = F_UV + 3 * FWD_UV;
+constexpr int FWD_ZV = 48;                             // z = [dx (30) | du~ (MT)] of one stage
+constexpr int F_ZV = 3 * STG_F, R_FWD_END = F_ZV + 3 * FWD_ZV;
 constexpr int R_SCR = R_BWD_END > R_FWD_END ? R_BWD_END : R_FWD_END;   // armijo reduction [64]
 constexpr int RICCATI_LDS_DOUBLES = R_SCR + 64;
 constexpr int RICCATI_LDS_BYTES = RICCATI_LDS_DOUBLES * int(sizeof(real));  // ~145 KiB at fp64 (dynamic LDS)
@@ -433,44 +433,59 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // The recursion  du~ = K dx + k,  dx+ = A~ dx + B~ du~ + b~  runs on wavefront 0 alone (a v_mfma_f64 holds a SIMD's matrix pipe for 64
   // cycles whatever its operands, so a matrix-vector product is cheaper as plain multiply-adds: each row's dot product is split over the
   // two halves of the wavefront and joined by one v_permlane32_swap); the hand-off du~ -> second product and dx+ -> next stage goes
-  // through LDS inside the wavefront, and the workgroup meets at ONE barrier per stage.  Everything off the chain runs one stage behind
-  // on the other wavefronts, from a ring of three staging buffers: wavefront 1 forms du = Pe + Px dx + Pu du~, wavefront 2 stores dx and
-  // accumulates the Armijo slope q~.dx + r~.du~, and wavefronts 1..3 stream the next stage's blocks and gains HBM -> registers -> LDS.
+  // through LDS inside the wavefront (z = [dx | du~], 48 numbers per stage), and the workgroup meets at ONE barrier per stage.
+  // Everything off the chain runs one stage behind, from rings of three buffers: wavefront 1 forms du = Pe + [Px | Pu] z with its rows
+  // of Px / Pu read straight from HBM into registers a stage ahead, wavefront 2 stores dx and accumulates the Armijo slope
+  // q~.dx + r~.du~, and wavefronts 2 and 3 stream A~, B~, b~, q~, r~ and the gains of the next stage HBM -> registers -> LDS.
   // All MT columns of B~ / Pu / K are multiplied: the producers pad with zeros (lq_node_kernel; riccatiGains).
-  constexpr int XV = FWD_XV, UV = FWD_UV;
+  constexpr int ZV = FWD_ZV;
+  constexpr int FWD_SMALL = OFF_PX - OFF_bt;          // b~ q~ r~ (+ padding)
+  static_assert(FWD_SMALL % 2 == 0 && OFF_PX % 2 == 0 && OFF_PU % 2 == 0, "16-byte units");
   constexpr int NPF = NTHR - 128;   // wavefronts 2 and 3 stream the blocks
-  constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_TAIL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
+  constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_SMALL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
+  constexpr int PFS = (FWD_SMALL / 2 + NTHR - 1) / NTHR;
   QM_TICK(12);
-  __syncthreads();   // full barrier: the gains written to HBM by wavefront 3 are read back below
+  __syncthreads();   // full barrier: the gains written to HBM above are read back below
   {
     StagePrefetch<PFH, NTHR> ph;
-    StagePrefetch<PFT, NTHR> pt;
+    StagePrefetch<PFS, NTHR> pt;
     StagePrefetch<PFG, NTHR> pg;
     ph.issue(stagesI, FWD_HEAD, tid);
-    pt.issue(stagesI + FWD_TAIL0, FWD_TAIL, tid);
+    pt.issue(stagesI + FWD_TAIL0, FWD_SMALL, tid);
     pg.issue(gainsI, GAIN_DOUBLES, tid);
-    for (int e = tid; e < 3 * XV + 3 * UV; e += NTHR) lds[F_XV + e] = 0.0_r;
+    for (int e = tid; e < 3 * ZV; e += NTHR) lds[F_ZV + e] = 0.0_r;
     ph.commit(lds + R_STG, FWD_HEAD, tid);
-    pt.commit(lds + R_STG + FWD_TAIL0, FWD_TAIL, tid);
+    pt.commit(lds + R_STG + FWD_TAIL0, FWD_SMALL, tid);
     pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
   __syncthreads();
-  if (tid < 30) lds[F_XV + tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
+  if (tid < 30) lds[F_ZV + tid] = a.x0[size_t(inst) * 30 + tid] - a.X[size_t(inst) * (N + 1) * 30 + tid];
   real armijo = 0.0_r;
   __syncthreads();
   const bool upper = lane >= 32;            // second half of the wavefront: the second half of every dot product
   const int rowl = lane & 31;               // row of a matrix-vector product handled by this lane
   const int rK = rowl < MT ? rowl : 0, rX = rowl < 30 ? rowl : 0;
   // the blocks of stage k + 1 are requested during iteration k - 1 and land in LDS during iteration k (an iteration is shorter than
-  // the HBM latency): the loads in flight live in registers of wavefronts 2 and 3 across the loop back-edge
+  // the HBM latency): the loads in flight live in registers across the loop back-edge
   StagePrefetch<PFH3, NPF> ph;
   StagePrefetch<PFT3, NPF> pt;
   StagePrefetch<PFG3, NPF> pg;
   if (wave >= 2 && N > 1) {
     ph.issue(stagesI + STAGE_DOUBLES, FWD_HEAD, tid - 128);
-    pt.issue(stagesI + STAGE_DOUBLES + FWD_TAIL0, FWD_TAIL, tid - 128);
+    pt.issue(stagesI + STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, tid - 128);
     pg.issue(gainsI + GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
   }
+  // wavefront 1: 24 numbers of row rX of [Px | Pu] per lane (lower half columns 0..23 of Px; upper half 24..29 of Px, then Pu) and Pe
+  QmD2 pr[12]; real pe = 0.0_r;
+  auto loadRows = [&](int stage) {
+    const real* rec = stagesI + size_t(stage) * STAGE_DOUBLES;
+    const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + OFF_PX + rX * 30 + (upper ? 24 : 0));
+    const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + OFF_PU + rX * MT);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pr[i] = (upper && i >= 3) ? p1[i - 3] : p0[i];
+    pe = rec[OFF_PE + rX];
+  };
+  if (wave == 1) loadRows(0);
 #pragma unroll 1
   for (int k = 0; k <= N; ++k) {   // iteration k: the chain does stage k (k < N), the others finish stage k - 1 and stage the blocks of k + 1
     const int sl = k % 3, slPrev = (k + 2) % 3, slNext = (k + 1) % 3;
@@ -478,39 +493,39 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     if (wave == 0) {
       if (k < N) {
         const real* stg = lds + R_STG + sl * STG_F; const real* gn = stg + STAGE_DOUBLES;
-        const real* xv = lds + F_XV + sl * XV; real* uv = lds + F_UV + sl * UV; real* xvNext = lds + F_XV + slNext * XV;
+        real* zv = lds + F_ZV + sl * ZV; real* zvNext = lds + F_ZV + slNext * ZV;
         // du~ = K dx + k: columns 0..14 on the lower half, 15..29 on the upper half
         const real* Krow = gn + OFF_KFB + rK * 30 + (upper ? 15 : 0);
-        const real* xh = xv + (upper ? 15 : 0);
+        const real* xh = zv + (upper ? 15 : 0);
         real s0 = upper ? 0.0_r : gn[OFF_kff + rK], s1 = 0.0_r;
 #pragma unroll
         for (int c = 0; c < 14; c += 2) { s0 += Krow[c] * xh[c]; s1 += Krow[c + 1] * xh[c + 1]; }
         s0 += Krow[14] * xh[14];
-        // the part of dx+ that needs no du~: A~ columns 0..24 on the lower half, 25..29 and b~ on the upper half
-        const real* Arow = stg + OFF_AT + rX * 30;
+        // dx+ = [A~ | B~] z + b~: columns 0..23 of A~ on the lower half; 24..29 of A~, then B~, and b~ on the upper half
+        const real* Arow = stg + OFF_AT + rX * 30 + (upper ? 24 : 0);
+        const real* zh = zv + (upper ? 24 : 0);
         real t0 = upper ? stg[OFF_bt + rX] : 0.0_r, t1 = 0.0_r;
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) { t0 += Arow[c] * zh[c]; t1 += Arow[c + 1] * zh[c + 1]; }      // needs no du~ on either half
         if (!upper) {
 #pragma unroll
-          for (int c = 0; c < 24; c += 2) { t0 += Arow[c] * xv[c]; t1 += Arow[c + 1] * xv[c + 1]; }
-          t0 += Arow[24] * xv[24];
-        } else {
-#pragma unroll
-          for (int c = 25; c < 30; ++c) t0 += Arow[c] * xv[c];
+          for (int c = 6; c < 24; c += 2) { t0 += Arow[c] * zh[c]; t1 += Arow[c + 1] * zh[c + 1]; }
         }
         const real sd = s0 + s1;
         const real du = sd + qmHalfXor32(sd, upper);
         QM_TICK(15);
-        if (lane < MT) uv[lane] = du;
+        if (lane < MT) zv[30 + lane] = du;
         QM_WAVE_SYNC();
         QM_TICK(16);
         if (upper) {    // B~ du~ on the upper half (18 columns)
           const real* Brow = stg + OFF_BT + rX * MT;
+          const real* uh = zv + 30;
 #pragma unroll
-          for (int j = 0; j < MT; j += 2) { t0 += Brow[j] * uv[j]; t1 += Brow[j + 1] * uv[j + 1]; }
+          for (int j = 0; j < MT; j += 2) { t0 += Brow[j] * uh[j]; t1 += Brow[j + 1] * uh[j + 1]; }
         }
         const real td = t0 + t1;
         const real nx = td + qmHalfXor32(td, upper);
-        if (lane < 30) xvNext[lane] = nx;
+        if (lane < 30) zvNext[lane] = nx;
       }
     } else {
       QM_TICK(15);
@@ -518,12 +533,12 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         if (k + 1 < N) {
           real* dst = lds + R_STG + slNext * STG_F;
           ph.commit(dst, FWD_HEAD, tid - 128);
-          pt.commit(dst + FWD_TAIL0, FWD_TAIL, tid - 128);
+          pt.commit(dst + FWD_TAIL0, FWD_SMALL, tid - 128);
           pg.commit(dst + STAGE_DOUBLES, GAIN_DOUBLES, tid - 128);
         }
         if (k + 2 < N) {
           ph.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES, FWD_HEAD, tid - 128);
-          pt.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES + FWD_TAIL0, FWD_TAIL, tid - 128);
+          pt.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, tid - 128);
           pg.issue(gainsI + size_t(k + 2) * GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
         }
       }
@@ -531,31 +546,23 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       if (k > 0) {
         const int j = k - 1;
         const real* stg = lds + R_STG + slPrev * STG_F;
-        const real* xv = lds + F_XV + slPrev * XV; const real* uv = lds + F_UV + slPrev * UV;
-        if (wave == 1) {   // du = Pe + Px dx + Pu du~: Px columns 0..24 on the lower half; Px 25..29, Pu and Pe on the upper half
-          const real* Prow = stg + OFF_PX + rX * 30;
-          real t0 = upper ? stg[OFF_PE + rX] : 0.0_r, t1 = 0.0_r;
-          if (!upper) {
+        const real* zv = lds + F_ZV + slPrev * ZV;
+        if (wave == 1) {   // du = Pe + [Px | Pu] z from the rows in registers; then the rows of the next stage are requested
+          const real* zh = zv + (upper ? 24 : 0);
+          real t0 = upper ? pe : 0.0_r, t1 = 0.0_r;
 #pragma unroll
-            for (int c = 0; c < 24; c += 2) { t0 += Prow[c] * xv[c]; t1 += Prow[c + 1] * xv[c + 1]; }
-            t0 += Prow[24] * xv[24];
-          } else {
-            const real* Urow = stg + OFF_PU + rX * MT;
-#pragma unroll
-            for (int c = 25; c < 30; ++c) t0 += Prow[c] * xv[c];
-#pragma unroll
-            for (int q = 0; q < MT; q += 2) { t0 += Urow[q] * uv[q]; t1 += Urow[q + 1] * uv[q + 1]; }
-          }
+          for (int i = 0; i < 12; ++i) { t0 += pr[i].x * zh[2 * i]; t1 += pr[i].y * zh[2 * i + 1]; }
           const real td = t0 + t1;
           const real duo = td + qmHalfXor32(td, upper);
           if (lane < 30) a.dU[(size_t(inst) * N + j) * 30 + lane] = duo;
+          if (k < N) loadRows(k);
         } else if (wave == 2) {   // dx out; Armijo slope q~ . dx + r~ . du~
           if (lane < 30) {
-            const real dxl = xv[lane];
+            const real dxl = zv[lane];
             a.dX[(size_t(inst) * (N + 1) + j) * 30 + lane] = dxl;
             armijo += stg[OFF_qt + lane] * dxl;
           } else if (lane >= 32 && lane < 32 + MT) {
-            armijo += stg[OFF_rt + (lane - 32)] * uv[lane - 32];     // rows >= m~ of du~ and of r~ are zero
+            armijo += stg[OFF_rt + (lane - 32)] * zv[30 + lane - 32];     // rows >= m~ of du~ and of r~ are zero
           }
         }
       }
@@ -567,7 +574,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   QM_TICK(13);
   QM_TICK_FLUSH;
   if (wave == 2 && lane < 30) {   // terminal node: dx_N sits in slot N % 3
-    const real dxl = lds[F_XV + (N % 3) * XV + lane];
+    const real dxl = lds[F_ZV + (N % 3) * ZV + lane];
     a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxl;
     armijo += stagesI[size_t(N) * STAGE_DOUBLES + OFF_qt + lane] * dxl;
   }
