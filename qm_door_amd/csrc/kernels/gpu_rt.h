@@ -116,6 +116,18 @@ using qmk::QmAcc; using qmk::QmD2; using qmk::QmGather;
 #define QM_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 // scheduling fence: keeps the compiler from hoisting a long run of v_readlane broadcasts (two SGPRs each) ahead of their uses
 #define QM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Phase clocks of the profiling build (-DQM_RICCATI_TIMING, tools/riccati_phase_probe.py): s_memtime deltas summed per slot in (scalar)
+// registers, written once at the end into a device symbol.  The product build compiles every QM_TICK to nothing.
+#ifdef QM_RICCATI_TIMING
+namespace qmk { __device__ unsigned long long qmRiccatiTicks[256]; }
+#define QM_TICK_DECL unsigned long long qmT = clock64(), qmTs[24] = {}
+#define QM_TICK(slot) do { const unsigned long long n_ = clock64(); qmTs[slot] += n_ - qmT; qmT = n_; } while (0)
+#define QM_TICK_FLUSH(base, cond) do { if (cond) for (int i_ = 0; i_ < 24; ++i_) qmk::qmRiccatiTicks[(base) + i_] += qmTs[i_]; } while (0)
+#else
+#define QM_TICK_DECL
+#define QM_TICK(slot)
+#define QM_TICK_FLUSH(base, cond)
+#endif
 // a per-lane integer the optimiser cannot see through: values derived from it (the lane == k ? 1 : 0 seeds of the AD sweep) are not
 // hoisted out of the loop it is refreshed in
 __device__ __forceinline__ int qmOpaqueLane(int v) { asm volatile("" : "+v"(v)); return v; }

@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   real* fin = bv + 84; real* pev = fin + 64; real* fb = pev + 12; real* ddp = fb + 36; real* ddv = ddp + 6;
   real* red = lds + L_RED;
 
+  QM_TICK_DECL;
   const real* tg = a.tgrid + size_t(inst) * (a.N + 1);
   const real t = tg[node];
   const real dt = a.dtgrid[size_t(inst) * (a.N + 1) + node];
@@ -97,6 +98,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const bool ftOn = a.eeContact && !terminal;
   const real Ke = ftOn ? st.ee_contact_stiffness : 0.0_r, muF = ftOn ? st.ee_force_mu : 0.0_r;
 
+  QM_TICK(0);
   // ---- rows of the AD sweep (ad_node_kernel)
   const real* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
   int nc = 0;
@@ -123,7 +125,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
 
+#ifdef QM_LQ_SAMEREC   // timing experiment only: every node writes the same record (no HBM write traffic)
+  real* rec = a.stages + size_t(blockIdx.x & 255) * STAGE_DOUBLES;
+#else
   real* rec = a.stages + (size_t(inst) * (a.N + 1) + node) * STAGE_DOUBLES;
+#endif
   real* dbg = a.debug ? a.debug + (size_t(inst) * (a.N + 1) + node) * DBG_DOUBLES : nullptr;
   int tIdx; real tAlpha;
   timeSegment(tTimes, a.K, t, tIdx, tAlpha);
@@ -136,6 +142,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   real qc = 0.0_r, costPart = 0.0_r;
   const real sc = terminal ? 1.0_r : dt;  // intermediate costs are scaled by dt, the terminal cost is not
 
+  QM_TICK(1);
   // ---- state cost, gradient entry c (lanes < 30): tracking + EE soft constraint (Gauss-Newton) + arm joint position soft box.
   //      The Hessian is never formed column-wise: qEntry(i, j) below assembles single entries where they are needed.
   {
@@ -199,6 +206,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     return;
   }
 
+  QM_TICK(2);
   // ---- Jacobian of the RK2 map Phi = x + dt/2 (k1 + k2): rows 12.. are x_j + dt v_j exactly, so only the twelve momentum /
   //      base-pose rows of [A | B] are dense (phid).
   if (dbg && c < 60) {
@@ -208,6 +216,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int i = 0; i < 12; ++i) bv[i] = x[i] + phiv[i] - xnext[i];
     for (int j = 0; j < 18; ++j) bv[12 + j] = x[12 + j] + dt * u[12 + j] - xnext[12 + j];
   }
+  QM_TICK(3);
   // ---- input cost: R' + friction-cone and arm-velocity barriers.  Lane c < 30 forms the gradient entry c and the barrier terms
   //      of its column; the terms go to LDS (fb: four 3x3 friction blocks, ddv: arm-velocity diagonal), R' itself stays in HBM / L1.
   {
@@ -284,6 +293,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int i = 0; i < nc; ++i) eqSq += ev[i] * ev[i];
   }
 
+  QM_TICK(4);
   // ================================================================== projection: QR of the velocity block of D^T (18 x nv)
   // The constraint set of the reference (QMInterface.cpp:116-131) has a fixed structure: a zero-force row is a unit vector on one
   // force input (C = 0), a zero-velocity / normal-velocity row depends on the inputs only through the 18 joint velocities.  So
@@ -323,6 +333,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
   }
+  QM_TICK(5);
   // Pall operand of the matrix cores, element (k, j) with k = 4 ks + h (this lane's row of k step ks) and j = 16 tq + l16:
   // rows k < 12 (force inputs, k steps 0..2) are synthesised -- Pe = pinned swing force in column 30, a unit entry in the Pu column
   // of a free stance force --, rows 12..29 come from LDS, rows 30 and 31 are zero.
@@ -459,6 +470,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
   QM_WAVE_SYNC();   // Pall complete; Q_v / Y (region X) are dead
+  QM_TICK(6);
   // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
 #pragma unroll
   for (int i = 12; i < 30; ++i) {
@@ -476,6 +488,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   QM_WAVE_SYNC();
 
+  QM_TICK(7);
   // ================================================================== products on the fp64 matrix cores
   // (1) rows 0..11 of [A~ | b~ | B~] = [A | b | 0] + B Pall
   const int nTn = nt > 16 ? 4 : 3;   // 16-column tiles of Pall in use
@@ -520,6 +533,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   if (dbg && c < 30) { for (int i = 0; i < 30; ++i) dbg[DBG_Q + i * 30 + c] = sc * qEntry(i, c); dbg[DBG_q + c] = qc; }
 
+  QM_TICK(8);
   // (2) W = R Pall and (3) G = Pall^T W, [Q~ | P~^T; P~ | R~] = [Q | 0; 0 | 0] + G, one 16-column tile of W at a time: the tile goes
   // through LDS (accumulator layout -> operand layout) and is consumed by the tiles (tm, tn) of G that the record needs:
   //   tn = 0, 1: tm = 0, 1 (state block, row 30 carries Pe^T R Px), 2 and 3 (P~; tm = 3 only when m~ > 16)
@@ -595,12 +609,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   QM_WAVE_SYNC();
   if (isX) rec[OFF_qt + lane] = qc + fin[lane];
   else if (isU) rec[OFF_rt + (lane - 32)] = fin[lane];
+  QM_TICK(9);
   // zero padding of B~, Pu (above) and r~ beyond m~ columns: the forward sweep of riccati_kernel multiplies whole MT-wide rows
   // (P~, R~ keep undefined padding: their consumer masks by m~)
   if (nt < MT) {
     if (lane >= 32 + nt && lane < 32 + MT) rec[OFF_rt + (lane - 32)] = 0.0_r;
     if (lane < 48) { const int i = lane >> 2, jj = nt + (lane & 3); if (jj < MT) rec[OFF_BT + i * MT + jj] = 0.0_r; }        // rows 0..11 of B~
   }
+  QM_TICK(10);
+  QM_TICK_FLUSH(128, blockIdx.x == 7);
 }
 
 }  // namespace qmk

@@ -40,19 +40,7 @@ struct RiccatiArgs {
 };
 
 constexpr int RICCATI_WAVES = 4;
-// Phase clock of the profiling build (tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING): s_memtime deltas of workgroup 0 summed per phase
-// and wavefront into a device symbol.  The product build compiles every QM_TICK to nothing.
-#ifdef QM_RICCATI_TIMING
-__device__ unsigned long long qmRiccatiTicks[4 * 32];
-// sums kept in (scalar) registers, written once at the end: a read-modify-write of global memory per tick costs ~300 cycles
-#define QM_TICK_DECL unsigned long long qmT = clock64(), qmTs[24] = {}
-#define QM_TICK(slot) do { const unsigned long long n_ = clock64(); qmTs[slot] += n_ - qmT; qmT = n_; } while (0)
-#define QM_TICK_FLUSH do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 24; ++i_) qmRiccatiTicks[(threadIdx.x >> 6) * 32 + i_] += qmTs[i_]; } while (0)
-#else
-#define QM_TICK_DECL
-#define QM_TICK(slot)
-#define QM_TICK_FLUSH
-#endif
+// Phase clocks of the profiling build: QM_TICK* (gpu_rt.h; tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING).  Nothing in the product build.
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
 constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 20;
 constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
@@ -572,7 +560,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QM_TICK(18);
   }
   QM_TICK(13);
-  QM_TICK_FLUSH;
+  QM_TICK_FLUSH((threadIdx.x >> 6) * 32, blockIdx.x == 0 && (threadIdx.x & 63) == 0);
   if (wave == 2 && lane < 30) {   // terminal node: dx_N sits in slot N % 3
     const real dxl = lds[F_ZV + (N % 3) * ZV + lane];
     a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxl;

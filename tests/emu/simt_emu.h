@@ -33,6 +33,9 @@ inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one p
 // arithmetic (a zero-padded tile operand, say) turns the results into NaN instead of passing by luck
 #define QM_POISON_LDS(ptr, count) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < int(count); ++i_) (ptr)[i_] = std::numeric_limits<qmk::real>::quiet_NaN(); __syncthreads(); } while (0)
 inline int qmOpaqueLane(int v) { return v; }
+#define QM_TICK_DECL
+#define QM_TICK(slot)
+#define QM_TICK_FLUSH(base, cond)
 #define QM_SCHED_FENCE()
 #define QM_LDS_BARRIER() __syncthreads()
 #define __device__

@@ -13,7 +13,7 @@ SLOTS = ["issue", "P1", "bar1", "P2", "bar2", "P3|P6a+gains", "commit", "bar3", 
 
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    print(build.build_library(force=True, extra_flags=("-DQM_RICCATI_TIMING",), out=LIB, obj_dir=os.path.dirname(LIB)))
+    print(build.build_library(force=True, extra_flags=("-DQM_RICCATI_TIMING",) + tuple(f for f in sys.argv if f.startswith("-D")), out=LIB, obj_dir=os.path.dirname(LIB)))
     sys.exit(0)
 
 abi.LIB_PATH = LIB
@@ -27,7 +27,7 @@ mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int
 for _ in range(3): sol.mpc(mb.args)
 lib = sol.lib
 lib.qmgpu_debug_riccati_ticks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * 128)()
+buf = (C.c_ulonglong * 256)()
 assert lib.qmgpu_debug_riccati_ticks(buf, 1) == 0
 sol.enable_timing(True)
 R = 10
@@ -35,7 +35,8 @@ for _ in range(R): sol.mpc(mb.args)
 torch.cuda.synchronize()
 ms = sol.kernel_ms_mean(R)
 assert lib.qmgpu_debug_riccati_ticks(buf, 0) == 0
-t = np.array(buf[:], dtype=np.float64).reshape(4, 32) / R
+raw = np.array(buf[:], dtype=np.float64) / R
+t = raw[:128].reshape(4, 32)
 tot = t[0, :24].sum()
 print("riccati kernel ms (with clocks):", round(ms[2], 4), " ticks per launch, wavefront 0:", int(tot), " => ticks per ms:", round(tot / ms[2]))
 print("per backward stage (ticks / %d stages), by wavefront:" % N)
@@ -43,3 +44,8 @@ for i, n in enumerate(SLOTS):
     per = t[:, i] / (1 if i in (12, 13) else N)
     print("  %-14s" % n, "  ".join("%8.0f" % v for v in per))
 print(json.dumps({"kernel_ms": ms[2], "slots": SLOTS, "ticks": t[:, :len(SLOTS)].tolist()}))
+
+LQ = ["inputs", "AD rows", "state cost", "flow-map Jacobian", "input cost", "QR projection", "Pall", "A~ B~ joint rows / transposes", "products (1)", "products (2)(3)", "padding / end"]
+lq = raw[128:128 + len(LQ)]
+print("lq_node_kernel, node 7 of instance 0 (two wavefronts share the SIMD): ticks per section, total", int(lq.sum()), " kernel ms", round(ms[1], 4))
+for n, v in zip(LQ, lq): print("  %-34s %8.0f  %4.1f %%" % (n, v, 100 * v / lq.sum()))
