@@ -54,6 +54,24 @@ __device__ __forceinline__ double qmRsqrtPos(double x) {
   return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
 }
 __device__ __forceinline__ float qmRsqrtPos(float x) { return __builtin_amdgcn_rsqf(x); }
+// acc += (bc of lane R of this lane's row of 16 lanes) * m in ONE instruction (DPP row_newbcast, legal on 64-bit operands since gfx90a):
+// the multiplier broadcast of a row operation without the v_readlane pair + wait state + separate multiply-add.  FIRST puts the two wait
+// states a DPP source needs after a VALU write in front (the hazard recogniser does not look into inline assembly).
+template <int R, bool FIRST> __device__ __forceinline__ void qmFmacRowBcast(double& acc, double bc, double m, double* = nullptr) {
+  if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
+}
+template <int R, bool FIRST> __device__ __forceinline__ void qmFmacRowBcast(float& acc, float bc, float m, float* = nullptr) {
+  if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
+  else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
+}
+// the value of lane (lane & 15) in every lane: lanes 0..15 replicated into the other three rows (ds_bpermute: the LDS crossbar, no LDS memory)
+__device__ __forceinline__ real qmReplicateRow0(real v, real* = nullptr) {
+  const int addr = (int(threadIdx.x) & 15) * 4;
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, qmLoWord(v));
+  const int hi = sizeof(real) == 8 ? __builtin_amdgcn_ds_bpermute(addr, qmHiWord(v)) : 0;
+  return qmFromWords(lo, hi, real());
+}
 // keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
 // into the select that consumes it and pays the LDS latency once per branch)
 #define QM_KEEP(x) asm volatile("" : "+v"(x))

@@ -42,7 +42,7 @@ struct RiccatiArgs {
 constexpr int RICCATI_WAVES = 4;
 // Phase clocks of the profiling build: QM_TICK* (gpu_rt.h; tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING).  Nothing in the product build.
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
-constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 20;
+constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 18;   // LDS_LL: 16 lanes writing 16 bytes each at this row stride (144 B) hit 64 distinct banks
 constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
 constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
 constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
@@ -93,9 +93,46 @@ template <int PF, int NTHR> struct StagePrefetch {
 
 // P3: rows 0..NT-1 of [H | G g] (T, one column per lane: lanes < MT the columns of H, lanes MT..MT+30 those of [G | g]) -> L (row c written by
 // lane c, 1 / L_cc on the diagonal) and W = L^-1 [G | g].  nt <= NT is the number of real pivots; rows / columns nt..NT-1 are identity.
-template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T, real* W, real* LL, int nt, int lane, int& status, real* scr) {
+// One elimination step, written as a template recursion so that the DPP controls are immediates.  Multipliers L[r][J] = (scaled row J)
+// at lane r: rows J + 1 (on the pivot chain) and J + 2 take them by v_readlane, rows J + 3 .. 15 by DPP row_newbcast from a copy of the
+// row's lanes 0..15 replicated into the four rows of 16 lanes -- ONE v_fmac_f64_dpp per row update instead of two v_readlane, a wait
+// state and the multiply-add -- applied one step late so that the replication's round trip through the LDS crossbar is off the chain;
+// rows 16, 17 (m~ > 16) by v_readlane.  Row updates of one row commute, so the order does not matter.
+template <int J, int R, int REND> struct RiccatiDppRows {
+  static __device__ __forceinline__ void run(real* col, real bc, real nc, real* scr) {
+    if constexpr (R < REND) { qmFmacRowBcast<R, R == J + 3>(col[R], bc, nc, scr); RiccatiDppRows<J, R + 1, REND>::run(col, bc, nc, scr); }
+  }
+};
+template <int NT, int J> struct RiccatiStep {
+  static constexpr int DEND = NT < 16 ? NT : 16;    // DPP rows end here
+  static __device__ __forceinline__ void run(real* col, real& inv, real& mine, real& bcP, real& ncP, int c, int& status, real* scr) {
+    if constexpr (J < NT) {
+      col[J] *= inv;                                     // row J of [L^T | W] / sqrt(pivot)
+      mine = c == J ? inv : mine;
+      const QmGather gj = qmGather(col[J], scr);
+      if constexpr (J + 1 < NT) {
+        col[J + 1] -= gj.get(J + 1) * col[J];
+        const real piv = qmReadLane(col[J + 1], J + 1, scr);
+        const bool ok = piv > REAL_PIVOT_MIN;
+        if (!ok) status = 1;
+        inv = qmRsqrtPos(ok ? piv : 1.0_r);              // started here: its latency hides behind the remaining updates
+      }
+      if constexpr (J + 2 < NT) col[J + 2] -= gj.get(J + 2) * col[J];
+      if constexpr (J >= 1) RiccatiDppRows<J - 1, J + 2, DEND>::run(col, bcP, ncP, scr);     // the previous step's rows J + 2 .. 15
+#pragma unroll
+      for (int r = (J + 3 > 16 ? J + 3 : 16); r < NT; ++r) col[r] -= gj.get(r) * col[J];
+      if constexpr (J + 3 < DEND) { bcP = qmReplicateRow0(col[J], scr); ncP = -col[J]; }
+      RiccatiStep<NT, J + 1>::run(col, inv, mine, bcP, ncP, c, status, scr);
+    }
+  }
+};
+
+template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T, real* W, real* LL, int nt, int lane, int& status, real* scr, unsigned long long* tk = nullptr) {
   const bool isH = lane < MT, isG = lane >= MT && lane < MT + 31;
   const int c = isH ? lane : (isG ? lane - MT : 0);
+#ifdef QM_RICCATI_TIMING
+  const unsigned long long tqA = clock64();
+#endif
   real col[NT];
 #pragma unroll
   for (int r = 0; r < NT; ++r) col[r] = T[r * LDS_Y + (isH ? 32 + c : c)];
@@ -107,45 +144,43 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
     const real e = (isH && r == c) ? 1.0_r : 0.0_r;
     col[r] = (live && r < nt) ? col[r] : e;
   }
-  // steps j >= nt meet identity columns (pivot 1, multipliers 0): no branch, one basic block.  The reciprocal square root of
-  // pivot j + 1 is started right after row j + 1 has received its update, so its latency hides behind the remaining updates.
-  real inv, mine = 1.0_r;
+#ifdef QM_RICCATI_TIMING
+  const unsigned long long tq0 = clock64();
+#endif
+  // steps j >= nt meet identity columns (pivot 1, multipliers 0): no branch, one basic block
+  real inv, mine = 1.0_r, bcP = 0.0_r, ncP = 0.0_r;
   {
     const real piv = qmReadLane(col[0], 0, scr);
     const bool ok = piv > REAL_PIVOT_MIN;
     if (!ok) status = 1;
     inv = qmRsqrtPos(ok ? piv : 1.0_r);
   }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    col[j] *= inv;                                     // row j of [L^T | W] / sqrt(pivot)
-    mine = c == j ? inv : mine;
-    const QmGather gj = qmGather(col[j], scr);
-    if (j + 1 < NT) {
-      col[j + 1] -= gj.get(j + 1) * col[j];
-      const real piv = qmReadLane(col[j + 1], j + 1, scr);
-      const bool ok = piv > REAL_PIVOT_MIN;
-      if (!ok) status = 1;
-      inv = qmRsqrtPos(ok ? piv : 1.0_r);
-    }
-#pragma unroll
-    for (int r = j + 2; r < NT; ++r) col[r] -= gj.get(r) * col[j];   // L[r][j] = gj.get(r) (zero for r >= nt: identity columns)
-  }
+  RiccatiStep<NT, 0>::run(col, inv, mine, bcP, ncP, c, status, scr);
+#ifdef QM_RICCATI_TIMING
+  { real keep_ = col[NT - 1]; QM_KEEP(keep_); col[NT - 1] = keep_; }
+  const unsigned long long tq1 = clock64();
+  tk[0] += tq0 - tqA; tk[1] += tq1 - tq0;
+#endif
   if (isH) {
     // lane c holds column c of L^T = row c of L in col[0..c]; entries right of the diagonal are elimination residue and never read
-#pragma unroll
-    for (int r = 0; r < NT; ++r) if (r == c) col[r] = mine;
 #pragma unroll
     for (int r = 0; r + 1 < NT; r += 2) { QmD2 v; v.x = col[r]; v.y = col[r + 1]; *reinterpret_cast<QmD2*>(LL + c * LDS_LL + r) = v; }
     if (NT & 1) LL[c * LDS_LL + NT - 1] = col[NT - 1];
 #pragma unroll
-    for (int r = NT; r < MT; ++r) LL[c * LDS_LL + r] = r == c ? 1.0_r : 0.0_r;   // identity rows / columns beyond the unrolled size
+    for (int r = NT; r < MT; ++r) LL[c * LDS_LL + r] = 0.0_r;                     // identity rows / columns beyond the unrolled size
+
   } else if (isG) {
 #pragma unroll
     for (int r = 0; r < NT; ++r) W[r * LDS_W + c] = col[r];          // rows >= nt are exactly zero
 #pragma unroll
     for (int r = NT; r < MT; ++r) W[r * LDS_W + c] = 0.0_r;          // (the buffer may hold a stage with more inputs)
   }
+  QM_WAVE_SYNC();
+  if (isH) LL[c * LDS_LL + c] = mine;   // the diagonal slot: 1 / L_cc (1 for an identity row), after the row itself (LDS writes of one wavefront complete in order)
+#ifdef QM_RICCATI_TIMING
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  tk[2] += clock64() - tq1;
+#endif
 }
 
 // [K | k] = -L^-T W of one stage by back-substitution, one column of [K | k] per lane (31 lanes of one wavefront), in the axpy order:
@@ -182,6 +217,11 @@ __device__ __forceinline__ void riccatiGainsOut(const real* kst, real* gain, int
   for (int i = 0; i < (GAIN_DOUBLES / 2 + 127) / 128; ++i) { const int idx = t + 128 * i; if (idx < GAIN_DOUBLES / 2) dst[idx] = src[idx]; }
 }
 
+#ifdef QM_RICCATI_TIMING
+#define QM_TK , qmTs + 19
+#else
+#define QM_TK
+#endif
 template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIMD riccati_kernel(RiccatiArgs a) {
   static_assert(NW == 4, "tile ownership below is written for four wavefronts");
   QM_DYNAMIC_LDS(lds);
@@ -326,12 +366,14 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QmAcc c6, d6;
     if (wave == 0) {
       // the elimination is unrolled for the stage's number of projected inputs: 18 stance, 17 three-leg support, 16 trot, 14 flight
+      __builtin_amdgcn_s_setprio(3);    // the wavefront on the critical path of the stage goes first at the shared units (LDS)
       switch (nt) {
-        case 16: riccatiFactorise<16>(T, W, LL, nt, lane, status, scr); break;
-        case 14: riccatiFactorise<14>(T, W, LL, nt, lane, status, scr); break;
-        case 17: riccatiFactorise<17>(T, W, LL, nt, lane, status, scr); break;
-        default: riccatiFactorise<MT>(T, W, LL, nt, lane, status, scr); break;
+        case 16: riccatiFactorise<16>(T, W, LL, nt, lane, status, scr QM_TK); break;
+        case 14: riccatiFactorise<14>(T, W, LL, nt, lane, status, scr QM_TK); break;
+        case 17: riccatiFactorise<17>(T, W, LL, nt, lane, status, scr QM_TK); break;
+        default: riccatiFactorise<MT>(T, W, LL, nt, lane, status, scr QM_TK); break;
       }
+      __builtin_amdgcn_s_setprio(0);
     } else {
       // the next stage's blocks HBM -> registers -> LDS by the three wavefronts that are off the critical path here; the other
       // staging buffer was last read before the final barrier of the previous stage

@@ -33,6 +33,7 @@ inline std::vector<std::unique_ptr<std::barrier<>>> g_emuWaveBarriers;  // one p
 // arithmetic (a zero-padded tile operand, say) turns the results into NaN instead of passing by luck
 #define QM_POISON_LDS(ptr, count) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < int(count); ++i_) (ptr)[i_] = std::numeric_limits<qmk::real>::quiet_NaN(); __syncthreads(); } while (0)
 inline int qmOpaqueLane(int v) { return v; }
+inline void __builtin_amdgcn_s_setprio(int) {}
 #define QM_TICK_DECL
 #define QM_TICK(slot)
 #define QM_TICK_FLUSH(base, cond)
@@ -73,6 +74,20 @@ template <class T> inline T qmShflXor(T v, int mask, T* scratch = nullptr) {
   return T(buf[lane ^ unsigned(mask)]);
 }
 
+template <int R, bool FIRST, class T> inline void qmFmacRowBcast(T& acc, T bc, T m, T* = nullptr) {   // v_fmac_*_dpp row_newbcast:R
+  const unsigned lane = threadIdx.x & 63u;
+  double* buf = emuXchgBuf(nullptr);
+  buf[lane] = double(bc);
+  QM_WAVE_SYNC();
+  acc += T(buf[(lane & ~15u) + unsigned(R)]) * m;
+}
+template <class T> inline T qmReplicateRow0(T v, T* = nullptr) {   // ds_bpermute with address lane & 15
+  const unsigned lane = threadIdx.x & 63u;
+  double* buf = emuXchgBuf(nullptr);
+  buf[lane] = double(v);
+  QM_WAVE_SYNC();
+  return T(buf[lane & 15u]);
+}
 template <class T> inline T qmHalfXor32(T v, bool) { return qmShflXor(v, 32); }   // v_permlane32_swap
 template <class T> inline T qmRowXor16(T v, bool) { return qmShflXor(v, 16); }    // v_permlane16_swap
 

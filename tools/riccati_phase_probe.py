@@ -43,6 +43,7 @@ print("per backward stage (ticks / %d stages), by wavefront:" % N)
 for i, n in enumerate(SLOTS):
     per = t[:, i] / (1 if i in (12, 13) else N)
     print("  %-14s" % n, "  ".join("%8.0f" % v for v in per))
+print("factorisation (wavefront 0): load columns %d, elimination loop %d, store L / W %d ticks per stage" % (raw[19] / N, raw[20] / N, raw[21] / N))
 print(json.dumps({"kernel_ms": ms[2], "slots": SLOTS, "ticks": t[:, :len(SLOTS)].tolist()}))
 
 LQ = ["inputs", "AD rows", "state cost", "flow-map Jacobian", "input cost", "QR projection", "Pall", "A~ B~ joint rows / transposes", "products (1)", "products (2)(3)", "padding / end"]

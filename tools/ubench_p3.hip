@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cmath>
 #include <vector>
+#include <utility>
 constexpr int MT = 18, NG = 31, LDS_Y = 80, LDS_W = 48, REPS = 50;
 __device__ __forceinline__ double rl(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -16,6 +17,18 @@ __device__ __forceinline__ double fastRsqrt(double x) {     // v_rsq_f64 + one t
 }
 __device__ __forceinline__ long long tick(double& a) { long long t; asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a)); return t; }
 
+template <int R, bool FIRST> __device__ __forceinline__ void fmacRowBcast(double& acc, double bc, double m) {   // acc += bc[lane r of my row of 16] * m
+  if (FIRST) asm volatile("s_nop 1\n v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
+}
+__device__ __forceinline__ double replicateRow0(double v, int addr) {   // value of lane (lane & 15), in every lane
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+template <int J, int R, int NT> struct RowUpd {
+  static __device__ __forceinline__ void run(double* col, double bc, double ncj) {
+    if constexpr (R < NT && R < 16) { fmacRowBcast<R, R == J + 2>(col[R], bc, ncj); RowUpd<J, R + 1, NT>::run(col, bc, ncj); }
+  }
+};
 // V = 0: readlane multipliers + ocml rsqrt (the kernel today); 1: readlane + fast rsqrt; 2: LDS broadcast multipliers + fast rsqrt
 // NT = compile-time number of pivots (rows >= NT are identity)
 template <int V, int NT> __global__ void p3(const double* Tin, double* Wout, double* LTout, long long* ticks) {
@@ -63,6 +76,19 @@ template <int V, int NT> __global__ void p3(const double* Tin, double* Wout, dou
             if (r + 1 < NT) col[r + 1] -= m.y * col[j];
           }
         }
+      } else if constexpr (V == 3) {
+        // multipliers of the rows j + 2 .. 15 by DPP row_newbcast from a copy of the pivot row's H lanes replicated into every row of 16
+        // lanes: ONE v_fmac_f64_dpp per row update; row j + 1 (on the pivot chain) and rows 16, 17 by v_readlane as before
+        const double ncj = -col[j];
+        const double bc = replicateRow0(col[j], (lane & 15) * 4);
+        if (j + 1 < NT) {
+          col[j + 1] -= rl(col[j], j + 1) * col[j];
+          const double piv = rl(col[j + 1], j + 1);
+          inv = fastRsqrt(piv > 0 ? piv : 1.0);
+        }
+        [&]<int... JJ>(std::integer_sequence<int, JJ...>) { ((JJ == j ? RowUpd<JJ, JJ + 2, NT>::run(col, bc, ncj) : void()), ...); }(std::make_integer_sequence<int, NT>{});
+#pragma unroll
+        for (int r = (j + 2 > 16 ? j + 2 : 16); r < NT; ++r) col[r] -= rl(col[j], r) * col[j];
       } else {
         if (j + 1 < NT) {
           col[j + 1] -= rl(col[j], j + 1) * col[j];
@@ -243,9 +269,11 @@ int main() {
   ref(18, L, W);
   run<0, 18>("readlane multipliers, ocml rsqrt", T, L, W, dT, dW, dL, dt);
   run<1, 18>("readlane multipliers, rsq + one correction", T, L, W, dT, dW, dL, dt);
+  run<3, 18>("DPP row_newbcast multipliers", T, L, W, dT, dW, dL, dt);
   ref(16, L, W);
   run<0, 16>("readlane multipliers, ocml rsqrt", T, L, W, dT, dW, dL, dt);
   run<1, 16>("readlane multipliers, rsq + one correction", T, L, W, dT, dW, dL, dt);
+  run<3, 16>("DPP row_newbcast multipliers", T, L, W, dT, dW, dL, dt);
   ref(14, L, W);
   runb<1, 3>("blocked MFMA, 1 row tile x 3 column tiles", 14, L, W, dT, dW, dL, dt);
   ref(16, L, W);
