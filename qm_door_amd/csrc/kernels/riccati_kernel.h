@@ -42,7 +42,7 @@ struct RiccatiArgs {
 constexpr int RICCATI_WAVES = 4;
 // Phase clocks of the profiling build: QM_TICK* (gpu_rt.h; tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING).  Nothing in the product build.
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
-constexpr int LDS_S = 48, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 18;   // LDS_LL: 16 lanes writing 16 bytes each at this row stride (144 B) hit 64 distinct banks
+constexpr int LDS_S = 50, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 18;   // LDS_LL / LDS_S: sixteen lanes one row apart (144 / 400 B) hit distinct banks: column walks are as conflict free as row walks
 constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
 constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
 constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
@@ -55,7 +55,8 @@ constexpr int LT_DOUBLES = 20 * LDS_LL;            // L [20][LDS_LL] row major, 
 constexpr int R_W = R_SV + 32;                    // W of the stage in flight and of the previous one (by stage parity): the gains of stage k + 1 are
 constexpr int R_LT = R_W + 2 * W_DOUBLES;         // formed while stage k factorises, from W / L^T of stage k + 1
 constexpr int R_KST = R_LT + 2 * LT_DOUBLES;        // the gains record [GAIN_DOUBLES] of two stages: formed here by one wavefront, copied to HBM by two others a stage later
-constexpr int R_BWD_END = R_KST + 2 * GAIN_DOUBLES;
+constexpr int R_SYM = R_KST + 2 * GAIN_DOUBLES;     // [32][LDS_TS] scratch of the wavefront-local symmetrisation (T is being read by the factorisation at that time)
+constexpr int R_BWD_END = R_SYM + 32 * LDS_TS;
 static_assert(R_KST % 2 == 0 && GAIN_DOUBLES % 2 == 0, "16-byte copies");
 // forward sweep (over everything above, dead by then): a ring of three staging buffers [3][STG_F], then the B-operand images of dx and du~
 constexpr int FWD_ZV = 48;                             // z = [dx (30) | du~ (MT)] of one stage
@@ -251,7 +252,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   {
     const real* rec = stagesI + size_t(N) * STAGE_DOUBLES;
     for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
-    if (tid < 32) sv[tid] = tid < 30 ? rec[OFF_qt + tid] : 0.0_r;
+    __syncthreads();
+    if (tid < 30) S[30 * LDS_S + tid] = rec[OFF_qt + tid];        // s: row 30 of S (the B operands carry a unit entry at (30, 30))
     for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES + 2 * GAIN_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;   // W, L, gains images of both parities (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
@@ -261,6 +263,40 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   __syncthreads();
   QM_TICK_DECL;
 
+  // ---- operand addressing of the products, per lane and independent of the stage: column jc of M = [A~ | b~ | . | B~ | .] (P1) and of
+  //      [P~ | r~ | . | R~ | .] (P2), entry (i, j) of [Q~ | q~] (P6a).  The producers pad B~ with zero columns beyond m~ and the factorisation
+  //      ignores rows / columns of T beyond m~, so nothing here depends on m~: the offsets are formed once, a lane without a source reads
+  //      offset 0 (a finite number) and multiplies by zero.
+  const int jc = wave * 16 + l16;          // my column of M / Y / T
+  int mOffK[8]; real mOne, mAdd7;          // P1: offset of M[k][jc] for my eight k; mAdd7: the unit entry at (30, 30) that picks s out of row 30 of S
+  int cOffR[8]; real cOne;                 // P2: offsets of the initial value of T[i][jc], i = h + 4 r and 16 + h + 4 r
+  int bOffK[8]; real b1One;                // P2: offsets of B~[k][la] (second row tile: B~[k][16 + la], only 16 + la < MT exists)
+  {
+    const bool jA = jc < 30, jb = jc == 30, jB = jc >= 32 && jc < 32 + MT;
+    const int mOff = jA ? OFF_AT + jc : (jb ? OFF_bt : (jB ? OFF_BT + (jc - 32) : 0));
+    const int mStr = jA ? 30 : (jb ? 1 : (jB ? MT : 0));
+    mOne = (jA || jb || jB) ? 1.0_r : 0.0_r;
+    const int cOff = jA ? OFF_PT + jc : (jb ? OFF_rt : (jB ? OFF_RT + (jc - 32) : 0));
+    const int cStr = jA ? 30 : (jb ? 1 : (jB ? MT : 0));
+    cOne = mOne;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;     // rows 30, 31: S[30] = s meets the unit entry below, S[31] = 0
+      mOffK[ks] = mOff + kc * mStr;
+      bOffK[ks] = OFF_BT + kc * MT + la;
+      QM_KEEP(mOffK[ks]); QM_KEEP(bOffK[ks]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
+      cOffR[r] = cOff + i0 * cStr; cOffR[4 + r] = cOff + (i1 < MT ? i1 : 0) * cStr;
+      QM_KEEP(cOffR[r]); QM_KEEP(cOffR[4 + r]);
+    }
+    mAdd7 = (h == 2 && jb) ? 1.0_r : 0.0_r;
+    b1One = 16 + la < MT ? 1.0_r : 0.0_r;
+    QM_KEEP(mOne); QM_KEEP(cOne); QM_KEEP(mAdd7); QM_KEEP(b1One);
+  }
+  const real m7One = h >= 2 ? 0.0_r : mOne;   // k step 7: rows 30, 31 of M carry no data
   int ncCur = ncI[N - 1], ncPrev = 0;   // constraint rows of stage k and of stage k + 1; the next one is loaded a stage ahead
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
@@ -271,87 +307,56 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
     QM_TICK(0);
-    // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T.  Every product runs on two accumulators per tile
-    //      (even / odd k steps): a dependent v_mfma_f64 issues every 64 cycles, an independent one every 16.
-    const int jc = wave * 16 + l16;          // my column of M / Y / T
-    const bool jA = jc < 30, jb = jc == 30, jB = jc >= 32 && jc < 32 + nt;
+    // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T
     if (wave < nTiles) {
-      const int mOff = jA ? OFF_AT + jc : (jb ? OFF_bt : (jB ? OFF_BT + (jc - 32) : 0));
-      const int mStr = jA ? 30 : (jb ? 1 : (jB ? MT : 0));
-      const bool mValid = jA || jb || jB;
-      QmAcc c0, c1, d0, d1;
-      real a0[8], a1[8], bv[8], s0[4], s1[4];   // all operands first (unconditional loads, selects afterwards): the LDS latency is paid once
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s0[r] = sv[h + 4 * r]; s1[r] = sv[16 + h + 4 * r]; }
+      QmAcc c0, c1;
+      real a0[8], a1[8], bv[8];   // all operands first: the LDS latency is paid once
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of S^T are zero: the clamped b operand is multiplied by 0
-        a0[ks] = S[kk * LDS_S + la]; a1[ks] = S[kk * LDS_S + 16 + la];  // S is symmetric: S[i][k] read as S[k][i]
-        bv[ks] = stg[mOff + kc * mStr];
+        const int kk = 4 * ks + h;
+        a0[ks] = S[kk * LDS_S + la]; a1[ks] = S[kk * LDS_S + 16 + la];  // S is symmetric: S[i][k] read as S[k][i]; row 30 is s
+        bv[ks] = stg[mOffK[ks]];
       }
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) QM_KEEP(bv[ks]);
+      for (int r = 0; r < 4; ++r) { c0[r] = 0.0_r; c1[r] = 0.0_r; }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { QM_KEEP(s0[r]); QM_KEEP(s1[r]); c0[r] = jb ? s0[r] : 0.0_r; c1[r] = jb ? s1[r] : 0.0_r; d0[r] = 0.0_r; d1[r] = 0.0_r; }
+      for (int ks = 0; ks < 7; ++ks) bv[ks] *= mOne;
+      bv[7] = bv[7] * m7One + mAdd7;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) bv[ks] = mValid ? bv[ks] : 0.0_r;
+      for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
 #pragma unroll
-      for (int ks = 0; ks < 8; ks += 2) {
-        qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr);
-        qmMfma(d0, a0[ks + 1], bv[ks + 1], scr); qmMfma(d1, a1[ks + 1], bv[ks + 1], scr);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r] + d0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r] + d1[r]; }
+      for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
     }
     QM_TICK(1);
     QM_LDS_BARRIER();
     QM_TICK(2);
     if (wave < nTiles) {
-      QmAcc c0, c1, d0, d1;
-      real p0[4], q0[4], w0[4], p1[4], q1[4], w1[4];
-      const int jcA = jA ? jc : 0, jcB = jB ? jc - 32 : 0;
+      QmAcc c0, c1;
+      real ci[8], a0[8], a1[8], bv[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
-        const int i0c = i0 < MT ? i0 : 0, i1c = i1 < MT ? i1 : 0;
-        p0[r] = stg[OFF_PT + i0c * 30 + jcA]; q0[r] = stg[OFF_rt + i0c]; w0[r] = stg[OFF_RT + i0c * MT + jcB];
-        p1[r] = stg[OFF_PT + i1c * 30 + jcA]; q1[r] = stg[OFF_rt + i1c]; w1[r] = stg[OFF_RT + i1c * MT + jcB];
-      }
-      const bool a0ok = la < nt, a1ok = 16 + la < nt;
-      const int a0c = la < MT ? la : 0, a1c = 16 + la < MT ? 16 + la : 0;
-      real a0[8], a1[8], bv[8];
+      for (int r = 0; r < 8; ++r) ci[r] = stg[cOffR[r]];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;  // rows 30,31 of Y are zero
+        const int kk = 4 * ks + h;          // rows 30, 31 of Y are zero
         bv[ks] = Y[kk * LDS_Y + jc];
-        a0[ks] = stg[OFF_BT + kc * MT + a0c]; a1[ks] = stg[OFF_BT + kc * MT + a1c];   // B~^T[i][k] = B~[k][i]
+        a0[ks] = stg[bOffK[ks]];            // B~^T[i][k] = B~[k][i]; columns beyond m~ are zero in the record
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { QM_KEEP(p0[r]); QM_KEEP(q0[r]); QM_KEEP(w0[r]); QM_KEEP(p1[r]); QM_KEEP(q1[r]); QM_KEEP(w1[r]); }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { QM_KEEP(a0[ks]); QM_KEEP(a1[ks]); }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
-        const real v0 = jA ? p0[r] : (jb ? q0[r] : (jB ? w0[r] : 0.0_r));
-        const real v1 = jA ? p1[r] : (jb ? q1[r] : (jB ? w1[r] : 0.0_r));
-        c0[r] = i0 < nt ? v0 : 0.0_r; c1[r] = i1 < nt ? v1 : 0.0_r; d0[r] = 0.0_r; d1[r] = 0.0_r;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { a0[ks] = a0ok ? a0[ks] : 0.0_r; a1[ks] = a1ok ? a1[ks] : 0.0_r; }
+      for (int r = 0; r < 4; ++r) c0[r] = ci[r] * cOne;
       if (mtTiles == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ks += 2) {
-          qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr);
-          qmMfma(d0, a0[ks + 1], bv[ks + 1], scr); qmMfma(d1, a1[ks + 1], bv[ks + 1], scr);
-        }
+        for (int ks = 0; ks < 8; ++ks) a1[ks] = stg[bOffK[ks] + (16 + la < MT ? 16 : 0)] * b1One;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r] + d0[r]; T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r] + d1[r]; }
+        for (int r = 0; r < 4; ++r) c1[r] = ci[4 + r] * cOne;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { T[(h + 4 * r) * LDS_Y + jc] = c0[r]; T[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
       } else {
 #pragma unroll
-        for (int ks = 0; ks < 8; ks += 2) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(d0, a0[ks + 1], bv[ks + 1], scr); }
+        for (int ks = 0; ks < 8; ++ks) qmMfma(c0, a0[ks], bv[ks], scr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(h + 4 * r) * LDS_Y + jc] = c0[r] + d0[r];
+        for (int r = 0; r < 4; ++r) T[(h + 4 * r) * LDS_Y + jc] = c0[r];
       }
     }
     QM_TICK(3);
@@ -363,7 +368,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     // S' is symmetric: only the tiles (0,0), (0,1) and (1,1) of the 32 x 32 update are formed, by wavefronts 1, 2, 3; the tile (1,0) is
     // the mirror of (0,1).  Tile t = (t >> 1, t & 1).
     const int myTile = wave == 1 ? 0 : (wave == 2 ? 1 : 3);
-    QmAcc c6, d6;
+    QmAcc c6;
     if (wave == 0) {
       // the elimination is unrolled for the stage's number of projected inputs: 18 stance, 17 three-leg support, 16 trot, 14 flight
       __builtin_amdgcn_s_setprio(3);    // the wavefront on the critical path of the stage goes first at the shared units (LDS)
@@ -379,7 +384,11 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       // staging buffer was last read before the final barrier of the previous stage
       StagePrefetch<PFW, NTHR - 64> pf;
       pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid - 64);
-      // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation)
+      // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation), symmetrised here: (C + C^T) / 2 on the diagonal
+      //      tiles through a scratch square inside the wavefront.  W^T W, subtracted after the factorisation, is symmetric bit for bit
+      //      (the same products in the same order on both sides), so S' needs no second pass.  Without the symmetrisation the
+      //      antisymmetric part of the rounding error is propagated by the OPEN-loop dynamics (it sees A~^T . A~ but not the cancelling
+      //      G^T H^-1 G) and grows ~1.13x per stage.
       const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
       real qv[4], qq[4];
 #pragma unroll
@@ -399,17 +408,30 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         QM_KEEP(qv[r]); QM_KEEP(qq[r]);
         const int i = tm * 16 + h + 4 * r;
         const real v = j < 30 ? qv[r] : (j == 30 ? qq[r] : 0.0_r);
-        c6[r] = i < 30 ? v : 0.0_r; d6[r] = 0.0_r;
+        c6[r] = i < 30 ? v : 0.0_r;
       }
 #pragma unroll
-      for (int ks = 0; ks < 8; ks += 2) { qmMfma(c6, av[ks], bw[ks], scr); qmMfma(d6, av[ks + 1], bw[ks + 1], scr); }
+      for (int ks = 0; ks < 8; ++ks) qmMfma(c6, av[ks], bw[ks], scr);
+      if (wave != 2) {    // diagonal tiles (0,0) and (1,1); column 30 (s') and the rows / columns beyond 29 stay as they are
+        real* SYM = lds + R_SYM;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) SYM[(tm * 16 + h + 4 * r) * LDS_TS + j] = c6[r];
+        QM_WAVE_SYNC();   // the transposed read meets this wavefront's own writes (LDS operations of one wavefront complete in order)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = tm * 16 + h + 4 * r;
+          const real m = SYM[j * LDS_TS + i];
+          c6[r] = (i < 30 && j < 30) ? 0.5_r * (c6[r] + m) : c6[r];
+        }
+      }
       // ---- gains of stage k + 1 (its W and L sit in the other parity's buffers)
-      //      into the LDS image of their record; wavefronts 1 and 2 send the image finished a stage ago (stage k + 2) to HBM
-      if (wave == 3) {
+      //      into the LDS image of their record (wavefront 2: its tile needs no symmetrisation); wavefronts 1 and 3 send the image finished a
+      //      stage ago (stage k + 2) to HBM
+      if (wave == 2) {
         if (k + 1 < N && lane < 31)
           riccatiGains(lds + R_W + ((k + 1) & 1) * W_DOUBLES, lds + R_LT + ((k + 1) & 1) * LT_DOUBLES, 30 - ncPrev, lane, lds + R_KST + ((k + 1) & 1) * GAIN_DOUBLES);
       } else if (k + 2 < N) {
-        riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, tid - 64);
+        riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
       }
       pf.commit(stgNext, OFF_PX, tid - 64);   // stage k - 1 lands in the other buffer
     }
@@ -417,33 +439,20 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QM_TICK(6);
     QM_LDS_BARRIER();
     QM_TICK(7);
-    // ---- P6b: - W^T W on the tiles' owners; the raw result goes to a scratch square (T is dead; stride 34 makes both the row and the
-    //      column walk conflict free), s' in place; after the barrier the diagonal tiles are symmetrised, S = (C + C^T) / 2, and the tile
-    //      (1,0) is copied from (0,1).  Without the symmetrisation the antisymmetric part of the rounding error is propagated by the
-    //      OPEN-loop dynamics (it sees A~^T . A~ but not the cancelling G^T H^-1 G) and grows ~1.13x per stage.
+    // ---- P6b: S' = P6a - W^T W on the tiles' owners, written straight into S (s' = column 30 -> row 30 of S); the owner of the tile
+    //      (0,1) also writes its mirror image (1,0)
     if (wave != 0) {
       const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
       real av[5], bw[5];
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -W[kk * LDS_W + tm * 16 + la]; bw[ks] = W[kk * LDS_W + j]; }
-      qmMfma(c6, av[0], bw[0], scr); qmMfma(d6, av[1], bw[1], scr); qmMfma(c6, av[2], bw[2], scr); qmMfma(d6, av[3], bw[3], scr); qmMfma(c6, av[4], bw[4], scr);
-      real v[4];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) qmMfma(c6, av[ks], bw[ks], scr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
-        v[r] = c6[r] + d6[r];
-        TS[i * LDS_TS + j] = v[r];
-        if (i < 30 && j == 30) sv[i] = v[r];
-      }
-      QM_WAVE_SYNC();   // the transposed read below meets this wavefront's own writes (LDS operations of one wavefront complete in order)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // diagonal tiles: S[i][j] = (C[i][j] + C[j][i]) / 2, both mine.  Tile (0,1): S[i][j] = C[i][j], and the lane also fills the element
-        // (i2, j2) = (16 + h + 4 r, l16) of the tile (1,0) with C[j2][i2].
-        const int i = tm * 16 + h + 4 * r, i2 = 16 + h + 4 * r;
-        const real m = TS[(wave == 2 ? l16 : j) * LDS_TS + (wave == 2 ? i2 : i)];
-        if (i < 30 && j < 30) S[i * LDS_S + j] = wave == 2 ? v[r] : 0.5_r * (v[r] + m);
-        if (wave == 2 && i2 < 30) S[i2 * LDS_S + l16] = m;
+        if (i < 30 && j < 30) { S[i * LDS_S + j] = c6[r]; if (wave == 2) S[j * LDS_S + i] = c6[r]; }
+        if (i < 30 && j == 30) S[30 * LDS_S + i] = c6[r];
       }
     }
     QM_TICK(8);
@@ -454,10 +463,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     ncPrev = ncCur; ncCur = ncLoad;
   }
   // ---- gains of stage 0 (nobody factorises any more)
-  if (wave == 3) { if (lane < 31) riccatiGains(lds + R_W, lds + R_LT, 30 - ncPrev, lane, lds + R_KST); }
-  else if (wave != 0 && N > 1) riccatiGainsOut(lds + R_KST + GAIN_DOUBLES, a.gains + (size_t(inst) * N + 1) * GAIN_DOUBLES, tid - 64);
+  if (wave == 2) { if (lane < 31) riccatiGains(lds + R_W, lds + R_LT, 30 - ncPrev, lane, lds + R_KST); }
+  else if (wave != 0 && N > 1) riccatiGainsOut(lds + R_KST + GAIN_DOUBLES, a.gains + (size_t(inst) * N + 1) * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
   QM_LDS_BARRIER();
-  if (wave == 1 || wave == 2) riccatiGainsOut(lds + R_KST, a.gains + size_t(inst) * N * GAIN_DOUBLES, tid - 64);
+  if (wave == 1 || wave == 3) riccatiGainsOut(lds + R_KST, a.gains + size_t(inst) * N * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
 
   // ================================================================== forward substitution
   // The recursion  du~ = K dx + k,  dx+ = A~ dx + B~ du~ + b~  runs on wavefront 0 alone (a v_mfma_f64 holds a SIMD's matrix pipe for 64
