@@ -106,9 +106,10 @@ template <int J, int R, int REND> struct RiccatiDppRows {
 };
 template <int NT, int J> struct RiccatiStep {
   static constexpr int DEND = NT < 16 ? NT : 16;    // DPP rows end here
-  static __device__ __forceinline__ void run(real* col, real& inv, real& mine, real& bcP, real& ncP, int c, int& status, real* scr) {
+  static __device__ __forceinline__ void run(real* col, real& inv, real& mine, real& bcP, real& ncP, int c, int& status, real* scr, real* out, int ostr) {
     if constexpr (J < NT) {
       col[J] *= inv;                                     // row J of [L^T | W] / sqrt(pivot)
+      out[J * ostr] = col[J];                            // final: element (c, J) of L for an H lane, (J, c) of W for a G lane (asynchronous LDS write)
       mine = c == J ? inv : mine;
       const QmGather gj = qmGather(col[J], scr);
       if constexpr (J + 1 < NT) {
@@ -123,7 +124,7 @@ template <int NT, int J> struct RiccatiStep {
 #pragma unroll
       for (int r = (J + 3 > 16 ? J + 3 : 16); r < NT; ++r) col[r] -= gj.get(r) * col[J];
       if constexpr (J + 3 < DEND) { bcP = qmReplicateRow0(col[J], scr); ncP = -col[J]; }
-      RiccatiStep<NT, J + 1>::run(col, inv, mine, bcP, ncP, c, status, scr);
+      RiccatiStep<NT, J + 1>::run(col, inv, mine, bcP, ncP, c, status, scr, out, ostr);
     }
   }
 };
@@ -156,26 +157,18 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
     if (!ok) status = 1;
     inv = qmRsqrtPos(ok ? piv : 1.0_r);
   }
-  RiccatiStep<NT, 0>::run(col, inv, mine, bcP, ncP, c, status, scr);
+  // every lane streams its finished rows out as the elimination goes: H lane c writes row c of L (entries right of the diagonal are
+  // elimination residue and never read), G lane c column c of W, the idle lanes a scratch word (row 19 of L)
+  real* out = isH ? LL + c * LDS_LL : (isG ? W + c : LL + 19 * LDS_LL);
+  const int ostr = isH ? 1 : (isG ? LDS_W : 0);
+  RiccatiStep<NT, 0>::run(col, inv, mine, bcP, ncP, c, status, scr, out, ostr);
 #ifdef QM_RICCATI_TIMING
   { real keep_ = col[NT - 1]; QM_KEEP(keep_); col[NT - 1] = keep_; }
   const unsigned long long tq1 = clock64();
   tk[0] += tq0 - tqA; tk[1] += tq1 - tq0;
 #endif
-  if (isH) {
-    // lane c holds column c of L^T = row c of L in col[0..c]; entries right of the diagonal are elimination residue and never read
 #pragma unroll
-    for (int r = 0; r + 1 < NT; r += 2) { QmD2 v; v.x = col[r]; v.y = col[r + 1]; *reinterpret_cast<QmD2*>(LL + c * LDS_LL + r) = v; }
-    if (NT & 1) LL[c * LDS_LL + NT - 1] = col[NT - 1];
-#pragma unroll
-    for (int r = NT; r < MT; ++r) LL[c * LDS_LL + r] = 0.0_r;                     // identity rows / columns beyond the unrolled size
-
-  } else if (isG) {
-#pragma unroll
-    for (int r = 0; r < NT; ++r) W[r * LDS_W + c] = col[r];          // rows >= nt are exactly zero
-#pragma unroll
-    for (int r = NT; r < MT; ++r) W[r * LDS_W + c] = 0.0_r;          // (the buffer may hold a stage with more inputs)
-  }
+  for (int r = NT; r < MT; ++r) out[r * ostr] = 0.0_r;   // identity rows / columns beyond the unrolled size; rows of W beyond m~ (the buffer may hold a stage with more inputs)
   QM_WAVE_SYNC();
   if (isH) LL[c * LDS_LL + c] = mine;   // the diagonal slot: 1 / L_cc (1 for an identity row), after the row itself (LDS writes of one wavefront complete in order)
 #ifdef QM_RICCATI_TIMING
@@ -186,15 +179,15 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
 
 // [K | k] = -L^-T W of one stage by back-substitution, one column of [K | k] per lane (31 lanes of one wavefront), in the axpy order:
 // the dependent chain is one multiply + one multiply-add per row, the other multiply-adds of a step are independent.
-__device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, int ntp, int lane, real* kst) {
-  real w[MT];
+template <int NTP> __device__ __forceinline__ void riccatiGainsN(const real* Wp, const real* LLp, int ntp, int lane, real* kst) {
+  real w[NTP];   // rows >= NTP of W are zero and those rows of L identity: their gains are zero
 #pragma unroll
-  for (int r = 0; r < MT; ++r) w[r] = Wp[r * LDS_W + lane];
+  for (int r = 0; r < NTP; ++r) w[r] = Wp[r * LDS_W + lane];
 #pragma unroll
-  for (int q = MT - 1; q >= 0; --q) {
-    real lrow[MT];   // row q of L up to and including the diagonal slot (= 1 / L_qq), the same address in every lane
+  for (int q = NTP - 1; q >= 0; --q) {
+    real lrow[NTP + 1];   // row q of L up to and including the diagonal slot (= 1 / L_qq), the same address in every lane
 #pragma unroll
-    for (int r = 0; r <= q; r += 2) { const QmD2 v = *reinterpret_cast<const QmD2*>(LLp + q * LDS_LL + r); lrow[r] = v.x; if (r + 1 < MT) lrow[r + 1] = v.y; }
+    for (int r = 0; r <= q; r += 2) { const QmD2 v = *reinterpret_cast<const QmD2*>(LLp + q * LDS_LL + r); lrow[r] = v.x; lrow[r + 1] = v.y; }
     w[q] *= lrow[q];
 #pragma unroll
     for (int r = 0; r < q; ++r) w[r] -= lrow[r] * w[q];
@@ -203,14 +196,20 @@ __device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, in
   real* gp = kst + (lane < 30 ? OFF_KFB + lane : OFF_kff);
   if (lane < 30) {
 #pragma unroll
-    for (int r = 0; r < MT; ++r) gp[r * 30] = r < ntp ? -w[r] : 0.0_r;
+    for (int r = 0; r < MT; ++r) gp[r * 30] = r < NTP ? (r < ntp ? -w[r < NTP ? r : 0] : 0.0_r) : 0.0_r;
   } else {
 #pragma unroll
-    for (int r = 0; r < MT; ++r) gp[r] = r < ntp ? -w[r] : 0.0_r;
+    for (int r = 0; r < MT; ++r) gp[r] = r < NTP ? (r < ntp ? -w[r < NTP ? r : 0] : 0.0_r) : 0.0_r;
   }
 }
-
-// LDS image of one gains record -> HBM by 128 threads (t in [0, 128)), 16 bytes per access
+__device__ __forceinline__ void riccatiGains(const real* Wp, const real* LLp, int ntp, int lane, real* kst) {
+  switch (ntp) {   // unrolled for the stage's number of projected inputs, as the factorisation
+    case 16: riccatiGainsN<16>(Wp, LLp, ntp, lane, kst); break;
+    case 14: riccatiGainsN<14>(Wp, LLp, ntp, lane, kst); break;
+    case 17: riccatiGainsN<17>(Wp, LLp, ntp, lane, kst); break;
+    default: riccatiGainsN<MT>(Wp, LLp, ntp, lane, kst); break;
+  }
+}
 __device__ __forceinline__ void riccatiGainsOut(const real* kst, real* gain, int t) {
   const QmD2* src = reinterpret_cast<const QmD2*>(kst);
   QmD2* dst = reinterpret_cast<QmD2*>(gain);
