@@ -13,13 +13,14 @@
 //   P1 Y  = S M  (+ s in column 30)        so Y = [S A~ | S b~ + s | . | S B~]
 //   P2 T  = B~^T Y + [P~ | r~ | . | R~]    so T = [G | g | . | H]
 //   P3 H  = L L^T,  W = L^-1 [G | g]       wavefront 0, one column of [H | G g] per lane in registers (49 lanes), row operations with the
-//                                          multipliers broadcast by v_readlane (no LDS round trip on the dependent chain): the H lanes end with
-//                                          L^T, the G lanes with W.  MEANWHILE wavefronts 1..3 -- which have nothing on the critical path --
-//                                          commit the next stage, form  [Q~ | q~] + A~^T [S A~ | y]  (P6a) and the gains of the PREVIOUS
-//                                          stage  [K | k] = -L^-T W  by back-substitution (they are only needed by the forward sweep)
-//   P6b [S' | s'] = P6a - W^T W,  symmetrised
-// Column 30 carries the affine terms (b~, y, g, k, s') through the same tiles as the matrices.  Zero padding: rows/columns
-// 30,31 of S, rows >= m~ of T / W / L^-1 are kept at exactly zero so that partial tiles need no predication on the k loops.
+//                                          multipliers broadcast by v_readlane / DPP row_newbcast (no LDS round trip on the dependent chain):
+//                                          the H lanes end with L, the G lanes with W.  MEANWHILE wavefronts 1..3 -- which have nothing on the
+//                                          critical path -- commit the next stage, form and symmetrise  [Q~ | q~] + A~^T [S A~ | y]  (P6a) and
+//                                          the gains of the PREVIOUS stage  [K | k] = -L^-T W  by back-substitution (only the forward sweep
+//                                          needs them)
+//   P6b [S' | s'] = P6a - W^T W            written straight into S; s' is kept as row 30 of S (M carries a unit entry at (30, 30))
+// Column 30 carries the affine terms (b~, y, g, k, s') through the same tiles as the matrices.  Zero padding: row / column 31 of S, rows >= m~
+// of W and the columns >= m~ of B~ (padded by lq_node_kernel) are exactly zero, so partial tiles need no predication.
 #pragma once
 #include "layout.h"
 #include "gpu_rt.h"
