@@ -82,8 +82,10 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   double kc[NP], uc[NP], myInv = 1.0;   // factor of the current K (row c of L, row c of L^T): survives across the polish steps, whose K is constant
 #pragma unroll
   for (int r = 0; r < NP; ++r) { kc[r] = 0.0; uc[r] = 0.0; }
+  QM_TICK_DECL;
 #pragma unroll 1
   for (; it < 70; ++it) {
+    QM_TICK(0);
     // ---- residuals
     const QmGather gz = qmGather(zc, red);
     double Dz;
@@ -133,6 +135,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       }
       rdz = colOn ? a0 + a1 : 0.0;
     }
+    QM_TICK(1);
     const double mu = allSum(rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
     const double nrd = allMax(fmax(fabs(rdz), fabs(rdv)));
     const double nrp = allMax(fmax(fabs(rp1), fabs(rp2)));
@@ -162,6 +165,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;
     }
 
+    QM_TICK(2);
     const double w1 = l1 / s1, w2 = l2 / s2, kvv = 1.0 + w1 + w2;
     if (polish <= 1) {   // the polish steps share one matrix: build and factorise it once
       // ---- K = G + DZ' diag(w) DZ: upper-triangle tiles on the matrix cores, mirrored into LDS
@@ -218,6 +222,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       }
       QM_WAVE_SYNC();
 
+      QM_TICK(3);
       // ---- factorisation K = L L^T by row operations: lane c holds column c of K in kc; after step j, kc[j] of lane c is
       //      L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
       myInv = 1.0;
@@ -250,6 +255,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       QM_WAVE_SYNC();
     }
 
+    QM_TICK(4);
     double dv = 0.0, ds1 = 0.0, ds2 = 0.0, dl1 = 0.0, dl2 = 0.0, dzc = 0.0;
     double alphaAff = 1.0, sigma = 0.0, cw = 1.0;
 #pragma unroll 1
@@ -334,6 +340,8 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       }
     }
   }
+  QM_TICK(5);
+  QM_TICK_FLUSH(160 + (NP == 36 ? 0 : (NP == 20 ? 8 : 16)), blockIdx.x == 0 && lane == 0);
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
   *vOut = v;
   return itOut;

@@ -29,9 +29,11 @@ lib = sol.lib
 lib.qmgpu_debug_riccati_ticks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 256)()
 assert lib.qmgpu_debug_riccati_ticks(buf, 1) == 0
+wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
+t_eval = G.dev(np.zeros(B), torch.float64)
 sol.enable_timing(True)
 R = 10
-for _ in range(R): sol.mpc(mb.args)
+for _ in range(R): sol.cycle(mb.args, t_eval, wb.args)
 torch.cuda.synchronize()
 ms = sol.kernel_ms_mean(R)
 assert lib.qmgpu_debug_riccati_ticks(buf, 0) == 0
@@ -50,3 +52,10 @@ LQ = ["inputs", "AD rows", "state cost", "flow-map Jacobian", "input cost", "QR 
 lq = raw[128:128 + len(LQ)]
 print("lq_node_kernel, node 7 of instance 0 (two wavefronts share the SIMD): ticks per section, total", int(lq.sum()), " kernel ms", round(ms[1], 4))
 for n, v in zip(LQ, lq): print("  %-34s %8.0f  %4.1f %%" % (n, v, 100 * v / lq.sum()))
+
+IPM = ["loop top", "residuals D z", "reductions / decisions", "K tiles (MFMA)", "factorisation", "two passes: substitutions, steps"]
+for base, name in ((160, "NP = 36"), (168, "NP = 20"), (176, "NP = 8")):
+    v = raw[base:base + 6]
+    if v.sum() > 0:
+        print("wbc interior point, %s, instance 0: total %d ticks of %.0f (kernel %.4f ms)" % (name, v.sum(), ms[4] * tot / ms[2] if ms[2] else 0, ms[4]))
+        for n_, x in zip(IPM, v): print("  %-40s %9.0f  %4.1f %%" % (n_, x, 100 * x / v.sum()))
