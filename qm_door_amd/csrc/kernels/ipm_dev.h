@@ -87,14 +87,20 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   for (; it < 70; ++it) {
     QM_TICK(0);
     // ---- residuals
-    const QmGather gz = qmGather(zc, red);
+    // vectors every lane needs element by element (z, the multipliers, the right-hand sides) go through one LDS line (io.wtL) and come
+    // back as broadcast reads, two numbers per ds_read_b128: a v_readlane pair + wait state per element costs three issue slots more
+    double* bc = io.red;     // (the exchange scratch of the host emulation: free on both builds; 64 entries used)
+    QM_WAVE_SYNC();
+    bc[lane] = zc;
+    QM_WAVE_SYNC();
     double Dz;
     {
       double d0 = 0.0, d1 = 0.0;
 #pragma unroll 1
-      for (int j = 0; j < NP; j += 4) {   // four LDS reads in flight, then the multiply-adds (a lone wavefront has nothing else to hide them)
+      for (int j = 0; j < NP; j += 4) {   // eight LDS reads in flight, then the multiply-adds (a lone wavefront has nothing else to hide them)
         const double t0 = DZ[rowL * LDZ_ + j], t1 = DZ[rowL * LDZ_ + j + 1], t2 = DZ[rowL * LDZ_ + j + 2], t3 = DZ[rowL * LDZ_ + j + 3];
-        d0 += t0 * gz.get(j); d1 += t1 * gz.get(j + 1); d0 += t2 * gz.get(j + 2); d1 += t3 * gz.get(j + 3);
+        const double z0 = bc[j], z1 = bc[j + 1], z2 = bc[j + 2], z3 = bc[j + 3];
+        d0 += t0 * z0; d1 += t1 * z1; d0 += t2 * z2; d1 += t3 * z3;
       }
       Dz = d0 + d1;
     }
@@ -122,16 +128,19 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
 #pragma unroll 1
       for (int j = 0; j < NP; j += 4) {   // G symmetric
         const double t0 = G[j * LDK_ + colL], t1 = G[(j + 1) * LDK_ + colL], t2 = G[(j + 2) * LDK_ + colL], t3 = G[(j + 3) * LDK_ + colL];
-        a0 += t0 * gz.get(j); a1 += t1 * gz.get(j + 1); a0 += t2 * gz.get(j + 2); a1 += t3 * gz.get(j + 3);
+        const double z0 = bc[j], z1 = bc[j + 1], z2 = bc[j + 2], z3 = bc[j + 3];
+        a0 += t0 * z0; a1 += t1 * z1; a0 += t2 * z2; a1 += t3 * z3;
       }
-      const QmGather gl = qmGather(lamR, red);
+      QM_WAVE_SYNC();
+      bc[lane] = lamR;
+      QM_WAVE_SYNC();
 #pragma unroll 1
       for (int i = 0; i < 56; i += 14) {
-        double t[14];
+        double t[14], g[14];
 #pragma unroll
-        for (int q = 0; q < 14; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
+        for (int q = 0; q < 14; ++q) { t[q] = DZ[(i + q) * LDZ_ + colL]; g[q] = bc[i + q]; }
 #pragma unroll
-        for (int q = 0; q < 14; q += 2) { a0 += t[q] * gl.get(i + q); a1 += t[q + 1] * gl.get(i + q + 1); }
+        for (int q = 0; q < 14; q += 2) { a0 += t[q] * g[q]; a1 += t[q + 1] * g[q + 1]; }
       }
       rdz = colOn ? a0 + a1 : 0.0;
     }
@@ -235,7 +244,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       for (int j = 0; j < NP; ++j) {
         const double piv = qmReadLane(kc[j], j, red);
         const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
-        const double inv = qmRsqrt(dfl);
+        const double inv = qmRsqrtPos(dfl);   // dfl >= pivotFloor > 0
         kc[j] = (lane == j) ? dfl * inv : kc[j] * inv;
         if (lane == j) myInv = inv;                              // 1 / L_jj
         const QmGather gk = qmGather(kc[j], red);                // L[r][j] = gk.get(r)
@@ -269,15 +278,17 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       // right-hand side of the reduced system
       double acc;
       {
-        const QmGather gt = qmGather(tz, red);
+        QM_WAVE_SYNC();
+        bc[lane] = tz;
+        QM_WAVE_SYNC();
         double a0 = -rdz, a1 = 0.0;
 #pragma unroll 1
         for (int i = 0; i < 56; i += 14) {
-          double t[14];
+          double t[14], g[14];
 #pragma unroll
-          for (int q = 0; q < 14; ++q) t[q] = DZ[(i + q) * LDZ_ + colL];
+          for (int q = 0; q < 14; ++q) { t[q] = DZ[(i + q) * LDZ_ + colL]; g[q] = bc[i + q]; }
 #pragma unroll
-          for (int q = 0; q < 14; q += 2) { a0 -= t[q] * gt.get(i + q); a1 -= t[q + 1] * gt.get(i + q + 1); }
+          for (int q = 0; q < 14; q += 2) { a0 -= t[q] * g[q]; a1 -= t[q + 1] * g[q + 1]; }
         }
         acc = colOn ? a0 + a1 : 0.0;
       }
@@ -303,12 +314,15 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       if (polish) { zc += dzc; ++polish; break; }
       double Ddz;
       {
-        const QmGather gd = qmGather(dzc, red);
+        QM_WAVE_SYNC();
+        bc[lane] = dzc;
+        QM_WAVE_SYNC();
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll 1
         for (int j = 0; j < NP; j += 4) {
           const double t0 = DZ[rowL * LDZ_ + j], t1 = DZ[rowL * LDZ_ + j + 1], t2 = DZ[rowL * LDZ_ + j + 2], t3 = DZ[rowL * LDZ_ + j + 3];
-          d0 += t0 * gd.get(j); d1 += t1 * gd.get(j + 1); d0 += t2 * gd.get(j + 2); d1 += t3 * gd.get(j + 3);
+          const double z0 = bc[j], z1 = bc[j + 1], z2 = bc[j + 2], z3 = bc[j + 3];
+          d0 += t0 * z0; d1 += t1 * z1; d0 += t2 * z2; d1 += t3 * z3;
         }
         Ddz = d0 + d1;
       }
