@@ -65,13 +65,14 @@ template <int R, bool FIRST> __device__ __forceinline__ void qmFmacRowBcast(floa
   if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
   else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(R));
 }
-// the value of lane (lane & 15) in every lane: lanes 0..15 replicated into the other three rows (ds_bpermute: the LDS crossbar, no LDS memory)
-__device__ __forceinline__ real qmReplicateRow0(real v, real* = nullptr) {
-  const int addr = (int(threadIdx.x) & 15) * 4;
+// the value of lane 16 G + (lane & 15) in every lane: one row of 16 lanes replicated into all four (ds_bpermute: the LDS crossbar, no LDS memory)
+template <int G> __device__ __forceinline__ real qmReplicateRow(real v, real* = nullptr) {
+  const int addr = (16 * G + (int(threadIdx.x) & 15)) * 4;
   const int lo = __builtin_amdgcn_ds_bpermute(addr, qmLoWord(v));
   const int hi = sizeof(real) == 8 ? __builtin_amdgcn_ds_bpermute(addr, qmHiWord(v)) : 0;
   return qmFromWords(lo, hi, real());
 }
+__device__ __forceinline__ real qmReplicateRow0(real v, real* s = nullptr) { return qmReplicateRow<0>(v, s); }
 // keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
 // into the select that consumes it and pays the LDS latency once per branch)
 #define QM_KEEP(x) asm volatile("" : "+v"(x))

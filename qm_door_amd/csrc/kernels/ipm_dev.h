@@ -26,6 +26,40 @@ struct IpmIo {
   double* red;          // wavefront exchange scratch of the host emulation (>= 1024 doubles)
 };
 
+// One step of the factorisation K = L L^T by row operations (lane c holds column c of K in kc), as a template recursion so that the DPP
+// controls are immediates.  Multipliers L[r][J] = (scaled row J) at lane r: rows J + 1 (on the pivot chain) and J + 2 take them by
+// v_readlane; rows J + 3 .. NP - 1 by DPP row_newbcast -- ONE v_fmac_f64_dpp per row update -- from copies of the row's lanes
+// 16 g .. 16 g + 15 replicated into the four rows of 16 lanes, applied one step late so that the replication (LDS crossbar) is off the
+// pivot chain.  Row updates of one row commute.
+template <int J, int R, int NP> struct IpmDppRows {
+  static __device__ __forceinline__ void run(double* kc, const double* bcP, double ncP, double* red) {
+    if constexpr (R < NP) { qmFmacRowBcast<R % 16, R == J + 3 || R % 16 == 0>(kc[R], bcP[R / 16], ncP, red); IpmDppRows<J, R + 1, NP>::run(kc, bcP, ncP, red); }
+  }
+};
+template <int NP, int J> struct IpmFactorStep {
+  static constexpr int NG = (NP + 15) / 16;
+  static __device__ __forceinline__ void run(double* kc, double& myInv, double* bcP, double& ncP, double pivotFloor, int lane, double* red) {
+    if constexpr (J < NP) {
+      const double piv = qmReadLane(kc[J], J, red);
+      const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
+      const double inv = qmRsqrtPos(dfl);                      // dfl >= pivotFloor > 0
+      kc[J] = (lane == J) ? dfl * inv : kc[J] * inv;
+      if (lane == J) myInv = inv;                              // 1 / L_jj
+      const QmGather gk = qmGather(kc[J], red);                // L[r][j] = gk.get(r)
+      if constexpr (J + 1 < NP) kc[J + 1] -= gk.get(J + 1) * kc[J];
+      if constexpr (J + 2 < NP) kc[J + 2] -= gk.get(J + 2) * kc[J];
+      if constexpr (J >= 1) IpmDppRows<J - 1, J + 2, NP>::run(kc, bcP, ncP, red);     // the previous step's rows J + 2 .. NP - 1
+      if constexpr (J + 3 < NP) {
+        if constexpr (NG > 0 && (J + 3) / 16 <= 0) bcP[0] = qmReplicateRow<0>(kc[J], red);
+        if constexpr (NG > 1 && (J + 3) / 16 <= 1) bcP[1] = qmReplicateRow<1>(kc[J], red);
+        if constexpr (NG > 2 && (J + 3) / 16 <= 2) bcP[2] = qmReplicateRow<2>(kc[J], red);
+        ncP = -kc[J];
+      }
+      IpmFactorStep<NP, J + 1>::run(kc, myInv, bcP, ncP, pivotFloor, lane, red);
+    }
+  }
+};
+
 // returns the iteration count; 60 = not converged
 template <int NP, int LDZ_, int LDK_>
 __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool rowActive, double sigma0, int lane, double* vOut) {
@@ -240,16 +274,9 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         const double kv = io.Kt[r * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
         kc[r] = (colOn && r < n) ? kv : ((r == lane) ? 1.0 : 0.0);   // identity padding beyond n
       }
-  #pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const double piv = qmReadLane(kc[j], j, red);
-        const double dfl = piv > pivotFloor ? piv : pivotFloor;  // pivots floored as in the oracle's choleskyFloored
-        const double inv = qmRsqrtPos(dfl);   // dfl >= pivotFloor > 0
-        kc[j] = (lane == j) ? dfl * inv : kc[j] * inv;
-        if (lane == j) myInv = inv;                              // 1 / L_jj
-        const QmGather gk = qmGather(kc[j], red);                // L[r][j] = gk.get(r)
-  #pragma unroll
-        for (int r = j + 1; r < NP; ++r) kc[r] -= gk.get(r) * kc[j];
+      {
+        double bcP[3] = {0.0, 0.0, 0.0}, ncP = 0.0;
+        IpmFactorStep<NP, 0>::run(kc, myInv, bcP, ncP, pivotFloor, lane, red);
       }
       // the back substitution L^T dz = t walks the COLUMNS of L^T: U[r][c] (c > r) sits in lane c, register r.  One transpose
       // through LDS per factorisation puts it into lane r, register c.

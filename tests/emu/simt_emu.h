@@ -81,13 +81,14 @@ template <int R, bool FIRST, class T> inline void qmFmacRowBcast(T& acc, T bc, T
   QM_WAVE_SYNC();
   acc += T(buf[(lane & ~15u) + unsigned(R)]) * m;
 }
-template <class T> inline T qmReplicateRow0(T v, T* = nullptr) {   // ds_bpermute with address lane & 15
+template <int G, class T> inline T qmReplicateRow(T v, T* = nullptr) {   // ds_bpermute with address 16 G + (lane & 15)
   const unsigned lane = threadIdx.x & 63u;
   double* buf = emuXchgBuf(nullptr);
   buf[lane] = double(v);
   QM_WAVE_SYNC();
-  return T(buf[lane & 15u]);
+  return T(buf[16u * unsigned(G) + (lane & 15u)]);
 }
+template <class T> inline T qmReplicateRow0(T v, T* s = nullptr) { return qmReplicateRow<0>(v, s); }
 template <class T> inline T qmHalfXor32(T v, bool) { return qmShflXor(v, 32); }   // v_permlane32_swap
 template <class T> inline T qmRowXor16(T v, bool) { return qmShflXor(v, 16); }    // v_permlane16_swap
 
