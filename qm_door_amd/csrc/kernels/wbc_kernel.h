@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   const int nsw = 4 - nst;
 
   for (int e = lane; e < MAXM * LDZ; e += 64) DZ[e] = 0.0;  // rows >= m0 are never written: the interior point only needs them finite
+  QM_TICK_DECL;
   // ---- S1: inputs
   if (lane < 55) rbd[lane] = a.rbd[size_t(inst) * 55 + lane];
   if (lane < 30) { xDes[lane] = a.xDes[size_t(inst) * 30 + lane]; uDes[lane] = a.uDes[size_t(inst) * 30 + lane]; il[lane] = a.inputLast[size_t(inst) * 30 + lane]; }
@@ -260,6 +261,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   if (lane < 30) a.inputLast[size_t(inst) * 30 + lane] = uDes[lane];  // WbcBase.cpp:225
   QM_WAVE_SYNC();
 
+  QM_TICK(0);
   // ---- S3: measured pass (zero generalized acceleration -> bias terms)
   bodyPass(md, qM, vM, nullptr, body, dof, lane);
   QM_WAVE_SYNC();
@@ -272,6 +274,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     for (int i = 0; i < 3; ++i) { wr[lane * 3 + i] = md.mass[lane] * (acc[i] + (i == 2 ? st.gravity : 0.0)); wr[57 + lane * 3 + i] = Iw_al[i] + t[i]; }
   }
   QM_WAVE_SYNC();
+  QM_TICK(1);
   // ---- S4: lane k = generalized velocity k: nle_k, column k of M, Jacobian columns
   // The Jacobian column of every (body b, velocity i) pair at the body's centre of mass is formed ONCE (by lane i, into the LDS that Z / Z_new / A Z
   // take over later) instead of by every lane for every pair: M[i][k] = sum_b J_bi^T diag(m_b, I_b) J_bk is then six multiply-adds per term.
@@ -351,6 +354,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   }
   QM_WAVE_SYNC();
 
+  QM_TICK(2);
   // ---- S5: desired pass.  v_des base from the centroidal map (WbcBase.cpp:217-219) with the MPC's own sweep.
   {
     double k1z[12];
@@ -417,6 +421,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   }
   QM_WAVE_SYNC();
 
+  QM_TICK(3);
   // ================================================================== hierarchical QP
   int status = 0;
   // x = 0, Z = I
@@ -450,6 +455,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
 #pragma unroll 1
   for (int level = 0; level < numLevels; ++level) {
     if (n == 0) break;  // FLY: nothing left to decide
+    QM_TICK(4);
     // ---- assemble this level's equality task A x = b  (rows r)
     for (int e = lane; e < MAXR * ND; e += 64) A[e] = 0.0;
     QM_WAVE_SYNC();
@@ -568,6 +574,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
 #ifdef QMGPU_EMU_DEBUG
     if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d r %d n %d b:", level, r, n); for (int i = 0; i < r; ++i) printf(" %.10g", bvec[i]); printf("\n"); }
 #endif
+    QM_TICK(5);
     // ---- reduced data: AZ = A Z (r x n), rhat = A x - b, DZ = D0 Z, fhat
     const int mOwn = (level == 0) ? m0 : 0, mPrev = (level == 0) ? 0 : m0;
     const int mRows = mOwn + mPrev;  // <= 56, one row per lane
@@ -600,6 +607,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
     QM_WAVE_SYNC();
 
+    QM_TICK(6);
     // ---- interior point iterations (ipm_dev.h): K on the matrix cores, factorisation and solves in registers
     const double pivotFloor = 1e-13 * qmAllMax(lane < n ? G[lane * LDK + lane] : 0.0, red);
     const bool own = mOwn > 0;
@@ -623,6 +631,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
       QM_WAVE_SYNC();
     }
     if (it >= 60) status |= (1 << level);
+    QM_TICK(7);
     // ---- x = x_prev + Z z (HoQp.h:31-34); keep the slack solution of task 0 (HoQp.cpp:152-158)
     double xn = 0.0;
     if (lane < ND) { xn = xs[lane]; for (int j = 0; j < n; ++j) xn += Z[lane * LDZ + j] * zs[j]; }
@@ -637,6 +646,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
 #endif
     if (level == numLevels - 1) break;
 
+    QM_TICK(8);
     // ---- Z <- Z null(A Z) (HoQp.cpp:126-133): Householder QR of (A Z)^T with dependent columns skipped
     {
       double dcol[ND];
@@ -703,6 +713,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     }
   }
   QM_WAVE_SYNC();
+  QM_TICK(9);
   // ---- updateCmd (WbcBase.cpp:580-595): tau = [M_j, -J_j^T] x + h_j
   if (lane < ND) a.out[size_t(inst) * 54 + lane] = xs[lane];
   if (lane < 18) {
@@ -712,6 +723,8 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     a.out[size_t(inst) * 54 + 36 + lane] = s;
   }
   if (lane == 0 && a.status) a.status[inst] = status;
+  QM_TICK(10);
+  QM_TICK_FLUSH(192, blockIdx.x == 0 && lane == 0);
 }
 
 }  // namespace qmk
