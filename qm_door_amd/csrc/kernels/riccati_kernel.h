@@ -50,10 +50,9 @@ constexpr int R_STG = 0;                          // two staging buffers: [2][ST
 constexpr int R_Y = R_STG + 2 * STG_B;            // Y [32][LDS_Y]
 constexpr int R_T = R_Y + 32 * LDS_Y;             // T [32][LDS_Y]
 constexpr int R_S = R_T + 32 * LDS_Y;             // S [32][LDS_S]
-constexpr int R_SV = R_S + 32 * LDS_S;            // s [32]
 constexpr int W_DOUBLES = 20 * LDS_W;             // W [20][LDS_W] of one stage
 constexpr int LT_DOUBLES = 20 * LDS_LL;            // L [20][LDS_LL] row major, strictly lower triangle; the diagonal slot holds 1 / L_cc
-constexpr int R_W = R_SV + 32;                    // W of the stage in flight and of the previous one (by stage parity): the gains of stage k + 1 are
+constexpr int R_W = R_S + 32 * LDS_S;              // W of the stage in flight and of the previous one (by stage parity): the gains of stage k + 1 are
 constexpr int R_LT = R_W + 2 * W_DOUBLES;         // formed while stage k factorises, from W / L^T of stage k + 1
 constexpr int R_KST = R_LT + 2 * LT_DOUBLES;        // the gains record [GAIN_DOUBLES] of two stages: formed here by one wavefront, copied to HBM by two others a stage later
 constexpr int R_SYM = R_KST + 2 * GAIN_DOUBLES;     // [32][LDS_TS] scratch of the wavefront-local symmetrisation (T is being read by the factorisation at that time)
@@ -240,8 +239,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const int inst = blockIdx.x;
   if (a.done[inst]) return;   // workgroup uniform
   const int N = a.N;
-  real* S = lds + R_S; real* sv = lds + R_SV; real* Y = lds + R_Y; real* T = lds + R_T;
-  real* TS = lds + R_T;   // [32][LDS_TS] raw S' of a stage (aliases T, dead after P4)
+  real* S = lds + R_S; real* Y = lds + R_Y; real* T = lds + R_T;
   real* scr = nullptr; real* red = lds + R_SCR;
   const real* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const real* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
