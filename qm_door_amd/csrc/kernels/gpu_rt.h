@@ -73,6 +73,9 @@ template <int G> __device__ __forceinline__ real qmReplicateRow(real v, real* = 
   return qmFromWords(lo, hi, real());
 }
 __device__ __forceinline__ real qmReplicateRow0(real v, real* s = nullptr) { return qmReplicateRow<0>(v, s); }
+// pointer to LDS that keeps its address space through a function call (a generic pointer to LDS compiles to flat loads)
+#define QM_LDS_CONST_PTR(T) const T __attribute__((address_space(3)))*
+#define QM_TO_LDS_PTR(T, p) ((const T __attribute__((address_space(3)))*)(p))
 // keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
 // into the select that consumes it and pays the LDS latency once per branch)
 #define QM_KEEP(x) asm volatile("" : "+v"(x))

@@ -43,8 +43,10 @@ struct DblIn {
 // NOT inlined: with this body inlined into the 35 k-instruction line-search kernel of the fp32 build the compiler produced a binary whose
 // equality-violation sum read stale registers (2-3x too large, different from run to run; tests/test_gpu_configs.py pins both symptoms).
 // As a called function the body is compiled once, for linesearch_kernel and ddp_rollout_kernel alike.
-__device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, const real* Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
+// WP: pointer type of the two 30 x 30 weight matrices: LDS (line search: staged once per workgroup) or generic (DDP rollouts).
+template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, WP Qw, WP Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
                                        bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq, real* xnOut = nullptr) {
+  QM_TICK_DECL;
   const ModelR& md = P.model;
   const SettingsR& st = P.settings;
   const int mode = sched.modes[phase];
@@ -103,6 +105,7 @@ __device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, con
       for (int i = 0; i < 12; ++i) phi[i] += 0.5_r * dt * f[i];
     }
   }
+  QM_TICK(0);
   if (terminal) { cost = c; return; }
   if (xnOut) {
     for (int i = 0; i < 12; ++i) xnOut[i] = x[i] + phi[i];
@@ -111,23 +114,30 @@ __device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, con
     for (int i = 0; i < 12; ++i) { const real d = x[i] + phi[i] - xnext[i]; dyn += d * d; }
     for (int j = 0; j < 18; ++j) { const real d = x[12 + j] + dt * u[12 + j] - xnext[12 + j]; dyn += d * d; }
   }
+  QM_TICK(1);
   // tracking cost
   int tIdx; real tAlpha;
   timeSegment(tTimes, K, t, tIdx, tAlpha);
   int nStance = 0;
   for (int k = 0; k < 4; ++k) nStance += contactOf(mode, k) ? 1 : 0;
   const real fzNom = nStance > 0 ? md.total_mass * st.gravity / nStance : 0.0_r;
-  for (int i = 0; i < 30; ++i) {
-    const real dxi = x[i] - xReference(tStates, K, tIdx, tAlpha, i);
-    const real dui = u[i] - ((i < 12 && (i % 3) == 2 && contactOf(mode, i / 3)) ? fzNom : 0.0_r);
-    real qs = 0.0_r, rs = 0.0_r;
-    for (int j = 0; j < 30; ++j) {
-      const real dxj = x[j] - xReference(tStates, K, tIdx, tAlpha, j);
-      const real duj = u[j] - ((j < 12 && (j % 3) == 2 && contactOf(mode, j / 3)) ? fzNom : 0.0_r);
-      qs += st.Q[i * 30 + j] * dxj; rs += Rw[i * 30 + j] * duj;
-    }
-    c += 0.5_r * dxi * qs + 0.5_r * dui * rs;
+  // deviations once, in registers; then the two quadratic forms fully unrolled: the weights are read with compile-time offsets from
+  // wave-uniform addresses (scalar loads), x / u / the reference are not touched again.  (The rolled double loop re-read x[j], u[j] and the
+  // reference states from HBM for each of the 900 (i, j) pairs: most of the kernel's time.)  Same order of operations as before.
+  real dx[30], du[30];
+#pragma unroll
+  for (int j = 0; j < 30; ++j) {
+    dx[j] = x[j] - xReference(tStates, K, tIdx, tAlpha, j);
+    du[j] = u[j] - ((j < 12 && (j % 3) == 2 && contactOf(mode, j / 3)) ? fzNom : 0.0_r);
   }
+#pragma unroll
+  for (int i = 0; i < 30; ++i) {
+    real qs = 0.0_r, rs = 0.0_r;
+#pragma unroll
+    for (int j = 0; j < 30; ++j) { qs += Qw[i * 30 + j] * dx[j]; rs += Rw[i * 30 + j] * du[j]; }
+    c += 0.5_r * dx[i] * qs + 0.5_r * du[i] * rs;
+  }
+  QM_TICK(2);
   const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta}, bv{st.joint_vel_barrier_mu, st.joint_vel_barrier_delta}, bf{st.friction_barrier_mu, st.friction_barrier_delta};
   for (int i = 0; i < 6; ++i) {
     const real lo = md.q_lower[12 + i], up = md.q_upper[12 + i];
@@ -139,11 +149,14 @@ __device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, con
     c += bf.value(st.friction_coefficient * fz - sqrt(fx * fx + fy * fy + st.friction_regularization));
   }
   cost = dt * c; dyn *= dt; eq *= dt;
+  QM_TICK(3);
+  QM_TICK_FLUSH(224, blockIdx.x == 0 && threadIdx.x == 5);
 }
 
 __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __shared__ real red[3 * 256];
   __shared__ real ctl[8];
+  __shared__ __attribute__((aligned(16))) real wQ[900], wR[900];   // state / input weights of the tracking cost: every lane reads all 1800 of them per node
   const int inst = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   if (a.done[inst]) return;   // converged in an earlier iteration of this call: outputs and statistics stay as they are
   const int N = a.N;
@@ -162,6 +175,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   const int nTr = nthr / half, myTr = tid / half, ltid = tid - myTr * half;
   real* Xt = a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30; real* Ut = a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
 
+  for (int e = tid; e < 900; e += nthr) { wQ[e] = st.Q[e]; wR[e] = a.Rw[e]; }   // visible after the first barrier below
   // baseline performance (sum of the LQ kernel's node metrics)
   real m0 = 0.0_r, d0 = 0.0_r, e0 = 0.0_r;
   for (int k = tid; k <= N; k += nthr) { const real* m = a.metrics + (size_t(inst) * (N + 1) + k) * NODE_METRICS; m0 += m[0]; d0 += m[1]; e0 += m[2]; }
@@ -190,7 +204,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     for (int k = ltid; k <= N; k += half) {
       real c, d, e;
       const bool term = k == N;
-      nodePerformance(*a.P, a.Rw, sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
+      nodePerformance(*a.P, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
       cs += c; ds += d; es += e;
     }
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;

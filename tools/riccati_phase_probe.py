@@ -64,3 +64,8 @@ WBC = ["S1-S2 inputs, coordinates", "S3 measured pass", "S4 nle, M, Jacobians", 
 v = raw[192:192 + len(WBC)]
 print("wbc_kernel, instance 0: total %d ticks (kernel %.4f ms)" % (v.sum(), ms[4]))
 for n_, x in zip(WBC, v): print("  %-60s %9.0f  %4.1f %%" % (n_[:60], x, 100 * x / v.sum()))
+
+LS = ["two model sweeps + constraints + EE cost", "defect", "tracking cost (two 30 x 30 forms)", "barriers"]
+v = raw[224:224 + len(LS)]
+print("linesearch nodePerformance, node 5 of instance 0 (all calls of a launch): total %d ticks (kernel %.4f ms)" % (v.sum(), ms[3]))
+for n_, x in zip(LS, v): print("  %-50s %9.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
