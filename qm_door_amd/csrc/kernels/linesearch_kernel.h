@@ -44,11 +44,9 @@ struct DblIn {
 // equality-violation sum read stale registers (2-3x too large, different from run to run; tests/test_gpu_configs.py pins both symptoms).
 // As a called function the body is compiled once, for linesearch_kernel and ddp_rollout_kernel alike.
 // WP: pointer type of the two 30 x 30 weight matrices: LDS (line search: staged once per workgroup) or generic (DDP rollouts).
-template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ProblemR& P, WP Qw, WP Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
+template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ModelR& md, const SettingsR& st, WP Qw, WP Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
                                        bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq, real* xnOut = nullptr) {
   QM_TICK_DECL;
-  const ModelR& md = P.model;
-  const SettingsR& st = P.settings;
   const int mode = sched.modes[phase];
   real eePosRef[3], eeQuatRef[4];
   eeReference(tTimes, tStates, K, t, eePosRef, eeQuatRef);
@@ -156,6 +154,7 @@ template <class WP> __device__ __attribute__((noinline)) void nodePerformance(co
 __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __shared__ real red[3 * 256];
   __shared__ real ctl[8];
+  __shared__ ModelR mdS;   // the model constants: the sweeps read them with wave-uniform indices, from LDS instead of through the scalar cache
   __shared__ __attribute__((aligned(16))) real wQ[900], wR[900];   // state / input weights of the tracking cost: every lane reads all 1800 of them per node
   const int inst = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   if (a.done[inst]) return;   // converged in an earlier iteration of this call: outputs and statistics stay as they are
@@ -176,6 +175,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   real* Xt = a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30; real* Ut = a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
 
   for (int e = tid; e < 900; e += nthr) { wQ[e] = st.Q[e]; wR[e] = a.Rw[e]; }   // visible after the first barrier below
+  { const int* src = reinterpret_cast<const int*>(&a.P->model); int* dst = reinterpret_cast<int*>(&mdS); for (int e = tid; e < int(sizeof(ModelR) / 4); e += nthr) dst[e] = src[e]; }
   // baseline performance (sum of the LQ kernel's node metrics)
   real m0 = 0.0_r, d0 = 0.0_r, e0 = 0.0_r;
   for (int k = tid; k <= N; k += nthr) { const real* m = a.metrics + (size_t(inst) * (N + 1) + k) * NODE_METRICS; m0 += m[0]; d0 += m[1]; e0 += m[2]; }
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     for (int k = ltid; k <= N; k += half) {
       real c, d, e;
       const bool term = k == N;
-      nodePerformance(*a.P, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
+      nodePerformance(mdS, st, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
       cs += c; ds += d; es += e;
     }
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;
