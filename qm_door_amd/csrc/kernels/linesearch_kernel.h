@@ -26,8 +26,17 @@ struct LsArgs {
   real* Xt; real* Ut;   // trial trajectories (scratch) [batch][N+1][30], [batch][N][30]
   real* outT; real* outX; real* outU; int* outMode; real* outStats;
   int iteration;   // SQP iteration of this call
+  int trialInLds;  // the trial trajectories fit the dynamic LDS of the launch (lsTrialLdsBytes): they never touch HBM
   int* done;       // [batch] convergence flags (see InitArgs)
 };
+
+// dynamic LDS of a line-search launch that keeps the trial trajectories on chip: 0 if they do not fit beside the static arrays
+constexpr int LS_STATIC_LDS_BYTES = (3 * 256 + 8 + 1800) * int(sizeof(real)) + int(sizeof(ModelR)) + 256;
+inline int lsTrialLdsBytes(int N) {
+  const int trials = (N + 1 <= 128) ? 2 : 1;
+  const long long need = (long long)trials * (2 * N + 1) * 30 * (long long)sizeof(real);
+  return need + LS_STATIC_LDS_BYTES <= 160 * 1024 ? int(need) : 0;
+}
 
 struct DblIn {
   const real* x; const real* u; real dtS; const real* k1;
@@ -172,7 +181,11 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   // the one of FilterLinesearch's loop.
   const int half = (N + 1 <= nthr / 2) ? nthr / 2 : nthr;
   const int nTr = nthr / half, myTr = tid / half, ltid = tid - myTr * half;
-  real* Xt = a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30; real* Ut = a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
+  // trial trajectories: in LDS when the launch reserved room for them (every lane then reads its node's x, u, x_next from LDS instead of
+  // 90 scattered HBM loads per node); in the HBM scratch otherwise (long horizons)
+  QM_DYNAMIC_LDS(trialLds);
+  real* Xt = a.trialInLds ? trialLds + size_t(myTr) * (2 * N + 1) * 30 : a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30;
+  real* Ut = a.trialInLds ? Xt + (N + 1) * 30 : a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
 
   for (int e = tid; e < 900; e += nthr) { wQ[e] = st.Q[e]; wR[e] = a.Rw[e]; }   // visible after the first barrier below
   { const int* src = reinterpret_cast<const int*>(&a.P->model); int* dst = reinterpret_cast<int*>(&mdS); for (int e = tid; e < int(sizeof(ModelR) / 4); e += nthr) dst[e] = src[e]; }

@@ -71,7 +71,10 @@ template <class Alloc> inline void ensureDdpBuffers(MpcBuffers& m, size_t B, siz
   m.dDdpMerit = static_cast<real*>(alloc(size_t(DDP_MAX_TRIALS) * B * 2, sizeof(real), true));
 }
 
-inline hipError_t prepareMpcKernels() { return QM_ALLOW_DYNAMIC_LDS(riccati_kernel<RICCATI_WAVES>, RICCATI_LDS_BYTES); }
+inline hipError_t prepareMpcKernels() {
+  const hipError_t e = QM_ALLOW_DYNAMIC_LDS(riccati_kernel<RICCATI_WAVES>, RICCATI_LDS_BYTES);
+  return e != hipSuccess ? e : QM_ALLOW_DYNAMIC_LDS(linesearch_kernel, 160 * 1024 - LS_STATIC_LDS_BYTES);
+}
 
 // events (optional, 7 entries as in qmgpu_api.hip): [0] start, [6] after ad_node, [1] after lq_node, [2] after riccati, [3] after the line search
 inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& io, int iterations, bool debugLq, hipEvent_t* ev) {
@@ -94,8 +97,8 @@ inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
     QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
     if (ev) (void)hipEventRecord(ev[2], s);
     LsArgs ls{m.dP, m.dRw, B, N, io.K, io.lineSearch, io.eeContact, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, m.ddX, m.ddU, io.targetTimes, io.targetStates, io.schedNum,
-              io.schedTimes, io.schedModes, m.dMetrics, m.dInstStats, m.dNodeMode, m.dXt, m.dUt, io.outT, io.outX, io.outU, io.outMode, io.outStats, it, m.dDone};
-    QM_LAUNCH(linesearch_kernel, B, 256, s, ls);
+              io.schedTimes, io.schedModes, m.dMetrics, m.dInstStats, m.dNodeMode, m.dXt, m.dUt, io.outT, io.outX, io.outU, io.outMode, io.outStats, it, lsTrialLdsBytes(N) > 0, m.dDone};
+    QM_LAUNCH_DYN(linesearch_kernel, B, 256, lsTrialLdsBytes(N), s, ls);
     if (ev) (void)hipEventRecord(ev[3], s);
   }
 }
