@@ -171,3 +171,28 @@ def test_relaxed_barrier_quadratic_branches_and_distinct_target_knots(interface,
     o = oracle.lq_node(0.0, dt, X[2, 0], U[2, 0], X[2, 1], False, nev, ev, md, tt[2], ts[2])
     curv = st_.joint_pos_barrier_mu / st_.joint_pos_barrier_delta ** 2          # 1e5; the end-effector Gauss-Newton term adds a few hundred on top
     assert curv <= o["Q"][24, 24] / dt <= curv + 2e3
+
+
+def test_horizon_beyond_the_line_search_lds_budget(interface, oracle):
+    """N = 300: the trial trajectories of the line search no longer fit its dynamic LDS (linesearch_kernel.h: lsTrialLdsBytes) and go through
+    the HBM scratch instead; the Riccati sweeps walk 300 stages.  fp64 against the oracle, and the fp32 build against fp64."""
+    import gpu_harness as G
+    B, N = 2, 300
+    mb, (x0, tt, ts, nev, ev, md) = _batch(G, interface, oracle, B, N, seed=8)
+    sol = G.make_solver(interface, B, N)
+    sol.mpc(mb.args)
+    r = mb.results()
+    assert (r["stats"][:, 7] == 0).all()
+    for i in range(B):
+        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert np.array_equal(r["mode"][i], ref["mode"])
+        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+        assert r["stats"][i][4] == ref["stats"][4]
+    sol32 = G.make_solver(interface, B, N, dtype="f32")
+    mb32, _ = _batch(G, interface, oracle, B, N, seed=8)
+    sol32.mpc(mb32.args)
+    r32 = mb32.results()
+    assert np.array_equal(r32["mode"], r["mode"]) and (r32["stats"][:, 4] == r["stats"][:, 4]).all()
+    assert np.abs(r32["X"] - r["X"]).max() <= 1e-4 * max(1.0, np.abs(r["X"]).max())
+    assert np.abs(r32["U"] - r["U"]).max() <= 1e-4 * max(1.0, np.abs(r["U"]).max())
