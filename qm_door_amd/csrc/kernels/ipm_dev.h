@@ -319,6 +319,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         }
         acc = colOn ? a0 + a1 : 0.0;
       }
+      QM_TICK(6);
       // L t = rhs (forward substitution; lane c owns row c of L)
       double tC = 0.0;
 #pragma unroll
@@ -327,6 +328,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         if (lane == r) tC = tr;
         acc -= (lane > r) ? kc[r] * tr : 0.0;
       }
+      QM_TICK(7);
       // L^T dz = t (back substitution; lane r owns row r of L^T in uc)
       {
         double bacc = tC;
@@ -338,6 +340,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         }
         dzc = colOn ? dzc : 0.0;
       }
+      QM_TICK(8);
       if (polish) { zc += dzc; ++polish; break; }
       double Ddz;
       {
@@ -353,6 +356,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         }
         Ddz = d0 + d1;
       }
+      QM_TICK(9);
       if (rowActive) {
         if (own) {
           dv = (rhsv + w1 * Ddz) / kvv;
@@ -379,10 +383,11 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         zc += al * dzc;
         if (rowActive) { s1 += al * ds1; l1 += al * dl1; if (own) { v += al * dv; s2 += al * ds2; l2 += al * dl2; } }
       }
+      QM_TICK(10);
     }
   }
   QM_TICK(5);
-  QM_TICK_FLUSH(160 + (NP == 36 ? 0 : (NP == 20 ? 8 : 16)), blockIdx.x == 0 && lane == 0);
+  QM_TICK_FLUSH(NP == 36 ? 160 : (NP == 20 ? 256 : 288), blockIdx.x == 0 && lane == 0);
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
   *vOut = v;
   return itOut;

@@ -27,7 +27,7 @@ mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int
 for _ in range(3): sol.mpc(mb.args)
 lib = sol.lib
 lib.qmgpu_debug_riccati_ticks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * 256)()
+buf = (C.c_ulonglong * 512)()
 assert lib.qmgpu_debug_riccati_ticks(buf, 1) == 0
 wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
 t_eval = G.dev(np.zeros(B), torch.float64)
@@ -53,9 +53,9 @@ lq = raw[128:128 + len(LQ)]
 print("lq_node_kernel, node 7 of instance 0 (two wavefronts share the SIMD): ticks per section, total", int(lq.sum()), " kernel ms", round(ms[1], 4))
 for n, v in zip(LQ, lq): print("  %-34s %8.0f  %4.1f %%" % (n, v, 100 * v / lq.sum()))
 
-IPM = ["loop top", "residuals D z", "reductions / decisions", "K tiles (MFMA)", "factorisation", "two passes: substitutions, steps"]
-for base, name in ((160, "NP = 36"), (168, "NP = 20"), (176, "NP = 8")):
-    v = raw[base:base + 6]
+IPM = ["(pass bookkeeping / loop back-edge)", "residuals D z, G z, D^T lambda", "reductions / decisions", "weights + K tiles (MFMA)", "factorisation + transposition", "(tail)", "pass: right-hand side (56-row product)", "pass: forward substitution", "pass: back substitution", "pass: D dz", "pass: steps, step lengths, reductions"]
+for base, name in ((160, "NP = 36"), (256, "NP = 20"), (288, "NP = 8")):
+    v = raw[base:base + 11]
     if v.sum() > 0:
         print("wbc interior point, %s, instance 0: total %d ticks of %.0f (kernel %.4f ms)" % (name, v.sum(), ms[4] * tot / ms[2] if ms[2] else 0, ms[4]))
         for n_, x in zip(IPM, v): print("  %-40s %9.0f  %4.1f %%" % (n_, x, 100 * x / v.sum()))
