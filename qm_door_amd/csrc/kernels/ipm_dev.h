@@ -24,7 +24,48 @@ struct IpmIo {
   double* wtL;          // [64] scratch: row weights
   double* zs;           // [36] out: solution (lanes >= n write 0)
   double* red;          // wavefront exchange scratch of the host emulation (>= 1024 doubles)
+  double* fork;         // [1] command word of the fork-join with the three helper wavefronts (wbc_kernel): 0 = leave, NP = K tiles of that size
 };
+
+// K = G + DZ' diag(w) DZ: the upper-triangle 16 x 16 tiles t with t % 4 == wave (wave < 0: all of them) on the matrix cores, written
+// (and mirrored) into the LDS square io.Kt.  Called by the solving wavefront and, between two workgroup barriers, by the three helper
+// wavefronts of wbc_kernel: a v_mfma_f64 holds one SIMD's matrix pipe for 64 cycles, the six tiles of NP = 36 are 84 of them.
+template <int NP, int LDZ_, int LDK_> __device__ __forceinline__ void ipmKTiles(const IpmIo& io, int wave, int lane) {
+  constexpr int TP = (NP + 15) / 16, KS = 14;
+  const int l16 = lane & 15, h = lane >> 4;
+  int t = 0;
+#pragma unroll
+  for (int ti = 0; ti < TP; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < TP; ++tj, ++t) {
+      if (wave >= 0 && (t & 3) != wave) continue;
+      QmAcc acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+        const double gv = io.G[(i < 36 ? i : 0) * LDK_ + (j < 36 ? j : 0)];
+        acc[r] = (i < 36 && j < 36) ? gv : 0.0;
+      }
+#pragma unroll 1
+      for (int k0 = 0; k0 < KS; k0 += 7) {   // the operands of seven k steps are read from LDS before the first matrix-core instruction
+        double av[7], bv[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int kk = 4 * (k0 + q) + h, ja = ti * 16 + l16, jb = tj * 16 + l16;
+          const double w = io.wtL[kk];
+          const double ra = io.DZ[kk * LDZ_ + (ja < 36 ? ja : 0)], rb = io.DZ[kk * LDZ_ + (jb < 36 ? jb : 0)];
+          av[q] = ja < NP ? w * ra : 0.0; bv[q] = jb < NP ? rb : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) qmMfma(acc, av[q], bv[q], io.red);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+        if (i < NP && j < NP) { io.Kt[i * LDK_ + j] = acc[r]; if (ti != tj) io.Kt[j * LDK_ + i] = acc[r]; }
+      }
+    }
+}
 
 // One step of the factorisation K = L L^T by row operations (lane c holds column c of K in kc), as a template recursion so that the DPP
 // controls are immediates.  Multipliers L[r][J] = (scaled row J) at lane r: rows J + 1 (on the pivot chain) and J + 2 take them by
@@ -214,54 +255,13 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       // ---- K = G + DZ' diag(w) DZ: upper-triangle tiles on the matrix cores, mirrored into LDS
       if (lane < 56) io.wtL[lane] = polish ? (isE ? rho : (isV ? 1.0 : 0.0)) : (rowActive ? (own ? w1 - w1 * w1 / kvv : w1) : 0.0);
       QM_WAVE_SYNC();
-      {
-        QmAcc acc[TP * (TP + 1) / 2];
-        {
-          int t = 0;
-  #pragma unroll
-          for (int ti = 0; ti < TP; ++ti)
-  #pragma unroll
-            for (int tj = ti; tj < TP; ++tj, ++t)
-  #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
-                const double gv = G[(i < 36 ? i : 0) * LDK_ + (j < 36 ? j : 0)];
-                acc[t][r] = (i < 36 && j < 36) ? gv : 0.0;
-              }
-        }
-        static_assert(KS % 7 == 0, "operand batches of seven k steps");
-  #pragma unroll 1
-        for (int k0 = 0; k0 < KS; k0 += 7) {   // the operands of seven k steps are read from LDS before the first matrix-core instruction
-          double wv[7], bv[7][TP];
-  #pragma unroll
-          for (int q = 0; q < 7; ++q) {
-            const int kk = 4 * (k0 + q) + h;
-            wv[q] = io.wtL[kk];
-  #pragma unroll
-            for (int t = 0; t < TP; ++t) {
-              const int j = t * 16 + l16;
-              const double raw = DZ[kk * LDZ_ + (j < 36 ? j : 0)];
-              bv[q][t] = j < NP ? raw : 0.0;
-            }
-          }
-  #pragma unroll
-          for (int q = 0; q < 7; ++q) {
-            double a[TP];
-  #pragma unroll
-            for (int t = 0; t < TP; ++t) a[t] = wv[q] * bv[q][t];
-            qmMfmaUpper<TP>(acc, a, bv[q], red);
-          }
-        }
-        int t = 0;
-  #pragma unroll
-        for (int ti = 0; ti < TP; ++ti)
-  #pragma unroll
-          for (int tj = ti; tj < TP; ++tj, ++t)
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
-              if (i < NP && j < NP) { io.Kt[i * LDK_ + j] = acc[t][r]; if (ti != tj) io.Kt[j * LDK_ + i] = acc[t][r]; }
-            }
+      if (NP > 16 && io.fork) {   // several tiles: the helper wavefronts take theirs between two workgroup barriers
+        io.fork[0] = double(NP);
+        QM_LDS_BARRIER();
+        ipmKTiles<NP, LDZ_, LDK_>(io, 0, lane);
+        QM_LDS_BARRIER();
+      } else {
+        ipmKTiles<NP, LDZ_, LDK_>(io, -1, lane);
       }
       QM_WAVE_SYNC();
 

@@ -62,6 +62,7 @@ constexpr int W_VH = W_G + ND * LDK;             // Householder vectors [MAXR][4
 constexpr int W_VEC = W_VH + MAXR * 40;          // vectors: x[36] z[36] g[36] rd[36] rhs[36] dz[36] fhat[56] lam[56] wt[56] tz[56] red[64]
 constexpr int WBC_LDS_DOUBLES = W_VEC + 6 * 36 + 4 * 56 + 1024 + 8;   // red[1024]: wavefront exchange scratch (only the host emulation uses more than 64)
 constexpr int WBC_LDS_BYTES = WBC_LDS_DOUBLES * 8;
+constexpr int WBC_THREADS = 256;   // the solving wavefront + three helpers (one per SIMD of the CU)
 // misc block
 constexpr int MI_FOOTPM = 0, MI_FOOTVM = 12, MI_FOOTDJV = 24, MI_FOOTPD = 36, MI_FOOTVD = 48, MI_EEPM = 60, MI_EEVM = 63, MI_EEWM = 66, MI_EEDJL = 69, MI_EEDJA = 72,
               MI_EERM = 75, MI_EEPD = 84, MI_EEVD = 87, MI_EERD = 90, MI_AL0 = 99, MI_BACC = 102, MI_JACC = 108 /*18*/, MI_BAX = 126 /*measured base Euler axes, 9*/;
@@ -217,10 +218,10 @@ __device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane)
   }
 }
 
-__global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
+__global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(WbcArgs a) {
   QM_DYNAMIC_LDS(lds);
   QM_POISON_LDS(lds, WBC_LDS_DOUBLES);
-  const int lane = threadIdx.x, inst = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, inst = blockIdx.x;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
   double fe[3] = {0.0, 0.0, 0.0};   // external force on the arm end-effector (force tracking; zero otherwise)
@@ -234,6 +235,20 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
   double* xs = lds + W_VEC; double* zs = xs + 36; double* gs = zs + 36; double* rds = gs + 36; double* rhs = rds + 36; double* dzs = rhs + 36;
   double* fhat = dzs + 36; double* lam = fhat + 56; double* wt = lam + 56; double* tzv = wt + 56; double* red = tzv + 56; double* ctl = red + 1024;
 
+  // Wavefront 0 solves the instance; the other three sit on the CU's idle SIMDs and take their share of the matrix-core tiles of the
+  // interior point between two workgroup barriers (ipm_dev.h: ipmKTiles).  Command word: ctl[4] (0 = leave).
+  double* forkCmd = ctl + 4;
+  if (wave != 0) {
+    const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
+    for (;;) {
+      QM_LDS_BARRIER();
+      const int op = int(forkCmd[0]);
+      if (op == 0) break;
+      if (op == 36) ipmKTiles<36, LDZ, LDK>(hio, wave, lane); else ipmKTiles<20, LDZ, LDK>(hio, wave, lane);
+      QM_LDS_BARRIER();
+    }
+    return;
+  }
   const int mode = a.mode[inst];
   const double period = a.period[inst], time = a.time[inst];
   bool contact[4]; int nst = 0;
@@ -614,7 +629,7 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     const double nRowsTot = qmAllSum(rowActive ? (own ? 2.0 : 1.0) : 0.0, red);
     int it = 0;
     if (nRowsTot > 0.0) {
-      IpmIo io{G, gs, DZ, fhat, K, wt, zs, red};
+      IpmIo io{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
       double vRow;
       if (n <= 8) it = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
       else if (n <= 20) it = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
@@ -723,6 +738,8 @@ __global__ void __launch_bounds__(64) wbc_kernel(WbcArgs a) {
     a.out[size_t(inst) * 54 + 36 + lane] = s;
   }
   if (lane == 0 && a.status) a.status[inst] = status;
+  forkCmd[0] = 0.0;      // release the helper wavefronts
+  QM_LDS_BARRIER();
   QM_TICK(10);
   QM_TICK_FLUSH(192, blockIdx.x == 0 && lane == 0);
 }

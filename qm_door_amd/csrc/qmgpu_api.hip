@@ -274,7 +274,7 @@ static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
   if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
   if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
   WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, w->ee_force};
-  QM_LAUNCH_DYN(wbc_kernel, w->batch, 64, WBC_LDS_BYTES, h->stream, wa);
+  QM_LAUNCH_DYN(wbc_kernel, w->batch, WBC_THREADS, WBC_LDS_BYTES, h->stream, wa);
   HIP_CHECK(hipGetLastError());
 }
 
