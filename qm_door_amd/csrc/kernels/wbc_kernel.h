@@ -237,18 +237,36 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 
   // Wavefront 0 solves the instance; the other three sit on the CU's idle SIMDs and take their share of the matrix-core tiles of the
   // interior point between two workgroup barriers (ipm_dev.h: ipmKTiles).  Command word: ctl[4] (0 = leave).
-  double* forkCmd = ctl + 4;
+  double* forkCmd = ctl + 4; double* forkJob = red + 512;   // (red[0..63] carries the interior point's broadcasts; nothing else of it is used on the GPU)
   if (wave != 0) {
     const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
     for (;;) {
       QM_LDS_BARRIER();
       const int op = int(forkCmd[0]);
       if (op == 0) break;
-      if (op == 36) ipmKTiles<36, LDZ, LDK>(hio, wave, lane); else ipmKTiles<20, LDZ, LDK>(hio, wave, lane);
+      if (op == 36) ipmKTiles<36, LDZ, LDK>(hio, wave, lane);
+      else if (op == 20) ipmKTiles<20, LDZ, LDK>(hio, wave, lane);
+      else {   // 100 / 101: C = A B / A^T B, described in forkJob (pointers as offsets from the LDS base)
+        const double* jA = lds + int(forkJob[0]); const double* jB = lds + int(forkJob[2]); double* jD = lds + int(forkJob[7]);
+        const int lda = int(forkJob[1]), ldb = int(forkJob[3]), jM = int(forkJob[4]), jN = int(forkJob[5]), jK = int(forkJob[6]), ldd = int(forkJob[8]);
+        if (op == 101) waveGemmTiles<true>(jA, lda, jB, ldb, jM, jN, jK, jD, ldd, forkJob[9], wave, lane, red);
+        else waveGemmTiles<false>(jA, lda, jB, ldb, jM, jN, jK, jD, ldd, forkJob[9], wave, lane, red);
+      }
       QM_LDS_BARRIER();
     }
     return;
   }
+  // C (M x N, LDS) = op(A) B with the four wavefronts sharing the tiles
+  auto forkGemm = [&](bool ta, const double* jA, int lda, const double* jB, int ldb, int jM, int jN, int jK, double* jD, int ldd, double diagAdd) {
+    if (lane == 0) {
+      forkJob[0] = double(jA - lds); forkJob[1] = lda; forkJob[2] = double(jB - lds); forkJob[3] = ldb; forkJob[4] = jM; forkJob[5] = jN; forkJob[6] = jK;
+      forkJob[7] = double(jD - lds); forkJob[8] = ldd; forkJob[9] = diagAdd; forkCmd[0] = ta ? 101.0 : 100.0;
+    }
+    QM_LDS_BARRIER();
+    if (ta) waveGemmTiles<true>(jA, lda, jB, ldb, jM, jN, jK, jD, ldd, diagAdd, 0, lane, red);
+    else waveGemmTiles<false>(jA, lda, jB, ldb, jM, jN, jK, jD, ldd, diagAdd, 0, lane, red);
+    QM_LDS_BARRIER();
+  };
   const int mode = a.mode[inst];
   const double period = a.period[inst], time = a.time[inst];
   bool contact[4]; int nst = 0;
@@ -595,11 +613,11 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     const int mRows = mOwn + mPrev;  // <= 56, one row per lane
     const double* AZp = AZ;
     if (level == 3) AZp = Z;  // A = I  =>  A Z = Z
-    else waveGemm<false>(A, ND, Z, LDZ, r, n, ND, lane, red, [&](int i, int j, double v) { AZ[i * LDZ + j] = v; });
+    else forkGemm(false, A, ND, Z, LDZ, r, n, ND, AZ, LDZ, 0.0);
     // D Z on the matrix cores; columns >= n stay zero padding (the interior point always spans whole tiles)
     for (int e = lane; e < m0 * LDZ; e += 64) DZ[e] = 0.0;
     QM_WAVE_SYNC();
-    waveGemm<false>(D0, ND, Z, LDZ, m0, n, ND, lane, red, [&](int i, int j, double v) { DZ[i * LDZ + j] = v; });
+    forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0);
     if (lane < r) {  // A x_prev - b (temporarily in tzv)
       double s;
       if (level == 3) s = xs[lane];
@@ -616,7 +634,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
     for (int e = lane; e < ND * LDK; e += 64) G[e] = 0.0;
     QM_WAVE_SYNC();
-    waveGemm<true>(AZp, LDZ, AZp, LDZ, n, n, r, lane, red, [&](int i, int j, double v) { G[i * LDK + j] = v + (i == j ? 1e-12 : 0.0); });
+    forkGemm(true, AZp, LDZ, AZp, LDZ, n, n, r, G, LDK, 1e-12);
     if (lane < ND) { double s = 0.0; if (lane < n) for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
     // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
@@ -720,7 +738,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         for (int q = 0; q < ND; ++q) K[q * LDK + lane] = nv[q];
       }
       QM_WAVE_SYNC();
-      waveGemm<false>(Z, LDZ, K, LDK, ND, nNew, ND, lane, red, [&](int i, int j, double v) { Zn[i * LDZ + j] = v; });
+      forkGemm(false, Z, LDZ, K, LDK, ND, nNew, ND, Zn, LDZ, 0.0);
       QM_WAVE_SYNC();
       for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
       n = nNew;
