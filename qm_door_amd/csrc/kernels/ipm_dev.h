@@ -67,6 +67,33 @@ template <int NP, int LDZ_, int LDK_> __device__ __forceinline__ void ipmKTiles(
     }
 }
 
+// sum over 14 of the 56 rows of DZ[i][column of this lane] * bc[i] (bc: io.red[0..63], published by the solving wavefront): the share
+// of wavefront `wave` of a 56-row column sum; the partial sums meet in io.red[128 + 64 wave + lane]
+template <int LDZ_> __device__ __forceinline__ void ipmColSumShare(const IpmIo& io, int wave, int lane) {
+  const int colL = lane < 36 ? lane : 0, i0 = 14 * wave;
+  const double* bc = io.red;
+  double t[14], g[14];
+#pragma unroll
+  for (int q = 0; q < 14; ++q) { t[q] = io.DZ[(i0 + q) * LDZ_ + colL]; g[q] = bc[i0 + q]; }
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 14; q += 2) { a0 += t[q] * g[q]; a1 += t[q + 1] * g[q + 1]; }
+  io.red[128 + 64 * wave + lane] = a0 + a1;
+}
+// the whole sum on four wavefronts (fork-join as for the K tiles), or on this one
+template <int LDZ_> __device__ __forceinline__ double ipmColSum(const IpmIo& io, int lane) {
+  if (io.fork) {
+    io.fork[0] = 200.0;
+    QM_LDS_BARRIER();
+    ipmColSumShare<LDZ_>(io, 0, lane);
+    QM_LDS_BARRIER();
+    return (io.red[128 + lane] + io.red[192 + lane]) + (io.red[256 + lane] + io.red[320 + lane]);
+  }
+  double s = 0.0;
+  for (int w = 0; w < 4; ++w) { ipmColSumShare<LDZ_>(io, w, lane); QM_WAVE_SYNC(); s += io.red[128 + 64 * w + lane]; }
+  return s;
+}
+
 // One step of the factorisation K = L L^T by row operations (lane c holds column c of K in kc), as a template recursion so that the DPP
 // controls are immediates.  Multipliers L[r][J] = (scaled row J) at lane r: rows J + 1 (on the pivot chain) and J + 2 take them by
 // v_readlane; rows J + 3 .. NP - 1 by DPP row_newbcast -- ONE v_fmac_f64_dpp per row update -- from copies of the row's lanes
@@ -209,15 +236,8 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       QM_WAVE_SYNC();
       bc[lane] = lamR;
       QM_WAVE_SYNC();
-#pragma unroll 1
-      for (int i = 0; i < 56; i += 14) {
-        double t[14], g[14];
-#pragma unroll
-        for (int q = 0; q < 14; ++q) { t[q] = DZ[(i + q) * LDZ_ + colL]; g[q] = bc[i + q]; }
-#pragma unroll
-        for (int q = 0; q < 14; q += 2) { a0 += t[q] * g[q]; a1 += t[q + 1] * g[q + 1]; }
-      }
-      rdz = colOn ? a0 + a1 : 0.0;
+      const double dtl = ipmColSum<LDZ_>(io, lane);     // D^T lambda: 56 rows, shared with the helper wavefronts
+      rdz = colOn ? (a0 + a1) + dtl : 0.0;
     }
     QM_TICK(1);
     const double mu = allSum(rowActive ? (s1 * l1 + (own ? s2 * l2 : 0.0)) : 0.0) / nRowsTot;
@@ -308,16 +328,8 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         QM_WAVE_SYNC();
         bc[lane] = tz;
         QM_WAVE_SYNC();
-        double a0 = -rdz, a1 = 0.0;
-#pragma unroll 1
-        for (int i = 0; i < 56; i += 14) {
-          double t[14], g[14];
-#pragma unroll
-          for (int q = 0; q < 14; ++q) { t[q] = DZ[(i + q) * LDZ_ + colL]; g[q] = bc[i + q]; }
-#pragma unroll
-          for (int q = 0; q < 14; q += 2) { a0 -= t[q] * g[q]; a1 -= t[q + 1] * g[q + 1]; }
-        }
-        acc = colOn ? a0 + a1 : 0.0;
+        const double dtt = ipmColSum<LDZ_>(io, lane);   // D^T t: 56 rows, shared with the helper wavefronts (every lane takes part in the barriers)
+        acc = colOn ? -rdz - dtt : 0.0;
       }
       QM_TICK(6);
       // L t = rhs (forward substitution; lane c owns row c of L)

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 
   // Wavefront 0 solves the instance; the other three sit on the CU's idle SIMDs and take their share of the matrix-core tiles of the
   // interior point between two workgroup barriers (ipm_dev.h: ipmKTiles).  Command word: ctl[4] (0 = leave).
-  double* forkCmd = ctl + 4; double* forkJob = red + 512;   // (red[0..63] carries the interior point's broadcasts; nothing else of it is used on the GPU)
+  double* forkCmd = ctl + 4; double* forkJob = red + 512;   // (red[0..63] carries the interior point's broadcasts, red[128..383] its partial sums; nothing else of it is used on the GPU)
   if (wave != 0) {
     const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
     for (;;) {
@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       if (op == 0) break;
       if (op == 36) ipmKTiles<36, LDZ, LDK>(hio, wave, lane);
       else if (op == 20) ipmKTiles<20, LDZ, LDK>(hio, wave, lane);
+      else if (op == 200) ipmColSumShare<LDZ>(hio, wave, lane);
       else {   // 100 / 101: C = A B / A^T B, described in forkJob (pointers as offsets from the LDS base)
         const double* jA = lds + int(forkJob[0]); const double* jB = lds + int(forkJob[2]); double* jD = lds + int(forkJob[7]);
         const int lda = int(forkJob[1]), ldb = int(forkJob[3]), jM = int(forkJob[4]), jN = int(forkJob[5]), jK = int(forkJob[6]), ldd = int(forkJob[8]);
