@@ -15,6 +15,7 @@
 // block eliminated analytically (it is diagonal), so the factorised system is n x n (n <= 36) instead of (n + 56)^2.
 // Only the highest-priority task may carry inequality rows (true for both reference controllers).
 #pragma once
+#include <type_traits>
 #include "../../../include/qmgpu.h"
 #include "gpu_rt.h"
 #ifndef QMGPU_DEBUG_INST
@@ -615,10 +616,12 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     const double* AZp = AZ;
     if (level == 3) AZp = Z;  // A = I  =>  A Z = Z
     else forkGemm(false, A, ND, Z, LDZ, r, n, ND, AZ, LDZ, 0.0);
+    QM_TICK(11);
     // D Z on the matrix cores; columns >= n stay zero padding (the interior point always spans whole tiles)
     for (int e = lane; e < m0 * LDZ; e += 64) DZ[e] = 0.0;
     QM_WAVE_SYNC();
     forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0);
+    QM_TICK(12);
     if (lane < r) {  // A x_prev - b (temporarily in tzv)
       double s;
       if (level == 3) s = xs[lane];
@@ -632,10 +635,12 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       fhat[lane] = s;
     }
     QM_WAVE_SYNC();
+    QM_TICK(13);
     // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
     for (int e = lane; e < ND * LDK; e += 64) G[e] = 0.0;
     QM_WAVE_SYNC();
     forkGemm(true, AZp, LDZ, AZp, LDZ, n, n, r, G, LDK, 1e-12);
+    QM_TICK(14);
     if (lane < ND) { double s = 0.0; if (lane < n) for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
     // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
@@ -681,14 +686,16 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     if (level == numLevels - 1) break;
 
     QM_TICK(8);
-    // ---- Z <- Z null(A Z) (HoQp.cpp:126-133): Householder QR of (A Z)^T with dependent columns skipped
-    {
-      double dcol[ND];
+    // ---- Z <- Z null(A Z) (HoQp.cpp:126-133): Householder QR of (A Z)^T with dependent columns skipped.  The columns live in registers,
+    //      NL = 8 / 20 / 36 entries (the current null-space dimension n padded, as the interior point's NP): entries >= n are zero
+    auto nullSpace = [&](auto NLc) {
+      constexpr int NL = decltype(NLc)::value;
+      double dcol[NL];
 #pragma unroll
-      for (int i = 0; i < ND; ++i) dcol[i] = (lane < r && i < n) ? AZ[lane * LDZ + i] : 0.0;
+      for (int i = 0; i < NL; ++i) dcol[i] = (lane < r && i < n) ? AZ[lane * LDZ + i] : 0.0;
       double n2 = 0.0;
 #pragma unroll
-      for (int i = 0; i < ND; ++i) n2 += dcol[i] * dcol[i];
+      for (int i = 0; i < NL; ++i) n2 += dcol[i] * dcol[i];
       const double tol2 = 1e-20 * wbcMax(red, lane, lane < r ? n2 : 0.0);
       int kk = 0;
 #pragma unroll 1
@@ -696,13 +703,13 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         if (lane == j) {
           double m2 = 0.0, dk = 0.0;
 #pragma unroll
-          for (int i = 0; i < ND; ++i) { if (i >= kk) m2 += dcol[i] * dcol[i]; if (i == kk) dk = dcol[i]; }
+          for (int i = 0; i < NL; ++i) { if (i >= kk) m2 += dcol[i] * dcol[i]; if (i == kk) dk = dcol[i]; }
           ctl[0] = m2;
           if (m2 > tol2) {
             const double nrm = sqrt(m2), alpha = dk > 0.0 ? -nrm : nrm;
             double vn = 0.0;
 #pragma unroll
-            for (int i = 0; i < ND; ++i) { const double vv = (i > kk) ? dcol[i] : ((i == kk) ? dk - alpha : 0.0); Vh[kk * 40 + i] = vv; vn += vv * vv; }
+            for (int i = 0; i < NL; ++i) { const double vv = (i > kk) ? dcol[i] : ((i == kk) ? dk - alpha : 0.0); Vh[kk * 40 + i] = vv; vn += vv * vv; }
             Vh[kk * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
           }
         }
@@ -711,40 +718,44 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         if (indep && lane > j && lane < r) {
           double s = 0.0;
 #pragma unroll
-          for (int i = 0; i < ND; ++i) s += Vh[kk * 40 + i] * dcol[i];
+          for (int i = 0; i < NL; ++i) s += Vh[kk * 40 + i] * dcol[i];
           s *= Vh[kk * 40 + 36];
 #pragma unroll
-          for (int i = 0; i < ND; ++i) dcol[i] -= s * Vh[kk * 40 + i];
+          for (int i = 0; i < NL; ++i) dcol[i] -= s * Vh[kk * 40 + i];
         }
         QM_WAVE_SYNC();
         if (indep) ++kk;
       }
+      QM_TICK(15);
       const int rank = kk, nNew = n - rank;
       // null vectors: Q e_{rank + lane}
-      double nv[ND];
+      double nv[NL];
 #pragma unroll
-      for (int i = 0; i < ND; ++i) nv[i] = (i == rank + lane && lane < nNew) ? 1.0 : 0.0;
+      for (int i = 0; i < NL; ++i) nv[i] = (i == rank + lane && lane < nNew) ? 1.0 : 0.0;
 #pragma unroll 1
       for (int k = rank - 1; k >= 0; --k) {
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < ND; ++i) s += Vh[k * 40 + i] * nv[i];
+        for (int i = 0; i < NL; ++i) s += Vh[k * 40 + i] * nv[i];
         s *= Vh[k * 40 + 36];
 #pragma unroll
-        for (int i = 0; i < ND; ++i) nv[i] -= s * Vh[k * 40 + i];
+        for (int i = 0; i < NL; ++i) nv[i] -= s * Vh[k * 40 + i];
       }
+      QM_TICK(16);
       // Z N on the matrix cores: the null vectors (one per lane) pass through LDS (the K scratch is free here)
       if (lane < nNew) {
 #pragma unroll
-        for (int q = 0; q < ND; ++q) K[q * LDK + lane] = nv[q];
+        for (int q = 0; q < NL; ++q) K[q * LDK + lane] = nv[q];
       }
       QM_WAVE_SYNC();
-      forkGemm(false, Z, LDZ, K, LDK, ND, nNew, ND, Zn, LDZ, 0.0);
+      forkGemm(false, Z, LDZ, K, LDK, ND, nNew, NL, Zn, LDZ, 0.0);   // columns >= n of Z are zero: NL terms
       QM_WAVE_SYNC();
       for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
       n = nNew;
       QM_WAVE_SYNC();
-    }
+      QM_TICK(17);
+    };
+    if (n <= 8) nullSpace(std::integral_constant<int, 8>{}); else if (n <= 20) nullSpace(std::integral_constant<int, 20>{}); else nullSpace(std::integral_constant<int, ND>{});
   }
   QM_WAVE_SYNC();
   QM_TICK(9);
