@@ -697,9 +697,54 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 #pragma unroll
       for (int i = 0; i < NL; ++i) n2 += dcol[i] * dcol[i];
       const double tol2 = 1e-20 * wbcMax(red, lane, lane < r ? n2 : 0.0);
-      int kk = 0;
+      int kk = 0, j0 = 0;
+      // As long as every column so far was independent the rank kk equals the column index j: the steps are unrolled with j as a
+      // compile-time constant, so the entries i < j drop out of every loop instead of being masked one by one against the runtime rank
+      // (a reflector cost ~650 instructions in the generic loop below, which takes over at the first dependent column).
+      bool fast = true;
+#pragma unroll
+      for (int j = 0; j < MAXR; ++j) {
+        if (j < NL && fast && j < r && j < n) {   // wave-uniform
+          if (lane == j) {
+            double m2 = 0.0;
+#pragma unroll
+            for (int i = j; i < NL; ++i) m2 += dcol[i] * dcol[i];
+            ctl[0] = m2;
+            if (m2 > tol2) {
+              const double dk = dcol[j < NL ? j : 0];
+              const double nrm = sqrt(m2), alpha = dk > 0.0 ? -nrm : nrm;
+              double vn = 0.0;
+#pragma unroll
+              for (int i = 0; i < NL; ++i) { const double vv = (i > j) ? dcol[i] : ((i == j) ? dk - alpha : 0.0); Vh[j * 40 + i] = vv; vn += vv * vv; }
+              Vh[j * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
+            }
+          }
+          QM_WAVE_SYNC();
+          const bool indep = ctl[0] > tol2;
+          if (indep) {
+            if (lane > j && lane < r) {
+              double sdot = 0.0;
+#pragma unroll
+              for (int i = j; i < NL; ++i) sdot += Vh[j * 40 + i] * dcol[i];
+              sdot *= Vh[j * 40 + 36];
+#pragma unroll
+              for (int i = j; i < NL; ++i) dcol[i] -= sdot * Vh[j * 40 + i];
+            }
+            kk = j + 1; j0 = j + 1;
+#ifdef QM_RICCATI_TIMING
+            qmTs[19] += 1;
+#endif
+          } else {
+            fast = false; j0 = j;
+          }
+          QM_WAVE_SYNC();
+        }
+      }
 #pragma unroll 1
-      for (int j = 0; j < r && kk < n; ++j) {
+      for (int j = j0; j < r && kk < n; ++j) {
+#ifdef QM_RICCATI_TIMING
+        qmTs[18] += 1;
+#endif
         if (lane == j) {
           double m2 = 0.0, dk = 0.0;
 #pragma unroll
