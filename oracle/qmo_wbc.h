@@ -329,7 +329,8 @@ inline bool choleskyFloored(Mat& A, double floorv) {
 // 256 bench instances: 45 -> 31 iterations per update; mean 32.8 -> 24.2).  A constant, so that both implementations start identically
 // whatever null-space basis they use; <= 0 selects sqrt(scale) (second / third attempts, see HoQp).
 constexpr double kLowerLevelStart = 300.0;
-inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, double sigma0 = 1.0) {
+inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, double sigma0 = 1.0,
+                      bool activeSetCorrection = false) {
   const int n = H.r;
   // rows that are identically zero carry no information (the reference's friction task creates them, WbcBase.cpp:458)
   std::vector<int> keep;
@@ -354,16 +355,24 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   // than slack) the equality-constrained QP is solved by a few augmented-Lagrangian Newton steps from the interior-point solution:
   //   grad = H z + c + D_A' (lam_A + rho r_A),  r = D z - f ;   (H + rho D_A' D_A) dz = -grad ;   lam_A += rho r_A(z + dz).
   // The result is kept only if it is primal feasible and its multipliers are non-negative (else the interior-point iterate stands).
+  // activeSetCorrection (levels without slack variables of their own, i.e. every level below the first): the multiplier estimates after
+  // the FIRST step already tell whether the guess was right (rho is large: they agree with the final ones to two digits).  If some are
+  // negative while the point is feasible, those rows are released and the polish starts again from the interior-point iterate (once);
+  // if the guess is still wrong after that the attempt is abandoned at once instead of after two more steps and the check.  On the
+  // bench set the slowest instance read one weakly active row too many at both early attempts and went on for five more interior-point
+  // iterations (12 + three polishes = 24 passes of its second level; now 14).
   auto tryPolish = [&]() -> bool {
     std::vector<int> act;
     for (int i = 0; i < m; ++i) if (lam[i] > s[i]) act.push_back(i);
     double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
     const double rho = 1e6 * std::max(1.0, hmax);
-    Mat K = H;
-    for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
-    if (choleskyFloored(K, pivotFloor)) {
+    for (int released = 0;; ) {
+      Mat K = H;
+      for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
+      if (!choleskyFloored(K, pivotFloor)) return false;
       Vec zp = z, lp(m, 0.0);
       for (int r : act) lp[r] = lam[r];
+      bool again = false;
       for (int step = 0; step < 3; ++step) {
         const Vec Dz = D * zp;
         Vec t(m, 0.0);
@@ -373,15 +382,28 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
         for (int i = 0; i < n; ++i) zp[i] += dz[i];
         const Vec Dz2 = D * zp;
         for (int r : act) lp[r] += rho * (Dz2[r] - f[r]);
+        if (activeSetCorrection && step == 0) {
+          double viol = -1e300, lmin = 0.0;
+          for (int i = 0; i < m; ++i) viol = std::max(viol, Dz2[i] - f[i]);
+          for (int r : act) lmin = std::min(lmin, lp[r]);
+          if (released == 0 && lmin < -1e-9 * scale && viol <= 1e-6 * scale) {
+            std::vector<int> kept;
+            for (int r : act) if (!(lp[r] < 0.0)) kept.push_back(r);
+            act.swap(kept); released = 1; again = true;
+            break;
+          }
+          if (!(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) return false;
+        }
       }
+      if (again) continue;
       const Vec Dz = D * zp;
       bool ok = true;
       for (int i = 0; i < m; ++i) if (!(Dz[i] - f[i] <= 1e-9 * scale)) ok = false;
       for (int r : act) if (!(lp[r] >= -1e-9 * scale)) ok = false;
       for (double v : zp) if (!(v == v)) ok = false;
       if (ok) { z = zp; return true; }
+      return false;
     }
-    return false;
   };
   int it = 0;
   int earlyTries = 0; double lastTryMu = 1e300;
@@ -498,12 +520,12 @@ struct HoQp {
     // 100x that, and the iteration starts from slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the
     // higher priorities' solution) and the failure is reported.  2 x 2048 random configurations: 6 second attempts, no skip.
     if (nz > 0) {
-      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? kLowerLevelStart : 1.0);
+      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? kLowerLevelStart : 1.0, numSlack == 0);
       for (int attempt = 1; attempt <= 2 && qpIters < 0; ++attempt) {
         Vec fr = fv;
         const double margin = attempt == 1 ? kInheritedMargin : 100.0 * kInheritedMargin;   // 1e-5, then 1e-3
         for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(margin, fr[numSlack + i]);
-        qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 40, nullptr, -1.0);
+        qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 40, nullptr, -1.0, numSlack == 0);
       }
       if (qpIters < 0) sol.assign(nz, 0.0);
     } else sol.clear();

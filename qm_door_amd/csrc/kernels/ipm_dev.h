@@ -175,6 +175,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
     return false;
   };
   int polish = 0;                       // 0 interior point; 1..3 polish step; 4 final check
+  bool released = false;                // this polish attempt has already dropped the rows with negative multiplier estimates once
   // the polish is first tried as soon as the active set can plausibly be read (mu <= 1e-6 scale, at most twice): an accepted
                                             // vertex is exact whatever iterate it started from, a rejected one resumes the interior point
   bool isE = false, isV = false;        // my row: pinned (equality) / violated soft row of this level (exact quadratic)
@@ -223,6 +224,20 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
       if (rejected && early) { early = false; polish = 0; continue; }   // back to the interior point (its slacks / multipliers were not touched)
       break;
     }
+    if (polish == 2 && !own) {
+      // active-set correction (the oracle's solveQpIpm, activeSetCorrection): the multiplier estimates after the first step already
+      // tell whether the active set was read correctly.  Negative ones at a feasible point: release those rows and start the polish
+      // again from the interior-point iterate (once); still wrong: abandon the attempt now, not after two more steps and the check
+      const double viol = allMax(rowActive ? rRow : -1e300);
+      const double lmin = allMin((rowActive && isE) ? lamE : 0.0);
+      const bool release = !released && lmin < -1e-9 * scale && viol <= 1e-6 * scale;
+      if (release || !(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) {
+        zc = zIpm;
+        if (release) { released = true; isE = isE && !(lamE < 0.0); lamE = isE ? l1 : 0.0; polish = 1; continue; }
+        if (early) { early = false; polish = 0; continue; }
+        break;
+      }
+    }
     const double lamR = polish ? (isE ? lamE + rho * rRow : (isV ? rRow : 0.0)) : (rowActive ? l1 : 0.0);
     double rdz;
     {
@@ -263,7 +278,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
         itOut = it;
         const bool c1 = rowActive && l1 > s1, c2 = rowActive && own && l2 > s2;
         isE = c1 && (!own || c2); isV = c1 && own && !c2;
-        lamE = isE ? l1 : 0.0; zIpm = zc; polish = 1;
+        lamE = isE ? l1 : 0.0; zIpm = zc; polish = 1; released = false;
         continue;                                                    // residuals again, now in polish form (zc may have been restored)
       }
       zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;

@@ -277,6 +277,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 
   for (int e = lane; e < MAXM * LDZ; e += 64) DZ[e] = 0.0;  // rows >= m0 are never written: the interior point only needs them finite
   QM_TICK_DECL;
+#ifdef QM_RICCATI_TIMING
+  const unsigned long long qmStart = clock64();
+#endif
   // ---- S1: inputs
   if (lane < 55) rbd[lane] = a.rbd[size_t(inst) * 55 + lane];
   if (lane < 30) { xDes[lane] = a.xDes[size_t(inst) * 30 + lane]; uDes[lane] = a.uDes[size_t(inst) * 30 + lane]; il[lane] = a.inputLast[size_t(inst) * 30 + lane]; }
@@ -670,6 +673,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       QM_WAVE_SYNC();
     }
     if (it >= 60) status |= (1 << level);
+#ifdef QM_RICCATI_TIMING
+    if (lane == 0 && inst < 256) qmk::qmRiccatiTicks[512 + inst * 4 + 1 + level] = (unsigned long long)it;
+#endif
     QM_TICK(7);
     // ---- x = x_prev + Z z (HoQp.h:31-34); keep the slack solution of task 0 (HoQp.cpp:152-158)
     double xn = 0.0;
@@ -817,6 +823,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   QM_LDS_BARRIER();
   QM_TICK(10);
   QM_TICK_FLUSH(192, blockIdx.x == 0 && lane == 0);
+#ifdef QM_RICCATI_TIMING
+  if (lane == 0 && inst < 256) qmk::qmRiccatiTicks[512 + inst * 4] = clock64() - qmStart;
+#endif
 }
 
 }  // namespace qmk

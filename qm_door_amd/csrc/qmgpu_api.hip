@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(int doubles, double* si
 // profiling build only (tools/riccati_phase_probe.py): the phase clocks of riccati_kernel's workgroup 0, [wavefront][16]
 int qmgpu_debug_riccati_ticks(unsigned long long* out64, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return QMGPU_ERR_HIP;
-  if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(qmk::qmRiccatiTicks), sizeof(unsigned long long) * 512) != hipSuccess) return QMGPU_ERR_HIP;
-  if (reset) { unsigned long long z[512] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(qmk::qmRiccatiTicks), z, sizeof(z)) != hipSuccess) return QMGPU_ERR_HIP; }
+  if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(qmk::qmRiccatiTicks), sizeof(unsigned long long) * 2048) != hipSuccess) return QMGPU_ERR_HIP;
+  if (reset) { static unsigned long long z[2048] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(qmk::qmRiccatiTicks), z, sizeof(z)) != hipSuccess) return QMGPU_ERR_HIP; }
   return QMGPU_OK;
 }
 #endif

@@ -27,7 +27,7 @@ mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int
 for _ in range(3): sol.mpc(mb.args)
 lib = sol.lib
 lib.qmgpu_debug_riccati_ticks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-buf = (C.c_ulonglong * 512)()
+buf = (C.c_ulonglong * 2048)()
 assert lib.qmgpu_debug_riccati_ticks(buf, 1) == 0
 wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
 t_eval = G.dev(np.zeros(B), torch.float64)
@@ -69,3 +69,11 @@ LS = ["two model sweeps + constraints + EE cost", "defect", "tracking cost (two 
 v = raw[224:224 + len(LS)]
 print("linesearch nodePerformance, node 5 of instance 0 (all calls of a launch): total %d ticks (kernel %.4f ms)" % (v.sum(), ms[3]))
 for n_, x in zip(LS, v): print("  %-50s %9.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
+
+# per-instance totals of the last wbc launch (not sums): ticks, interior-point iterations of the three levels
+pi = np.array(buf[512:512 + 4 * B], dtype=np.float64).reshape(B, 4)
+tk, its = pi[:, 0], pi[:, 1:]
+print("wbc_kernel per instance (last launch): ticks mean %.0f  median %.0f  p90 %.0f  max %.0f  => max/mean %.3f; iterations per level mean %s max %s; total mean %.1f max %d"
+      % (tk.mean(), np.median(tk), np.percentile(tk, 90), tk.max(), tk.max() / tk.mean(), np.round(its.mean(0), 2).tolist(), its.max(0).astype(int).tolist(), its.sum(1).mean(), int(its.sum(1).max())))
+worst = np.argsort(-tk)[:6]
+print("  slowest instances:", [(int(i), int(tk[i]), its[i].astype(int).tolist()) for i in worst])
