@@ -61,7 +61,9 @@ constexpr int W_K = W_DZ + MAXM * LDZ;           // K / Cholesky [36][LDK]
 constexpr int W_G = W_K + ND * LDK;              // G = AZ^T AZ + eps [36][LDK]
 constexpr int W_VH = W_G + ND * LDK;             // Householder vectors [MAXR][40]
 constexpr int W_VEC = W_VH + MAXR * 40;          // vectors: x[36] z[36] g[36] rd[36] rhs[36] dz[36] fhat[56] lam[56] wt[56] tz[56] red[64]
-constexpr int WBC_LDS_DOUBLES = W_VEC + 6 * 36 + 4 * 56 + 1024 + 8;   // red[1024]: wavefront exchange scratch (only the host emulation uses more than 64)
+constexpr int W_BODY2 = W_VEC + 6 * 36 + 4 * 56 + 1024 + 8;   // (red[1024]: wavefront exchange scratch, only the host emulation uses more than 64) body / dof tables of the desired pass (wavefront 1)
+constexpr int W_DOF2 = W_BODY2 + 640;
+constexpr int WBC_LDS_DOUBLES = W_DOF2 + 144;
 constexpr int WBC_LDS_BYTES = WBC_LDS_DOUBLES * 8;
 constexpr int WBC_THREADS = 256;   // the solving wavefront + three helpers (one per SIMD of the CU)
 // misc block
@@ -239,7 +241,78 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   // Wavefront 0 solves the instance; the other three sit on the CU's idle SIMDs and take their share of the matrix-core tiles of the
   // interior point between two workgroup barriers (ipm_dev.h: ipmKTiles).  Command word: ctl[4] (0 = leave).
   double* forkCmd = ctl + 4; double* forkJob = red + 512;   // (red[0..63] carries the interior point's broadcasts, red[128..383] its partial sums; nothing else of it is used on the GPU)
+  // ---- S5: desired pass (WbcBase.cpp:205-237), on wavefront 1 while wavefront 0 runs the measured pass, M, nle and the Jacobians: it has its own
+  //      body / dof tables and writes only v_des of the base and the desired entries of mi, none of which is read before the join after S4.
+  //      v_des base from the centroidal map (WbcBase.cpp:217-219) with the MPC's own sweep.
+  auto desiredPass = [&](double* body, double* dof) {
+    {
+      double k1z[12];
+  #pragma unroll
+      for (int i = 0; i < 12; ++i) k1z[i] = 0.0;
+      const DblIn din{xDes, uDes, 0.0, k1z};
+      double f[12];
+      BaseMotion<double> bm;
+      centroidalSweep<double>(md, st.gravity, din, [&](int, Vec3<double>, Vec3<double>) {}, [&](Vec3<double>, const Mat3<double>&) { return Vec3<double>(); }, f, bm);
+      if (lane == 0) for (int i = 0; i < 6; ++i) vD[i] = f[6 + i];
+    }
+    QM_WAVE_SYNC();
+    bodyPass(md, qD, vD, mi + MI_JACC, body, dof, lane);
+    QM_WAVE_SYNC();
+    if (lane == 0) {
+      // momentum rate produced by (v_des, joint accelerations, zero base acceleration): Adot v + Aj qdd_j (WbcBase.cpp:231-234)
+      double ct[3] = {0, 0, 0};
+      for (int b = 0; b < QMGPU_NB; ++b) for (int i = 0; i < 3; ++i) ct[i] += md.mass[b] * body[b * 33 + 12 + i];
+      for (int i = 0; i < 3; ++i) ct[i] /= md.total_mass;
+      double hl[3] = {0, 0, 0}, ha[3] = {0, 0, 0}, Ic[6] = {0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < QMGPU_NB; ++b) {
+        const double* o = body + b * 33;
+        double pos[3], vel[3], acc[3], Iw_w[3], Iw_al[3], t[3], r[3], t2[3];
+        pointKin(md, body, b, md.com[b], pos, vel, acc);
+        symMul(o + 15, o + 21, Iw_w); symMul(o + 15, o + 24, Iw_al); cross3(o + 21, Iw_w, t);
+        for (int i = 0; i < 3; ++i) r[i] = pos[i] - ct[i];
+        double ma[3] = {md.mass[b] * acc[0], md.mass[b] * acc[1], md.mass[b] * acc[2]};
+        cross3(r, ma, t2);
+        const double rr = dot3(r, r), m = md.mass[b];
+        for (int i = 0; i < 3; ++i) { hl[i] += ma[i]; ha[i] += Iw_al[i] + t[i] + t2[i]; }
+        Ic[0] += o[15] + m * (rr - r[0] * r[0]); Ic[1] += o[16] - m * r[0] * r[1]; Ic[2] += o[17] - m * r[0] * r[2];
+        Ic[3] += o[18] + m * (rr - r[1] * r[1]); Ic[4] += o[19] - m * r[1] * r[2]; Ic[5] += o[20] + m * (rr - r[2] * r[2]);
+      }
+      double rl[3] = {-hl[0], -hl[1], -md.total_mass * st.gravity - hl[2]}, ra[3] = {-ha[0], -ha[1], -ha[2]};
+      for (int c = 0; c < 4; ++c) {
+        double pos[3], vel[3], acc[3], t[3], r[3];
+        pointKin(md, body, md.foot_body[c], md.foot_offset[c], pos, vel, acc);
+        for (int i = 0; i < 3; ++i) { mi[MI_FOOTPD + 3 * c + i] = pos[i]; mi[MI_FOOTVD + 3 * c + i] = vel[i]; r[i] = pos[i] - ct[i]; rl[i] += uDes[3 * c + i]; }
+        cross3(r, uDes + 3 * c, t);
+        for (int i = 0; i < 3; ++i) ra[i] += t[i];
+      }
+      {  // external end-effector force in the desired momentum rate (zero without force tracking)
+        double pos[3], vel[3], acc[3], t[3], r[3];
+        pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
+        for (int i = 0; i < 3; ++i) { r[i] = pos[i] - ct[i]; rl[i] += fe[i]; }
+        cross3(r, fe, t);
+        for (int i = 0; i < 3; ++i) ra[i] += t[i];
+      }
+      // wdot = Ic^-1 ra ; euler acceleration = T^-1 wdot ; linear = rl/m - wdot x (c - p0)
+      Sym3<double> S; S.xx = Ic[0]; S.xy = Ic[1]; S.xz = Ic[2]; S.yy = Ic[3]; S.yz = Ic[4]; S.zz = Ic[5];
+      const Vec3<double> wd = solveSym3(S, Vec3<double>(ra[0], ra[1], ra[2]));
+      const double wdv[3] = {wd.x, wd.y, wd.z}, rc[3] = {ct[0] - qD[0], ct[1] - qD[1], ct[2] - qD[2]};
+      double t[3];
+      cross3(wdv, rc, t);
+      double sz, cz, sy, cy;
+      sincos(qD[3], &sz, &cz); sincos(qD[4], &sy, &cy);
+      const double tmp = (cz * wd.x + sz * wd.y) / cy;
+      for (int i = 0; i < 3; ++i) mi[MI_BACC + i] = rl[i] / md.total_mass - t[i];
+      mi[MI_BACC + 3] = sy * tmp + wd.z; mi[MI_BACC + 4] = cz * wd.y - sz * wd.x; mi[MI_BACC + 5] = tmp;
+      double pos[3], vel[3], acc[3];
+      pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
+      for (int i = 0; i < 3; ++i) { mi[MI_EEPD + i] = pos[i]; mi[MI_EEVD + i] = vel[i]; }
+      for (int i = 0; i < 9; ++i) mi[MI_EERD + i] = body[md.ee_body * 33 + i];
+    }
+    QM_WAVE_SYNC();
+  };
   if (wave != 0) {
+    QM_LDS_BARRIER();                                     // inputs and coordinates (S1, S2) are in LDS
+    if (wave == 1) desiredPass(lds + W_BODY2, lds + W_DOF2);
     const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
     for (;;) {
       QM_LDS_BARRIER();
@@ -248,6 +321,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       if (op == 36) ipmKTiles<36, LDZ, LDK>(hio, wave, lane);
       else if (op == 20) ipmKTiles<20, LDZ, LDK>(hio, wave, lane);
       else if (op == 200) ipmColSumShare<LDZ>(hio, wave, lane);
+      else if (op == 300) {}                                // join of the desired pass
       else {   // 100 / 101: C = A B / A^T B, described in forkJob (pointers as offsets from the LDS base)
         const double* jA = lds + int(forkJob[0]); const double* jB = lds + int(forkJob[2]); double* jD = lds + int(forkJob[7]);
         const int lda = int(forkJob[1]), ldb = int(forkJob[3]), jM = int(forkJob[4]), jN = int(forkJob[5]), jK = int(forkJob[6]), ldd = int(forkJob[8]);
@@ -297,7 +371,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     for (int i = 0; i < 6; ++i) qD[i] = xDes[6 + i];
   }
   if (lane < 30) a.inputLast[size_t(inst) * 30 + lane] = uDes[lane];  // WbcBase.cpp:225
-  QM_WAVE_SYNC();
+  QM_LDS_BARRIER();      // wavefront 1 starts the desired pass (S5) from here
 
   QM_TICK(0);
   // ---- S3: measured pass (zero generalized acceleration -> bias terms)
@@ -393,71 +467,10 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   QM_WAVE_SYNC();
 
   QM_TICK(2);
-  // ---- S5: desired pass.  v_des base from the centroidal map (WbcBase.cpp:217-219) with the MPC's own sweep.
-  {
-    double k1z[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) k1z[i] = 0.0;
-    const DblIn din{xDes, uDes, 0.0, k1z};
-    double f[12];
-    BaseMotion<double> bm;
-    centroidalSweep<double>(md, st.gravity, din, [&](int, Vec3<double>, Vec3<double>) {}, [&](Vec3<double>, const Mat3<double>&) { return Vec3<double>(); }, f, bm);
-    if (lane == 0) for (int i = 0; i < 6; ++i) vD[i] = f[6 + i];
-  }
-  QM_WAVE_SYNC();
-  bodyPass(md, qD, vD, mi + MI_JACC, body, dof, lane);
-  QM_WAVE_SYNC();
-  if (lane == 0) {
-    // momentum rate produced by (v_des, joint accelerations, zero base acceleration): Adot v + Aj qdd_j (WbcBase.cpp:231-234)
-    double ct[3] = {0, 0, 0};
-    for (int b = 0; b < QMGPU_NB; ++b) for (int i = 0; i < 3; ++i) ct[i] += md.mass[b] * body[b * 33 + 12 + i];
-    for (int i = 0; i < 3; ++i) ct[i] /= md.total_mass;
-    double hl[3] = {0, 0, 0}, ha[3] = {0, 0, 0}, Ic[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < QMGPU_NB; ++b) {
-      const double* o = body + b * 33;
-      double pos[3], vel[3], acc[3], Iw_w[3], Iw_al[3], t[3], r[3], t2[3];
-      pointKin(md, body, b, md.com[b], pos, vel, acc);
-      symMul(o + 15, o + 21, Iw_w); symMul(o + 15, o + 24, Iw_al); cross3(o + 21, Iw_w, t);
-      for (int i = 0; i < 3; ++i) r[i] = pos[i] - ct[i];
-      double ma[3] = {md.mass[b] * acc[0], md.mass[b] * acc[1], md.mass[b] * acc[2]};
-      cross3(r, ma, t2);
-      const double rr = dot3(r, r), m = md.mass[b];
-      for (int i = 0; i < 3; ++i) { hl[i] += ma[i]; ha[i] += Iw_al[i] + t[i] + t2[i]; }
-      Ic[0] += o[15] + m * (rr - r[0] * r[0]); Ic[1] += o[16] - m * r[0] * r[1]; Ic[2] += o[17] - m * r[0] * r[2];
-      Ic[3] += o[18] + m * (rr - r[1] * r[1]); Ic[4] += o[19] - m * r[1] * r[2]; Ic[5] += o[20] + m * (rr - r[2] * r[2]);
-    }
-    double rl[3] = {-hl[0], -hl[1], -md.total_mass * st.gravity - hl[2]}, ra[3] = {-ha[0], -ha[1], -ha[2]};
-    for (int c = 0; c < 4; ++c) {
-      double pos[3], vel[3], acc[3], t[3], r[3];
-      pointKin(md, body, md.foot_body[c], md.foot_offset[c], pos, vel, acc);
-      for (int i = 0; i < 3; ++i) { mi[MI_FOOTPD + 3 * c + i] = pos[i]; mi[MI_FOOTVD + 3 * c + i] = vel[i]; r[i] = pos[i] - ct[i]; rl[i] += uDes[3 * c + i]; }
-      cross3(r, uDes + 3 * c, t);
-      for (int i = 0; i < 3; ++i) ra[i] += t[i];
-    }
-    {  // external end-effector force in the desired momentum rate (zero without force tracking)
-      double pos[3], vel[3], acc[3], t[3], r[3];
-      pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
-      for (int i = 0; i < 3; ++i) { r[i] = pos[i] - ct[i]; rl[i] += fe[i]; }
-      cross3(r, fe, t);
-      for (int i = 0; i < 3; ++i) ra[i] += t[i];
-    }
-    // wdot = Ic^-1 ra ; euler acceleration = T^-1 wdot ; linear = rl/m - wdot x (c - p0)
-    Sym3<double> S; S.xx = Ic[0]; S.xy = Ic[1]; S.xz = Ic[2]; S.yy = Ic[3]; S.yz = Ic[4]; S.zz = Ic[5];
-    const Vec3<double> wd = solveSym3(S, Vec3<double>(ra[0], ra[1], ra[2]));
-    const double wdv[3] = {wd.x, wd.y, wd.z}, rc[3] = {ct[0] - qD[0], ct[1] - qD[1], ct[2] - qD[2]};
-    double t[3];
-    cross3(wdv, rc, t);
-    double sz, cz, sy, cy;
-    sincos(qD[3], &sz, &cz); sincos(qD[4], &sy, &cy);
-    const double tmp = (cz * wd.x + sz * wd.y) / cy;
-    for (int i = 0; i < 3; ++i) mi[MI_BACC + i] = rl[i] / md.total_mass - t[i];
-    mi[MI_BACC + 3] = sy * tmp + wd.z; mi[MI_BACC + 4] = cz * wd.y - sz * wd.x; mi[MI_BACC + 5] = tmp;
-    double pos[3], vel[3], acc[3];
-    pointKin(md, body, md.ee_body, md.ee_offset, pos, vel, acc);
-    for (int i = 0; i < 3; ++i) { mi[MI_EEPD + i] = pos[i]; mi[MI_EEVD + i] = vel[i]; }
-    for (int i = 0; i < 9; ++i) mi[MI_EERD + i] = body[md.ee_body * 33 + i];
-  }
-  QM_WAVE_SYNC();
+  // ---- S5 runs on wavefront 1 (desiredPass above); join: its results are in LDS once everybody has passed this pair of barriers
+  if (lane == 0) forkCmd[0] = 300.0;
+  QM_LDS_BARRIER();
+  QM_LDS_BARRIER();
 
   QM_TICK(3);
   // ================================================================== hierarchical QP
