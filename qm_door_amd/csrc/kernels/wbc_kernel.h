@@ -482,10 +482,14 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   const int m0 = 36 + 5 * nst + 3 * nsw;
   for (int e = lane; e < MAXM * ND; e += 64) D0[e] = 0.0;
   QM_WAVE_SYNC();
-  if (lane < 18) {  // WbcBase.cpp:392-415; the LF leg limits are reused for every leg (WbcBase.cpp:599-600)
+  // WbcBase.cpp:392-415; the LF leg limits are reused for every leg (WbcBase.cpp:599-600).  Rows i and 18 + i = +-[M_joint | -J_joint^T], element by element
+  for (int e = lane; e < 18 * ND; e += 64) {
+    const int i = e / ND, j = e - i * ND;
+    const double v = j < NVV ? M[(6 + i) * NVV + j] : -Jf[(j - NVV) * NVV + 6 + i];
+    D0[e] = v; D0[18 * ND + e] = -v;
+  }
+  if (lane < 18) {
     const int i = lane;
-    for (int j = 0; j < NVV; ++j) { D0[i * ND + j] = M[(6 + i) * NVV + j]; D0[(18 + i) * ND + j] = -M[(6 + i) * NVV + j]; }
-    for (int j = 0; j < 12; ++j) { D0[i * ND + 24 + j] = -Jf[j * NVV + 6 + i]; D0[(18 + i) * ND + 24 + j] = Jf[j * NVV + 6 + i]; }
     const double lim = i < 12 ? md.effort_limit[i % 3] : md.effort_limit[i];
     f0[i] = lim - nle[6 + i]; f0[18 + i] = lim + nle[6 + i];
   }
