@@ -128,9 +128,17 @@ template <int NP, int J> struct IpmFactorStep {
   }
 };
 
-// returns the iteration count; 60 = not converged
+// returns the iteration count (60 = not converged) and this lane's slack value
+// A called function, not inlined: the kernel around it sits at 512 VGPRs with scratch, and three inlined instantiations of this body add
+// ~1400 scalar-register spills to it; as a function each instantiation gets its own allocation.  The arrays arrive as offsets into the
+// workgroup's dynamic LDS and are re-based on that symbol here, so that every access stays a ds_ instruction (pointers passed through a
+// call are generic: the same body ran 20 % slower on flat loads).
+struct IpmOff { int G, g, DZ, fhat, Kt, wtL, zs, red, fork; };
+struct IpmResult { int iterations; double v; };
 template <int NP, int LDZ_, int LDK_>
-__device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool rowActive, double sigma0, int lane, double* vOut) {
+__device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m0, bool own, bool rowActive, double sigma0, int lane) {
+  QM_DYNAMIC_LDS(ldsBase);
+  const IpmIo io{ldsBase + off.G, ldsBase + off.g, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork};
   constexpr int TP = (NP + 15) / 16;           // 16-wide tiles per dimension
   constexpr int KS = 14;                       // k steps of 4 rows: 56 inequality rows
   const int l16 = lane & 15, h = lane >> 4;
@@ -416,8 +424,7 @@ __device__ inline int ipmSolve(const IpmIo& io, int n, int m0, bool own, bool ro
   QM_TICK(5);
   QM_TICK_FLUSH(NP == 36 ? 160 : (NP == 20 ? 256 : 288), blockIdx.x == 0 && lane == 0);
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
-  *vOut = v;
-  return itOut;
+  return IpmResult{itOut, v};
 }
 
 }  // namespace qmk

@@ -522,14 +522,18 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         for (int j = 0; j < 12; ++j) A[lane * ND + 24 + j] = -Jf[j * NVV + lane];
         bvec[lane] = -nle[lane];
       }
-      if (lane == 32) {
+      {   // rows of Jacobians are copied by one lane per column (lanes 32..55), the right-hand sides by lane 56
+        const int jc = lane - 32;
         int row = 6;
         for (int c = 0; c < 4; ++c) if (contact[c]) {  // no contact motion (WbcBase.cpp:418-433)
-          for (int q = 0; q < 3; ++q) { for (int j = 0; j < NVV; ++j) A[(row + q) * ND + j] = Jf[(3 * c + q) * NVV + j]; bvec[row + q] = -mi[MI_FOOTDJV + 3 * c + q]; }
+          for (int q = 0; q < 3; ++q) {
+            if (jc >= 0 && jc < NVV) A[(row + q) * ND + jc] = Jf[(3 * c + q) * NVV + jc];
+            if (lane == 56) bvec[row + q] = -mi[MI_FOOTDJV + 3 * c + q];
+          }
           row += 3;
         }
         for (int c = 0; c < 4; ++c) if (!contact[c]) {  // swing feet carry no force (WbcBase.cpp:440-449)
-          for (int q = 0; q < 3; ++q) { A[(row + q) * ND + 24 + 3 * c + q] = 1.0; bvec[row + q] = 0.0; }
+          if (lane == 56) for (int q = 0; q < 3; ++q) { A[(row + q) * ND + 24 + 3 * c + q] = 1.0; bvec[row + q] = 0.0; }
           row += 3;
         }
       }
@@ -591,7 +595,6 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
             double eerr[3];
             rotErr(mi + MI_EERD, mi + MI_EERM, eerr);
             for (int q = 0; q < 3; ++q) {
-              for (int j = 0; j < NVV; ++j) { A[(row + q) * ND + j] = Ja[q * NVV + j]; A[(row + 3 + q) * ND + j] = (j >= 3 && j < 6) ? 0.0 : Ja[(3 + q) * NVV + j]; }
               bvec[row + q] = st.kp_ee_linear[q] * (mi[MI_EEPD + q] - mi[MI_EEPM + q]) + st.kd_ee_linear[q] * (mi[MI_EEVD + q] - mi[MI_EEVM + q]) - mi[MI_EEDJL + q];
               bvec[row + 3 + q] = st.kp_ee_angular[q] * eerr[q] + st.kd_ee_angular[q] * (-mi[MI_EEWM + q]) - mi[MI_EEDJA + q];
             }
@@ -606,9 +609,20 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
           for (int c = 0; c < 4; ++c) if (!contact[c]) {  // swing legs, weight 100 (WbcBase.cpp:323-346, HierarchicalWbc.cpp:29)
             for (int q = 0; q < 3; ++q) {
               const double acc2 = st.kp_swing * (mi[MI_FOOTPD + 3 * c + q] - mi[MI_FOOTPM + 3 * c + q]) + st.kd_swing * (mi[MI_FOOTVD + 3 * c + q] - mi[MI_FOOTVM + 3 * c + q]);
-              for (int j = 0; j < NVV; ++j) A[(row + q) * ND + j] = 100.0 * Jf[(3 * c + q) * NVV + j];
               bvec[row + q] = 100.0 * (acc2 - mi[MI_FOOTDJV + 3 * c + q]);
             }
+            row += 3;
+          }
+        }
+        if (lane >= 32 && lane < 32 + NVV) {   // the Jacobian rows of the same tasks, one lane per column (lane 0 is busy with the right-hand sides)
+          const int j = lane - 32;
+          int row = 4;
+          if (a.variant == 0) {
+            for (int q = 0; q < 3; ++q) { A[(row + q) * ND + j] = Ja[q * NVV + j]; A[(row + 3 + q) * ND + j] = (j >= 3 && j < 6) ? 0.0 : Ja[(3 + q) * NVV + j]; }
+            row += 6;
+          } else row += 2;
+          for (int c = 0; c < 4; ++c) if (!contact[c]) {
+            for (int q = 0; q < 3; ++q) A[(row + q) * ND + j] = 100.0 * Jf[(3 * c + q) * NVV + j];
             row += 3;
           }
         }
@@ -673,11 +687,12 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     const double nRowsTot = qmAllSum(rowActive ? (own ? 2.0 : 1.0) : 0.0, red);
     int it = 0;
     if (nRowsTot > 0.0) {
-      IpmIo io{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
-      double vRow;
-      if (n <= 8) it = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
-      else if (n <= 20) it = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
-      else it = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane, &vRow);
+      const IpmOff io{int(G - lds), int(gs - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds)};
+      IpmResult res;
+      if (n <= 8) res = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane);
+      else if (n <= 20) res = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane);
+      else res = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane);
+      it = res.iterations;
       QM_WAVE_SYNC();
     } else {
       // no inequality rows at all: z = -G^-1 g  (LDS Cholesky; never on the hot path of the reference's task sets)

@@ -226,5 +226,6 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 #define QM_LAUNCH(kernel, grid, block, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
 #define QM_LAUNCH_DYN(kernel, grid, block, shmemBytes, stream, ...) emuLaunch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block))
-#define QM_DYNAMIC_LDS(name) static qmk::real name[20480]  /* the CU's whole LDS at fp64 */
+static qmk::real g_emuDynamicLds[20480];   /* the CU's whole LDS at fp64; one workgroup runs at a time, and a kernel and the functions it calls see the same array (extern __shared__ on the GPU) */
+#define QM_DYNAMIC_LDS(name) qmk::real* const name = g_emuDynamicLds
 #define QM_ALLOW_DYNAMIC_LDS(kernel, bytes) 0
