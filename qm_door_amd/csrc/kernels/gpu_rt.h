@@ -79,6 +79,10 @@ __device__ __forceinline__ real qmReplicateRow0(real v, real* s = nullptr) { ret
 // keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
 // into the select that consumes it and pays the LDS latency once per branch)
 #define QM_KEEP(x) asm volatile("" : "+v"(x))
+// LDS pointer whose value the compiler may not fold: accesses through it use ONE address register plus the immediate offset of the
+// instruction.  With the address known at compile time (dynamic LDS starts at a link-time constant) a fully unrolled loop materialises a
+// separate address per access in a scalar register, spills them into vector lanes and pays v_readlane + v_mov per LDS instruction.
+#define QM_OPAQUE_LDS(T, name, p) T __attribute__((address_space(3)))* name = (T __attribute__((address_space(3)))*)(p); asm volatile("" : "+v"(name))
 // upper-triangle tile set of a symmetric product: acc[(ti,tj), ti <= tj] += A_ti B_tj for one k step of 4
 template <int TP> __device__ __forceinline__ void qmMfmaUpper(QmAcc* acc, const real* a, const real* b, real* = nullptr) {
   int t = 0;

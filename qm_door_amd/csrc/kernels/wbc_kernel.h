@@ -728,6 +728,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     //      NL = 8 / 20 / 36 entries (the current null-space dimension n padded, as the interior point's NP): entries >= n are zero
     auto nullSpace = [&](auto NLc) {
       constexpr int NL = decltype(NLc)::value;
+      QM_OPAQUE_LDS(double, VhL, Vh);   // one address register + immediate offsets for the reflector table
       double dcol[NL];
 #pragma unroll
       for (int i = 0; i < NL; ++i) dcol[i] = (lane < r && i < n) ? AZ[lane * LDZ + i] : 0.0;
@@ -753,8 +754,8 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
               const double nrm = sqrt(m2), alpha = dk > 0.0 ? -nrm : nrm;
               double vn = 0.0;
 #pragma unroll
-              for (int i = 0; i < NL; ++i) { const double vv = (i > j) ? dcol[i] : ((i == j) ? dk - alpha : 0.0); Vh[j * 40 + i] = vv; vn += vv * vv; }
-              Vh[j * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
+              for (int i = 0; i < NL; ++i) { const double vv = (i > j) ? dcol[i] : ((i == j) ? dk - alpha : 0.0); VhL[j * 40 + i] = vv; vn += vv * vv; }
+              VhL[j * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
             }
           }
           QM_WAVE_SYNC();
@@ -763,10 +764,10 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
             if (lane > j && lane < r) {
               double sdot = 0.0;
 #pragma unroll
-              for (int i = j; i < NL; ++i) sdot += Vh[j * 40 + i] * dcol[i];
-              sdot *= Vh[j * 40 + 36];
+              for (int i = j; i < NL; ++i) sdot += VhL[j * 40 + i] * dcol[i];
+              sdot *= VhL[j * 40 + 36];
 #pragma unroll
-              for (int i = j; i < NL; ++i) dcol[i] -= sdot * Vh[j * 40 + i];
+              for (int i = j; i < NL; ++i) dcol[i] -= sdot * VhL[j * 40 + i];
             }
             kk = j + 1; j0 = j + 1;
 #ifdef QM_RICCATI_TIMING
@@ -792,8 +793,8 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
             const double nrm = sqrt(m2), alpha = dk > 0.0 ? -nrm : nrm;
             double vn = 0.0;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) { const double vv = (i > kk) ? dcol[i] : ((i == kk) ? dk - alpha : 0.0); Vh[kk * 40 + i] = vv; vn += vv * vv; }
-            Vh[kk * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
+            for (int i = 0; i < NL; ++i) { const double vv = (i > kk) ? dcol[i] : ((i == kk) ? dk - alpha : 0.0); VhL[kk * 40 + i] = vv; vn += vv * vv; }
+            VhL[kk * 40 + 36] = vn > 0.0 ? 2.0 / vn : 0.0;
           }
         }
         QM_WAVE_SYNC();
@@ -801,10 +802,10 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         if (indep && lane > j && lane < r) {
           double s = 0.0;
 #pragma unroll
-          for (int i = 0; i < NL; ++i) s += Vh[kk * 40 + i] * dcol[i];
-          s *= Vh[kk * 40 + 36];
+          for (int i = 0; i < NL; ++i) s += VhL[kk * 40 + i] * dcol[i];
+          s *= VhL[kk * 40 + 36];
 #pragma unroll
-          for (int i = 0; i < NL; ++i) dcol[i] -= s * Vh[kk * 40 + i];
+          for (int i = 0; i < NL; ++i) dcol[i] -= s * VhL[kk * 40 + i];
         }
         QM_WAVE_SYNC();
         if (indep) ++kk;
@@ -819,10 +820,10 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       for (int k = rank - 1; k >= 0; --k) {
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) s += Vh[k * 40 + i] * nv[i];
-        s *= Vh[k * 40 + 36];
+        for (int i = 0; i < NL; ++i) s += VhL[k * 40 + i] * nv[i];
+        s *= VhL[k * 40 + 36];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) nv[i] -= s * Vh[k * 40 + i];
+        for (int i = 0; i < NL; ++i) nv[i] -= s * VhL[k * 40 + i];
       }
       QM_TICK(16);
       // Z N on the matrix cores: the null vectors (one per lane) pass through LDS (the K scratch is free here)

@@ -164,6 +164,7 @@ inline float qmRsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline double qmRsqrtPos(double x) { return 1.0 / std::sqrt(x); }
 inline float qmRsqrtPos(float x) { return 1.0f / std::sqrt(x); }
 #define QM_KEEP(x) (void)(x)
+#define QM_OPAQUE_LDS(T, name, p) T* name = (p)
 #define QM_LDS_CONST_PTR(T) const T*
 #define QM_TO_LDS_PTR(T, p) ((const T*)(p))
 namespace qmk {
