@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BATCH_PER_GPU = 256
 HORIZON_N = 100
-TRAFFIC_FILE = "r02l_traffic.json"   # rocprofv3 PMC passes of this same command, summarised (bytes per launch)
+TRAFFIC_FILE = "r02m_traffic.json"   # rocprofv3 PMC passes of this same command, summarised (bytes per launch)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public spec, v_mfma_f64_16x16x4_f64 (not listed in MI355X_MICROARCH.md)
 
 
