@@ -58,6 +58,7 @@ extern "C" {
 #define QMGPU_NWBC_OUT 54
 #define QMGPU_MAX_EVENTS 40 /* per-instance mode-schedule capacity */
 #define QMGPU_NSTATS 10
+#define QMGPU_F32_MAX_TARGET_KNOTS 64 /* target knots per instance an fp32 handle (qmgpu_create_ex, QMGPU_F32) can stage; more -> QMGPU_ERR_CAPACITY */
 
 typedef enum qmgpu_status {
   QMGPU_OK = 0,

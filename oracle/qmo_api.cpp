@@ -107,10 +107,10 @@ void qmo_lq_node(const qmgpu_problem* P, double t, double dt, const double* x, c
 }
 
 // One SQP iteration. warmX/warmU may be NULL (initializer: x_k = x0, u_k = weight compensation; QMInitializer.cpp:33-41).
-int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, const double* timeGrid, int K, const double* ttimes, const double* tstates,
-                  int nEv, const double* ev, const int32_t* modes, const double* warmX, const double* warmU, int lineSearch, double* outT, double* outX,
-                  double* outU, int32_t* outMode, double* stats) {
-  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, g_contactRef}};
+static int mpcSolveImpl(const qmgpu_problem* P, int N, double t0, const double* x0, const double* timeGrid, int K, const double* ttimes, const double* tstates,
+                        const double* contactRef, int nEv, const double* ev, const int32_t* modes, const double* warmX, const double* warmU, int lineSearch,
+                        double* outT, double* outX, double* outU, int32_t* outMode, double* stats) {
+  Problem pr{P, inputWeight(*P), ModeSchedule{nEv, ev, modes}, Target{K, ttimes, tstates, contactRef}};
   std::vector<double> tg(N + 1);
   for (int k = 0; k <= N; ++k) tg[k] = timeGrid ? timeGrid[k] : t0 + k * P->settings.dt;
   std::vector<double> X((N + 1) * 30), U(N * 30);
@@ -134,6 +134,68 @@ int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, co
   std::copy(r.U.begin(), r.U.end(), outU);
   if (stats) { stats[0] = r.merit0; stats[1] = r.viol0; stats[2] = r.merit1; stats[3] = r.viol1; stats[4] = r.alpha; stats[5] = r.stepType; stats[6] = r.armijo; stats[7] = r.status; stats[8] = iterations; stats[9] = convergence; }
   return r.status;
+}
+int qmo_mpc_solve(const qmgpu_problem* P, int N, double t0, const double* x0, const double* timeGrid, int K, const double* ttimes, const double* tstates,
+                  int nEv, const double* ev, const int32_t* modes, const double* warmX, const double* warmU, int lineSearch, double* outT, double* outX,
+                  double* outU, int32_t* outMode, double* stats) {
+  return mpcSolveImpl(P, N, t0, x0, timeGrid, K, ttimes, tstates, g_contactRef, nEv, ev, modes, warmX, warmU, lineSearch, outT, outX, outU, outMode, stats);
+}
+
+// MPC_MRT_Interface::evaluatePolicy as QMController::update uses it (qm_controllers/src/QMController.cpp:134-142): linear interpolation of the
+// state / input trajectories at t (the input trajectory has N entries: its last one is held), planned mode = mode of the node interval holding t.
+static void policyEval(int N, const double* tg, const double* X, const double* U, const int32_t* modes, double t, double* x, double* u, int32_t* mode) {
+  int idx; double alpha;
+  timeSegment(tg, N + 1, t, &idx, &alpha);
+  for (int i = 0; i < 30; ++i) x[i] = alpha * X[idx * 30 + i] + (1.0 - alpha) * X[(idx + 1) * 30 + i];
+  const int i0 = std::min(idx, N - 1), i1 = std::min(idx + 1, N - 1);
+  for (int i = 0; i < 30; ++i) u[i] = alpha * U[i0 * 30 + i] + (1.0 - alpha) * U[i1 * 30 + i];
+  int k = 0;
+  while (k < N && tg[k + 1] < t) ++k;
+  *mode = modes[k];
+}
+
+// The whole control cycle of a BATCH of independent instances, results returned -- what qmgpu_cycle_batch computes (MPC solve, policy evaluation at
+// tEval, WBC update), one instance at a time on `threads` host threads (instance i on thread i % threads; every solve is self-contained).  The GPU
+// parity tests use it to compare EVERY instance of the BASELINE configurations instead of a sample.  rbd == null: MPC only.
+// Per-instance inputs: t0 [B] (null: 0), x0 [B][30], target knots [B][K] / [B][K][37], contact reference [B][K][6] or null, mode schedule
+// nEv [B] / ev [B][QMGPU_MAX_EVENTS] / modes [B][QMGPU_MAX_EVENTS + 1]; tEval / period / time [B], rbd [B][55], inputLast [B][30] (in / out),
+// eeForce [B][3] or null.  Returns the number of instances whose Riccati factorisation or WBC reported a failure.
+int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int threads, const double* t0, const double* x0, const double* ttimes, const double* tstates,
+                       const double* contactRef, const int32_t* nEv, const double* ev, const int32_t* modes, int lineSearch, const double* tEval, const double* rbd,
+                       const double* period, const double* time, double* inputLast, const double* eeForce, int variant, double* outX, double* outU,
+                       int32_t* outMode, double* outStats, double* outPolicy /*[B][60] or null*/, int32_t* outPolicyMode /*[B] or null*/, double* outWbc /*[B][54]*/,
+                       int32_t* outWbcStatus /*[B]*/) {
+  if (threads < 1) threads = 1;
+  mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20);
+  std::vector<int> failed(threads, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([=, &failed]() {
+      std::vector<double> T(N + 1);
+      for (int i = t; i < batch; i += threads) {
+        double* Xi = outX + size_t(i) * (N + 1) * 30; double* Ui = outU + size_t(i) * N * 30; int32_t* Mi = outMode + size_t(i) * (N + 1);
+        double* Si = outStats + size_t(i) * QMGPU_NSTATS;
+        const int rc = mpcSolveImpl(P, N, t0 ? t0[i] : 0.0, x0 + size_t(i) * 30, nullptr, K, ttimes + size_t(i) * K, tstates + size_t(i) * K * 37,
+                                    contactRef ? contactRef + size_t(i) * K * 6 : nullptr, nEv[i], ev + size_t(i) * QMGPU_MAX_EVENTS,
+                                    modes + size_t(i) * (QMGPU_MAX_EVENTS + 1), nullptr, nullptr, lineSearch, T.data(), Xi, Ui, Mi, Si);
+        int bad = rc != 0;
+        if (rbd) {
+          double xd[30], ud[30]; int32_t md;
+          policyEval(N, T.data(), Xi, Ui, Mi, tEval[i], xd, ud, &md);
+          if (outPolicy) for (int j = 0; j < 30; ++j) { outPolicy[size_t(i) * 60 + j] = xd[j]; outPolicy[size_t(i) * 60 + 30 + j] = ud[j]; }
+          if (outPolicyMode) outPolicyMode[i] = md;
+          const int ws = wbcUpdate(*P, variant, xd, ud, rbd + size_t(i) * 55, md, period[i], time[i], inputLast + size_t(i) * 30, outWbc + size_t(i) * 54, nullptr,
+                                   eeForce ? eeForce + size_t(i) * 3 : nullptr);
+          outWbcStatus[i] = ws;
+          bad = bad || ws != 0;
+        }
+        failed[t] += bad;
+      }
+    });
+  for (auto& th : pool) th.join();
+  int n = 0;
+  for (int v : failed) n += v;
+  return n;
 }
 
 // DDP variant (ddpIteration): warmU [N][30] or null -> the initializer's inputs; warmX [N+1][30] or null -> open-loop rollout of the inputs

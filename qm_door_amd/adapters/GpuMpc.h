@@ -31,7 +31,9 @@ class GpuSqpSolver final : public ocs2::SolverBase {
  public:
   static constexpr int kMaxKnots = 32;
 
-  GpuSqpSolver(qmgpu_handle handle, const qmgpu_problem& problem, int maxNodes) : h_(handle), P_(problem), maxNodes_(maxNodes) {
+  // `ocp` is what upstream's SqpSolver receives (QMController.cpp:288-289 passes qmInterface_->getOptimalControlProblem()): kept as a copy only to
+  // answer SolverBase::getOptimalControlProblem() -- the kernels evaluate the same problem from the qmgpu_problem loaded from the same files.
+  GpuSqpSolver(qmgpu_handle handle, const qmgpu_problem& problem, int maxNodes, const ocs2::OptimalControlProblem& ocp) : h_(handle), P_(problem), maxNodes_(maxNodes), ocp_(ocp) {
     if (!handle || maxNodes < 1) throw std::invalid_argument("[GpuSqpSolver] bad arguments");
     layout();
     check(hipMalloc(&dev_, devBytes_), "hipMalloc");
@@ -53,6 +55,8 @@ class GpuSqpSolver final : public ocs2::SolverBase {
   void getPrimalSolution(ocs2::scalar_t /*finalTime*/, ocs2::PrimalSolution* out) const override { *out = primal_; }
   const ocs2::PerformanceIndex& getPerformanceIndeces() const override { return performance_; }
   size_t getNumIterations() const override { return iterations_; }
+  const ocs2::OptimalControlProblem& getOptimalControlProblem() const override { return ocp_; }
+  std::string getBenchmarkingInfo() const override { return "[GpuSqpSolver] per-kernel times: qmgpu_enable_timing / qmgpu_kernel_ms_mean on the handle"; }
   const std::vector<ocs2::PerformanceIndex>& getIterationsLog() const override { return log_; }
   // value function / multipliers are not exposed by this solver (the reference never queries them; SURVEY.md 8(b) allows the throw)
   ocs2::ScalarFunctionQuadraticApproximation getValueFunction(ocs2::scalar_t, const ocs2::vector_t&) const override { throw std::runtime_error("[GpuSqpSolver] getValueFunction not implemented"); }
@@ -148,11 +152,14 @@ class GpuSqpSolver final : public ocs2::SolverBase {
     char* hout = static_cast<char*>(pinned_);   // the input block has been consumed by the H2D copy queued before the kernels
     check(hipMemcpyAsync(hout, dCur, outBytes_, hipMemcpyDeviceToHost, copyStream_), "hipMemcpyAsync D2H");
     check(hipStreamSynchronize(copyStream_), "hipStreamSynchronize");
-    outSet_ = cur; prevNodes_ = N;
 
     const double* T = at<double>(hout, out_.T); const double* X = at<double>(hout, out_.X); const double* U = at<double>(hout, out_.U);
     std::copy(at<double>(hout, out_.stats), at<double>(hout, out_.stats) + QMGPU_NSTATS, stats_);
+    // A failed factorisation leaves the iterate where it was (the line search takes no step: out_x / out_u = the incoming iterate).  The failed
+    // block is NOT committed: the next run warm-starts from the last good solution (outSet_ / prevNodes_ unchanged), as upstream's solver keeps
+    // its previous primal solution when runImpl throws.
     if (stats_[7] != 0.0) throw std::runtime_error("[GpuSqpSolver] Riccati factorisation failed (projected Hessian not positive definite)");
+    outSet_ = cur; prevNodes_ = N;
     ocs2::PrimalSolution p;
     p.timeTrajectory_.assign(T, T + N + 1);
     p.stateTrajectory_.resize(size_t(N) + 1);
@@ -181,6 +188,7 @@ class GpuSqpSolver final : public ocs2::SolverBase {
   qmgpu_handle h_;
   qmgpu_problem P_;
   int maxNodes_;
+  ocs2::OptimalControlProblem ocp_;
   In in_{};
   Out out_{};
   size_t inBytes_ = 0, outBytes_ = 0, devBytes_ = 0, warmX_ = 0, warmU_ = 0;

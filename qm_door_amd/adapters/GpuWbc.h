@@ -10,6 +10,8 @@
 #include <qm_wbc/WbcBase.h>
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -28,8 +30,15 @@ class GpuWbc : public WbcBase {
     hip(hipHostMalloc(&pinned_, kBytes, hipHostMallocDefault), "hipHostMalloc");
     hip(hipStreamCreate(&stream_), "hipStreamCreate");
     check(qmgpu_set_stream(h_, stream_));
+    // Run-time gains.  WbcBase binds ITS dynamic_reconfigure server (<controller>/wbc) to a private, non-virtual callback that edits base-class
+    // members this class never reads (WbcBase.h:61, WbcBase.cpp:62-67,74-121), so that server cannot reach the GPU path.  The same
+    // qm_wbc::WbcWeightConfig is therefore served a second time under <controller>/wbc_gpu; requests arrive on a spinner thread, are staged
+    // under the mutex and applied at the start of the next update() on the ros_control thread (calls on one qmgpu handle must be serialised).
+    ros::NodeHandle nhGains(nh, "wbc_gpu");
+    dynamicSrv_ = std::make_shared<dynamic_reconfigure::Server<qm_wbc::WbcWeightConfig>>(nhGains);
+    dynamicSrv_->setCallback([this](qm_wbc::WbcWeightConfig& c, uint32_t) { stageGains(c); });
   }
-  ~GpuWbc() override {
+  ~GpuWbc() {   // (the reference's WbcBase declares no virtual destructor; the controller's shared_ptr was made from this type)
     qmgpu_set_stream(h_, nullptr);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (pinned_) (void)hipHostFree(pinned_);
@@ -41,6 +50,8 @@ class GpuWbc : public WbcBase {
   ocs2::vector_t update(const ocs2::vector_t& stateDesired, const ocs2::vector_t& inputDesired, const ocs2::vector_t& rbdStateMeasured, size_t mode,
                         ocs2::scalar_t period, ocs2::scalar_t time) override {
     if (stateDesired.size() != 30 || inputDesired.size() != 30 || rbdStateMeasured.size() != 55) throw std::runtime_error("[GpuWbc] bad vector sizes");
+    std::lock_guard<std::mutex> lock(mutex_);
+    if (settingsDirty_) { check(qmgpu_update_settings(h_, &P_.settings)); settingsDirty_ = false; }
     // one instance per call: 30 + 30 + 55 + 2 doubles and the mode up, 54 doubles and the status down (the batched entry point is for fleets)
     double* host = static_cast<double*>(pinned_);
     std::copy(stateDesired.data(), stateDesired.data() + 30, host + kXd);
@@ -68,8 +79,10 @@ class GpuWbc : public WbcBase {
 
   // Run-time gain changes (what WbcBase::dynamicCallback does with the dynamic_reconfigure server, WbcBase.cpp:74-121): edit the
   // settings copy and push it; takes effect for the next update(), no handle re-creation.
-  qmgpu_settings& settings() { return P_.settings; }
-  void pushSettings() { check(qmgpu_update_settings(h_, &P_.settings)); }
+  // Programmatic route: edit under the lock, applied by the next update().
+  template <class F> void editSettings(F&& edit) { std::lock_guard<std::mutex> lock(mutex_); edit(P_.settings); settingsDirty_ = true; }
+  qmgpu_settings settingsCopy() { std::lock_guard<std::mutex> lock(mutex_); return P_.settings; }
+  dynamic_reconfigure::Server<qm_wbc::WbcWeightConfig>& gainServer() { return *dynamicSrv_; }
   int lastStatus() const { return lastStatus_; }
 
  private:
@@ -78,9 +91,29 @@ class GpuWbc : public WbcBase {
   static constexpr size_t kBytes = kDoubles * sizeof(double);
   static void check(int st) { if (st != QMGPU_OK) throw std::runtime_error(std::string("[GpuWbc] ") + qmgpu_strerror(st) + ": " + qmgpu_last_error()); }
   static void hip(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string("[GpuWbc] ") + what + ": " + hipGetErrorString(e)); }
+  // WbcBase::dynamicCallback (WbcBase.cpp:74-121), field for field, into the settings block of the C ABI
+  void stageGains(const qm_wbc::WbcWeightConfig& c) {
+    std::lock_guard<std::mutex> lock(mutex_);
+    qmgpu_settings& s = P_.settings;
+    const double kpj[6] = {c.kp_arm_joint_1, c.kp_arm_joint_2, c.kp_arm_joint_3, c.kp_arm_joint_4, c.kp_arm_joint_5, c.kp_arm_joint_6};
+    const double kdj[6] = {c.kd_arm_joint_1, c.kd_arm_joint_2, c.kd_arm_joint_3, c.kd_arm_joint_4, c.kd_arm_joint_5, c.kd_arm_joint_6};
+    for (int i = 0; i < 6; ++i) { s.kp_arm_joint[i] = kpj[i]; s.kd_arm_joint[i] = kdj[i]; }
+    s.kp_ee_linear[0] = c.kp_ee_linear_x; s.kp_ee_linear[1] = c.kp_ee_linear_y; s.kp_ee_linear[2] = c.kp_ee_linear_z;
+    s.kd_ee_linear[0] = c.kd_ee_linear_x; s.kd_ee_linear[1] = c.kd_ee_linear_y; s.kd_ee_linear[2] = c.kd_ee_linear_z;
+    s.kp_ee_angular[0] = c.kp_ee_angular_x; s.kp_ee_angular[1] = c.kp_ee_angular_y; s.kp_ee_angular[2] = c.kp_ee_angular_z;
+    s.kd_ee_angular[0] = c.kd_ee_angular_x; s.kd_ee_angular[1] = c.kd_ee_angular_y; s.kd_ee_angular[2] = c.kd_ee_angular_z;
+    s.kp_swing = c.kp_swing; s.kd_swing = c.kd_swing;
+    s.kp_base_height = c.baseHeightKp; s.kd_base_height = c.baseHeightKd;
+    s.kp_base_angular = c.kp_base_angular; s.kd_base_angular = c.kd_base_angular;
+    s.kp_base_linear = c.kp_base_linear; s.kd_base_linear = c.kd_base_linear;
+    settingsDirty_ = true;
+  }
   qmgpu_handle h_;
   qmgpu_problem P_;
   int variant_;
+  std::mutex mutex_;               // update() (ros_control thread) vs gain requests (spinner thread)
+  bool settingsDirty_ = false;
+  std::shared_ptr<dynamic_reconfigure::Server<qm_wbc::WbcWeightConfig>> dynamicSrv_;
   void* dev_ = nullptr;
   void* pinned_ = nullptr;
   hipStream_t stream_ = nullptr;

@@ -17,7 +17,12 @@ namespace qm {
 class QMGpuController : public QMController {
  public:
   ~QMGpuController() override {
-    mpc_.reset(); wbc_.reset();          // the solver / WBC objects hold the handles' streams: they go first
+    // The base destructor stops the MPC thread (QMController.cpp:343-347) -- but it runs AFTER this one, and mpcMrtInterface_ holds MPC_BASE&
+    // (*mpc_): an advanceMpc() still in flight would touch a freed solver, a destroyed stream and freed device memory.  Stop the thread first
+    // (both members are protected, QMController.h:82-83; joining twice is harmless: the base finds the thread no longer joinable).
+    controllerRunning_ = false;
+    if (mpcThread_.joinable()) mpcThread_.join();
+    mpc_.reset(); wbc_.reset();          // the solver / WBC objects hold the handles' streams: they go before the handles
     qmgpu_destroy(mpcHandle_); qmgpu_destroy(wbcHandle_);
   }
 
@@ -26,7 +31,7 @@ class QMGpuController : public QMController {
   // that function (:290-306) on the new object: those lines only talk to MPC_BASE / SolverBase.
   void setupMpc(ros::NodeHandle& controller_nh) override {
     ensureHandles();
-    auto solver = std::make_unique<GpuSqpSolver>(mpcHandle_, problem_, kMaxNodes);
+    auto solver = std::make_unique<GpuSqpSolver>(mpcHandle_, problem_, kMaxNodes, qmInterface_->getOptimalControlProblem());
     mpc_ = std::make_shared<GpuMpc>(qmInterface_->mpcSettings(), std::move(solver));
     finishMpcSetup(controller_nh);
   }

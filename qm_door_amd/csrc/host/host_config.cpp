@@ -325,11 +325,13 @@ int qmgpu_tile_gait(const qmgpu_gait* gait, double t_phase0, double t_begin, dou
 // `transition_stance_time` (model_settings.phaseTransitionStanceTime, task.info:11) is inserted; then the template is tiled.
 int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transition_stance_time, double t_switch, double t_begin, double t_end, int32_t* num_events,
                       double* event_times, int32_t* modes) {
-  if (!gait || !num_events || !event_times || !modes || gait->num_modes < 1 || prev_mode < 0 || prev_mode > 15) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad gait");
+  if (!gait || !num_events || !event_times || !modes || gait->num_modes < 1 || gait->num_modes > QMGPU_MAX_EVENTS || prev_mode < 0 || prev_mode > 15)
+    return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad gait (1 <= num_modes <= QMGPU_MAX_EVENTS, 0 <= prev_mode <= 15)");
+  if (!std::isfinite(t_switch) || !std::isfinite(t_begin) || !std::isfinite(t_end) || !std::isfinite(transition_stance_time)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "gait times must be finite");
   const bool transition = prev_mode != 15 && prev_mode != gait->modes[0] && transition_stance_time > 0.0;
   const double t_phase0 = transition ? t_switch + transition_stance_time : t_switch;
   const double period = gait->switching_times[gait->num_modes] - gait->switching_times[0];
-  if (!(period > 0.0)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "gait period must be positive");
+  if (!(period > 0.0) || !std::isfinite(period)) return setError(QMGPU_ERR_INVALID_ARGUMENT, "gait period must be positive and finite");
   std::vector<double> ev;
   std::vector<int> md;
   // first tiled cycle: the one BEFORE the cycle that contains t_begin (so that a swing phase straddling the template boundary keeps
@@ -345,7 +347,10 @@ int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transiti
   else if (start > t_phase0) md.back() = 15;   // the horizon starts cycles after the switch: what precedes the first tiled cycle is never looked up
   ev.push_back(start);
   double t = start;
-  while (t < t_end) {
+  // bounded like the device tiler (frontend_kernel.h): more than QMGPU_MAX_EVENTS + 2 cycles either overflow the event table or add nothing
+  bool truncated = false;
+  for (int cycle = 0; t < t_end; ++cycle) {
+    if (cycle >= QMGPU_MAX_EVENTS + 2) { truncated = true; break; }
     for (int i = 0; i < gait->num_modes; ++i) {
       md.push_back(gait->modes[i]);
       t += gait->switching_times[i + 1] - gait->switching_times[i];
@@ -362,6 +367,7 @@ int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transiti
     md2.push_back(md[i + 1]);
   }
   if (int(ev2.size()) > QMGPU_MAX_EVENTS) return setError(QMGPU_ERR_CAPACITY, "mode schedule needs more than QMGPU_MAX_EVENTS events");
+  (void)truncated;   // a truncated tiling that did not overflow is a template without mode changes: complete as it is
   *num_events = int(ev2.size());
   for (size_t i = 0; i < ev2.size(); ++i) event_times[i] = ev2[i];
   for (size_t i = 0; i < md2.size(); ++i) modes[i] = md2[i];

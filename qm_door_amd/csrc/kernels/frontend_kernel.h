@@ -154,11 +154,13 @@ __global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
   const int gi = a.gaitIndex[i];
   if (gi < 0 || gi >= a.numTemplates) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
   const qmgpu_gait& g = a.templates[gi];
+  if (g.num_modes < 1 || g.num_modes > QMGPU_MAX_EVENTS) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }   // before switching_times[num_modes] is touched
   const double period = g.switching_times[g.num_modes] - g.switching_times[0];
-  if (g.num_modes < 1 || !(period > 0.0)) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
+  if (!(period > 0.0) || !(period < 1e300)) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
   const int prevMode = a.prevMode ? a.prevMode[i] : 15;
   if (prevMode < 0 || prevMode > 15) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }
   const double tSwitch = a.tPhase0[i], tBegin = a.tBegin[i], tEnd = a.tEnd[i];
+  if (!(fabs(tSwitch) < 1e300) || !(fabs(tBegin) < 1e300) || !(fabs(tEnd) < 1e300)) { stanceOnly(QMGPU_ERR_INVALID_ARGUMENT); return; }   // NaN / infinite times
   const bool transition = prevMode != 15 && prevMode != g.modes[0] && a.transitionStance > 0.0;
   const double tPhase0 = transition ? tSwitch + a.transitionStance : tSwitch;
   double start = tPhase0;
@@ -179,7 +181,9 @@ __global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
   if (transition && start == tPhase0) push(tSwitch, 15);
   double t = start;
   double evTime = start;
-  while (t < tEnd && !overflow) {
+  // At most QMGPU_MAX_EVENTS + 2 cycles: a template with a mode change yields an event per cycle (more cycles overflow anyway), one without
+  // changes yields none however often it is tiled -- so the bound changes no result, it only ends the loop (as host_config.cpp: qmgpu_switch_gait).
+  for (int cycle = 0; t < tEnd && !overflow && cycle < QMGPU_MAX_EVENTS + 2; ++cycle) {
     for (int m = 0; m < g.num_modes; ++m) {
       push(evTime, g.modes[m]);
       t += g.switching_times[m + 1] - g.switching_times[m];

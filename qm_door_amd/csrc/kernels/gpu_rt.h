@@ -9,9 +9,20 @@
 #include <hip/hip_runtime.h>
 #include "real.h"
 namespace qmk {
-// Lanes of a wavefront execute in lockstep and LDS operations of one wavefront complete in issue order, so an intra-wave LDS
-// hand-off needs no hardware barrier -- only a compiler scheduling fence.
+// Intra-wavefront LDS hand-off (lane a writes, lane b of the SAME wavefront reads).  Hardware: the lanes of a wavefront execute one
+// instruction stream and the LDS operations of one wavefront complete in issue order, so no s_barrier and no s_waitcnt is needed.
+// Compiler: the hand-off is a release by the writer and an acquire by the reader at wavefront scope, and it is stated as such --
+//   fence release (wavefront) ; llvm.amdgcn.wave.barrier ; fence acquire (wavefront)
+// The fences emit no instruction (SIMemoryLegalizer drops wavefront-scope fences: nothing to wait for), but at the IR level they are
+// what forbids moving, merging or forwarding LDS accesses across the hand-off; the wave barrier keeps the machine scheduler from
+// moving anything across it.  Round 2 used the bare wave barrier, whose memory semantics depend on the LLVM version (IntrNoMem until
+// 2023; this ROCm 7.2 compiler declares it without a memory attribute, i.e. already as a clobber -- DESIGN.md section 4.7).
+// -DQM_WAVE_SYNC_BARE restores the bare form (tools/wbc_variants.py builds it as one of the variants that must agree).
+#ifdef QM_WAVE_SYNC_BARE
 #define QM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define QM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 // ---- a register value as 32-bit words (v_readlane / DPP / permlane move 32 bits): one word for fp32, two for fp64
 __device__ __forceinline__ double qmFromWords(int lo, int hi, double) { return __hiloint2double(hi, lo); }
 __device__ __forceinline__ float qmFromWords(int lo, int, float) { return __int_as_float(lo); }

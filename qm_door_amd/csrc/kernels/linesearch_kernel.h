@@ -207,8 +207,10 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   real alpha = 1.0_r, merit1 = merit0, viol1 = viol0;
   int stepType = 0;
   bool accepted = false;
+  // A failed Riccati factorisation (pivots replaced by 1: the direction is garbage) takes no trial at all: alpha = 0, the new iterate IS the
+  // incoming one -- as the oracle's sqpIteration, which returns (X, U) unchanged with status 1 (workgroup-uniform: read from HBM by every thread).
 #pragma unroll 1
-  for (int trial = 0; trial < 64; ++trial) {
+  for (int trial = 0; trial < (ricStatus == 0.0_r ? 64 : 0); ++trial) {
     const real alphaMine = myTr ? alpha * st.alpha_decay : alpha;
     for (int e = ltid; e < (N + 1) * 30; e += half) Xt[e] = X[e] + alphaMine * dX[e];
     for (int e = ltid; e < N * 30; e += half) Ut[e] = U[e] + alphaMine * dU[e];

@@ -70,6 +70,15 @@ constexpr int WBC_THREADS = 256;   // the solving wavefront + three helpers (one
 constexpr int MI_FOOTPM = 0, MI_FOOTVM = 12, MI_FOOTDJV = 24, MI_FOOTPD = 36, MI_FOOTVD = 48, MI_EEPM = 60, MI_EEVM = 63, MI_EEWM = 66, MI_EEDJL = 69, MI_EEDJA = 72,
               MI_EERM = 75, MI_EEPD = 84, MI_EEVD = 87, MI_EERD = 90, MI_AL0 = 99, MI_BACC = 102, MI_JACC = 108 /*18*/, MI_BAX = 126 /*measured base Euler axes, 9*/;
 
+// -DQM_WBC_DUMP (tools/wbc_variants.py, experiments only): instance 0 copies its whole LDS carve to a device symbol at a few checkpoints, so that two
+// build variants of the kernel can be compared array by array (qmgpu_debug_wbc_dump).  The product build compiles every QM_WBC_CHECKPOINT to nothing.
+#if defined(QM_WBC_DUMP) && !defined(QMGPU_HOST_EMULATION)
+constexpr int WBC_DUMP_POINTS = 8;
+__device__ double qmWbcDump[WBC_DUMP_POINTS * 17000];
+#define QM_WBC_CHECKPOINT(cp) do { if (blockIdx.x == 0 && wave == 0) { QM_WAVE_SYNC(); for (int e_ = lane; e_ < WBC_LDS_DOUBLES; e_ += 64) qmk::qmWbcDump[(cp) * 17000 + e_] = lds[e_]; QM_WAVE_SYNC(); } } while (0)
+#else
+#define QM_WBC_CHECKPOINT(cp)
+#endif
 __device__ __forceinline__ void cross3(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
@@ -222,21 +231,32 @@ __device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane)
 }
 
 __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(WbcArgs a) {
+#if defined(QM_WBC_OPAQUE_MASK) && !defined(QMGPU_HOST_EMULATION)
+  // Experiment (tools/wbc_variants.py): array group g of the LDS carve is addressed through one opaque
+  // address-space-3 base register when bit g of the mask is set (round 2's "whole base opaque" = mask 31 returned wrong torques).
   QM_DYNAMIC_LDS(lds);
+  QM_OPAQUE_LDS(double, ldsO, lds);
+  double* ldsQ = (double*)ldsO;
+#define QM_WBC_BASE(g) ((((QM_WBC_OPAQUE_MASK) >> (g)) & 1) ? ldsQ : lds)
+#else
+  QM_DYNAMIC_LDS(lds);
+#define QM_WBC_BASE(g) lds
+#endif
   QM_POISON_LDS(lds, WBC_LDS_DOUBLES);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, inst = blockIdx.x;
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
   double fe[3] = {0.0, 0.0, 0.0};   // external force on the arm end-effector (force tracking; zero otherwise)
   if (a.eeForce) for (int i = 0; i < 3; ++i) fe[i] = a.eeForce[size_t(inst) * 3 + i];
-  double* in = lds + W_IN; double* rbd = in; double* xDes = in + 55; double* uDes = in + 85; double* il = in + 115;
-  double* qM = lds + W_Q; double* vM = qM + 24; double* qD = qM + 48; double* vD = qM + 72;
-  double* body = lds + W_BODY; double* dof = lds + W_DOF; double* wr = lds + W_WR; double* M = lds + W_M; double* nle = lds + W_NLE;
-  double* Jf = lds + W_JF; double* Ja = lds + W_JA; double* mi = lds + W_MISC;
-  double* A = lds + W_A; double* bvec = lds + W_B; double* D0 = lds + W_D0; double* f0 = lds + W_F0; double* v0 = f0 + MAXM;
-  double* Z = lds + W_Z; double* Zn = lds + W_ZN; double* AZ = lds + W_AZ; double* DZ = lds + W_DZ; double* K = lds + W_K; double* G = lds + W_G; double* Vh = lds + W_VH;
-  double* xs = lds + W_VEC; double* zs = xs + 36; double* gs = zs + 36; double* rds = gs + 36; double* rhs = rds + 36; double* dzs = rhs + 36;
-  double* fhat = dzs + 36; double* lam = fhat + 56; double* wt = lam + 56; double* tzv = wt + 56; double* red = tzv + 56; double* ctl = red + 1024;
+  // opaque-mask groups: 0 inputs | 1 coordinates | 2 model | 3 task equalities | 4 task inequalities | 5 QP matrices | 6 small vectors | 7 row vectors | 8 exchange scratch + control words
+  double* in = QM_WBC_BASE(0) + W_IN; double* rbd = in; double* xDes = in + 55; double* uDes = in + 85; double* il = in + 115;
+  double* qM = QM_WBC_BASE(1) + W_Q; double* vM = qM + 24; double* qD = qM + 48; double* vD = qM + 72;
+  double* body = QM_WBC_BASE(2) + W_BODY; double* dof = QM_WBC_BASE(2) + W_DOF; double* wr = QM_WBC_BASE(2) + W_WR; double* M = QM_WBC_BASE(2) + W_M; double* nle = QM_WBC_BASE(2) + W_NLE;
+  double* Jf = QM_WBC_BASE(2) + W_JF; double* Ja = QM_WBC_BASE(2) + W_JA; double* mi = QM_WBC_BASE(2) + W_MISC;
+  double* A = QM_WBC_BASE(3) + W_A; double* bvec = QM_WBC_BASE(3) + W_B; double* D0 = QM_WBC_BASE(4) + W_D0; double* f0 = QM_WBC_BASE(4) + W_F0; double* v0 = f0 + MAXM;
+  double* Z = QM_WBC_BASE(5) + W_Z; double* Zn = QM_WBC_BASE(5) + W_ZN; double* AZ = QM_WBC_BASE(5) + W_AZ; double* DZ = QM_WBC_BASE(5) + W_DZ; double* K = QM_WBC_BASE(5) + W_K; double* G = QM_WBC_BASE(5) + W_G; double* Vh = QM_WBC_BASE(5) + W_VH;
+  double* xs = QM_WBC_BASE(6) + W_VEC; double* zs = xs + 36; double* gs = zs + 36; double* rds = gs + 36; double* rhs = rds + 36; double* dzs = rhs + 36;
+  double* fhat = QM_WBC_BASE(7) + (W_VEC + 6 * 36); double* lam = fhat + 56; double* wt = lam + 56; double* tzv = wt + 56; double* red = QM_WBC_BASE(8) + (W_VEC + 6 * 36 + 4 * 56); double* ctl = red + 1024;
 
   // Wavefront 0 solves the instance; the other three sit on the CU's idle SIMDs and take their share of the matrix-core tiles of the
   // interior point between two workgroup barriers (ipm_dev.h: ipmKTiles).  Command word: ctl[4] (0 = leave).
@@ -314,9 +334,22 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     QM_LDS_BARRIER();                                     // inputs and coordinates (S1, S2) are in LDS
     if (wave == 1) desiredPass(lds + W_BODY2, lds + W_DOF2);
     const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
+#if defined(QM_WBC_DUMP) && !defined(QMGPU_HOST_EMULATION)
+    int dbgIt = 0;
+#endif
     for (;;) {
       QM_LDS_BARRIER();
       const int op = int(forkCmd[0]);
+#if defined(QM_WBC_DUMP) && !defined(QMGPU_HOST_EMULATION)
+      // what each helper wavefront saw, in order: tail of checkpoint image (wave - 1): per iteration [op, exec lo, exec hi, wave, first active lane, job M, N, K]
+      if (blockIdx.x == 0 && dbgIt < 45) {
+        const unsigned long long ex = __builtin_amdgcn_read_exec();
+        double* o = qmk::qmWbcDump + ((wave - 1) * 17000 + 16640 + dbgIt * 8);
+        o[0] = double(op); o[1] = double(unsigned(ex)); o[2] = double(unsigned(ex >> 32)); o[3] = double(wave); o[4] = double(__builtin_amdgcn_readfirstlane(lane));
+        o[5] = forkJob[4]; o[6] = forkJob[5]; o[7] = forkJob[6];
+      }
+      ++dbgIt;
+#endif
       if (op == 0) break;
       if (op == 36) ipmKTiles<36, LDZ, LDK>(hio, wave, lane);
       else if (op == 20) ipmKTiles<20, LDZ, LDK>(hio, wave, lane);
@@ -472,6 +505,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   QM_LDS_BARRIER();
   QM_LDS_BARRIER();
 
+  QM_WBC_CHECKPOINT(0);   // model, Jacobians, desired pass
   QM_TICK(3);
   // ================================================================== hierarchical QP
   int status = 0;
@@ -643,6 +677,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 #ifdef QMGPU_EMU_DEBUG
     if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d r %d n %d b:", level, r, n); for (int i = 0; i < r; ++i) printf(" %.10g", bvec[i]); printf("\n"); }
 #endif
+    if (level == 0) QM_WBC_CHECKPOINT(1);   // task 0: A, b, D0, f0
     QM_TICK(5);
     // ---- reduced data: AZ = A Z (r x n), rhat = A x - b, DZ = D0 Z, fhat
     const int mOwn = (level == 0) ? m0 : 0, mPrev = (level == 0) ? 0 : m0;
@@ -680,6 +715,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
     QM_WAVE_SYNC();
 
+    if (level == 0) QM_WBC_CHECKPOINT(2);   // reduced data of level 0: AZ, DZ, fhat, G, g
     QM_TICK(6);
     // ---- interior point iterations (ipm_dev.h): K on the matrix cores, factorisation and solves in registers
     const double pivotFloor = 1e-13 * qmAllMax(lane < n ? G[lane * LDK + lane] : 0.0, red);
@@ -708,6 +744,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 #ifdef QM_RICCATI_TIMING
     if (lane == 0 && inst < 256) qmk::qmRiccatiTicks[512 + inst * 4 + 1 + level] = (unsigned long long)it;
 #endif
+    if (level == 0) QM_WBC_CHECKPOINT(3);   // z of level 0
     QM_TICK(7);
     // ---- x = x_prev + Z z (HoQp.h:31-34); keep the slack solution of task 0 (HoQp.cpp:152-158)
     double xn = 0.0;
@@ -721,6 +758,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     QM_WAVE_SYNC();
     if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d it %d x:", level, it); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
 #endif
+    if (level == 0) QM_WBC_CHECKPOINT(4);   // x, v0 after level 0
     if (level == numLevels - 1) break;
 
     QM_TICK(8);
@@ -840,8 +878,11 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       QM_TICK(17);
     };
     if (n <= 8) nullSpace(std::integral_constant<int, 8>{}); else if (n <= 20) nullSpace(std::integral_constant<int, 20>{}); else nullSpace(std::integral_constant<int, ND>{});
+    if (level == 0) QM_WBC_CHECKPOINT(5);   // Z after the first null space
+    if (level == 1) QM_WBC_CHECKPOINT(6);
   }
   QM_WAVE_SYNC();
+  QM_WBC_CHECKPOINT(7);
   QM_TICK(9);
   // ---- updateCmd (WbcBase.cpp:580-595): tau = [M_j, -J_j^T] x + h_j
   if (lane < ND) a.out[size_t(inst) * 54 + lane] = xs[lane];

@@ -218,6 +218,15 @@ int qmgpu_debug_riccati_ticks(unsigned long long* out64, int reset) {
 }
 #endif
 
+#ifdef QM_WBC_DUMP
+// experiment build only (tools/wbc_variants.py): LDS images of instance 0 of the last wbc_kernel launch at the kernel's checkpoints
+extern "C" int qmgpu_debug_wbc_dump(double* out, int doubles) {
+  if (hipDeviceSynchronize() != hipSuccess) return QMGPU_ERR_HIP;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(qmk::qmWbcDump), sizeof(double) * size_t(doubles)) != hipSuccess) return QMGPU_ERR_HIP;
+  return QMGPU_OK;
+}
+#endif
+
 int qmgpu_debug_poison(qmgpu_handle h) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
@@ -242,6 +251,7 @@ static void checkMpcArgs(qmgpu_handle h, const qmgpu_mpc_args* a) {
   if (!h || !a) throw std::invalid_argument("null argument");
   if (a->batch < 1 || a->num_nodes < 1 || a->num_target_knots < 1) throw std::invalid_argument("batch, num_nodes and num_target_knots must be positive");
   if (a->batch > h->maxBatch || a->num_nodes > h->maxNodes) throw CapacityError("batch / num_nodes exceed the capacity given to qmgpu_create");
+  if (h->dtype == QMGPU_F32 && a->num_target_knots > QMGPU_F32_MAX_TARGET_KNOTS) throw CapacityError("an fp32 handle stages at most QMGPU_F32_MAX_TARGET_KNOTS target knots per instance");
   if (!a->x0 || !a->target_times || !a->target_states || !a->sched_num_events || !a->sched_event_times || !a->sched_modes) throw std::invalid_argument("missing MPC input pointer");
   if (!a->time_grid && !a->t0) throw std::invalid_argument("either t0 or time_grid is required");
   if (!a->out_t || !a->out_x || !a->out_u || !a->out_mode) throw std::invalid_argument("missing MPC output pointer");

@@ -15,7 +15,7 @@ static_assert(sizeof(qmk::real) == 4, "compile this file with -DQM_REAL=float -D
 
 namespace qmk {   // = qmk32 in this translation unit
 
-constexpr int kMaxKnots32 = 64;
+constexpr int kMaxKnots32 = QMGPU_F32_MAX_TARGET_KNOTS;   // include/qmgpu.h; checked by checkMpcArgs (QMGPU_ERR_CAPACITY) before this translation unit is reached
 
 __global__ void __launch_bounds__(256) narrow_kernel(const double* src, float* dst, size_t n) {
   for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) dst[i] = float(src[i]);

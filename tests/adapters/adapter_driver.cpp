@@ -2,8 +2,12 @@
 // a controller derived from qm::QMGpuController runs its setupMpc / setupWbc hooks, then the MPC thread's `mpc_->run(t, x)` and the
 // update tick's `wbc_->update(...)`.  OCS2 / ROS types are the stand-ins of tests/adapters/mock.  Reads one text file of inputs,
 // writes one text file of results; tests/test_adapters.py compares them with the same solve made directly through the C ABI.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <thread>
 #include <iostream>
 #include <vector>
 
@@ -17,6 +21,11 @@ struct Harness : qm::QMGpuController {
   using qm::QMController::qmInterface_;
   using qm::QMController::wbc_;
   using qm::QMController::rbdConversions_;
+  using qm::QMController::setupMrt;
+  using qm::QMController::mpcRunning_;
+  using qm::QMController::mrtRuns_;
+  using qm::QMController::mrtState_;
+  using qm::QMController::mrtTime_;
 };
 ocs2::vector_t readVec(std::istream& in, int n) { ocs2::vector_t v(n); for (int i = 0; i < n; ++i) in >> v[i]; return v; }
 void writeVec(std::ostream& out, const ocs2::vector_t& v) { out.precision(17); for (long i = 0; i < v.size(); ++i) out << v[i] << (i + 1 < v.size() ? ' ' : '\n'); }
@@ -49,11 +58,15 @@ int main(int argc, char** argv) {
     ctl.setupMpc(nh);
     ctl.setupWbc(nh, argv[1]);
     if (!ctl.mpc_ || !ctl.wbc_ || !ctl.rbdConversions_) throw std::runtime_error("hooks did not install mpc_ / wbc_ / rbdConversions_");
+    if (ctl.mpc_->getSolverPtr()->getOptimalControlProblem().id != ctl.qmInterface_->getOptimalControlProblem().id) throw std::runtime_error("solver does not hand back the interface's OCP");
 
+    double lastT = 0.0;
+    ocs2::vector_t lastX;
     for (int r = 0; r < runs; ++r) {          // MPC thread: advanceMpc -> MPC_BASE::run(t, x)
       double t = 0.0;
       in >> t;
       const ocs2::vector_t x = readVec(in, 30);
+      lastT = t; lastX = x;
       ctl.mpc_->run(t, x);
       ocs2::PrimalSolution p;
       ctl.mpc_->getSolverPtr()->getPrimalSolution(t + horizon, &p);
@@ -68,19 +81,60 @@ int main(int argc, char** argv) {
     }
     int ticks = 0;
     in >> ticks;
+    ocs2::vector_t lastXd, lastUd, lastRbd;
+    size_t lastMode = 15;
     for (int k = 0; k < ticks; ++k) {          // update(): wbc_->update(optimizedState, optimizedInput, measuredRbdState, plannedMode, period, time)
       const ocs2::vector_t xd = readVec(in, 30), ud = readVec(in, 30), rbd = readVec(in, 55);
       size_t mode = 0; double period = 0.0, time = 0.0;
       in >> mode >> period >> time;
+      if (!in) throw std::runtime_error("input file too short");
+      lastXd = xd; lastUd = ud; lastRbd = rbd; lastMode = mode;
       out << "wbc " << k << '\n';
       writeVec(out, ctl.wbc_->update(xd, ud, rbd, mode, period, time));
     }
-    // run-time gain change (dynamic_reconfigure path): doubled swing gains must change nothing in full stance and are accepted
+    // run-time gain change: a dynamic_reconfigure request on <controller>/wbc_gpu arrives on ANOTHER thread while update() ticks; it is staged
+    // under the adapter's mutex and applied by the next update().  Same gains -> same torques; doubled base-height gain -> different torques.
     auto* gw = dynamic_cast<qm::GpuWbc*>(ctl.wbc_.get());
-    gw->settings().kp_base_height *= 2.0;
-    gw->pushSettings();
+    if (!gw) throw std::runtime_error("wbc_ is not a GpuWbc");
+    if (ticks > 0) {
+      in.clear();
+      const qmgpu_settings s0 = gw->settingsCopy();
+      qm_wbc::WbcWeightConfig cfg;
+      cfg.kp_arm_joint_1 = s0.kp_arm_joint[0]; cfg.kp_arm_joint_2 = s0.kp_arm_joint[1]; cfg.kp_arm_joint_3 = s0.kp_arm_joint[2]; cfg.kp_arm_joint_4 = s0.kp_arm_joint[3];
+      cfg.kp_arm_joint_5 = s0.kp_arm_joint[4]; cfg.kp_arm_joint_6 = s0.kp_arm_joint[5];
+      cfg.kd_arm_joint_1 = s0.kd_arm_joint[0]; cfg.kd_arm_joint_2 = s0.kd_arm_joint[1]; cfg.kd_arm_joint_3 = s0.kd_arm_joint[2]; cfg.kd_arm_joint_4 = s0.kd_arm_joint[3];
+      cfg.kd_arm_joint_5 = s0.kd_arm_joint[4]; cfg.kd_arm_joint_6 = s0.kd_arm_joint[5];
+      cfg.kp_ee_linear_x = s0.kp_ee_linear[0]; cfg.kp_ee_linear_y = s0.kp_ee_linear[1]; cfg.kp_ee_linear_z = s0.kp_ee_linear[2];
+      cfg.kd_ee_linear_x = s0.kd_ee_linear[0]; cfg.kd_ee_linear_y = s0.kd_ee_linear[1]; cfg.kd_ee_linear_z = s0.kd_ee_linear[2];
+      cfg.kp_ee_angular_x = s0.kp_ee_angular[0]; cfg.kp_ee_angular_y = s0.kp_ee_angular[1]; cfg.kp_ee_angular_z = s0.kp_ee_angular[2];
+      cfg.kd_ee_angular_x = s0.kd_ee_angular[0]; cfg.kd_ee_angular_y = s0.kd_ee_angular[1]; cfg.kd_ee_angular_z = s0.kd_ee_angular[2];
+      cfg.kp_swing = s0.kp_swing; cfg.kd_swing = s0.kd_swing; cfg.baseHeightKp = s0.kp_base_height; cfg.baseHeightKd = s0.kd_base_height;
+      cfg.kp_base_angular = s0.kp_base_angular; cfg.kd_base_angular = s0.kd_base_angular; cfg.kp_base_linear = s0.kp_base_linear; cfg.kd_base_linear = s0.kd_base_linear;
+      const ocs2::vector_t before = gw->update(lastXd, lastUd, lastRbd, lastMode, 0.002, 30.0);
+      std::thread spinner([&]() { gw->gainServer().fire(cfg); });            // identical gains, from another thread, while ...
+      const ocs2::vector_t during = gw->update(lastXd, lastUd, lastRbd, lastMode, 0.002, 30.002);   // ... the update thread ticks
+      spinner.join();
+      const ocs2::vector_t same = gw->update(lastXd, lastUd, lastRbd, lastMode, 0.002, 30.004);
+      cfg.baseHeightKp *= 2.0;
+      std::thread spinner2([&]() { gw->gainServer().fire(cfg); });
+      spinner2.join();
+      const ocs2::vector_t changed = gw->update(lastXd, lastUd, lastRbd, lastMode, 0.002, 30.006);
+      double dSame = 0.0, dChanged = 0.0;
+      for (int i = 36; i < 54; ++i) { dSame = std::max(dSame, std::fabs(same[i] - during[i])); dChanged = std::max(dChanged, std::fabs(changed[i] - same[i])); }
+      out.precision(17);
+      out << "gains " << dSame << ' ' << dChanged << ' ' << (gw->settingsCopy().kp_base_height / s0.kp_base_height) << ' ' << before.size() << '\n';
+    }
+    // teardown with the MPC thread running (QMController::setupMrt, QMController.cpp:309-335): the derived destructor must stop and join it before the
+    // solver, its stream and the handles go -- the object is destroyed at the end of this block while advanceMpc() is being called in a loop
+    if (runs > 0) {
+      ctl.mrtTime_ = lastT; ctl.mrtState_ = lastX;
+      ctl.setupMrt();
+      ctl.mpcRunning_ = true;
+      while (ctl.mrtRuns_ < 3) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      out << "mrt " << ctl.mrtRuns_ << '\n';
+    }
     out << "done\n";
-    if (!in) throw std::runtime_error("input file too short");
+    out.flush();
   } catch (const std::exception& e) {
     std::fprintf(stderr, "adapter_driver: %s\n", e.what());
     return 1;

@@ -8,11 +8,13 @@ using namespace ocs2;
 using namespace legged_robot;
 class QMInterface {
  public:
+  const OptimalControlProblem& getOptimalControlProblem() const { return problem_; }   // QMInterface.h:37
   const mpc::Settings& mpcSettings() const { return mpcSettings_; }
   PinocchioInterface& getPinocchioInterface() { return pinocchio_; }
   const CentroidalModelInfo& getCentroidalModelInfo() const { return info_; }
   std::shared_ptr<SwitchedModelReferenceManager> getSwitchedModelReferenceManagerPtr() const { return referenceManagerPtr_; }
   std::shared_ptr<ReferenceManagerInterface> getReferenceManagerPtr() const { return referenceManagerPtr_; }
+  OptimalControlProblem problem_{42};
   mpc::Settings mpcSettings_;
   PinocchioInterface pinocchio_;
   CentroidalModelInfo info_;

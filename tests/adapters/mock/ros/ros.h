@@ -7,6 +7,10 @@ namespace ros {
 class Publisher {};
 class NodeHandle {
  public:
+  NodeHandle() = default;
+  NodeHandle(const NodeHandle& parent, const std::string& ns) : ns_(parent.ns_ + "/" + ns) {}
+  const std::string& getNamespace() const { return ns_; }
+  std::string ns_;
   template <class M> Publisher advertise(const std::string& topic, unsigned queue) { advertised.push_back(topic); (void)queue; return Publisher(); }
   std::vector<std::string> advertised;
 };

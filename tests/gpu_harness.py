@@ -4,12 +4,20 @@ import torch
 
 from qm_door_amd import abi, api
 
+# "cuda": the product path.  "cpu" is set only by bench.py --emulate (the CPU test of the multi-rank bench: host-emulated kernels, tests/emu).
+DEVICE = "cuda"
+
 
 def dev(a, dtype=None):
     t = torch.as_tensor(np.ascontiguousarray(a))
     if dtype is not None:
         t = t.to(dtype)
-    return t.cuda().contiguous()
+    return t.to(DEVICE).contiguous()
+
+
+def _sync():
+    if DEVICE == "cuda":
+        torch.cuda.synchronize()
 
 
 class MpcBatch:
@@ -26,16 +34,16 @@ class MpcBatch:
         self.wx = dev(warm[0], f64) if warm else None
         self.wu = dev(warm[1], f64) if warm else None
         self.tg = dev(time_grid, f64) if time_grid is not None else None
-        self.oT = torch.zeros((B, N + 1), dtype=f64, device="cuda"); self.oX = torch.zeros((B, N + 1, 30), dtype=f64, device="cuda")
-        self.oU = torch.zeros((B, N, 30), dtype=f64, device="cuda"); self.oM = torch.zeros((B, N + 1), dtype=torch.int32, device="cuda")
-        self.oS = torch.zeros((B, abi.NSTATS), dtype=f64, device="cuda")
+        self.oT = torch.zeros((B, N + 1), dtype=f64, device=DEVICE); self.oX = torch.zeros((B, N + 1, 30), dtype=f64, device=DEVICE)
+        self.oU = torch.zeros((B, N, 30), dtype=f64, device=DEVICE); self.oM = torch.zeros((B, N + 1), dtype=torch.int32, device=DEVICE)
+        self.oS = torch.zeros((B, abi.NSTATS), dtype=f64, device=DEVICE)
         K = target_times.shape[1]
         assert target_states.shape == (B, K, 37)
         self.args = api.GpuSolver.mpc_args(B, N, self.x0, self.tt, self.ts, self.sn, self.se, self.sm, self.oT, self.oX, self.oU, self.oM, self.oS, t0=self.t0,
                                            time_grid=self.tg, warm_x=self.wx, warm_u=self.wu, line_search=line_search)
 
     def results(self):
-        torch.cuda.synchronize()
+        _sync()
         return dict(T=self.oT.cpu().numpy(), X=self.oX.cpu().numpy(), U=self.oU.cpu().numpy(), mode=self.oM.cpu().numpy(), stats=self.oS.cpu().numpy())
 
 
@@ -47,15 +55,17 @@ class WbcBatch:
         self.xd = dev(state_desired, f64) if state_desired is not None else None
         self.ud = dev(input_desired, f64) if input_desired is not None else None
         self.mode = dev(mode, torch.int32) if mode is not None else None
-        self.out = torch.zeros((B, 54), dtype=f64, device="cuda"); self.status = torch.zeros(B, dtype=torch.int32, device="cuda")
+        self.out = torch.zeros((B, 54), dtype=f64, device=DEVICE); self.status = torch.zeros(B, dtype=torch.int32, device=DEVICE)
         self.args = api.GpuSolver.wbc_args(B, self.rbd, self.period, self.time, self.il, self.out, self.status, self.xd, self.ud, self.mode, variant)
 
     def results(self):
-        torch.cuda.synchronize()
+        _sync()
         return dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), input_last=self.il.cpu().numpy())
 
 
 def make_solver(interface, max_batch, max_nodes, dtype="f64"):
+    if DEVICE != "cuda":
+        return api.GpuSolver(interface, max_batch, max_nodes, device=0, dtype=dtype)
     s = api.GpuSolver(interface, max_batch, max_nodes, device=torch.cuda.current_device(), dtype=dtype)
     s.set_stream(torch.cuda.current_stream().cuda_stream)
     return s

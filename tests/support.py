@@ -223,6 +223,46 @@ class Oracle:
                               p(le), feet_height, arm_dist, start[0], start[1], start[2], p(x0), p(tt), p(ts))
         return x0, tt, ts, le
 
+    def cycle_batch(self, N, x0, ttimes, tstates, nev, ev, modes, t0=None, contact=None, line_search=True, t_eval=None, rbd=None, period=None, time=None,
+                    input_last=None, ee_force=None, variant=0, threads=None):
+        """qmo_cycle_batch_mt: the whole control cycle (MPC solve -> policy evaluation at t_eval -> WBC update) of EVERY instance of a batch on
+        `threads` host threads (default: the CPUs this process may use).  Shapes as the C ABI: x0 [B][30], ttimes [B][K], tstates [B][K][37],
+        nev [B] (or a scalar), ev [B][MAX_EVENTS] / modes [B][MAX_EVENTS + 1] (or one schedule for all).  rbd None: MPC only."""
+        B = x0.shape[0]
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        x0 = f64(x0); ttimes = f64(ttimes); tstates = f64(tstates)
+        K = ttimes.shape[1]
+        assert tstates.shape == (B, K, 37)
+        nev = np.ascontiguousarray(np.broadcast_to(np.asarray(nev, dtype=np.int32), (B,)))
+        ev = f64(np.broadcast_to(ev, (B, abi.MAX_EVENTS))); modes = np.ascontiguousarray(np.broadcast_to(modes, (B, abi.MAX_EVENTS + 1)), dtype=np.int32)
+        t0 = None if t0 is None else f64(t0)
+        contact = None if contact is None else f64(contact)
+        X, U, M, st = np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+        pol, pm, wout, wst = np.zeros((B, 60)), np.zeros(B, dtype=np.int32), np.zeros((B, 54)), np.zeros(B, dtype=np.int32)
+        il = None
+        if rbd is not None:
+            rbd = f64(rbd); t_eval = f64(np.broadcast_to(0.0 if t_eval is None else t_eval, (B,)))
+            period = f64(np.broadcast_to(0.002 if period is None else period, (B,))); time = f64(np.broadcast_to(20.0 if time is None else time, (B,)))
+            il = np.zeros((B, 30)) if input_last is None else np.array(input_last, dtype=np.float64)
+            ee_force = None if ee_force is None else f64(ee_force)
+        if threads is None:
+            threads = len(os.sched_getaffinity(0))
+            try:   # a cgroup quota below the visible CPU count (the GPU boxes: 256 hardware threads, 16 CPUs granted)
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    threads = max(1, min(threads, int(np.ceil(int(q) / int(per)))))
+            except (OSError, ValueError):
+                pass
+        fn = self.lib.qmo_cycle_batch_mt
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 8
+        bad = fn(C.byref(self.P), B, N, K, int(threads), p(t0), p(x0), p(ttimes), p(tstates), p(contact), p(nev), p(ev), p(modes), int(line_search), p(t_eval), p(rbd),
+                 p(period), p(time), p(il), p(ee_force), int(variant), p(X), p(U), p(M), p(st), p(pol), p(pm), p(wout), p(wst))
+        out = dict(X=X, U=U, mode=M, stats=st, failed=bad)
+        if rbd is not None:
+            out.update(x_des=pol[:, :30], u_des=pol[:, 30:], policy_mode=pm, out=wout, status=wst, input_last=il)
+        return out
+
     def time_cycles_node_threads(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, node_threads=3, line_search=True):
         """Seconds for `count` MPC+WBC cycles, one instance at a time, `node_threads` workers over the shooting nodes (task.info:78)."""
         f = self.lib.qmo_time_cycles_node_threads
@@ -314,3 +354,51 @@ def ee_contact_force(oracle, x, contact_knot, stiffness=FT_STIFFNESS):
     """f_e = -K (p_ee(x) - p_env) of the contact model at state x for one knot [f_ref(3), p_env(3)]"""
     _, _, ee, _, _ = oracle.kinematics(x, np.zeros(30))
     return -stiffness * (ee - contact_knot[3:6])
+
+
+# ------------------------------------------------------------------------------------------------ whole-batch parity (every instance, not a sample)
+def rel_inf(got, ref):
+    """||got - ref||_inf / max(1, ||ref||_inf) per instance (axis 0 = instance)"""
+    B = ref.shape[0]
+    d = np.abs(got.reshape(B, -1) - ref.reshape(B, -1)).max(axis=1)
+    return d / np.maximum(1.0, np.abs(ref.reshape(B, -1)).max(axis=1))
+
+
+def parity_report(name, got, ref, keys=("X", "U"), tau=True, record=True):
+    """Per-instance deviations of a GPU batch against the oracle batch: max / p99 / median per block, exact agreement of modes and step lengths.
+    Appends the numbers to gpurun_out/parity.json (copied to profiles/r03_parity.json for the record)."""
+    rep = {"instances": int(ref["X"].shape[0])}
+    for k in keys:
+        e = rel_inf(got[k], ref[k])
+        rep[k] = {"max": float(e.max()), "p99": float(np.percentile(e, 99)), "median": float(np.median(e)), "argmax": int(e.argmax())}
+    if tau and "out" in ref:
+        e = rel_inf(got["out"][:, 36:], ref["out"][:, 36:])
+        rep["tau"] = {"max": float(e.max()), "p99": float(np.percentile(e, 99)), "median": float(np.median(e)), "argmax": int(e.argmax())}
+        rep["wbc_status_nonzero"] = [int((got["status"] != 0).sum()), int((ref["status"] != 0).sum())]
+    rep["modes_equal"] = bool(np.array_equal(got["mode"], ref["mode"]))
+    rep["alpha_equal"] = int((got["stats"][:, 4] == ref["stats"][:, 4]).sum())
+    rep["step_type_equal"] = int((got["stats"][:, 5] == ref["stats"][:, 5]).sum())
+    rep["riccati_status_nonzero"] = [int((got["stats"][:, 7] != 0).sum()), int((ref["stats"][:, 7] != 0).sum())]
+    if record:
+        import json
+        path = os.path.join(ROOT, "gpurun_out", "parity.json")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            allrep = json.load(open(path))
+        except (OSError, ValueError):
+            allrep = {}
+        allrep[name] = rep
+        json.dump(allrep, open(path, "w"), indent=1)
+    return rep
+
+
+def assert_parity(rep, tol=1e-6, tau_tol=1e-6):
+    B = rep["instances"]
+    assert rep["modes_equal"], rep
+    assert rep["alpha_equal"] == B and rep["step_type_equal"] == B, rep
+    assert rep["riccati_status_nonzero"] == [0, 0], rep
+    for k in ("X", "U"):
+        assert rep[k]["max"] <= tol, (k, rep)
+    if "tau" in rep:
+        assert rep["wbc_status_nonzero"] == [0, 0], rep
+        assert rep["tau"]["max"] <= tau_tol, rep

@@ -88,3 +88,20 @@ def test_fp32_translation_unit_contains_no_fp64_arithmetic():
                 assert not f64, (name, sorted(set(f64)))
     assert seen == set(arithmetic), seen
     assert "v_mfma_f32_16x16x4_f32" in text and "v_mfma_f64" not in text
+
+
+def test_generated_device_structs_are_current():
+    """kernels/problem_r.h (the fp32 build's mirrors of qmgpu_model / qmgpu_settings + the field-by-field conversion) is generated from
+    include/qmgpu.h; a field added to the public header and not regenerated would silently be missing from the fp32 path."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(S.ROOT, "tools", "gen_problem_r.py"), "--check"])
+    assert r.returncode == 0, "run python tools/gen_problem_r.py"
+
+
+def test_inline_assembly_has_no_data_hazard_the_compiler_cannot_see():
+    """tools/check_asm_hazards.py on the device assembly of both translation units (hipcc cross-compiles here): the DPP multiply-adds written as
+    inline assembly (gpu_rt.h: qmFmacRowBcast) must not read a source register a VALU instruction wrote in the two preceding wait states."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(S.ROOT, "tools", "check_asm_hazards.py"), "--build"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "DPP instructions, 0 hazards" in r.stdout

@@ -45,7 +45,7 @@ def _write_inputs(path, nev, ev, md, tt, ts, horizon, runs, ticks):
 
 def _read_outputs(path):
     toks = open(path).read().split()
-    i, runs, wbc = 0, [], []
+    i, runs, wbc, extra = 0, [], [], {}
     while toks[i] != "done":
         if toks[i] == "run":
             n1, iters, pre = int(toks[i + 2]), int(toks[i + 3]), int(toks[i + 4]); i += 5
@@ -57,9 +57,13 @@ def _read_outputs(path):
         elif toks[i] == "wbc":
             i += 2
             wbc.append(np.array(toks[i:i + 54], dtype=float)); i += 54
+        elif toks[i] == "gains":
+            extra["gains"] = [float(t) for t in toks[i + 1:i + 5]]; i += 5
+        elif toks[i] == "mrt":
+            extra["mrt_runs"] = int(toks[i + 1]); i += 2
         else:
             raise AssertionError(f"unexpected token {toks[i]}")
-    return runs, wbc
+    return runs, wbc, extra
 
 
 @pytest.mark.gpu
@@ -106,9 +110,14 @@ def test_adapters_reproduce_the_direct_c_abi_solves(interface, oracle):
         _write_inputs(fin, nev, ev, md, tt, ts, horizon, [(0.0, x0), (dt, x1)], ticks)
         d = abi.DATA_DIR
         p = subprocess.run([exe, f"{d}/task.info", f"{d}/aliengo_z1.urdf", f"{d}/reference.info", fin, fout], capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stderr
-        runs, wbc = _read_outputs(fout)
+        assert p.returncode == 0, p.stderr       # (a crash while the controller is torn down with its MPC thread running would show here)
+        runs, wbc, extra = _read_outputs(fout)
     assert len(runs) == 2 and len(wbc) == 2
+    # gains through the dynamic_reconfigure stand-in on another thread: identical gains change nothing, a doubled base-height gain is applied by the
+    # next update() and moves the torques; the MPC thread made >= 3 solves before the controller was destroyed under it
+    d_same, d_changed, ratio, out_len = extra["gains"]
+    assert d_same == 0.0 and d_changed > 1e-6 and ratio == 2.0 and out_len == 54
+    assert extra["mrt_runs"] >= 3
     for k, (run, ref, N) in enumerate(((runs[0], r1, N1), (runs[1], r2, N2))):
         assert run["T"].shape == (N + 1,) and np.array_equal(run["T"], ref["T"][0])
         assert run["pre"] == k + 1 and run["iters"] == 1 and run["policy"] == N + 1     # preSolverRun reached the wrapped manager; feed-forward policy

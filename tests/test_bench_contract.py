@@ -25,5 +25,52 @@ def test_bench_line_and_forced_collective():
     assert cfg["collective"].startswith("all_gather") and cfg["gather_matches_local_results"] is True
     assert cfg["gathered_bytes_per_step"] == 256 * (101 * 30 + 100 * 30 + 54 + 101) * 8 and len(cfg["per_rank_value"]) == 1
     assert cfg["results_finite_and_converged"] is True
+    assert cfg["workload"].startswith("configs[1]")
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic_source" in r
+    # north_star's evidence fields: matrix-core busy fraction and HBM GB/s of the roofline kernel (counters of the committed PMC passes, labelled)
+    assert 0.0 < r["mfma_busy"] < 1.0 and 0.0 < r["hbm_gbps"] < 8000.0 and r["traffic"] > 0 and "profiles/" in r["traffic_source"]
+    assert set(r["hbm_gbps_by_kernel"]) >= {"ad_node_kernel", "lq_node_kernel", "riccati_kernel", "wbc_kernel"}
+
+
+@pytest.mark.gpu
+def test_bench_scenario_every_instance_against_oracle(interface):
+    """The bench's OWN scenario (bench.build_scenario: EE target from StartingPosition.h constants, schedule from qmgpu_tile_gait) -- all 256 instances of
+    one cycle against the multi-threaded oracle, not only `results_finite_and_converged`."""
+    import numpy as np
+    import torch
+    import bench
+    import gpu_harness as G
+    import support as S
+    B, N = bench.BATCH_PER_GPU, bench.HORIZON_N
+    sc = bench.build_scenario(interface, B, seed=0)
+    sol = G.make_solver(interface, B, N)
+    mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int32), np.tile(sc["ev"], (B, 1)), np.tile(sc["md"], (B, 1)), N)
+    wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
+    sol.cycle(mb.args, G.dev(np.zeros(B), torch.float64), wb.args)
+    got = mb.results(); got.update(wb.results())
+    ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, sc["x0"], sc["tt"], sc["ts"], sc["nev"], sc["ev"], sc["md"], rbd=sc["rbd"])
+    S.assert_parity(S.parity_report("bench_scenario_configs1_256xN100", got, ref))
+
+
+def test_bench_two_ranks_on_the_emulation_path():
+    """CPU: `python bench.py --gpus 2` without a launcher environment starts its own two ranks (torch.distributed.run on 127.0.0.1); with --emulate
+    the kernels are the host-emulated ones and the collective runs over gloo.  End to end: configs[2] shards of ONE global batch, all-gather, the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emulate", "--batch-per-gpu", "2", "--nodes", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # rank 0 prints the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1
+    cfg = d["config"]
+    assert cfg["workload"].startswith("configs[2]: ONE global batch of 4") and cfg["global_batch"] == 4 and cfg["batch_per_gpu"] == 2
+    assert cfg["gather_matches_local_results"] is True and cfg["results_finite_and_converged"] is True
+    assert len(cfg["per_rank_value"]) == 2 and cfg["collective"].startswith("all_gather")
+    assert "EMULATED" in d["data"] and "cpu_baseline" not in d
+
+
+def test_bench_refuses_a_changed_workload_outside_the_emulation():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch-per-gpu", "8"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "BASELINE" in (p.stderr + p.stdout)

@@ -109,7 +109,37 @@ def test_gpu_gait_schedule_matches_host_tiler_and_feeds_the_mpc(interface, oracl
     sol.mpc(mb.args)
     r = mb.results()
     assert np.isfinite(r["X"]).all()
-    for i in (0, 100, 511):
-        ref = oracle.mpc_solve(N, float(t_begin[i]), x0[i], tt[i], ts[i], int(n[i]), ev[i], md[i])
-        assert np.array_equal(r["mode"][i], ref["mode"])
-        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+    ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, x0, tt, ts, n, ev, md, t0=t_begin)      # every instance, each on its own device-made schedule
+    S.assert_parity(S.parity_report("gait_frontend_512xN20_all_templates", r, ref, tau=False))
+
+
+def test_malformed_gait_templates_are_refused_by_host_and_device_tilers():
+    """num_modes outside 1..QMGPU_MAX_EVENTS is refused before switching_times[num_modes] is read; non-finite times are refused; a template whose modes
+    are all STANCE ends (it used to tile for ever: no event is ever pushed) -- on the host tiler and on the device kernel (emulated here)."""
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    gs = api.GaitSchedule(lib=lib)
+    lib.qmgpu_switch_gait.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    good = gs.template("trot")
+    too_many, none = gs.template("trot"), gs.template("trot")
+    too_many.num_modes = abi.MAX_EVENTS + 1; none.num_modes = 0
+    stance = abi.Gait(); stance.num_modes = 2
+    stance.modes[0] = stance.modes[1] = 15
+    stance.switching_times[0], stance.switching_times[1], stance.switching_times[2] = 0.0, 0.5, 1.0
+
+    def host(g, t_end, prev=15):
+        nn = abi.i32(0); e = (abi.d * abi.MAX_EVENTS)(); m = (abi.i32 * (abi.MAX_EVENTS + 1))()
+        return lib.qmgpu_switch_gait(C.byref(g), prev, 0.1, 0.0, 0.0, t_end, C.byref(nn), e, m), nn.value
+
+    assert host(too_many, 1.0)[0] == abi.ERR_INVALID_ARGUMENT and host(none, 1.0)[0] == abi.ERR_INVALID_ARGUMENT
+    assert host(good, float("inf"))[0] == abi.ERR_INVALID_ARGUMENT and host(good, float("nan"))[0] == abi.ERR_INVALID_ARGUMENT
+    assert host(stance, 1e9) == (0, 0)                         # a billion seconds of stance: no events, and it returns
+    assert host(good, 1e9)[0] == abi.ERR_CAPACITY              # a billion seconds of trot: does not fit, and it returns
+    sol = api.GpuSolver(itf, max_batch=6, max_nodes=4)
+    templates = (abi.Gait * 4)(good, too_many, none, stance)
+    idx = np.array([0, 1, 2, 3, 3, 0], dtype=np.int32)
+    t_end = np.array([1.0, 1.0, 1.0, 1e9, 2.0, np.inf])
+    n, ev, md, st = np.zeros(6, dtype=np.int32), np.zeros((6, abi.MAX_EVENTS)), np.zeros((6, abi.MAX_EVENTS + 1), dtype=np.int32), np.zeros(6, dtype=np.int32)
+    sol.gait_schedule(templates, idx, np.zeros(6), np.zeros(6), t_end, n, ev, md, st)
+    assert st.tolist() == [0, abi.ERR_INVALID_ARGUMENT, abi.ERR_INVALID_ARGUMENT, 0, 0, abi.ERR_INVALID_ARGUMENT]
+    assert n[3] == 0 and n[4] == 0 and (md[3] == 15).all() and n[0] > 0

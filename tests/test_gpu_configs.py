@@ -3,8 +3,8 @@
   config 3: batch 2048, randomised base pose + EE target (the 8-GPU weak-scaling workload, here all on one GPU)
   config 5: mixed gait schedule stance -> trot -> flying_trot -> static_walk (nc in {12, 14, 16, 13}, FLY nodes), N = 200, batch 1024,
             in fp64 against the oracle, and the fp32-vs-fp64 sweep of the same batch (MPC kernels in fp32, qmgpu_create_ex)
-Sampled instances are compared with the oracle at the north_star tolerance; the whole batch must be finite, factorised and carry
-bit-exact mode tables.
+EVERY instance is compared with the oracle (qmo_cycle_batch_mt on all host threads) at the north_star tolerance; the numbers go to
+gpurun_out/parity.json (-> profiles/r03_parity.json).
 """
 import numpy as np
 import pytest
@@ -56,29 +56,18 @@ def test_config5_mixed_gaits_n200_batch1024(interface, oracle):
     r = mb.results()
     assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and (r["stats"][:, 7] == 0).all()
     assert np.array_equal(r["mode"], np.tile(modes, (B, 1)))
-    for i in (0, 511, 1023):
-        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
-        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
-        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
-        assert r["stats"][i][4] == ref["stats"][4]
+    ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md)     # all 1024 instances, MPC only
+    S.assert_parity(S.parity_report("configs4_fp64_1024xN200_mixed_gaits", r, ref, tau=False))
 
 
 def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
     import gpu_harness as G
     import torch
+    import bench
     B, N = 2048, 100
-    rng = np.random.default_rng(1)
-    x_nom = interface.initial_state
-    x0 = np.tile(x_nom, (B, 1))
-    xy = rng.uniform(-0.5, 0.5, (B, 2)); yaw = rng.uniform(-0.5, 0.5, B)
-    x0[:, 6:8] = xy; x0[:, 9] = yaw
-    ts = np.zeros((B, 1, 37)); tt = np.zeros((B, 1))
-    for i in range(B):   # target = hold the randomised base pose; EE = base + Rz(yaw) (0.6, 0, 0.036) + U(-0.1, 0.1)^3, yaw-only orientation
-        c, s = np.cos(yaw[i]), np.sin(yaw[i])
-        ee = np.r_[xy[i, 0] + c * 0.6, xy[i, 1] + s * 0.6, x_nom[8] + 0.036] + rng.uniform(-0.1, 0.1, 3)
-        ts[i, 0] = np.r_[x0[i], ee, 0.0, 0.0, np.sin(yaw[i] / 2), np.cos(yaw[i] / 2)]
-    nev, ev, md = S.trot_schedule(N * interface.problem.settings.dt + 1.0)
-    rbd = np.zeros((B, 55)); rbd[:, 0:3] = x0[:, 9:12]; rbd[:, 3:6] = x0[:, 6:9]; rbd[:, 6:24] = x0[:, 12:30]
+    sc = bench.build_config3(interface)        # the ONE global batch `bench.py --gpus 8` shards (seed 1), here all of it on one GPU
+    x0, tt, ts, nev, ev, md, rbd = sc["x0"], sc["tt"], sc["ts"], sc["nev"], sc["ev"], sc["md"], sc["rbd"]
+    assert x0.shape == (B, 30) and np.abs(x0[:, 6:8]).max() <= 0.5 and np.abs(x0[:, 9]).max() <= 0.5
     sol = G.make_solver(interface, B, N)
     mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
     wb = G.WbcBatch(rbd, np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
@@ -86,12 +75,9 @@ def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
     r, w = mb.results(), wb.results()
     assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(w["out"]).all()
     assert (r["stats"][:, 7] == 0).all() and (w["status"] == 0).all()
-    for i in (0, 1000, 2047):
-        ref = oracle.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
-        assert np.abs(r["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
-        assert np.abs(r["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
-        st, out, _ = oracle.wbc_update(ref["X"][0], ref["U"][0], rbd[i], int(ref["mode"][0]), 0.002, 20.0, np.zeros(30))
-        assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
+    r.update(w)
+    ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, rbd=rbd)     # all 2048 instances, MPC + policy + WBC
+    S.assert_parity(S.parity_report("configs2_2048xN100_random_pose", r, ref))
 
 
 def test_config5_fp32_vs_fp64_sweep(interface, oracle):
@@ -120,7 +106,5 @@ def test_config5_fp32_vs_fp64_sweep(interface, oracle):
     x0 = S.perturbed_states(interface.initial_state, 1024, seed=3)
     tgt = S.nominal_target(oracle, interface.initial_state)
     nev, ev, md = _mixed_schedule(200 * dt + 0.2)
-    ref = oracle.mpc_solve(200, 0.0, x0[7], np.zeros(1), tgt[None, :].copy(), nev, ev, md)
-    r64 = out["f64"]["mpc"]
-    assert np.abs(r64["X"][7] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
-    assert np.abs(r64["U"][7] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+    ref = S.Oracle(interface.problem, fast=True).cycle_batch(200, x0, np.zeros((1024, 1)), np.tile(tgt, (1024, 1, 1)), nev, ev, md)
+    S.assert_parity(S.parity_report("configs4_fp64_leg_of_the_sweep_1024xN200", out["f64"]["mpc"], ref, tau=False))

@@ -1,9 +1,15 @@
-"""-m gpu: the product library and the profiling build of the same sources (tools/riccati_phase_probe.py --build: -DQM_RICCATI_TIMING,
-phase clocks only) must compute the same cycle.  wbc_kernel is a 400+-VGPR kernel; in round 2 a variant of it was computed correctly by one
-of the two builds and wrongly by the other (profiles/r02_notes.md), which the parity tests of a single build cannot see.  The profiling
-library is an optional artefact (git-ignored, travels with the snapshot when it has been built here): absent or older than the kernel
-sources -> skipped."""
+"""-m gpu: build variants of the SAME kernel sources must compute the same cycle.
+
+wbc_kernel is a 400+-VGPR kernel with called functions; in round 2 a variant of it was computed correctly by one build and wrongly by another of
+the same sources, which the parity tests of a single binary cannot see.  tools/wbc_variants.py builds the library with phase clocks
+(-DQM_RICCATI_TIMING), at -O2, with a low inliner threshold and with round 2's bare wave barrier; every variant runs one MPC + WBC cycle at batch
+256 (twice, the second WBC from the first one's inputLast) and the WBC alone on every contact mode (both controllers, start-up branch), and must
+agree with the product library: modes / status words bit-exact, X, U and the WBC output within 1e-9.
+
+The variant libraries are built by __graft_entry__.build() (git-ignored, they travel with the snapshot like libqmgpu.so); one that is missing or
+older than the kernel sources is a FAILURE here, not a skip -- a green run of this file means the variants really ran."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -11,48 +17,37 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROBE = os.path.join(ROOT, "qm_door_amd", "build", "ticks", "libqmgpu_ticks.so")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import wbc_variants as V  # noqa: E402
+
+REQUIRED = [n for n, (_, req, _) in V.VARIANTS.items() if req]
 
 
-def _probe_is_current():
-    if not os.path.exists(PROBE):
-        return False
-    csrc = os.path.join(ROOT, "qm_door_amd", "csrc")
-    newest = 0.0
-    for d, _, files in os.walk(csrc):
-        for f in files:
-            newest = max(newest, os.path.getmtime(os.path.join(d, f)))
-    return os.path.getmtime(PROBE) >= newest
+@pytest.fixture(scope="module")
+def product_cycle(hip_lib):
+    return V.cycle_all_modes(hip_lib)
 
 
-def _cycle(lib, B, N):
-    import torch
-    import bench
-    import gpu_harness as G
-    from qm_door_amd import api
-    itf = api.QMInterface(lib=lib)
-    sc = bench.build_scenario(itf, B, seed=1)
-    sol = G.make_solver(itf, B, N)
-    mb = G.MpcBatch(sc["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int32), np.tile(sc["ev"], (B, 1)), np.tile(sc["md"], (B, 1)), N)
-    wb = G.WbcBatch(sc["rbd"], np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
-    t_eval = G.dev(np.zeros(B), torch.float64)
-    for _ in range(2):   # the second cycle runs the WBC from the first one's inputLast
-        sol.cycle(mb.args, t_eval, wb.args)
-    r, w = mb.results(), wb.results()
-    sol.close()
-    return r, w
+def test_at_least_three_variants_are_required():
+    assert len(REQUIRED) >= 3 and {"ticks", "o2"} <= set(REQUIRED)
 
 
-def test_product_and_profiling_builds_agree(hip_lib):
-    if not _probe_is_current():
-        pytest.skip("profiling build absent or stale (python tools/riccati_phase_probe.py --build)")
+@pytest.mark.parametrize("name", REQUIRED)
+def test_variant_agrees_with_the_product_build(name, product_cycle):
     from qm_door_amd import abi
-    probe = abi.load_library(PROBE)
-    B, N = 128, 40
-    r0, w0 = _cycle(hip_lib, B, N)
-    r1, w1 = _cycle(probe, B, N)
-    assert (w0["status"] == 0).all() and (w1["status"] == 0).all()
-    assert np.array_equal(r0["mode"], r1["mode"])
-    for k in ("X", "U"):
-        assert np.abs(r0[k] - r1[k]).max() <= 1e-9 * max(1.0, np.abs(r0[k]).max()), k
-    assert np.abs(w0["out"] - w1["out"]).max() <= 1e-8 * max(1.0, np.abs(w0["out"]).max())
+    assert V.is_current(name), f"{V.lib_path(name)} is missing or stale: python tools/wbc_variants.py --build {name} (or __graft_entry__.build())"
+    got = V.cycle_all_modes(abi.load_library(V.lib_path(name)))
+    assert (product_cycle["wbc_status"] == 0).all()
+    rep = V.compare(product_cycle, got)
+    for key, r in rep.items():
+        if "equal" in r:
+            assert r["equal"], (name, key, r)          # contact modes, WBC status words: bit-exact
+        else:
+            assert r["finite"] and r["max_rel"] <= 1e-9, (name, key, r)
+
+
+def test_every_contact_mode_is_exercised(product_cycle):
+    # the mode sweep of cycle_all_modes: ten contact modes x 32 instances, three controller configurations, all levels converge
+    for k in ("wbc_modes_status_v0_t20", "wbc_modes_status_v0_t1", "wbc_modes_status_v1_t20"):
+        assert product_cycle[k].shape == (320,) and (product_cycle[k] == 0).all(), k
+    assert np.isfinite(product_cycle["wbc_modes_v0_t20"]).all()

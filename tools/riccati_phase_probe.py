@@ -1,6 +1,6 @@
 """Phase clocks of riccati_kernel (profiling build, -DQM_RICCATI_TIMING): where the cycles of a backward stage go, per wavefront.
 
-  python tools/riccati_phase_probe.py --build      # here (hipcc): qm_door_amd/build/ticks/libqmgpu_ticks.so
+  python tools/riccati_phase_probe.py --build      # here (hipcc): qm_door_amd/build/variants/ticks/libqmgpu_ticks.so
   python tools/riccati_phase_probe.py              # on the GPU box: runs the bench scenario, prints the s_memtime sums of workgroup 0
 The product library carries no clocks (QM_TICK compiles to nothing)."""
 import ctypes as C, json, os, sys
@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from qm_door_amd import abi, build
-LIB = os.path.join(ROOT, "qm_door_amd", "build", "ticks", "libqmgpu_ticks.so")
+LIB = os.path.join(ROOT, "qm_door_amd", "build", "variants", "ticks", "libqmgpu_ticks.so")   # = tools/wbc_variants.py lib_path("ticks")
 SLOTS = ["issue", "P1", "bar1", "P2", "bar2", "P3|P6a+gains", "commit", "bar3", "P6b", "bar4", "symm", "bar5", "tail", "fwd-tail", "F:top", "F:K.dx | issue", "F:sync | work", "F:B.du | commit", "F:barrier"]
 
 if "--build" in sys.argv:
