@@ -41,7 +41,11 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, obj_dir=
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     api_o, mpc32_o, host_o = os.path.join(OBJ, "qmgpu_api.o"), os.path.join(OBJ, "qmgpu_mpc32.o"), os.path.join(OBJ, "host_config.o")
-    hip_flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *extra_flags]
+    # -enable-ipra=0: LLVM's interprocedural register allocation (on by default for AMDGPU) miscompiles a call on wbc_kernel's helper wavefront path in
+    # some build variants of these sources (reproducer tools/wbc_variants.py --run opq x_noipra); with it off every variant
+    # computes the same cycle.  a variant switches it back on with extra_flags = (-mllvm, -enable-ipra=1).
+    ipra = [] if any(str(f).startswith("-enable-ipra") for f in extra_flags) else ["-mllvm", "-enable-ipra=0"]
+    hip_flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *ipra, *extra_flags]
     # the kernel sources are written in terms of `real` (kernels/real.h) and compiled twice: fp64 = every kernel + the C ABI,
     # fp32 = the MPC kernels a second time in namespace qmk32
     cmds = [

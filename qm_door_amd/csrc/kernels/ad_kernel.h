@@ -146,7 +146,15 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   };
   auto putGlobal = [&](int base, int row, real dval, real vval, real cval) { if (live) putRow(ad + base, row, dval, vval, cval); };
 
+  // phase clocks of the profiling build (workgroup 1000; tools/riccati_phase_probe.py): 0 inputs | 1 first sweep | 2 constraint rows + J1 | 3 second sweep |
+  // 4 J2 operand + chain rule on the matrix cores | 5 J1 += J2 in place | 6 phi rows out.  Plus, per workgroup, wall-clock start / end (100 MHz) for the
+  // occupancy picture of the launch (rounds, tail).
+  QM_TICK_DECL;
+#ifdef QM_RICCATI_TIMING
+  const unsigned long long qmWgStart = wall_clock64();
+#endif
   int nc = 0;
+  QM_TICK(0);
 #pragma unroll 1
   for (int stage = 0; stage < 2; ++stage) {
     const AdIn in{x, u, stage ? x2 : x, dd, stage ? dt : 0.0_r};
@@ -181,6 +189,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
           return fe;
         },
         f, bm);
+    QM_TICK(stage ? 3 : 1);
     if (stage == 0) {
       // ---- equality constraints in the insertion order of QMInterface.cpp:116-131
       if (!terminal) {
@@ -228,6 +237,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
         for (int i = 0; i < 6; ++i) x2[6 + i] = fma(dt, f.kin[i].v, x[6 + i]);
       }
       QM_WAVE_SYNC();
+      QM_TICK(2);
     } else {
       // ---- second stage: J2[:, 0:12] as a matrix-core operand, the rest of J2 stays in registers until J1 has been multiplied
       if (dd < 3) {
@@ -266,6 +276,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
         }
       }
       QM_WAVE_SYNC();   // J1 has been read by every lane: the slot owners add J2 (+ dt J2[:, q_j] into the v_j columns) in place
+      QM_TICK(4);
       {
         const real sh = dd >= 3 ? dt : 0.0_r;
         auto addRow = [&](int row, real dval, real vval, real cval) {
@@ -281,6 +292,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
         for (int i = 0; i < 6; ++i) addRow(6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0_r : 0.0_r));
       }
       QM_WAVE_SYNC();
+      QM_TICK(5);
       // ---- phi = dt/2 (k1 + k2): rows leave in accumulator layout (4 rows x 128-byte runs per store instruction)
 #pragma unroll
       for (int g = 0; g < AD_NODES; ++g) {
@@ -307,6 +319,11 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
     }
   }
   if (live && dd == 0) { a.stageNc[gnode] = nc; a.nodeMode[gnode] = mode; }
+  QM_TICK(6);
+  QM_TICK_FLUSH(320, blockIdx.x == 1000 && lane == 0);
+#ifdef QM_RICCATI_TIMING
+  if (lane == 0 && blockIdx.x < QM_AD_WG_CLOCKS) { qmk::qmAdWgClock[2 * blockIdx.x] = qmWgStart; qmk::qmAdWgClock[2 * blockIdx.x + 1] = wall_clock64(); }
+#endif
 }
 
 }  // namespace qmk

@@ -156,7 +156,8 @@ using qmk::QmAcc; using qmk::QmD2; using qmk::QmGather;
 // Phase clocks of the profiling build (-DQM_RICCATI_TIMING, tools/riccati_phase_probe.py): s_memtime deltas summed per slot in (scalar)
 // registers, written once at the end into a device symbol.  The product build compiles every QM_TICK to nothing.
 #ifdef QM_RICCATI_TIMING
-namespace qmk { __device__ unsigned long long qmRiccatiTicks[2048]; }
+#define QM_AD_WG_CLOCKS 9216
+namespace qmk { __device__ unsigned long long qmRiccatiTicks[2048]; __device__ unsigned long long qmAdWgClock[2 * QM_AD_WG_CLOCKS]; }
 #define QM_TICK_DECL unsigned long long qmT = clock64(), qmTs[24] = {}
 #define QM_TICK(slot) do { const unsigned long long n_ = clock64(); qmTs[slot] += n_ - qmT; qmT = n_; } while (0)
 #define QM_TICK_FLUSH(base, cond) do { if (cond) for (int i_ = 0; i_ < 24; ++i_) qmk::qmRiccatiTicks[(base) + i_] += qmTs[i_]; } while (0)

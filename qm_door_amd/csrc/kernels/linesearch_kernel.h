@@ -143,6 +143,10 @@ template <class WP> __device__ __attribute__((noinline)) void nodePerformance(co
 #pragma unroll
     for (int j = 0; j < 30; ++j) { qs += Qw[i * 30 + j] * dx[j]; rs += Rw[i * 30 + j] * du[j]; }
     c += 0.5_r * dx[i] * qs + 0.5_r * du[i] * rs;
+    // One row of weights at a time.  Without the fence the fp32 build's scheduler hoists all 450 ds_read_b128 of the 1800 weights in front of the
+    // first multiply-add, runs out of registers and parks 5.9 KB per lane in scratch (740 spill instructions in this function): the fp32 line
+    // search then takes 1.50 ms where the fp64 one takes 0.56 (1024 x N = 200, profiles/r02_fp32_sweep.json).
+    if (sizeof(real) == 4) QM_SCHED_FENCE();
   }
   QM_TICK(2);
   const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta}, bv{st.joint_vel_barrier_mu, st.joint_vel_barrier_delta}, bf{st.friction_barrier_mu, st.friction_barrier_delta};

@@ -85,7 +85,15 @@ __device__ __forceinline__ double dot3(const double* a, const double* b) { retur
 // Recursive pass: placements, twists and bias accelerations (generalized accelerations: 0 for the base, qddj for joints).
 // The five kinematic chains hanging off the base (four legs of three joints, the arm of six: checked in qmgpu_create) are walked side by
 // side, chain c in lane c; every lane publishes the bodies of its own chain to LDS, lane 0 the base as well.
-__device__ inline void bodyPass(const qmgpu_model& md, const double* q, const double* v, const double* qddj, double* body, double* dof, int lane) {
+#ifndef QM_WBC_EXP
+#define QM_WBC_EXP 0     // experiments of tools/wbc_variants.py on the opaque-base failure; 0 in the product
+#endif
+#if QM_WBC_EXP == 2
+__device__ __forceinline__ void bodyPass(
+#else
+__device__ inline void bodyPass(
+#endif
+const qmgpu_model& md, const double* q, const double* v, const double* qddj, double* body, double* dof, int lane) {
   double sz, cz, sy, cy, sx, cx;
   qmSinCos(q[3], sz, cz); qmSinCos(q[4], sy, cy); qmSinCos(q[5], sx, cx);
   double R0[9] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx, sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx, -sy, cy * sx, cy * cx};  // row major
@@ -332,7 +340,16 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   };
   if (wave != 0) {
     QM_LDS_BARRIER();                                     // inputs and coordinates (S1, S2) are in LDS
+#if QM_WBC_EXP == 3
+    if (wave == 2) desiredPass(lds + W_BODY2, lds + W_DOF2);     // experiment: the desired pass on helper wavefront 2 instead of 1
+#else
     if (wave == 1) desiredPass(lds + W_BODY2, lds + W_DOF2);
+#endif
+#if QM_WBC_EXP == 4
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // experiment: drain every outstanding memory operation before the fork-join loop
+#elif QM_WBC_EXP == 5
+    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);   // experiment: pure timing -- every helper arrives ~16 k cycles later
+#endif
     const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
 #if defined(QM_WBC_DUMP) && !defined(QMGPU_HOST_EMULATION)
     int dbgIt = 0;

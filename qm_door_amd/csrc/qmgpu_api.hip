@@ -216,6 +216,13 @@ int qmgpu_debug_riccati_ticks(unsigned long long* out64, int reset) {
   if (reset) { static unsigned long long z[2048] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(qmk::qmRiccatiTicks), z, sizeof(z)) != hipSuccess) return QMGPU_ERR_HIP; }
   return QMGPU_OK;
 }
+// wall-clock (100 MHz) start / end of every ad_node_kernel workgroup of the last launch
+int qmgpu_debug_ad_wg_clocks(unsigned long long* out64, int count) {
+  if (hipDeviceSynchronize() != hipSuccess) return QMGPU_ERR_HIP;
+  if (count > 2 * QM_AD_WG_CLOCKS) count = 2 * QM_AD_WG_CLOCKS;
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(qmk::qmAdWgClock), sizeof(unsigned long long) * size_t(count)) != hipSuccess) return QMGPU_ERR_HIP;
+  return QMGPU_OK;
+}
 #endif
 
 #ifdef QM_WBC_DUMP

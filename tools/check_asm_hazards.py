@@ -82,7 +82,8 @@ def check(path, verbose=False):
 def build_asm(out_dir, extra=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     csrc = os.path.join(ROOT, "qm_door_amd", "csrc")
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "--offload-device-only", "-S", *extra]
+    ipra = [] if any(str(f).startswith("-enable-ipra") for f in extra) else ["-mllvm", "-enable-ipra=0"]   # as qm_door_amd/build.py
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *ipra, "--offload-device-only", "-S", *extra]
     jobs = [(base + [os.path.join(csrc, "qmgpu_api.hip"), "-o", os.path.join(out_dir, "api.s")]),
             (base + ["-DQM_REAL=float", "-Dqmk=qmk32", os.path.join(csrc, "qmgpu_mpc32.hip"), "-o", os.path.join(out_dir, "mpc32.s")])]
     procs = [subprocess.Popen(j, stderr=subprocess.DEVNULL) for j in jobs]

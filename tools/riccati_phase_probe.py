@@ -77,3 +77,25 @@ print("wbc_kernel per instance (last launch): ticks mean %.0f  median %.0f  p90 
       % (tk.mean(), np.median(tk), np.percentile(tk, 90), tk.max(), tk.max() / tk.mean(), np.round(its.mean(0), 2).tolist(), its.max(0).astype(int).tolist(), its.sum(1).mean(), int(its.sum(1).max())))
 worst = np.argsort(-tk)[:6]
 print("  slowest instances:", [(int(i), int(tk[i]), its[i].astype(int).tolist()) for i in worst])
+
+AD = ["inputs (x, u, schedule, references)", "first sweep (21 tangents x 3 nodes)", "constraint rows + J1 rows into LDS", "second sweep", "J2 operand + chain rule (matrix cores)",
+      "J1 += J2 in place", "phi rows out"]
+v = raw[320:320 + len(AD)]
+print("ad_node_kernel, workgroup 1000 (three nodes): total %d ticks (kernel %.4f ms)" % (v.sum(), ms[0]))
+for n_, x in zip(AD, v): print("  %-50s %9.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
+# occupancy picture of the last ad_node launch: when every workgroup started / ended (100 MHz wall clock)
+nwg = (B * (N + 1) + 2) // 3
+cl = (C.c_ulonglong * (2 * nwg))()
+lib.qmgpu_debug_ad_wg_clocks.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+assert lib.qmgpu_debug_ad_wg_clocks(cl, 2 * nwg) == 0
+clk = np.array(cl[:], dtype=np.float64).reshape(nwg, 2)
+t0 = clk[:, 0].min()
+st_us, en_us = (clk[:, 0] - t0) / 100.0, (clk[:, 1] - t0) / 100.0
+dur = en_us - st_us
+print("ad_node_kernel launch: %d workgroups; workgroup duration mean %.1f us (min %.1f, max %.1f); last start %.1f us, last end %.1f us" % (nwg, dur.mean(), dur.min(), dur.max(), st_us.max(), en_us.max()))
+edges = np.arange(0.0, en_us.max() + 20.0, 20.0)
+run = [(int(((st_us < e + 10) & (en_us > e + 10)).sum())) for e in edges]
+print("  workgroups in flight every 20 us:", run)
+full = max(run)
+tail = sum(1 for r in run if r < 0.5 * full) * 20.0
+print("  peak %d in flight (1024 SIMDs x 1 wavefront); time below half of the peak: %.0f us of %.0f us" % (full, tail, en_us.max()))

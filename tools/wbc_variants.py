@@ -29,18 +29,23 @@ VARIANTS = {
     "o2": (("-O2",), True, "-O2 instead of -O3: different inlining / unrolling decisions"),
     "noinl": (("-mllvm", "-inline-threshold=40"), True, "inliner threshold 40 (default 225 at -O3): helpers that are inlined in the product become calls"),
     "bare": (("-DQM_WAVE_SYNC_BARE",), True, "round 2's QM_WAVE_SYNC (bare wave barrier, no fences)"),
-    "opq": (("-DQM_WBC_OPAQUE_MASK=511",), False, "round 2's failing experiment: whole LDS carve of wbc_kernel behind one opaque address-space-3 base"),
+    "ipra": (("-mllvm", "-enable-ipra=1"), True, "interprocedural register allocation on (LLVM's default for AMDGPU; rounds 1-2 shipped this)"),
+    "opq_noipra": (("-DQM_WBC_OPAQUE_MASK=511",), True, "whole LDS carve of wbc_kernel behind one opaque address-space-3 base: wrong torques with IPRA on (round 2), correct with it off"),
+    "opq": (("-DQM_WBC_OPAQUE_MASK=511", "-mllvm", "-enable-ipra=1"), False, "round 2's failing experiment (REPRODUCER: returns wrong torques): opaque LDS base + IPRA on"),
 }
 # bisection of the failing mask (wbc_kernel.h: nine array groups): coarse groups {inputs+coordinates, task arrays, vectors} = bits 0,1 | 3,4 | 6,7,8 fail
 # together; F = that set, F minus one fine group each
 _F = 0b111011011
-VARIANTS["f_all"] = (("-DQM_WBC_OPAQUE_MASK=%d" % _F,), False, "the failing coarse triple")
-for _b in (0, 1, 3, 4, 6, 7, 8):
-    VARIANTS["f_no%d" % _b] = (("-DQM_WBC_OPAQUE_MASK=%d" % (_F & ~(1 << _b)),), False, "the failing triple without fine group %d" % _b)
+VARIANTS["f_all"] = (("-DQM_WBC_OPAQUE_MASK=%d" % _F, "-mllvm", "-enable-ipra=1"), False, "groups {inputs, coordinates, tasks, vectors} opaque, IPRA on: correct (the failure needs four of the five coarse groups)")
 
 
+_OPQ = ("-DQM_WBC_OPAQUE_MASK=511", "-mllvm", "-enable-ipra=1")   # the failing combination; each experiment below changes ONE thing
+VARIANTS["x_inline"] = ((*_OPQ, "-DQM_WBC_EXP=2"), False, "failing combination, bodyPass inlined (no call on the helper wavefront's extra path): correct")
+VARIANTS["x_wave2"] = ((*_OPQ, "-DQM_WBC_EXP=3"), False, "failing combination, desired pass on helper wavefront 2: fails too (the failure follows the call)")
+VARIANTS["x_drain"] = ((*_OPQ, "-DQM_WBC_EXP=4"), False, "failing combination, s_waitcnt vmcnt(0) lgkmcnt(0) before the fork-join loop: still fails (not memory ordering)")
+VARIANTS["x_sleep"] = ((*_OPQ, "-DQM_WBC_EXP=5"), False, "failing combination, helpers sleep before the fork-join loop: still fails (not timing)")
 VARIANTS["dump"] = (("-DQM_WBC_DUMP",), False, "product + LDS dump checkpoints of instance 0")
-VARIANTS["dump_opq"] = (("-DQM_WBC_DUMP", "-DQM_WBC_OPAQUE_MASK=511"), False, "whole-base opaque + LDS dump checkpoints")
+VARIANTS["dump_opq"] = (("-DQM_WBC_DUMP", "-DQM_WBC_OPAQUE_MASK=511", "-mllvm", "-enable-ipra=1"), False, "failing combination + LDS dump checkpoints (the instrumentation of the helper loop hides the failure)")
 
 # LDS carve of wbc_kernel.h (doubles), for naming what differs between two dumps
 CARVE = {'IN': 0, 'Q': 160, 'BODY': 256, 'DOF': 896, 'WR': 1040, 'M': 1160, 'NLE': 1736, 'JF': 1760, 'JA': 2048, 'MISC': 2192, 'A': 2336, 'B': 3128, 'D0': 3152, 'F0': 5168, 'Z': 5280,
