@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
             putVel(nc + 2, vf.z + st.position_error_gain * (x[8] + r.z), 2, st.position_error_gain);
             nc += 3;
           } else {  // zeroForce (QMInterface.cpp:123-124) then normalVelocity (QMPreComputation.cpp:56-66)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) putGlobal(AD_CD, nc + q, 0.0_r, 0.0_r, isVal ? u[3 * c + q] : (dd == 6 + 3 * c + q ? 1.0_r : 0.0_r));
+            // rows nc .. nc + 2: C = 0, D = unit vector on force input 3 c + q, e = u[3 c + q] -- known from the mode alone, so they are NOT stored:
+            // lq_node_kernel synthesises them (1.5 KB per swing foot and node each way)
             real zp, zv;
             swingReference(st, sched, c, t, phase, zp, zv);
             putVel(nc + 3, vf.z - zv + st.position_error_gain * (x[8] + r.z - zp), 2, st.position_error_gain);

@@ -17,7 +17,8 @@ constexpr int OFF_RT = OFF_PT + MT * 30;     // R~   [MT][MT]
 constexpr int OFF_bt = OFF_RT + MT * MT;     // b~   [30]
 constexpr int OFF_qt = OFF_bt + 30;          // q~   [30]
 constexpr int OFF_rt = OFF_qt + 30;          // r~   [MT]
-constexpr int OFF_PX = OFF_rt + MT + 2;      // Px   [30][30]   (du = Pe + Px dx + Pu du~)
+constexpr int OFF_PX = OFF_rt + MT + 2;      // Px   [30][30]   (du = Pe + Px dx + Pu du~); rows 0..11 (force inputs) are structurally zero: NOT written by
+                                             //      lq_node_kernel and NOT read by the forward sweep / the DDP rollout (2.9 KB per stage each way)
 constexpr int OFF_PU = OFF_PX + 900;         // Pu   [30][MT]
 constexpr int OFF_PE = OFF_PU + 30 * MT;     // Pe   [30]
 constexpr int STAGE_DOUBLES = OFF_PE + 30 + 6;  // 4760, multiple of 8

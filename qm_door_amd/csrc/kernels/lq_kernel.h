@@ -102,11 +102,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // ---- rows of the AD sweep (ad_node_kernel)
   const real* ad = a.adrows + (size_t(inst) * (a.N + 1) + node) * AD_DOUBLES;
   int nc = 0;
-  if (!terminal) for (int k = 0; k < 4; ++k) nc += contactOf(mode, k) ? 3 : 4;
+  int zfForce[NCMAX];   // force input a zero-force row pins (swing foot), or -1: those rows are not stored by ad_node_kernel (C = 0, D = unit vector, e = u)
+#pragma unroll
+  for (int r = 0; r < NCMAX; ++r) zfForce[r] = -1;
+  if (!terminal) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (contactOf(mode, k)) nc += 3;
+      else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int r = 0; r < NCMAX; ++r) if (r == nc + q) zfForce[r] = 3 * k + q;
+        }
+        nc += 4;
+      }
+    }
+  }
+  const int firstStored = contactOf(mode, 0) ? 0 : 3;   // first row ad_node_kernel stored: a stance foot's first velocity row or a swing foot's normal-velocity row
+  // force input pinned by row r of the constraint set, or -1 (recomputed from the mode: the debug dump below indexes it with a run-time row)
+  auto zeroForceInputOf = [&](int r) {
+    int row = 0, res = -1;
+    for (int k = 0; k < 4; ++k) {
+      if (contactOf(mode, k)) row += 3;
+      else { if (r >= row && r < row + 3) res = 3 * k + (r - row); row += 4; }
+    }
+    return res;
+  };
   {
     real cdv[NCMAX], eev[6];   // all global loads in flight before the first LDS store
 #pragma unroll
-    for (int r = 0; r < NCMAX; ++r) cdv[r] = ad[AD_CD + (r < nc ? r : 0) * 64 + lane];
+    for (int r = 0; r < NCMAX; ++r) {
+      if (zfForce[r] >= 0) cdv[r] = lane == 60 ? uG[zfForce[r]] : 0.0_r;   // wave uniform: no load for a zero-force row
+      else cdv[r] = ad[AD_CD + (r < nc ? r : firstStored) * 64 + lane];     // (rows >= nc re-read a row that exists; their values are never used)
+    }
 #pragma unroll
     for (int q = 0; q < 6; ++q) eev[q] = ad[AD_EE + q * 64 + lane];
     // [C | D_v]: state columns from lanes 0..29, joint-velocity columns (inputs 12..29) from lanes 42..59, e from lane 60.  The
@@ -284,7 +313,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (dbg && c < 30) {
     for (int i = 0; i < 30; ++i) dbg[DBG_R + i * 30 + c] = rEntry(i, c);
     dbg[DBG_b + c] = bv[c]; dbg[DBG_r + c] = rv[c];
-    for (int r = 0; r < nc; ++r) { dbg[DBG_C + r * 30 + c] = ad[AD_CD + r * 64 + c]; dbg[DBG_D + r * 30 + c] = ad[AD_CD + r * 64 + 30 + c]; }
+    for (int r = 0; r < nc; ++r) {
+      const int zf = zeroForceInputOf(r);
+      dbg[DBG_C + r * 30 + c] = zf >= 0 ? 0.0_r : ad[AD_CD + r * 64 + c];
+      dbg[DBG_D + r * 30 + c] = zf >= 0 ? (c == zf ? 1.0_r : 0.0_r) : ad[AD_CD + r * 64 + 30 + c];
+    }
     if (c < nc) dbg[DBG_e + c] = ev[c];
   }
   real dynSq = 0.0_r, eqSq = 0.0_r;   // lane 0: node metrics (x, u, ... leave LDS below)
@@ -442,8 +475,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int i = 0; i < 12; ++i) {
         const real pe = pev[i];
         const real val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0_r : 0.0_r);
-        if (lane < 30) rec[OFF_PX + i * 30 + lane] = 0.0_r;
-        else if (lane == 30) rec[OFF_PE + i] = pe;
+        if (lane == 30) rec[OFF_PE + i] = pe;      // (Px rows 0..11 are zero by structure: not stored, layout.h)
         else if (lane >= 32 && lane < 32 + MT) rec[OFF_PU + i * MT + (lane - 32)] = val;   // columns >= m~ are written as zeros (puColOf < m~)
       }
     }

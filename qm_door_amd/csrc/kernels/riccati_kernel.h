@@ -518,8 +518,13 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const real* rec = stagesI + size_t(stage) * STAGE_DOUBLES;
     const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + OFF_PX + rX * 30 + (upper ? 24 : 0));
     const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + OFF_PU + rX * MT);
+    const bool forceRow = rX < 12;   // Px rows of the force inputs are structurally zero and not stored (layout.h): no load
 #pragma unroll
-    for (int i = 0; i < 12; ++i) pr[i] = (upper && i >= 3) ? p1[i - 3] : p0[i];
+    for (int i = 0; i < 12; ++i) {
+      if (upper && i >= 3) pr[i] = p1[i - 3];
+      else if (forceRow) { pr[i].x = 0.0_r; pr[i].y = 0.0_r; }
+      else pr[i] = p0[i];
+    }
     pe = rec[OFF_PE + rX];
   };
   if (wave == 1) loadRows(0);

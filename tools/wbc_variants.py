@@ -109,15 +109,25 @@ def lib_path(name):
     return os.path.join(VDIR, name, "libqmgpu_%s.so" % name)
 
 
+def source_hash(name):
+    """sha256 over the kernel / ABI sources and the variant's flags: what a variant library was built from (modification times do not survive every copy)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(ROOT, "include", "qmgpu.h"), os.path.join(ROOT, "qm_door_amd", "build.py")]
+    for d, _, fs in os.walk(os.path.join(ROOT, "qm_door_amd", "csrc")):
+        files += [os.path.join(d, f) for f in fs]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode()); h.update(open(f, "rb").read())
+    h.update(repr(VARIANTS[name][0]).encode())
+    return h.hexdigest()
+
+
 def is_current(name):
     p = lib_path(name)
-    if not os.path.exists(p):
+    try:
+        return os.path.exists(p) and open(p + ".srchash").read().strip() == source_hash(name)
+    except OSError:
         return False
-    newest = 0.0
-    for d, _, files in os.walk(os.path.join(ROOT, "qm_door_amd", "csrc")):
-        for f in files:
-            newest = max(newest, os.path.getmtime(os.path.join(d, f)))
-    return os.path.getmtime(p) >= newest
 
 
 def build(names, force=True):
@@ -127,6 +137,7 @@ def build(names, force=True):
         out = lib_path(n)
         os.makedirs(os.path.dirname(out), exist_ok=True)
         qb.build_library(force=force, extra_flags=VARIANTS[n][0], out=out, obj_dir=os.path.dirname(out))
+        open(out + ".srchash", "w").write(source_hash(n) + "\n")
         return out
     with ThreadPoolExecutor(max_workers=3) as ex:
         for p in ex.map(one, names):
