@@ -104,6 +104,8 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   const int node = gnode % (a.N + 1), inst = gnode / (a.N + 1);
   const bool live = lane < AD_NODES * AD_DIRS && gRaw < total && !a.done[inst];   // this lane's results reach HBM
   const bool terminal = node == a.N;
+  // (QM_CONSTANT_REF -- scalar loads for the model constants, gpu_rt.h -- was measured here and NOT kept: 57 s_load instead of 353 vector loads per
+  //  wavefront, but the scalar results do not fit the SGPR file of a kernel that already sits at 512 VGPRs: 243 instead of 64 VGPR spills, 0.50 -> 0.72 ms)
   const ModelR& md = a.P->model;
   const SettingsR& st = a.P->settings;
   // column of the AD row each of this lane's three values goes to
@@ -144,10 +146,15 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
     real* r = dst + row * 64;
     if (owner) { r[cD] = dval; r[cV] = vval; r[cC] = cval; }
   };
-  auto putGlobal = [&](int base, int row, real dval, real vval, real cval) { if (live) putRow(ad + base, row, dval, vval, cval); };
+  // rows that leave for HBM: streaming (non-temporal) stores -- 51 KB per workgroup that nothing on this CU reads again must not push the 2.9 KB of model
+  // constants out of the vector L1 (the first sweep of a workgroup, right after the previous workgroup's rows went out, cost 1.9 x the second one)
+  auto putGlobal = [&](int base, int row, real dval, real vval, real cval) {
+    real* r = ad + base + row * 64;
+    if (live && owner) { QM_STREAM_STORE(&r[cD], dval); QM_STREAM_STORE(&r[cV], vval); QM_STREAM_STORE(&r[cC], cval); }
+  };
 
   // phase clocks of the profiling build (workgroup 1000; tools/riccati_phase_probe.py): 0 inputs | 1 first sweep | 2 constraint rows + J1 | 3 second sweep |
-  // 4 J2 operand + chain rule on the matrix cores | 5 J1 += J2 in place | 6 phi rows out.  Plus, per workgroup, wall-clock start / end (100 MHz) for the
+  // 4 J2 operand + chain rule on the matrix cores | 5 J1 += J2 in place | 6 phi rows out | 7 foot callbacks (parking) | 8 end-effector callback (pose error rows).  Plus, per workgroup, wall-clock start / end (100 MHz) for the
   // occupancy picture of the launch (rounds, tail).
   QM_TICK_DECL;
 #ifdef QM_RICCATI_TIMING
@@ -163,14 +170,17 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
     centroidalSweep2<Du, Du3, Du3>(
         md, st.gravity, in,
         [&](int c, Vec3<Du> r, Vec3<Du3> v) {
+          QM_TICK(stage ? 3 : 1);
           if (stage == 0) {
             real* p = park + (c * 15) * 64;
             p[0] = r.x.v; p[64] = r.x.d; p[128] = r.y.v; p[192] = r.y.d; p[256] = r.z.v; p[320] = r.z.d;
             p[384] = v.x.v; p[448] = v.x.d; p[512] = v.x.e; p[576] = v.y.v; p[640] = v.y.d; p[704] = v.y.e; p[768] = v.z.v; p[832] = v.z.d; p[896] = v.z.e;
           }
+          QM_TICK(7);
         },
         [&](Vec3<Du> r, const Mat3<Du>& R) {
           // external force of the compliant contact: linear in the base position (force-type slot of lanes 3..5), configuration tangent -K dr
+          QM_TICK(stage ? 3 : 1);
           const real* xs = stage ? x2 : x;
           const Vec3<Du3> fe(Du3(-Ke * (xs[6] + r.x.v - pEnv[0]), -Ke * r.x.d, dd == 3 ? -Ke : 0.0_r), Du3(-Ke * (xs[7] + r.y.v - pEnv[1]), -Ke * r.y.d, dd == 4 ? -Ke : 0.0_r),
                              Du3(-Ke * (xs[8] + r.z.v - pEnv[2]), -Ke * r.z.d, dd == 5 ? -Ke : 0.0_r));
@@ -186,6 +196,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
               putGlobal(AD_EE, q, hq[q].d, 0.0_r, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0_r : ((q < 3 && dd == 19) ? hf : 0.0_r)));
             }
           }
+          QM_TICK(8);
           return fe;
         },
         f, bm);
@@ -312,7 +323,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
             const real s = L1g[i * 64 + c];
             // terminal node: the slope itself (one stage); otherwise dt/2 (J1 + J2 + dt J2x J1), the value column without the product
             const real v = termG ? 0.5_r * s : 0.5_r * dtG * (c < 60 ? fma(dtG, acc[g][tn][r], s) : s);
-            if (liveG) adG[AD_PHI + i * 64 + c] = v;
+            if (liveG) QM_STREAM_STORE(&adG[AD_PHI + i * 64 + c], v);
           }
         }
       }

@@ -87,6 +87,23 @@ __device__ __forceinline__ real qmReplicateRow0(real v, real* s = nullptr) { ret
 // pointer to LDS that keeps its address space through a function call (a generic pointer to LDS compiles to flat loads)
 #define QM_LDS_CONST_PTR(T) const T __attribute__((address_space(3)))*
 #define QM_TO_LDS_PTR(T, p) ((const T __attribute__((address_space(3)))*)(p))
+// Read-only problem data (model, settings, constant weight matrices) seen through the CONSTANT address space.  A kernel that has stored to global memory can
+// no longer prove that a later load from a plain global pointer is unclobbered, so the backend fetches even wave-uniform constants with VECTOR loads
+// (ad_node_kernel: 353 global_load per wavefront and not one s_load in its sweep loop, each waited for on a one-wavefront-per-SIMD chain; round 3, PMC:
+// SQ_INSTS_VMEM_RD 3.0e6 vs SQ_INSTS_SMEM 6.9e4 per launch).  Loads from address space 4 are invariant by definition: wave-uniform addresses become
+// s_load_* through the scalar cache again.  Only for memory nothing writes while the kernel runs (the qmgpu_problem copy, R').
+// (The pointer passes through an empty asm in scalar registers: a plain generic -> constant -> generic cast pair is folded away before the
+// address-space inference sees it.)
+template <class T> __device__ __forceinline__ const T* qmConstantPtr(const T* p) {
+  const T __attribute__((address_space(4)))* p4 = (const T __attribute__((address_space(4)))*)(p);
+  asm("" : "+s"(p4));
+  return (const T*)p4;
+}
+#define QM_CONSTANT_REF(T, lvalue) (*qmk::qmConstantPtr<T>(&(lvalue)))
+#define QM_CONSTANT_PTR(T, ptr) (qmk::qmConstantPtr<T>(ptr))
+// streaming store: data written once and not read again by this kernel (goes out with the non-temporal cache policy)
+#define QM_STREAM_STORE(ptr, value) __builtin_nontemporal_store((value), (ptr))
+#define QM_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)   // read once, never again by this CU
 // keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
 // into the select that consumes it and pays the LDS latency once per branch)
 #define QM_KEEP(x) asm volatile("" : "+v"(x))

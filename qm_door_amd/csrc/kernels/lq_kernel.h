@@ -154,6 +154,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
   for (int i = 0; i < 12; ++i) { phid[i] = ad[AD_PHI + i * 64 + lane]; phiv[i] = ad[AD_PHI + i * 64 + 60]; }
 
+  // (the record stores stay ordinary stores: as streaming stores -- QM_STREAM_STORE, which ad_node_kernel uses for its rows -- they made this kernel slower,
+  //  0.656 -> 0.686 ms, and streaming loads of the AD rows as well, 0.656 -> 0.676 ms; measured in round 3)
 #ifdef QM_LQ_SAMEREC   // timing experiment only: every node writes the same record (no HBM write traffic)
   real* rec = a.stages + size_t(blockIdx.x & 255) * STAGE_DOUBLES;
 #else

@@ -514,17 +514,16 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   }
   // wavefront 1: 24 numbers of row rX of [Px | Pu] per lane (lower half columns 0..23 of Px; upper half 24..29 of Px, then Pu) and Pe
   QmD2 pr[12]; real pe = 0.0_r;
+  const real pxMul = rX < 12 ? 0.0_r : 1.0_r;            // Px entries of a force row count as zero
+  const real grpBMul = upper ? 1.0_r : pxMul;             // entries i >= 3 of pr: Px (lower half) or Pu (upper half)
   auto loadRows = [&](int stage) {
     const real* rec = stagesI + size_t(stage) * STAGE_DOUBLES;
-    const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + OFF_PX + rX * 30 + (upper ? 24 : 0));
+    // Px rows of the force inputs (rX < 12) are structurally zero and not stored (layout.h): those lanes re-read row 12 (the cache lines lane 12 fetches
+    // anyway: no extra HBM traffic, no divergent branch around the register-staged loads); the products with these entries are scaled by pxMul = 0 below
+    const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + OFF_PX + (rX < 12 ? 12 : rX) * 30 + (upper ? 24 : 0));
     const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + OFF_PU + rX * MT);
-    const bool forceRow = rX < 12;   // Px rows of the force inputs are structurally zero and not stored (layout.h): no load
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      if (upper && i >= 3) pr[i] = p1[i - 3];
-      else if (forceRow) { pr[i].x = 0.0_r; pr[i].y = 0.0_r; }
-      else pr[i] = p0[i];
-    }
+    for (int i = 0; i < 12; ++i) pr[i] = (upper && i >= 3) ? p1[i - 3] : p0[i];
     pe = rec[OFF_PE + rX];
   };
   if (wave == 1) loadRows(0);
@@ -591,10 +590,12 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const real* zv = lds + F_ZV + slPrev * ZV;
         if (wave == 1) {   // du = Pe + [Px | Pu] z from the rows in registers; then the rows of the next stage are requested
           const real* zh = zv + (upper ? 24 : 0);
-          real t0 = upper ? pe : 0.0_r, t1 = 0.0_r;
+          real a0 = 0.0_r, a1 = 0.0_r, b0 = 0.0_r, b1 = 0.0_r;   // entries 0..2 are Px on both halves; 3..11 Px on the lower half, Pu on the upper
 #pragma unroll
-          for (int i = 0; i < 12; ++i) { t0 += pr[i].x * zh[2 * i]; t1 += pr[i].y * zh[2 * i + 1]; }
-          const real td = t0 + t1;
+          for (int i = 0; i < 3; ++i) { a0 += pr[i].x * zh[2 * i]; a1 += pr[i].y * zh[2 * i + 1]; }
+#pragma unroll
+          for (int i = 3; i < 12; ++i) { b0 += pr[i].x * zh[2 * i]; b1 += pr[i].y * zh[2 * i + 1]; }
+          const real td = (upper ? pe : 0.0_r) + ((a0 + a1) * pxMul + (b0 + b1) * grpBMul);
           const real duo = td + qmHalfXor32(td, upper);
           if (lane < 30) a.dU[(size_t(inst) * N + j) * 30 + lane] = duo;
           if (k < N) loadRows(k);

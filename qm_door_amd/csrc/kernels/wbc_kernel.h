@@ -252,6 +252,8 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 #endif
   QM_POISON_LDS(lds, WBC_LDS_DOUBLES);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, inst = blockIdx.x;
+  // (the model constants reach this kernel through ~800 vector loads per instance -- after its first global store a kernel cannot use scalar loads for them,
+  //  gpu_rt.h: QM_CONSTANT_REF; a copy of the struct in LDS was measured in round 3 and not kept: 0.4405 -> 0.4445 ms, the loads are batched well enough)
   const qmgpu_model& md = a.P->model;
   const qmgpu_settings& st = a.P->settings;
   double fe[3] = {0.0, 0.0, 0.0};   // external force on the arm end-effector (force tracking; zero otherwise)

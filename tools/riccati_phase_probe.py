@@ -79,7 +79,7 @@ worst = np.argsort(-tk)[:6]
 print("  slowest instances:", [(int(i), int(tk[i]), its[i].astype(int).tolist()) for i in worst])
 
 AD = ["inputs (x, u, schedule, references)", "first sweep (21 tangents x 3 nodes)", "constraint rows + J1 rows into LDS", "second sweep", "J2 operand + chain rule (matrix cores)",
-      "J1 += J2 in place", "phi rows out"]
+      "J1 += J2 in place", "phi rows out", "foot callbacks of both sweeps (parking in LDS)", "end-effector callback of both sweeps (pose error rows out)"]
 v = raw[320:320 + len(AD)]
 print("ad_node_kernel, workgroup 1000 (three nodes): total %d ticks (kernel %.4f ms)" % (v.sum(), ms[0]))
 for n_, x in zip(AD, v): print("  %-50s %9.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
