@@ -104,6 +104,8 @@ template <class T> __device__ __forceinline__ const T* qmConstantPtr(const T* p)
 // streaming store: data written once and not read again by this kernel (goes out with the non-temporal cache policy)
 #define QM_STREAM_STORE(ptr, value) __builtin_nontemporal_store((value), (ptr))
 #define QM_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)   // read once, never again by this CU
+// a load that is served by the L2 and does not allocate in the CU's vector L1 (agent-scope relaxed atomic load: global_load ... sc1)
+#define QM_L2_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 // keeps a value in a register at this point: loads placed before it stay unconditional (the compiler otherwise sinks an LDS read
 // into the select that consumes it and pays the LDS latency once per branch)
 #define QM_KEEP(x) asm volatile("" : "+v"(x))

@@ -39,6 +39,7 @@ inline void __builtin_amdgcn_s_setprio(int) {}
 #define QM_TICK_FLUSH(base, cond)
 #define QM_STREAM_STORE(ptr, value) (*(ptr) = (value))
 #define QM_STREAM_LOAD(ptr) (*(ptr))
+#define QM_L2_LOAD(ptr) (*(ptr))
 #define QM_CONSTANT_REF(T, lvalue) (lvalue)
 #define QM_CONSTANT_PTR(T, ptr) (ptr)
 #define QM_SCHED_FENCE()
