@@ -31,7 +31,7 @@ struct LsArgs {
 };
 
 // dynamic LDS of a line-search launch that keeps the trial trajectories on chip: 0 if they do not fit beside the static arrays
-constexpr int LS_STATIC_LDS_BYTES = (3 * 256 + 8 + 1800) * int(sizeof(real)) + int(sizeof(ModelR)) + 256;
+constexpr int LS_STATIC_LDS_BYTES = (3 * 256 + 8 + 1800) * int(sizeof(real)) + int(sizeof(ModelR)) + 256 * 4 + 256;
 inline int lsTrialLdsBytes(int N) {
   const int trials = (N + 1 <= 128) ? 2 : 1;
   const long long need = (long long)trials * (2 * N + 1) * 30 * (long long)sizeof(real);
@@ -53,7 +53,10 @@ struct DblIn {
 // equality-violation sum read stale registers (2-3x too large, different from run to run; tests/test_gpu_configs.py pins both symptoms).
 // As a called function the body is compiled once, for linesearch_kernel and ddp_rollout_kernel alike.
 // WP: pointer type of the two 30 x 30 weight matrices: LDS (line search: staged once per workgroup) or generic (DDP rollouts).
-template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ModelR& md, const SettingsR& st, WP Qw, WP Rw, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
+// weightStructure: 0 = Q and R' dense; 1 = Q diagonal and R' = diag (forces 0..11) + dense block (leg joint velocities 12..23, the block QMInterface.cpp:283-296 maps
+// through the foot Jacobian) + diag (arm 24..29) -- what the reference's task.info produces; decided by the caller from the actual values.  The structured forms skip
+// products with exact zeros in the same order of accumulation: bit-identical results.
+template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ModelR& md, const SettingsR& st, WP Qw, WP Rw, int weightStructure, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
                                        bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq, real* xnOut = nullptr) {
   QM_TICK_DECL;
   const int mode = sched.modes[phase];
@@ -137,6 +140,18 @@ template <class WP> __device__ __attribute__((noinline)) void nodePerformance(co
     dx[j] = x[j] - xReference(tStates, K, tIdx, tAlpha, j);
     du[j] = u[j] - ((j < 12 && (j % 3) == 2 && contactOf(mode, j / 3)) ? fzNom : 0.0_r);
   }
+  if (weightStructure == 1) {   // wave uniform
+#pragma unroll
+    for (int i = 0; i < 30; ++i) {
+      real qs = 0.0_r, rs = 0.0_r;
+      qs += Qw[i * 30 + i] * dx[i];
+      if (i >= 12 && i < 24) {
+#pragma unroll
+        for (int j = 12; j < 24; ++j) rs += Rw[i * 30 + j] * du[j];
+      } else rs += Rw[i * 30 + i] * du[i];
+      c += 0.5_r * dx[i] * qs + 0.5_r * du[i] * rs;
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < 30; ++i) {
     real qs = 0.0_r, rs = 0.0_r;
@@ -167,6 +182,7 @@ template <class WP> __device__ __attribute__((noinline)) void nodePerformance(co
 __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __shared__ real red[3 * 256];
   __shared__ real ctl[8];
+  __shared__ int structVotes[256];   // per thread: one of my weight entries lies outside the structured pattern
   __shared__ ModelR mdS;   // the model constants: the sweeps read them with wave-uniform indices, from LDS instead of through the scalar cache
   __shared__ __attribute__((aligned(16))) real wQ[900], wR[900];   // state / input weights of the tracking cost: every lane reads all 1800 of them per node
   const int inst = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -191,7 +207,19 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   real* Xt = a.trialInLds ? trialLds + size_t(myTr) * (2 * N + 1) * 30 : a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30;
   real* Ut = a.trialInLds ? Xt + (N + 1) * 30 : a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
 
-  for (int e = tid; e < 900; e += nthr) { wQ[e] = st.Q[e]; wR[e] = a.Rw[e]; }   // visible after the first barrier below
+  // the weights into LDS; while copying, every thread checks its entries against the structured pattern (nodePerformance: weightStructure): any entry outside it
+  // clears the flag (ctl[7], set by thread 0 before this kernel's first barrier... it is initialised below by the thread that owns entry 0)
+  {
+    bool outside = false;
+    for (int e = tid; e < 900; e += nthr) {
+      const real q = st.Q[e], r = a.Rw[e];
+      wQ[e] = q; wR[e] = r;
+      const int i = e / 30, j = e - 30 * i;
+      const bool legBlock = i >= 12 && i < 24 && j >= 12 && j < 24;
+      outside = outside || (i != j && q != 0.0_r) || (i != j && !legBlock && r != 0.0_r);
+    }
+    structVotes[tid] = outside ? 1 : 0;
+  }
   { const int* src = reinterpret_cast<const int*>(&a.P->model); int* dst = reinterpret_cast<int*>(&mdS); for (int e = tid; e < int(sizeof(ModelR) / 4); e += nthr) dst[e] = src[e]; }
   // baseline performance (sum of the LQ kernel's node metrics)
   real m0 = 0.0_r, d0 = 0.0_r, e0 = 0.0_r;
@@ -200,11 +228,13 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __syncthreads();
   if (tid == 0) {
     real s0 = 0, s1 = 0, s2 = 0;
-    for (int i = 0; i < nthr; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; }
-    ctl[0] = s0; ctl[1] = sqrt(s1 + s2);
+    int dense = 0;
+    for (int i = 0; i < nthr; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; dense |= structVotes[i]; }
+    ctl[0] = s0; ctl[1] = sqrt(s1 + s2); ctl[7] = dense ? 0.0_r : 1.0_r;
   }
   __syncthreads();
   const real merit0 = ctl[0], viol0 = ctl[1];
+  const int weightStructure = int(ctl[7]);
   const real armijo = a.instStats[size_t(inst) * 4 + 0];
   const real ricStatus = a.instStats[size_t(inst) * 4 + 1];
 
@@ -223,7 +253,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     for (int k = ltid; k <= N; k += half) {
       real c, d, e;
       const bool term = k == N;
-      nodePerformance(mdS, st, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
+      nodePerformance(mdS, st, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), weightStructure, sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
       cs += c; ds += d; es += e;
     }
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;

@@ -223,3 +223,31 @@ def test_emu_fp32_build_of_the_mpc_chain(emu):
         assert np.abs(U64 - U32).max() <= 2e-5 * max(1.0, np.abs(U64).max())
     ref = orc.mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
     assert np.abs(out["f64", 0][1][0] - ref["X"]).max() <= 1e-8
+
+
+def test_emu_dense_tracking_weights_take_the_general_path():
+    """The line search evaluates the tracking cost with structured forms when Q is diagonal and R' = diag + leg block + diag (what the reference's task.info
+    produces) and with the dense forms otherwise; the kernel decides from the actual values.  A Q with off-diagonal entries must take the dense path
+    and still match the oracle (merit of the accepted step, trajectories); the default weights give the same solve as before (all other tests)."""
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    Q = np.array(itf.problem.settings.Q[:]).reshape(30, 30)
+    assert np.count_nonzero(Q - np.diag(np.diag(Q))) == 0            # the reference's Q is diagonal: the structured path is the default
+    Q[6, 7] = Q[7, 6] = 120.0; Q[12, 15] = Q[15, 12] = 1.5; Q[0, 9] = Q[9, 0] = -3.0
+    for k, v in enumerate(Q.ravel()):
+        itf.problem.settings.Q[k] = float(v)
+    orc = S.Oracle(itf.problem)
+    B, N = 2, 5
+    x0 = S.perturbed_states(itf.initial_state, B, seed=21)
+    tgt = S.nominal_target(orc, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.03)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+    oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+    a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B))
+    sol.mpc(a)
+    for i in range(B):
+        ref = orc.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert np.abs(oX[i] - ref["X"]).max() <= 1e-8 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(oU[i] - ref["U"]).max() <= 1e-8 * max(1.0, np.abs(ref["U"]).max())
+        assert np.allclose(oS[i][:7], ref["stats"][:7], rtol=1e-8, atol=1e-10)      # merit before / after the step includes the off-diagonal terms
