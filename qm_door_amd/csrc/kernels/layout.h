@@ -9,19 +9,28 @@
 namespace qmk {
 
 constexpr int NX = 30, NU = 30, MT = 18, NCMAX = 16;
-constexpr int OFF_AT = 0;                    // A~   [30][30]
-constexpr int OFF_BT = OFF_AT + 900;         // B~   [30][MT]
+constexpr int OFF_AT = 0;                    // rows 0..11: A~ [12][30] (dense rows of the RK2 map); rows 12..29: Px rows 12..29 (see below)
+constexpr int OFF_BT = OFF_AT + 900;         // rows 0..11: B~ [12][MT];                               rows 12..29: Pu rows 12..29
 constexpr int OFF_QT = OFF_BT + 30 * MT;     // Q~   [30][30]
 constexpr int OFF_PT = OFF_QT + 900;         // P~   [MT][30]
 constexpr int OFF_RT = OFF_PT + MT * 30;     // R~   [MT][MT]
 constexpr int OFF_bt = OFF_RT + MT * MT;     // b~   [30]
 constexpr int OFF_qt = OFF_bt + 30;          // q~   [30]
 constexpr int OFF_rt = OFF_qt + 30;          // r~   [MT]
-constexpr int OFF_PX = OFF_rt + MT + 2;      // Px   [30][30]   (du = Pe + Px dx + Pu du~); rows 0..11 (force inputs) are structurally zero: NOT written by
-                                             //      lq_node_kernel and NOT read by the forward sweep / the DDP rollout (2.9 KB per stage each way)
-constexpr int OFF_PU = OFF_PX + 900;         // Pu   [30][MT]
-constexpr int OFF_PE = OFF_PU + 30 * MT;     // Pe   [30]
-constexpr int STAGE_DOUBLES = OFF_PE + 30 + 6;  // 4760, multiple of 8
+constexpr int OFF_DTPREV = OFF_rt + MT;      // step of node k - 1 and of node k + 1: what the consumer needs to form the joint rows of the record it stages NEXT
+constexpr int OFF_DTNEXT = OFF_DTPREV + 1;   // (backward / forward order) arrives with the record it is processing -- no load of its own on the sweep
+constexpr int OFF_TAIL = OFF_rt + MT + 2;    // end of what the backward sweep reads (3284)
+// The joint rows (12..29) of the projected dynamics are not data of their own: x_j+ = x_j + dt v_j exactly, so
+//   A~[i][:] = e_i + dt Px[i][:],   B~[i][:] = dt Pu[i][:]      (i >= 12; du = Pe + Px dx + Pu du~)
+// and the record holds Px / Pu THERE, once; riccati_kernel forms the A~ / B~ rows while the staged copy lands in LDS (jointRowsToDynamics).
+// Rows 0..11 of Px (force inputs) are structurally zero and exist nowhere; rows 0..11 of Pu (unit vectors of the free stance forces) follow the tail.
+// 6.9 KB per stage less written by lq_node_kernel and less read by the forward sweep than with separate A~ B~ / Px Pu copies (round 3).
+constexpr int OFF_PU0 = OFF_TAIL;            // Pu rows 0..11 [12][MT]
+constexpr int OFF_PE = OFF_PU0 + 12 * MT;    // Pe   [30]
+constexpr int STAGE_DOUBLES = OFF_PE + 30 + 6;  // 3536, multiple of 8
+// offsets of row i of Px (i >= 12) and of Pu (any i)
+constexpr int offPxRow(int i) { return OFF_AT + i * 30; }
+constexpr int offPuRow(int i) { return i < 12 ? OFF_PU0 + i * MT : OFF_BT + i * MT; }
 static_assert(STAGE_DOUBLES % 8 == 0, "stage records stay 64-byte aligned");
 
 // feedback record written by the backward sweep for the forward sweep: K [MT][30], k [MT]

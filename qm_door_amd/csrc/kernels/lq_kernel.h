@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const real pe = pev[i];
         const real val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0_r : 0.0_r);
         if (lane == 30) rec[OFF_PE + i] = pe;      // (Px rows 0..11 are zero by structure: not stored, layout.h)
-        else if (lane >= 32 && lane < 32 + MT) rec[OFF_PU + i * MT + (lane - 32)] = val;   // columns >= m~ are written as zeros (puColOf < m~)
+        else if (lane >= 32 && lane < 32 + MT) rec[OFF_PU0 + i * MT + (lane - 32)] = val;   // columns >= m~ are written as zeros (puColOf < m~)
       }
     }
 #pragma unroll
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;   // i: joint-velocity input 12 + i
         if (i < 18) {
           PA[i * PAW + j] = j <= 30 ? pc[t4][r] : 0.0_r;
-          if (j < 30) rec[OFF_PX + (12 + i) * 30 + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + 12 + i] = pc[t4][r];
+          if (j < 30) rec[offPxRow(12 + i) + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + 12 + i] = pc[t4][r];   // Px rows live in the A~ area (layout.h)
         }
       }
     if (lane >= 32 && lane < PAW) {
@@ -498,20 +498,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int i = 0; i < 18; ++i) {
         const real qv = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
         PA[i * PAW + lane] = isQ2 ? qv : 0.0_r;
-        rec[OFF_PU + (12 + i) * MT + jj] = isQ2 ? qv : 0.0_r;                          // jj < MT = PAW - 32: zero padding included
+        rec[offPuRow(12 + i) + jj] = isQ2 ? qv : 0.0_r;                             // (the B~ area) jj < MT = PAW - 32: zero padding included
       }
     }
   }
-  const bool isX = lane < 30, isE = lane == 30, isU = lane >= 32 && lane < 32 + nt;
+  const bool isX = lane < 30, isU = lane >= 32 && lane < 32 + nt;
   QM_WAVE_SYNC();   // Pall complete; Q_v / Y (region X) are dead
   QM_TICK(6);
-  // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity)
-#pragma unroll
-  for (int i = 12; i < 30; ++i) {
-    const real pv = PA[(i - 12) * PAW + (lane < PAW ? lane : 0)];
-    if (isX) rec[OFF_AT + i * 30 + lane] = (lane == i ? 1.0_r : 0.0_r) + dt * pv;
-    else if (isE) rec[OFF_bt + i] = bv[i] + dt * pv;
-    else if (lane >= 32 && lane < 32 + MT) rec[OFF_BT + i * MT + (lane - 32)] = isU ? dt * pv : 0.0_r;   // columns >= m~: zero padding
+  // rows 12..29 of [A~ | b~ | B~] = [I | b | 0] + dt Pall (the joint rows of B are dt * identity): A~ and B~ rows are NOT stored -- riccati_kernel forms them
+  // from the Px / Pu rows above (layout.h) --, only b~
+  if (lane >= 12 && lane < 30) rec[OFF_bt + lane] = bv[lane] + dt * PA[(lane - 12) * PAW + 30];
+  if (lane == 32 || lane == 33) {   // the neighbours' steps for riccati_kernel (layout.h)
+    const int nb = lane == 32 ? node - 1 : node + 1;
+    rec[lane == 32 ? OFF_DTPREV : OFF_DTNEXT] = (nb >= 0 && nb < a.N) ? a.dtgrid[size_t(inst) * (a.N + 1) + nb] : 0.0_r;
   }
   {  // transposed dense rows: At[j][i] = A[i][j], Bt[k][i] = B[i][k], i < 12 (columns 12..15 and rows 30,31 zero)
     real* dst = (lane < 30) ? AT + lane * LDT : (lane < 60 ? BT + (lane - 30) * LDT : AT + 30 * LDT + (lane - 60) * LDT);

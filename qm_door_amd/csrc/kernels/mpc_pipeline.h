@@ -93,7 +93,7 @@ inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
     if (ev) (void)hipEventRecord(ev[6], s);
     QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
     if (ev) (void)hipEventRecord(ev[1], s);
-    RiccatiArgs ra{B, N, m.dStages, m.dStageNc, io.x0, m.dX, m.dGains, m.ddX, m.ddU, m.dInstStats, m.dDone};
+    RiccatiArgs ra{B, N, m.dStages, m.dStageNc, m.dDtgrid, io.x0, m.dX, m.dGains, m.ddX, m.ddU, m.dInstStats, m.dDone};
     QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
     if (ev) (void)hipEventRecord(ev[2], s);
     LsArgs ls{m.dP, m.dRw, B, N, io.K, io.lineSearch, io.eeContact, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, m.ddX, m.ddU, io.targetTimes, io.targetStates, io.schedNum,
@@ -119,7 +119,7 @@ inline void enqueueDdpKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
   if (ev) (void)hipEventRecord(ev[6], s);
   QM_LAUNCH(lq_node_kernel, B * (N + 1), 64, s, la);
   if (ev) (void)hipEventRecord(ev[1], s);
-  RiccatiArgs ri{B, N, m.dStages, m.dStageNc, io.x0, m.dX, m.dGains, m.ddX, m.ddU, m.dInstStats, m.dDone};
+  RiccatiArgs ri{B, N, m.dStages, m.dStageNc, m.dDtgrid, io.x0, m.dX, m.dGains, m.ddX, m.ddU, m.dInstStats, m.dDone};
   QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ri);
   if (ev) (void)hipEventRecord(ev[2], s);
   ra.trials = trials; ra.Xout = m.dDdpX; ra.Uout = m.dDdpU;

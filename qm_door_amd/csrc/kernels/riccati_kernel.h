@@ -31,6 +31,7 @@ struct RiccatiArgs {
   int batch, N;
   const real* stages;   // [batch][N+1][STAGE_DOUBLES]
   const int* stageNc;     // [batch][N+1]
+  const real* dtgrid;   // [batch][N+1] step of every node: the joint rows of A~ / B~ are formed from Px / Pu with it (layout.h)
   const real* x0;       // [batch][30]
   const real* X;        // [batch][N+1][30]
   real* gains;          // [batch][N][GAIN_DOUBLES]
@@ -44,7 +45,7 @@ constexpr int RICCATI_WAVES = 4;
 // Phase clocks of the profiling build: QM_TICK* (gpu_rt.h; tools/riccati_phase_probe.py, -DQM_RICCATI_TIMING).  Nothing in the product build.
 // LDS strides (doubles) = 16 mod 32: the four k-rows x sixteen consecutive columns one MFMA operand read touches hit distinct banks
 constexpr int LDS_S = 50, LDS_Y = 80, LDS_W = 48, LDS_TS = 34, LDS_LL = 18;   // LDS_LL / LDS_S: sixteen lanes one row apart (144 / 400 B) hit distinct banks: column walks are as conflict free as row walks
-constexpr int STG_B = OFF_PX + 4;                 // doubles of a record the backward sweep needs (padded)
+constexpr int STG_B = OFF_TAIL + 4;               // doubles of a record the backward sweep needs (padded)
 constexpr int STG_F = STAGE_DOUBLES + GAIN_DOUBLES;  // record + gains of one stage for the forward sweep
 constexpr int R_STG = 0;                          // two staging buffers: [2][STG_B] backward, [2][STG_F] forward (over Y / T, dead by then)
 constexpr int R_Y = R_STG + 2 * STG_B;            // Y [32][LDS_Y]
@@ -89,8 +90,35 @@ template <int PF, int NTHR> struct StagePrefetch {
     QM_PF_FOR_EACH(QM_PF_COMMIT)
 #undef QM_PF_COMMIT
   }
+  // the same for a copy that starts at the head of a record: rows 12..29 of the A~ / B~ areas arrive as Px / Pu (layout.h) and land as
+  // A~ = e_i + dt Px, B~ = dt Pu -- one multiply-add per number, the operands exactly those lq_node_kernel used when it still wrote these rows.
+  // jm: three bits per 16-byte unit of this thread (jointRowMask below): joint row | unit diagonal in .x | in .y
+  __device__ __forceinline__ void commitDynamics(real* dst, int n, int tid, unsigned jm, real dt) const {
+    QmD2* d2 = reinterpret_cast<QmD2*>(dst);
+    const int n2 = n >> 1;
+#define QM_PF_COMMITD(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (idx < n2) { const unsigned f = jm >> (3 * K); const real m = (f & 1u) ? dt : 1.0_r; \
+      QmD2 w; w.x = fma(V.x, m, (f & 2u) ? 1.0_r : 0.0_r); w.y = fma(V.y, m, (f & 4u) ? 1.0_r : 0.0_r); d2[idx] = w; } }
+    QM_PF_FOR_EACH(QM_PF_COMMITD)
+#undef QM_PF_COMMITD
+  }
 #undef QM_PF_FOR_EACH
 };
+
+template <int PF, int NTHR> __device__ __forceinline__ unsigned jointRowMask(int tid) {
+  static_assert(3 * PF <= 32 && OFF_AT == 0 && OFF_BT == 900 && MT % 2 == 0, "one register of flags; a 16-byte unit never straddles two rows");
+  unsigned jm = 0;
+#pragma unroll
+  for (int K = 0; K < PF; ++K) {
+    const int e = 2 * (tid + K * NTHR);
+    const bool inA = e < OFF_BT, inB = e >= OFF_BT && e < OFF_QT;
+    const int row = inA ? e / 30 : (inB ? (e - OFF_BT) / MT : 0), col = e - row * 30;
+    const bool joint = (inA || inB) && row >= 12;
+    if (joint) jm |= 1u << (3 * K);
+    if (joint && inA && col == row) jm |= 2u << (3 * K);
+    if (joint && inA && col + 1 == row) jm |= 4u << (3 * K);
+  }
+  return jm;
+}
 
 // P3: rows 0..NT-1 of [H | G g] (T, one column per lane: lanes < MT the columns of H, lanes MT..MT+30 those of [G | g]) -> L (row c written by
 // lane c, 1 / L_cc on the diagonal) and W = L^-1 [G | g].  nt <= NT is the number of real pivots; rows / columns nt..NT-1 are identity.
@@ -227,12 +255,12 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   QM_DYNAMIC_LDS(lds);
   QM_POISON_LDS(lds, RICCATI_LDS_DOUBLES);
   constexpr int NTHR = NW * 64;
-  constexpr int PFB = (OFF_PX / 2 + NTHR - 1) / NTHR;
-  constexpr int PFW = (OFF_PX / 2 + NTHR - 64 - 1) / (NTHR - 64);   // the same copy by three wavefronts
-  // forward sweep: only A~ B~ (the head of the record) and b~ q~ r~ Px Pu Pe (its tail) are read; Q~ P~ R~ in between are not
-  constexpr int FWD_HEAD = OFF_QT, FWD_TAIL0 = OFF_bt, FWD_TAIL = STAGE_DOUBLES - OFF_bt;
-  static_assert(FWD_HEAD % 2 == 0 && FWD_TAIL0 % 2 == 0 && FWD_TAIL % 2 == 0, "16-byte units");
-  constexpr int PFH = (FWD_HEAD / 2 + NTHR - 1) / NTHR, PFT = (FWD_TAIL / 2 + NTHR - 1) / NTHR;
+  constexpr int PFB = (OFF_TAIL / 2 + NTHR - 1) / NTHR;
+  constexpr int PFW = (OFF_TAIL / 2 + NTHR - 64 - 1) / (NTHR - 64);   // the same copy by three wavefronts
+  // forward sweep: only the head of the record (A~ B~ rows 0..11, Px Pu rows 12..29) and b~ q~ r~, Pu rows 0..11, Pe (its tail) are read; Q~ P~ R~ in between are not
+  constexpr int FWD_HEAD = OFF_QT, FWD_TAIL0 = OFF_bt;
+  static_assert(FWD_HEAD % 2 == 0 && FWD_TAIL0 % 2 == 0, "16-byte units");
+  constexpr int PFH = (FWD_HEAD / 2 + NTHR - 1) / NTHR;
   constexpr int PFG = (GAIN_DOUBLES / 2 + NTHR - 1) / NTHR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, h = lane >> 4, la = qmARow(l16);   // MFMA operand coordinates of this lane; la: row of an A operand (gpu_rt.h)
@@ -244,6 +272,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const real* stagesI = a.stages + size_t(inst) * (N + 1) * STAGE_DOUBLES;
   const real* gainsI = a.gains + size_t(inst) * N * GAIN_DOUBLES;
   const int* ncI = a.stageNc + size_t(inst) * (N + 1);
+  const real* dtI = a.dtgrid + size_t(inst) * (N + 1);
   int status = 0;
 
   // ---- terminal value function S_N = Q_N, s_N = q_N (zero padded), and the first stage to process
@@ -255,8 +284,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES + 2 * GAIN_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;   // W, L, gains images of both parities (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
     StagePrefetch<PFB, NTHR> pf;
-    pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_PX, tid);
-    pf.commit(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_PX, tid);
+    pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_TAIL, tid);
+    pf.commitDynamics(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_TAIL, tid, jointRowMask<PFB, NTHR>(tid), dtI[N - 1]);
   }
   __syncthreads();
   QM_TICK_DECL;
@@ -296,6 +325,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   }
   const real m7One = h >= 2 ? 0.0_r : mOne;   // k step 7: rows 30, 31 of M carry no data
   int ncCur = ncI[N - 1], ncPrev = 0;   // constraint rows of stage k and of stage k + 1; the next one is loaded a stage ahead
+  const unsigned jmW = wave > 0 ? jointRowMask<PFW, NTHR - 64>(tid - 64) : 0u;   // which of my units of the staged copy are joint-row entries
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
     const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
@@ -381,7 +411,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       // the next stage's blocks HBM -> registers -> LDS by the three wavefronts that are off the critical path here; the other
       // staging buffer was last read before the final barrier of the previous stage
       StagePrefetch<PFW, NTHR - 64> pf;
-      pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_PX, tid - 64);
+      pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_TAIL, tid - 64);
       // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation), symmetrised here: (C + C^T) / 2 on the diagonal
       //      tiles through a scratch square inside the wavefront.  W^T W, subtracted after the factorisation, is symmetric bit for bit
       //      (the same products in the same order on both sides), so S' needs no second pass.  Without the symmetrisation the
@@ -431,7 +461,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       } else if (k + 2 < N) {
         riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
       }
-      pf.commit(stgNext, OFF_PX, tid - 64);   // stage k - 1 lands in the other buffer
+      pf.commitDynamics(stgNext, OFF_TAIL, tid - 64, jmW, stg[OFF_DTPREV]);   // stage k - 1 lands in the other buffer, its joint rows as A~ / B~ (its step came with stage k)
     }
     QM_TICK(5);
     QM_TICK(6);
@@ -476,8 +506,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // q~.dx + r~.du~, and wavefronts 2 and 3 stream A~, B~, b~, q~, r~ and the gains of the next stage HBM -> registers -> LDS.
   // All MT columns of B~ / Pu / K are multiplied: the producers pad with zeros (lq_node_kernel; riccatiGains).
   constexpr int ZV = FWD_ZV;
-  constexpr int FWD_SMALL = OFF_PX - OFF_bt;          // b~ q~ r~ (+ padding)
-  static_assert(FWD_SMALL % 2 == 0 && OFF_PX % 2 == 0 && OFF_PU % 2 == 0, "16-byte units");
+  constexpr int FWD_SMALL = OFF_TAIL - OFF_bt;        // b~ q~ r~ (+ padding)
+  static_assert(FWD_SMALL % 2 == 0 && OFF_PU0 % 2 == 0 && (OFF_AT + 24) % 2 == 0, "16-byte units");
   constexpr int NPF = NTHR - 128;   // wavefronts 2 and 3 stream the blocks
   constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_SMALL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
   constexpr int PFS = (FWD_SMALL / 2 + NTHR - 1) / NTHR;
@@ -491,7 +521,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     pt.issue(stagesI + FWD_TAIL0, FWD_SMALL, tid);
     pg.issue(gainsI, GAIN_DOUBLES, tid);
     for (int e = tid; e < 3 * ZV; e += NTHR) lds[F_ZV + e] = 0.0_r;
-    ph.commit(lds + R_STG, FWD_HEAD, tid);
+    ph.commitDynamics(lds + R_STG, FWD_HEAD, tid, jointRowMask<PFH, NTHR>(tid), dtI[0]);
     pt.commit(lds + R_STG + FWD_TAIL0, FWD_SMALL, tid);
     pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
@@ -507,6 +537,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   StagePrefetch<PFH3, NPF> ph;
   StagePrefetch<PFT3, NPF> pt;
   StagePrefetch<PFG3, NPF> pg;
+  const unsigned jmF = wave >= 2 ? jointRowMask<PFH3, NPF>(tid - 128) : 0u;
   if (wave >= 2 && N > 1) {
     ph.issue(stagesI + STAGE_DOUBLES, FWD_HEAD, tid - 128);
     pt.issue(stagesI + STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, tid - 128);
@@ -519,9 +550,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   auto loadRows = [&](int stage) {
     const real* rec = stagesI + size_t(stage) * STAGE_DOUBLES;
     // Px rows of the force inputs (rX < 12) are structurally zero and not stored (layout.h): those lanes re-read row 12 (the cache lines lane 12 fetches
-    // anyway: no extra HBM traffic, no divergent branch around the register-staged loads); the products with these entries are scaled by pxMul = 0 below
-    const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + OFF_PX + (rX < 12 ? 12 : rX) * 30 + (upper ? 24 : 0));
-    const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + OFF_PU + rX * MT);
+    // anyway: no extra HBM traffic, no divergent branch around the register-staged loads); the products with these entries are scaled by pxMul = 0 below.
+    // Rows >= 12 of Px / Pu are the raw joint rows of the record's head -- the lines wavefronts 2 and 3 stream for the chain: the second reader meets them in L2.
+    const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + offPxRow(rX < 12 ? 12 : rX) + (upper ? 24 : 0));
+    const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + offPuRow(rX));
 #pragma unroll
     for (int i = 0; i < 12; ++i) pr[i] = (upper && i >= 3) ? p1[i - 3] : p0[i];
     pe = rec[OFF_PE + rX];
@@ -573,7 +605,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       if (wave >= 2) {
         if (k + 1 < N) {
           real* dst = lds + R_STG + slNext * STG_F;
-          ph.commit(dst, FWD_HEAD, tid - 128);
+          ph.commitDynamics(dst, FWD_HEAD, tid - 128, jmF, lds[R_STG + sl * STG_F + OFF_DTNEXT]);   // the step of stage k + 1 came with stage k
           pt.commit(dst + FWD_TAIL0, FWD_SMALL, tid - 128);
           pg.commit(dst + STAGE_DOUBLES, GAIN_DOUBLES, tid - 128);
         }
