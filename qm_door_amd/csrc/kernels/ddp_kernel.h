@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(64) ddp_rollout_kernel(DdpArgs a) {
       for (int i = 0; i < 30; ++i) {
         real s = alpha * rec[OFF_PE + i];
         if (i >= 12) for (int c = 0; c < 30; ++c) s += rec[offPxRow(i) + c] * dx[c];   // rows 0..11 (force inputs) of Px are structurally zero and not stored (layout.h)
-        for (int r = 0; r < nt; ++r) s += rec[offPuRow(i) + r] * dut[r];
+        if (i >= 12) { for (int r = 0; r < nt; ++r) s += rec[offPuRow(i) + r] * dut[r]; }
+        else { const int pc = puColumnOfForce(int(rec[OFF_MODE]), i); if (pc >= 0) s += dut[pc]; }   // force rows of Pu: unit vectors, not stored (layout.h)
         u[i] = un[i] + s;
       }
     }

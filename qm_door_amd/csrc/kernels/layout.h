@@ -23,14 +23,21 @@ constexpr int OFF_TAIL = OFF_rt + MT + 2;    // end of what the backward sweep r
 // The joint rows (12..29) of the projected dynamics are not data of their own: x_j+ = x_j + dt v_j exactly, so
 //   A~[i][:] = e_i + dt Px[i][:],   B~[i][:] = dt Pu[i][:]      (i >= 12; du = Pe + Px dx + Pu du~)
 // and the record holds Px / Pu THERE, once; riccati_kernel forms the A~ / B~ rows while the staged copy lands in LDS (jointRowsToDynamics).
-// Rows 0..11 of Px (force inputs) are structurally zero and exist nowhere; rows 0..11 of Pu (unit vectors of the free stance forces) follow the tail.
-// 6.9 KB per stage less written by lq_node_kernel and less read by the forward sweep than with separate A~ B~ / Px Pu copies (round 3).
-constexpr int OFF_PU0 = OFF_TAIL;            // Pu rows 0..11 [12][MT]
-constexpr int OFF_PE = OFF_PU0 + 12 * MT;    // Pe   [30]
-constexpr int STAGE_DOUBLES = OFF_PE + 30 + 6;  // 3536, multiple of 8
-// offsets of row i of Px (i >= 12) and of Pu (any i)
+// Rows 0..11 (force inputs) of Px are structurally zero and rows 0..11 of Pu are unit vectors on the free stance forces in foot order (zero rows for a swing
+// foot, whose force Pe pins): neither exists in the record; the consumers form them from the node's contact mode, which rides in the record's tail.
+// 6.9 + 1.7 KB per stage less written by lq_node_kernel and less read by the forward sweep than with separate A~ B~ / Px Pu copies (round 3).
+constexpr int OFF_PE = OFF_TAIL;             // Pe   [30]
+constexpr int OFF_MODE = OFF_PE + 30;        // contact mode of the node (as a real), then one zero
+constexpr int STAGE_DOUBLES = OFF_MODE + 2 + 4;  // 3320, multiple of 8
+// offsets of row i >= 12 of Px and of Pu
 constexpr int offPxRow(int i) { return OFF_AT + i * 30; }
-constexpr int offPuRow(int i) { return i < 12 ? OFF_PU0 + i * MT : OFF_BT + i * MT; }
+constexpr int offPuRow(int i) { return OFF_BT + i * MT; }
+// column of Pu that carries the unit entry of force input i < 12, or -1 (swing foot): stance feet in foot order, three columns each (lq_node_kernel: puColOf)
+constexpr int puColumnOfForce(int mode, int i) {
+  int nb = 0, col = -1;
+  for (int leg = 0; leg < 4; ++leg) { const int st = (mode >> (3 - leg)) & 1; if (st && i / 3 == leg) col = 3 * nb + i % 3; nb += st; }
+  return col;
+}
 static_assert(STAGE_DOUBLES % 8 == 0, "stage records stay 64-byte aligned");
 
 // feedback record written by the backward sweep for the forward sweep: K [MT][30], k [MT]

@@ -470,17 +470,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const real b0 = Ym[kk * LDY + l16], b1 = Ym[kk * LDY + 16 + l16];
       qmMfma(pc[0], a0, b0, red); qmMfma(pc[1], a0, b1, red); qmMfma(pc[2], a1, b0, red); qmMfma(pc[3], a1, b1, red);
     }
-    // Pall: rows 0..11 (forces): Px = 0, Pe = pinned swing forces, unit Pu columns for the free stance forces (record only);
+    // Pall: rows 0..11 (forces): Px = 0, Pu = unit columns of the free stance forces -- neither is stored (layout.h) --, Pe = pinned swing forces;
     //       rows 12..29 (joint velocities): [Px | Pe] from the tiles, Pu = Q_v2 (record and LDS)
-    if (lane < PAW) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        const real pe = pev[i];
-        const real val = lane == 30 ? pe : ((lane >= 32 && puColOf[i] >= 0 && lane - 32 == puColOf[i]) ? 1.0_r : 0.0_r);
-        if (lane == 30) rec[OFF_PE + i] = pe;      // (Px rows 0..11 are zero by structure: not stored, layout.h)
-        else if (lane >= 32 && lane < 32 + MT) rec[OFF_PU0 + i * MT + (lane - 32)] = val;   // columns >= m~ are written as zeros (puColOf < m~)
-      }
-    }
+    if (lane < 12) rec[OFF_PE + lane] = pev[lane];
+    else if (lane == 30 || lane == 31) rec[OFF_PE + lane] = lane == 30 ? real(mode) : 0.0_r;   // OFF_MODE: the consumers rebuild the force rows of Pu from it
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
@@ -625,7 +618,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
               const int i = tm * 16 + h + 4 * r;
               const real v = g[tm][r];
               if (i < 30) {
-                if (j < 30) rec[OFF_QT + i * 30 + j] = v;
+                if (j < 30 && !(tm == 1 && tn == 0)) rec[OFF_QT + i * 30 + j] = v;   // Q~ is symmetric and the backward sweep reads the tiles (0,0), (0,1), (1,1) only: rows 16..29 x columns 0..15 are not stored
               } else if (i == 30) {
                 if (j < 30) fin[j] += v;                                   // Pe^T R Px
               } else if (i >= 32 && i < 32 + nt) {

@@ -507,7 +507,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // All MT columns of B~ / Pu / K are multiplied: the producers pad with zeros (lq_node_kernel; riccatiGains).
   constexpr int ZV = FWD_ZV;
   constexpr int FWD_SMALL = OFF_TAIL - OFF_bt;        // b~ q~ r~ (+ padding)
-  static_assert(FWD_SMALL % 2 == 0 && OFF_PU0 % 2 == 0 && (OFF_AT + 24) % 2 == 0, "16-byte units");
+  static_assert(FWD_SMALL % 2 == 0 && (OFF_AT + 24) % 2 == 0 && OFF_BT % 2 == 0 && MT % 2 == 0, "16-byte units");
   constexpr int NPF = NTHR - 128;   // wavefronts 2 and 3 stream the blocks
   constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_SMALL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
   constexpr int PFS = (FWD_SMALL / 2 + NTHR - 1) / NTHR;
@@ -544,19 +544,19 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     pg.issue(gainsI + GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
   }
   // wavefront 1: 24 numbers of row rX of [Px | Pu] per lane (lower half columns 0..23 of Px; upper half 24..29 of Px, then Pu) and Pe
-  QmD2 pr[12]; real pe = 0.0_r;
-  const real pxMul = rX < 12 ? 0.0_r : 1.0_r;            // Px entries of a force row count as zero
-  const real grpBMul = upper ? 1.0_r : pxMul;             // entries i >= 3 of pr: Px (lower half) or Pu (upper half)
+  QmD2 pr[12]; real pe = 0.0_r, modeR = 0.0_r;
+  const real pxMul = rX < 12 ? 0.0_r : 1.0_r;            // the stored entries of a force row (Px: zero; Pu: a unit vector, formed below) do not count
   auto loadRows = [&](int stage) {
     const real* rec = stagesI + size_t(stage) * STAGE_DOUBLES;
     // Px rows of the force inputs (rX < 12) are structurally zero and not stored (layout.h): those lanes re-read row 12 (the cache lines lane 12 fetches
     // anyway: no extra HBM traffic, no divergent branch around the register-staged loads); the products with these entries are scaled by pxMul = 0 below.
     // Rows >= 12 of Px / Pu are the raw joint rows of the record's head -- the lines wavefronts 2 and 3 stream for the chain: the second reader meets them in L2.
     const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + offPxRow(rX < 12 ? 12 : rX) + (upper ? 24 : 0));
-    const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + offPuRow(rX));
+    const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + offPuRow(rX < 12 ? 12 : rX));
 #pragma unroll
     for (int i = 0; i < 12; ++i) pr[i] = (upper && i >= 3) ? p1[i - 3] : p0[i];
     pe = rec[OFF_PE + rX];
+    modeR = rec[OFF_MODE];     // the same address in every lane
   };
   if (wave == 1) loadRows(0);
 #pragma unroll 1
@@ -627,7 +627,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
           for (int i = 0; i < 3; ++i) { a0 += pr[i].x * zh[2 * i]; a1 += pr[i].y * zh[2 * i + 1]; }
 #pragma unroll
           for (int i = 3; i < 12; ++i) { b0 += pr[i].x * zh[2 * i]; b1 += pr[i].y * zh[2 * i + 1]; }
-          const real td = (upper ? pe : 0.0_r) + ((a0 + a1) * pxMul + (b0 + b1) * grpBMul);
+          // force row i < 12 of Pu: a unit entry in the column of its free stance force (layout.h: puColumnOfForce) -- the one product 1 * du~[column]
+          const int puCol = puColumnOfForce(int(modeR), rX);
+          const real freeForce = zv[30 + (puCol >= 0 ? puCol : 0)];
+          const real td = (upper ? pe : 0.0_r) + ((a0 + a1) * pxMul + (b0 + b1) * pxMul) + ((upper && rowl < 12 && puCol >= 0) ? freeForce : 0.0_r);
           const real duo = td + qmHalfXor32(td, upper);
           if (lane < 30) a.dU[(size_t(inst) * N + j) * 30 + lane] = duo;
           if (k < N) loadRows(k);
