@@ -148,9 +148,15 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   };
   // rows that leave for HBM: streaming (non-temporal) stores -- 51 KB per workgroup that nothing on this CU reads again must not push the 2.9 KB of model
   // constants out of the vector L1 (the first sweep of a workgroup, right after the previous workgroup's rows went out, cost 1.9 x the second one)
-  auto putGlobal = [&](int base, int row, real dval, real vval, real cval) {
+  // stateOnly: a row that does not depend on the inputs (the end-effector pose error): its columns 30..59 are identically zero, lq_node_kernel does not read them
+  // and they are not written (one of the four 128-byte lines of the row never exists)
+  auto putGlobal = [&](int base, int row, real dval, real vval, real cval, bool stateOnly = false) {
     real* r = ad + base + row * 64;
-    if (live && owner) { QM_STREAM_STORE(&r[cD], dval); QM_STREAM_STORE(&r[cV], vval); QM_STREAM_STORE(&r[cC], cval); }
+    if (live && owner) {
+      QM_STREAM_STORE(&r[cD], dval);
+      if (!stateOnly || cV < 30) QM_STREAM_STORE(&r[cV], vval);
+      if (!stateOnly || cC < 30 || cC >= 60) QM_STREAM_STORE(&r[cC], cval);
+    }
   };
 
   // phase clocks of the profiling build (workgroup 1000; tools/riccati_phase_probe.py): 0 inputs | 1 first sweep | 2 constraint rows + J1 | 3 second sweep |
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
             for (int q = 0; q < 6; ++q) {
               // padding column 61 of the three position rows carries the force error f_e - f_ref for lq_node_kernel's soft constraint
               const real hf = q < 3 ? (q == 0 ? fe.x.v : (q == 1 ? fe.y.v : fe.z.v)) - fRef[q < 3 ? q : 0] : 0.0_r;
-              putGlobal(AD_EE, q, hq[q].d, 0.0_r, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0_r : ((q < 3 && dd == 19) ? hf : 0.0_r)));
+              putGlobal(AD_EE, q, hq[q].d, 0.0_r, isVal ? hq[q].v : ((q < 3 && dd == 3 + q) ? 1.0_r : ((q < 3 && dd == 19) ? hf : 0.0_r)), true);
             }
           }
           QM_TICK(8);

@@ -325,7 +325,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   }
   const real m7One = h >= 2 ? 0.0_r : mOne;   // k step 7: rows 30, 31 of M carry no data
   int ncCur = ncI[N - 1], ncPrev = 0;   // constraint rows of stage k and of stage k + 1; the next one is loaded a stage ahead
-  const unsigned jmW = wave > 0 ? jointRowMask<PFW, NTHR - 64>(tid - 64) : 0u;   // which of my units of the staged copy are joint-row entries
+  // the staged copy of the next record is shared by wavefronts 1, 3, 2 IN THAT ORDER: the last, partial round of 16-byte units goes to 1 and 3 -- wavefront 2 also
+  // runs the deferred gains and is the one closest to the factorisation's length
+  const int ptid = wave == 1 ? lane : (wave == 3 ? 64 + lane : 128 + lane);
+  const unsigned jmW = wave > 0 ? jointRowMask<PFW, NTHR - 64>(ptid) : 0u;   // which of my units of the staged copy are joint-row entries
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
     const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
@@ -411,7 +414,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       // the next stage's blocks HBM -> registers -> LDS by the three wavefronts that are off the critical path here; the other
       // staging buffer was last read before the final barrier of the previous stage
       StagePrefetch<PFW, NTHR - 64> pf;
-      pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_TAIL, tid - 64);
+      pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_TAIL, ptid);
       // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation), symmetrised here: (C + C^T) / 2 on the diagonal
       //      tiles through a scratch square inside the wavefront.  W^T W, subtracted after the factorisation, is symmetric bit for bit
       //      (the same products in the same order on both sides), so S' needs no second pass.  Without the symmetrisation the
@@ -461,7 +464,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       } else if (k + 2 < N) {
         riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
       }
-      pf.commitDynamics(stgNext, OFF_TAIL, tid - 64, jmW, stg[OFF_DTPREV]);   // stage k - 1 lands in the other buffer, its joint rows as A~ / B~ (its step came with stage k)
+      pf.commitDynamics(stgNext, OFF_TAIL, ptid, jmW, stg[OFF_DTPREV]);   // stage k - 1 lands in the other buffer, its joint rows as A~ / B~ (its step came with stage k)
     }
     QM_TICK(5);
     QM_TICK(6);
