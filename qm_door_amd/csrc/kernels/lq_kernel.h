@@ -618,13 +618,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
               const int i = tm * 16 + h + 4 * r;
               const real v = g[tm][r];
               if (i < 30) {
-                if (j < 30 && !(tm == 1 && tn == 0)) rec[OFF_QT + i * 30 + j] = v;   // Q~ is symmetric and the backward sweep reads the tiles (0,0), (0,1), (1,1) only: rows 16..29 x columns 0..15 are not stored
+                if (j < 30 && !(tm == 1 && tn == 0) && !(tm == tn && j < i)) rec[OFF_QT + i * 30 + j] = v;   // Q~ is symmetric and the backward sweep reads the tile (0,1) and the upper triangles of (0,0), (1,1) only: nothing else is stored
               } else if (i == 30) {
                 if (j < 30) fin[j] += v;                                   // Pe^T R Px
               } else if (i >= 32 && i < 32 + nt) {
                 if (j < 30) rec[OFF_PT + (i - 32) * 30 + j] = v;
                 else if (j == 30) fin[i] += v;                             // Pu^T R Pe
-                else if (j >= 32 && j < 32 + nt) rec[OFF_RT + (i - 32) * MT + (j - 32)] = v;
+                else if (j >= 32 && j <= i) rec[OFF_RT + (i - 32) * MT + (j - 32)] = v;          // R~: the lower triangle (the backward sweep reads the mirror image for the rest)
               }
             }
           }

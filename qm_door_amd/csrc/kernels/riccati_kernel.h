@@ -316,7 +316,13 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i0 = h + 4 * r, i1 = 16 + h + 4 * r;
-      cOffR[r] = cOff + i0 * cStr; cOffR[4 + r] = cOff + (i1 < MT ? i1 : 0) * cStr;
+      const int i1c = i1 < MT ? i1 : 0;
+      cOffR[r] = cOff + i0 * cStr; cOffR[4 + r] = cOff + i1c * cStr;
+      if (jB) {   // R~ is stored as its lower triangle (lq_node_kernel): an entry above the diagonal is read from its mirror image
+        const int jr = jc - 32;
+        if (jr > i0) cOffR[r] = OFF_RT + jr * MT + i0;
+        if (jr > i1c) cOffR[4 + r] = OFF_RT + jr * MT + i1c;
+      }
       QM_KEEP(cOffR[r]); QM_KEEP(cOffR[4 + r]);
     }
     mAdd7 = (h == 2 && jb) ? 1.0_r : 0.0_r;
@@ -425,7 +431,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r, ic = i < 30 ? i : 0;
-        qv[r] = stg[OFF_QT + ic * 30 + (j < 30 ? j : 0)]; qq[r] = stg[OFF_qt + ic];
+        const int jq = j < 30 ? j : 0;   // diagonal tiles: only the upper triangle of the symmetric Q~ is stored (lq_node_kernel)
+        qv[r] = stg[OFF_QT + (tm == tn && jq < ic ? jq * 30 + ic : ic * 30 + jq)]; qq[r] = stg[OFF_qt + ic];
       }
       const int ai = tm * 16 + la < 30 ? tm * 16 + la : 29;   // rows 30,31 of the result are discarded
       real av[8], bw[8];
