@@ -79,24 +79,25 @@ template <int PF, int NTHR> struct StagePrefetch {
   __device__ __forceinline__ void issue(const real* src, int n, int tid) {
     const QmD2* s2 = reinterpret_cast<const QmD2*>(src);
     const int n2 = n >> 1;
-#define QM_PF_ISSUE(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; V = s2[idx < n2 ? idx : tid]; }
+  // (only the last round of units can be partial: PF is the rounded-up quotient -- every other round copies without a test)
+#define QM_PF_ISSUE(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; V = s2[(K + 1 < PF || idx < n2) ? idx : tid]; }
     QM_PF_FOR_EACH(QM_PF_ISSUE)
 #undef QM_PF_ISSUE
   }
   __device__ __forceinline__ void commit(real* dst, int n, int tid) const {
     QmD2* d2 = reinterpret_cast<QmD2*>(dst);
     const int n2 = n >> 1;
-#define QM_PF_COMMIT(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (idx < n2) d2[idx] = V; }
+#define QM_PF_COMMIT(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (K + 1 < PF || idx < n2) d2[idx] = V; }
     QM_PF_FOR_EACH(QM_PF_COMMIT)
 #undef QM_PF_COMMIT
   }
   // the same for a copy that starts at the head of a record: rows 12..29 of the A~ / B~ areas arrive as Px / Pu (layout.h) and land as
   // A~ = e_i + dt Px, B~ = dt Pu -- one multiply-add per number, the operands exactly those lq_node_kernel used when it still wrote these rows.
   // jm: three bits per 16-byte unit of this thread (jointRowMask below): joint row | unit diagonal in .x | in .y
-  __device__ __forceinline__ void commitDynamics(real* dst, int n, int tid, unsigned jm, real dt) const {
+  __device__ __forceinline__ void commitDynamics(real* dst, int n, int tid, unsigned long long jm, real dt) const {
     QmD2* d2 = reinterpret_cast<QmD2*>(dst);
     const int n2 = n >> 1;
-#define QM_PF_COMMITD(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (idx < n2) { const unsigned f = jm >> (3 * K); const real m = (f & 1u) ? dt : 1.0_r; \
+#define QM_PF_COMMITD(K, V) if constexpr (PF > K) { const int idx = tid + K * NTHR; if (K + 1 < PF || idx < n2) { const unsigned f = unsigned(jm >> (3 * K)); const real m = (f & 1u) ? dt : 1.0_r; \
       QmD2 w; w.x = fma(V.x, m, (f & 2u) ? 1.0_r : 0.0_r); w.y = fma(V.y, m, (f & 4u) ? 1.0_r : 0.0_r); d2[idx] = w; } }
     QM_PF_FOR_EACH(QM_PF_COMMITD)
 #undef QM_PF_COMMITD
@@ -104,18 +105,18 @@ template <int PF, int NTHR> struct StagePrefetch {
 #undef QM_PF_FOR_EACH
 };
 
-template <int PF, int NTHR> __device__ __forceinline__ unsigned jointRowMask(int tid) {
-  static_assert(3 * PF <= 32 && OFF_AT == 0 && OFF_BT == 900 && MT % 2 == 0, "one register of flags; a 16-byte unit never straddles two rows");
-  unsigned jm = 0;
+template <int PF, int NTHR> __device__ __forceinline__ unsigned long long jointRowMask(int tid) {
+  static_assert(3 * PF <= 64 && OFF_AT == 0 && OFF_BT == 900 && MT % 2 == 0, "one register of flags; a 16-byte unit never straddles two rows");
+  unsigned long long jm = 0;
 #pragma unroll
   for (int K = 0; K < PF; ++K) {
     const int e = 2 * (tid + K * NTHR);
     const bool inA = e < OFF_BT, inB = e >= OFF_BT && e < OFF_QT;
     const int row = inA ? e / 30 : (inB ? (e - OFF_BT) / MT : 0), col = e - row * 30;
     const bool joint = (inA || inB) && row >= 12;
-    if (joint) jm |= 1u << (3 * K);
-    if (joint && inA && col == row) jm |= 2u << (3 * K);
-    if (joint && inA && col + 1 == row) jm |= 4u << (3 * K);
+    if (joint) jm |= 1ull << (3 * K);
+    if (joint && inA && col == row) jm |= 2ull << (3 * K);
+    if (joint && inA && col + 1 == row) jm |= 4ull << (3 * K);
   }
   return jm;
 }
@@ -334,7 +335,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // the staged copy of the next record is shared by wavefronts 1, 3, 2 IN THAT ORDER: the last, partial round of 16-byte units goes to 1 and 3 -- wavefront 2 also
   // runs the deferred gains and is the one closest to the factorisation's length
   const int ptid = wave == 1 ? lane : (wave == 3 ? 64 + lane : 128 + lane);
-  const unsigned jmW = wave > 0 ? jointRowMask<PFW, NTHR - 64>(ptid) : 0u;   // which of my units of the staged copy are joint-row entries
+  const unsigned long long jmW = wave > 0 ? jointRowMask<PFW, NTHR - 64>(ptid) : 0ull;   // which of my units of the staged copy are joint-row entries
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
     const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
@@ -518,7 +519,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   constexpr int ZV = FWD_ZV;
   constexpr int FWD_SMALL = OFF_TAIL - OFF_bt;        // b~ q~ r~ (+ padding)
   static_assert(FWD_SMALL % 2 == 0 && (OFF_AT + 24) % 2 == 0 && OFF_BT % 2 == 0 && MT % 2 == 0, "16-byte units");
-  constexpr int NPF = NTHR - 128;   // wavefronts 2 and 3 stream the blocks
+  constexpr int NPF = 64;           // wavefronts 2 and 3 stream the blocks, a whole stage each, taking turns
   constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_SMALL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
   constexpr int PFS = (FWD_SMALL / 2 + NTHR - 1) / NTHR;
   QM_TICK(12);
@@ -542,17 +543,23 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   const bool upper = lane >= 32;            // second half of the wavefront: the second half of every dot product
   const int rowl = lane & 31;               // row of a matrix-vector product handled by this lane
   const int rK = rowl < MT ? rowl : 0, rX = rowl < 30 ? rowl : 0;
-  // the blocks of stage k + 1 are requested during iteration k - 1 and land in LDS during iteration k (an iteration is shorter than
-  // the HBM latency): the loads in flight live in registers across the loop back-edge
+  // The blocks of stage k + 1 land in LDS during iteration k and were requested during iteration k - 2: an iteration (~0.8 us) is shorter than the HBM latency
+  // under load.  Wavefronts 2 and 3 take turns -- wavefront 2 lands a WHOLE stage in the even iterations, wavefront 3 in the odd ones --, so each has one
+  // register set in flight for two iterations and, at its commit, nothing of its own that is newer: two sets per wavefront were built first and the compiler's
+  // wait-count insertion waited for the newer set at every commit (behind a branch, in straight-line pairs of iterations, with unconditional requests alike:
+  // vmcnt(9) .. vmcnt(0) where vmcnt(19) .. vmcnt(10) would do; 0.516 -> 0.521-0.553 ms).  The wavefront that is not landing a stage stores dx and
+  // accumulates the Armijo slope.  The loads in flight live in registers across the loop back-edge.
   StagePrefetch<PFH3, NPF> ph;
   StagePrefetch<PFT3, NPF> pt;
   StagePrefetch<PFG3, NPF> pg;
-  const unsigned jmF = wave >= 2 ? jointRowMask<PFH3, NPF>(tid - 128) : 0u;
-  if (wave >= 2 && N > 1) {
-    ph.issue(stagesI + STAGE_DOUBLES, FWD_HEAD, tid - 128);
-    pt.issue(stagesI + STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, tid - 128);
-    pg.issue(gainsI + GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
-  }
+  const unsigned long long jmF = wave >= 2 ? jointRowMask<PFH3, NPF>(lane) : 0ull;
+  auto requestStage = [&](int stage) {
+    ph.issue(stagesI + size_t(stage) * STAGE_DOUBLES, FWD_HEAD, lane);
+    pt.issue(stagesI + size_t(stage) * STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, lane);
+    pg.issue(gainsI + size_t(stage) * GAIN_DOUBLES, GAIN_DOUBLES, lane);
+  };
+  if (wave == 2 && N > 1) requestStage(1);
+  if (wave == 3 && N > 2) requestStage(2);
   // wavefront 1: 24 numbers of row rX of [Px | Pu] per lane (lower half columns 0..23 of Px; upper half 24..29 of Px, then Pu) and Pe
   QmD2 pr[12]; real pe = 0.0_r, modeR = 0.0_r;
   const real pxMul = rX < 12 ? 0.0_r : 1.0_r;            // the stored entries of a force row (Px: zero; Pu: a unit vector, formed below) do not count
@@ -577,34 +584,40 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       if (k < N) {
         const real* stg = lds + R_STG + sl * STG_F; const real* gn = stg + STAGE_DOUBLES;
         real* zv = lds + F_ZV + sl * ZV; real* zvNext = lds + F_ZV + slNext * ZV;
+        // Every product is split in the middle between the two halves of the wavefront (row r of the product on lanes r and 32 + r): the same instruction
+        // stream on both halves, so all LDS operands are requested before the first multiply-add, and the part of dx+ that has to wait for du~ is 9
+        // multiply-adds, not 18.
         // du~ = K dx + k: columns 0..14 on the lower half, 15..29 on the upper half
         const real* Krow = gn + OFF_KFB + rK * 30 + (upper ? 15 : 0);
         const real* xh = zv + (upper ? 15 : 0);
+        const real* Arow = stg + OFF_AT + rX * 30 + (upper ? 15 : 0);
+        real kv[15], av[15], xv[15];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) { kv[c] = Krow[c]; xv[c] = xh[c]; av[c] = Arow[c]; }
         real s0 = upper ? 0.0_r : gn[OFF_kff + rK], s1 = 0.0_r;
-#pragma unroll
-        for (int c = 0; c < 14; c += 2) { s0 += Krow[c] * xh[c]; s1 += Krow[c + 1] * xh[c + 1]; }
-        s0 += Krow[14] * xh[14];
-        // dx+ = [A~ | B~] z + b~: columns 0..23 of A~ on the lower half; 24..29 of A~, then B~, and b~ on the upper half
-        const real* Arow = stg + OFF_AT + rX * 30 + (upper ? 24 : 0);
-        const real* zh = zv + (upper ? 24 : 0);
         real t0 = upper ? stg[OFF_bt + rX] : 0.0_r, t1 = 0.0_r;
+        const real* Brow = stg + OFF_BT + rX * MT + (upper ? 9 : 0);
+        real bw[9];
 #pragma unroll
-        for (int c = 0; c < 6; c += 2) { t0 += Arow[c] * zh[c]; t1 += Arow[c + 1] * zh[c + 1]; }      // needs no du~ on either half
-        if (!upper) {
+        for (int j = 0; j < 9; ++j) bw[j] = Brow[j];
 #pragma unroll
-          for (int c = 6; c < 24; c += 2) { t0 += Arow[c] * zh[c]; t1 += Arow[c + 1] * zh[c + 1]; }
-        }
+        for (int c = 0; c < 14; c += 2) { s0 += kv[c] * xv[c]; s1 += kv[c + 1] * xv[c + 1]; }
+        s0 += kv[14] * xv[14];
         const real sd = s0 + s1;
         const real du = sd + qmHalfXor32(sd, upper);
         QM_TICK(15);
         if (lane < MT) zv[30 + lane] = du;
+        // dx+ = [A~ | B~] z + b~: the A~ dx half (needs no du~) while du~ makes its way through LDS
+#pragma unroll
+        for (int c = 0; c < 14; c += 2) { t0 += av[c] * xv[c]; t1 += av[c + 1] * xv[c + 1]; }
+        t0 += av[14] * xv[14];
         QM_WAVE_SYNC();
         QM_TICK(16);
-        if (upper) {    // B~ du~ on the upper half (18 columns)
-          const real* Brow = stg + OFF_BT + rX * MT;
-          const real* uh = zv + 30;
+        {
+          const real* uh = zv + 30 + (upper ? 9 : 0);
 #pragma unroll
-          for (int j = 0; j < MT; j += 2) { t0 += Brow[j] * uh[j]; t1 += Brow[j + 1] * uh[j + 1]; }
+          for (int j = 0; j < 8; j += 2) { t0 += bw[j] * uh[j]; t1 += bw[j + 1] * uh[j + 1]; }
+          t0 += bw[8] * uh[8];
         }
         const real td = t0 + t1;
         const real nx = td + qmHalfXor32(td, upper);
@@ -612,18 +625,15 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       }
     } else {
       QM_TICK(15);
-      if (wave >= 2) {
+      const bool landing = wave >= 2 && ((k ^ wave) & 1) == 0;   // wavefront 2 in the even iterations, wavefront 3 in the odd ones
+      if (landing) {
         if (k + 1 < N) {
           real* dst = lds + R_STG + slNext * STG_F;
-          ph.commitDynamics(dst, FWD_HEAD, tid - 128, jmF, lds[R_STG + sl * STG_F + OFF_DTNEXT]);   // the step of stage k + 1 came with stage k
-          pt.commit(dst + FWD_TAIL0, FWD_SMALL, tid - 128);
-          pg.commit(dst + STAGE_DOUBLES, GAIN_DOUBLES, tid - 128);
+          ph.commitDynamics(dst, FWD_HEAD, lane, jmF, lds[R_STG + sl * STG_F + OFF_DTNEXT]);   // the step of stage k + 1 came with stage k
+          pt.commit(dst + FWD_TAIL0, FWD_SMALL, lane);
+          pg.commit(dst + STAGE_DOUBLES, GAIN_DOUBLES, lane);
         }
-        if (k + 2 < N) {
-          ph.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES, FWD_HEAD, tid - 128);
-          pt.issue(stagesI + size_t(k + 2) * STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, tid - 128);
-          pg.issue(gainsI + size_t(k + 2) * GAIN_DOUBLES, GAIN_DOUBLES, tid - 128);
-        }
+        if (k + 3 < N) requestStage(k + 3);
       }
       QM_TICK(16);
       if (k > 0) {
@@ -632,11 +642,16 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const real* zv = lds + F_ZV + slPrev * ZV;
         if (wave == 1) {   // du = Pe + [Px | Pu] z from the rows in registers; then the rows of the next stage are requested
           const real* zh = zv + (upper ? 24 : 0);
+          real zz[24];   // all of z first: the LDS latency is paid once (left to itself the compiler waits for every 16 bytes before the next request)
+#pragma unroll
+          for (int i = 0; i < 24; ++i) zz[i] = zh[i];
+#pragma unroll
+          for (int i = 0; i < 24; ++i) QM_KEEP(zz[i]);
           real a0 = 0.0_r, a1 = 0.0_r, b0 = 0.0_r, b1 = 0.0_r;   // entries 0..2 are Px on both halves; 3..11 Px on the lower half, Pu on the upper
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { a0 += pr[i].x * zh[2 * i]; a1 += pr[i].y * zh[2 * i + 1]; }
+          for (int i = 0; i < 3; ++i) { a0 += pr[i].x * zz[2 * i]; a1 += pr[i].y * zz[2 * i + 1]; }
 #pragma unroll
-          for (int i = 3; i < 12; ++i) { b0 += pr[i].x * zh[2 * i]; b1 += pr[i].y * zh[2 * i + 1]; }
+          for (int i = 3; i < 12; ++i) { b0 += pr[i].x * zz[2 * i]; b1 += pr[i].y * zz[2 * i + 1]; }
           // force row i < 12 of Pu: a unit entry in the column of its free stance force (layout.h: puColumnOfForce) -- the one product 1 * du~[column]
           const int puCol = puColumnOfForce(int(modeR), rX);
           const real freeForce = zv[30 + (puCol >= 0 ? puCol : 0)];
@@ -644,7 +659,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
           const real duo = td + qmHalfXor32(td, upper);
           if (lane < 30) a.dU[(size_t(inst) * N + j) * 30 + lane] = duo;
           if (k < N) loadRows(k);
-        } else if (wave == 2) {   // dx out; Armijo slope q~ . dx + r~ . du~
+        } else if (!landing) {   // dx out; Armijo slope q~ . dx + r~ . du~
           if (lane < 30) {
             const real dxl = zv[lane];
             a.dX[(size_t(inst) * (N + 1) + j) * 30 + lane] = dxl;
@@ -666,9 +681,11 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     a.dX[(size_t(inst) * (N + 1) + N) * 30 + lane] = dxl;
     armijo += stagesI[size_t(N) * STAGE_DOUBLES + OFF_qt + lane] * dxl;
   }
-  // reduce armijo over the lanes of wavefront 2 through LDS
+  // reduce armijo over the lanes of wavefronts 2 and 3 through LDS
   __syncthreads();
   if (wave == 2) red[lane] = armijo;
+  __syncthreads();
+  if (wave == 3) red[lane] += armijo;
   __syncthreads();
   if (tid == 0) {
     real s = 0.0_r;
