@@ -27,7 +27,8 @@ constexpr int OFF_TAIL = OFF_rt + MT + 2;    // end of what the backward sweep r
 // foot, whose force Pe pins): neither exists in the record; the consumers form them from the node's contact mode, which rides in the record's tail.
 // 6.9 + 1.7 KB per stage less written by lq_node_kernel and less read by the forward sweep than with separate A~ B~ / Px Pu copies (round 3).
 constexpr int OFF_PE = OFF_TAIL;             // Pe   [30]
-constexpr int OFF_MODE = OFF_PE + 30;        // contact mode of the node (as a real), then one zero
+constexpr int OFF_MODE = OFF_PE + 30;        // contact mode of the node (as a real)
+constexpr int OFF_DT = OFF_MODE + 1;         // step of the node itself (the forward sweep multiplies its joint rows by it)
 constexpr int STAGE_DOUBLES = OFF_MODE + 2 + 4;  // 3320, multiple of 8
 // offsets of row i >= 12 of Px and of Pu
 constexpr int offPxRow(int i) { return OFF_AT + i * 30; }

@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // Pall: rows 0..11 (forces): Px = 0, Pu = unit columns of the free stance forces -- neither is stored (layout.h) --, Pe = pinned swing forces;
     //       rows 12..29 (joint velocities): [Px | Pe] from the tiles, Pu = Q_v2 (record and LDS)
     if (lane < 12) rec[OFF_PE + lane] = pev[lane];
-    else if (lane == 30 || lane == 31) rec[OFF_PE + lane] = lane == 30 ? real(mode) : 0.0_r;   // OFF_MODE: the consumers rebuild the force rows of Pu from it
+    else if (lane == 30 || lane == 31) rec[OFF_PE + lane] = lane == 30 ? real(mode) : dt;   // OFF_MODE: the consumers rebuild the force rows of Pu from it; OFF_DT
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll

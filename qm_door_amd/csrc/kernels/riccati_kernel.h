@@ -60,7 +60,7 @@ constexpr int R_SYM = R_KST + 2 * GAIN_DOUBLES;     // [32][LDS_TS] scratch of t
 constexpr int R_BWD_END = R_SYM + 32 * LDS_TS;
 static_assert(R_KST % 2 == 0 && GAIN_DOUBLES % 2 == 0, "16-byte copies");
 // forward sweep (over everything above, dead by then): a ring of three staging buffers [3][STG_F], then the B-operand images of dx and du~
-constexpr int FWD_ZV = 48;                             // z = [dx (30) | du~ (MT)] of one stage
+constexpr int FWD_ZV = 80;                             // z = [dx (30) | du~ (MT) | Px dx + Pu du~ of the joint rows (30, entries 12..29 used) | 2] of one stage
 constexpr int F_ZV = 3 * STG_F, R_FWD_END = F_ZV + 3 * FWD_ZV;
 constexpr int R_SCR = R_BWD_END > R_FWD_END ? R_BWD_END : R_FWD_END;   // armijo reduction [64]
 constexpr int RICCATI_LDS_DOUBLES = R_SCR + 64;
@@ -517,7 +517,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // q~.dx + r~.du~, and wavefronts 2 and 3 stream A~, B~, b~, q~, r~ and the gains of the next stage HBM -> registers -> LDS.
   // All MT columns of B~ / Pu / K are multiplied: the producers pad with zeros (lq_node_kernel; riccatiGains).
   constexpr int ZV = FWD_ZV;
-  constexpr int FWD_SMALL = OFF_TAIL - OFF_bt;        // b~ q~ r~ (+ padding)
+  constexpr int FWD_SMALL = STAGE_DOUBLES - OFF_bt;   // b~ q~ r~ (neighbours' steps) Pe, mode, step (+ padding)
   static_assert(FWD_SMALL % 2 == 0 && (OFF_AT + 24) % 2 == 0 && OFF_BT % 2 == 0 && MT % 2 == 0, "16-byte units");
   constexpr int NPF = 64;           // wavefronts 2 and 3 stream the blocks, a whole stage each, taking turns
   constexpr int PFH3 = (FWD_HEAD / 2 + NPF - 1) / NPF, PFT3 = (FWD_SMALL / 2 + NPF - 1) / NPF, PFG3 = (GAIN_DOUBLES / 2 + NPF - 1) / NPF;
@@ -532,7 +532,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     pt.issue(stagesI + FWD_TAIL0, FWD_SMALL, tid);
     pg.issue(gainsI, GAIN_DOUBLES, tid);
     for (int e = tid; e < 3 * ZV; e += NTHR) lds[F_ZV + e] = 0.0_r;
-    ph.commitDynamics(lds + R_STG, FWD_HEAD, tid, jointRowMask<PFH, NTHR>(tid), dtI[0]);
+    ph.commit(lds + R_STG, FWD_HEAD, tid);   // the forward sweep works on the record as it is: rows 12..29 of the head are Px / Pu (see the chain below)
     pt.commit(lds + R_STG + FWD_TAIL0, FWD_SMALL, tid);
     pg.commit(lds + R_STG + STAGE_DOUBLES, GAIN_DOUBLES, tid);
   }
@@ -552,7 +552,6 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   StagePrefetch<PFH3, NPF> ph;
   StagePrefetch<PFT3, NPF> pt;
   StagePrefetch<PFG3, NPF> pg;
-  const unsigned long long jmF = wave >= 2 ? jointRowMask<PFH3, NPF>(lane) : 0ull;
   auto requestStage = [&](int stage) {
     ph.issue(stagesI + size_t(stage) * STAGE_DOUBLES, FWD_HEAD, lane);
     pt.issue(stagesI + size_t(stage) * STAGE_DOUBLES + FWD_TAIL0, FWD_SMALL, lane);
@@ -560,22 +559,6 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   };
   if (wave == 2 && N > 1) requestStage(1);
   if (wave == 3 && N > 2) requestStage(2);
-  // wavefront 1: 24 numbers of row rX of [Px | Pu] per lane (lower half columns 0..23 of Px; upper half 24..29 of Px, then Pu) and Pe
-  QmD2 pr[12]; real pe = 0.0_r, modeR = 0.0_r;
-  const real pxMul = rX < 12 ? 0.0_r : 1.0_r;            // the stored entries of a force row (Px: zero; Pu: a unit vector, formed below) do not count
-  auto loadRows = [&](int stage) {
-    const real* rec = stagesI + size_t(stage) * STAGE_DOUBLES;
-    // Px rows of the force inputs (rX < 12) are structurally zero and not stored (layout.h): those lanes re-read row 12 (the cache lines lane 12 fetches
-    // anyway: no extra HBM traffic, no divergent branch around the register-staged loads); the products with these entries are scaled by pxMul = 0 below.
-    // Rows >= 12 of Px / Pu are the raw joint rows of the record's head -- the lines wavefronts 2 and 3 stream for the chain: the second reader meets them in L2.
-    const QmD2* p0 = reinterpret_cast<const QmD2*>(rec + offPxRow(rX < 12 ? 12 : rX) + (upper ? 24 : 0));
-    const QmD2* p1 = reinterpret_cast<const QmD2*>(rec + offPuRow(rX < 12 ? 12 : rX));
-#pragma unroll
-    for (int i = 0; i < 12; ++i) pr[i] = (upper && i >= 3) ? p1[i - 3] : p0[i];
-    pe = rec[OFF_PE + rX];
-    modeR = rec[OFF_MODE];     // the same address in every lane
-  };
-  if (wave == 1) loadRows(0);
 #pragma unroll 1
   for (int k = 0; k <= N; ++k) {   // iteration k: the chain does stage k (k < N), the others finish stage k - 1 and stage the blocks of k + 1
     const int sl = k % 3, slPrev = (k + 2) % 3, slNext = (k + 1) % 3;
@@ -586,7 +569,9 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         real* zv = lds + F_ZV + sl * ZV; real* zvNext = lds + F_ZV + slNext * ZV;
         // Every product is split in the middle between the two halves of the wavefront (row r of the product on lanes r and 32 + r): the same instruction
         // stream on both halves, so all LDS operands are requested before the first multiply-add, and the part of dx+ that has to wait for du~ is 9
-        // multiply-adds, not 18.
+        // multiply-adds, not 18.  The head of the record is used as it is (layout.h): rows 0..11 are [A~ | B~], rows 12..29 [Px | Pu], so with
+        // s = row . [dx; du~]:   dx+_i = b~_i + s (i < 12),   dx+_i = b~_i + dx_i + dt s (joint rows: x_j+ = x_j + dt v_j exactly),
+        // and s of a joint row is also what wavefront 1 needs for du = Pe + Px dx + Pu du~: it goes out next to dx+ -- nobody reads Px / Pu a second time.
         // du~ = K dx + k: columns 0..14 on the lower half, 15..29 on the upper half
         const real* Krow = gn + OFF_KFB + rK * 30 + (upper ? 15 : 0);
         const real* xh = zv + (upper ? 15 : 0);
@@ -595,7 +580,9 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
         for (int c = 0; c < 15; ++c) { kv[c] = Krow[c]; xv[c] = xh[c]; av[c] = Arow[c]; }
         real s0 = upper ? 0.0_r : gn[OFF_kff + rK], s1 = 0.0_r;
-        real t0 = upper ? stg[OFF_bt + rX] : 0.0_r, t1 = 0.0_r;
+        const bool jointRow = rX >= 12;
+        const real tail = upper ? stg[OFF_bt + rX] : (jointRow ? zv[rX] : 0.0_r);   // b~_i on one half, dx_i of a joint row on the other
+        const real mul = jointRow ? stg[OFF_DT] : 1.0_r;
         const real* Brow = stg + OFF_BT + rX * MT + (upper ? 9 : 0);
         real bw[9];
 #pragma unroll
@@ -607,7 +594,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const real du = sd + qmHalfXor32(sd, upper);
         QM_TICK(15);
         if (lane < MT) zv[30 + lane] = du;
-        // dx+ = [A~ | B~] z + b~: the A~ dx half (needs no du~) while du~ makes its way through LDS
+        // the [A~; Px] dx half (needs no du~) while du~ makes its way through LDS
+        real t0 = 0.0_r, t1 = 0.0_r;
 #pragma unroll
         for (int c = 0; c < 14; c += 2) { t0 += av[c] * xv[c]; t1 += av[c + 1] * xv[c + 1]; }
         t0 += av[14] * xv[14];
@@ -619,8 +607,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
           for (int j = 0; j < 8; j += 2) { t0 += bw[j] * uh[j]; t1 += bw[j + 1] * uh[j + 1]; }
           t0 += bw[8] * uh[8];
         }
-        const real td = t0 + t1;
-        const real nx = td + qmHalfXor32(td, upper);
+        const real th = t0 + t1;
+        const real sRow = th + qmHalfXor32(th, upper);            // s, complete on both halves
+        const real nx = (tail + qmHalfXor32(tail, upper)) + mul * sRow;
+        if (lane >= 12 && lane < 30) zv[48 + lane] = sRow;
         if (lane < 30) zvNext[lane] = nx;
       }
     } else {
@@ -629,7 +619,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       if (landing) {
         if (k + 1 < N) {
           real* dst = lds + R_STG + slNext * STG_F;
-          ph.commitDynamics(dst, FWD_HEAD, lane, jmF, lds[R_STG + sl * STG_F + OFF_DTNEXT]);   // the step of stage k + 1 came with stage k
+          ph.commit(dst, FWD_HEAD, lane);
           pt.commit(dst + FWD_TAIL0, FWD_SMALL, lane);
           pg.commit(dst + STAGE_DOUBLES, GAIN_DOUBLES, lane);
         }
@@ -640,25 +630,12 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const int j = k - 1;
         const real* stg = lds + R_STG + slPrev * STG_F;
         const real* zv = lds + F_ZV + slPrev * ZV;
-        if (wave == 1) {   // du = Pe + [Px | Pu] z from the rows in registers; then the rows of the next stage are requested
-          const real* zh = zv + (upper ? 24 : 0);
-          real zz[24];   // all of z first: the LDS latency is paid once (left to itself the compiler waits for every 16 bytes before the next request)
-#pragma unroll
-          for (int i = 0; i < 24; ++i) zz[i] = zh[i];
-#pragma unroll
-          for (int i = 0; i < 24; ++i) QM_KEEP(zz[i]);
-          real a0 = 0.0_r, a1 = 0.0_r, b0 = 0.0_r, b1 = 0.0_r;   // entries 0..2 are Px on both halves; 3..11 Px on the lower half, Pu on the upper
-#pragma unroll
-          for (int i = 0; i < 3; ++i) { a0 += pr[i].x * zz[2 * i]; a1 += pr[i].y * zz[2 * i + 1]; }
-#pragma unroll
-          for (int i = 3; i < 12; ++i) { b0 += pr[i].x * zz[2 * i]; b1 += pr[i].y * zz[2 * i + 1]; }
-          // force row i < 12 of Pu: a unit entry in the column of its free stance force (layout.h: puColumnOfForce) -- the one product 1 * du~[column]
-          const int puCol = puColumnOfForce(int(modeR), rX);
-          const real freeForce = zv[30 + (puCol >= 0 ? puCol : 0)];
-          const real td = (upper ? pe : 0.0_r) + ((a0 + a1) * pxMul + (b0 + b1) * pxMul) + ((upper && rowl < 12 && puCol >= 0) ? freeForce : 0.0_r);
-          const real duo = td + qmHalfXor32(td, upper);
-          if (lane < 30) a.dU[(size_t(inst) * N + j) * 30 + lane] = duo;
-          if (k < N) loadRows(k);
+        if (wave == 1) {   // du = Pe + Px dx + Pu du~: joint rows from the chain's s, force rows from the contact mode (layout.h: puColumnOfForce)
+          if (lane < 30) {
+            const int puCol = puColumnOfForce(int(stg[OFF_MODE]), lane < 12 ? lane : 0);
+            const real rowPart = lane >= 12 ? zv[48 + lane] : (puCol >= 0 ? zv[30 + (puCol >= 0 ? puCol : 0)] : 0.0_r);
+            a.dU[(size_t(inst) * N + j) * 30 + lane] = stg[OFF_PE + lane] + rowPart;
+          }
         } else if (!landing) {   // dx out; Armijo slope q~ . dx + r~ . du~
           if (lane < 30) {
             const real dxl = zv[lane];
