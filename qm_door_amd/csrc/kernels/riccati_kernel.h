@@ -487,11 +487,16 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       for (int ks = 0; ks < 5; ++ks) { const int kk = 4 * ks + h; av[ks] = -W[kk * LDS_W + tm * 16 + la]; bw[ks] = W[kk * LDS_W + j]; }
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) qmMfma(c6, av[ks], bw[ks], scr);
+      // one store per accumulator register, no branch: an entry of the padding (row / column 30, 31: they must stay zero) goes to a scratch word of the
+      // symmetrisation square (free here), the s' entry (column 30) to row 30 of S; the mirror image of the off-diagonal tile likewise
+      real* sink = lds + R_SYM + lane;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = tm * 16 + h + 4 * r;
-        if (i < 30 && j < 30) { S[i * LDS_S + j] = c6[r]; if (wave == 2) S[j * LDS_S + i] = c6[r]; }
-        if (i < 30 && j == 30) S[30 * LDS_S + i] = c6[r];
+        const bool inS = i < 30 && j < 30;
+        real* dst = inS ? S + i * LDS_S + j : ((i < 30 && j == 30) ? S + 30 * LDS_S + i : sink);
+        *dst = c6[r];
+        if (wave == 2) { real* mir = inS ? S + j * LDS_S + i : sink + 64; *mir = c6[r]; }
       }
     }
     QM_TICK(8);
@@ -572,6 +577,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         // multiply-adds, not 18.  The head of the record is used as it is (layout.h): rows 0..11 are [A~ | B~], rows 12..29 [Px | Pu], so with
         // s = row . [dx; du~]:   dx+_i = b~_i + s (i < 12),   dx+_i = b~_i + dx_i + dt s (joint rows: x_j+ = x_j + dt v_j exactly),
         // and s of a joint row is also what wavefront 1 needs for du = Pe + Px dx + Pu du~: it goes out next to dx+ -- nobody reads Px / Pu a second time.
+        // (Odd row strides for the image the chain walks -- 31 / 19 doubles instead of the record's 30 / 18, against bank conflicts of one row per lane -- were
+        //  built and measured in round 3: 1.10 k -> 1.05 k ticks for this phase, 0.493 -> 0.495 ms for the launch: not kept.)
         // du~ = K dx + k: columns 0..14 on the lower half, 15..29 on the upper half
         const real* Krow = gn + OFF_KFB + rK * 30 + (upper ? 15 : 0);
         const real* xh = zv + (upper ? 15 : 0);
