@@ -57,7 +57,8 @@ constexpr int R_W = R_S + 32 * LDS_S;              // W of the stage in flight a
 constexpr int R_LT = R_W + 2 * W_DOUBLES;         // formed while stage k factorises, from W / L^T of stage k + 1
 constexpr int R_KST = R_LT + 2 * LT_DOUBLES;        // the gains record [GAIN_DOUBLES] of two stages: formed here by one wavefront, copied to HBM by two others a stage later
 constexpr int R_SYM = R_KST + 2 * GAIN_DOUBLES;     // [32][LDS_TS] scratch of the wavefront-local symmetrisation (T is being read by the factorisation at that time)
-constexpr int R_BWD_END = R_SYM + 32 * LDS_TS;
+constexpr int R_Y2 = R_SYM + 32 * LDS_TS;            // [16][LDS_Y] second half of the k sum of Y rows 16..31 when only three column tiles exist (P1 below)
+constexpr int R_BWD_END = R_Y2 + 16 * LDS_Y;
 static_assert(R_KST % 2 == 0 && GAIN_DOUBLES % 2 == 0, "16-byte copies");
 // forward sweep (over everything above, dead by then): a ring of three staging buffers [3][STG_F], then the B-operand images of dx and du~
 constexpr int FWD_ZV = 80;                             // z = [dx (30) | du~ (MT) | Px dx + Pu du~ of the joint rows (30, entries 12..29 used) | 2] of one stage
@@ -284,6 +285,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     if (tid < 30) S[30 * LDS_S + tid] = rec[OFF_qt + tid];        // s: row 30 of S (the B operands carry a unit entry at (30, 30))
     for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES + 2 * GAIN_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;   // W, L, gains images of both parities (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
+    for (int e = tid; e < 16 * LDS_Y; e += NTHR) lds[R_Y2 + e] = 0.0_r;
     StagePrefetch<PFB, NTHR> pf;
     pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_TAIL, tid);
     pf.commitDynamics(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_TAIL, tid, jointRowMask<PFB, NTHR>(tid), dtI[N - 1]);
@@ -331,6 +333,21 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QM_KEEP(mOne); QM_KEEP(cOne); QM_KEEP(mAdd7); QM_KEEP(b1One);
   }
   const real m7One = h >= 2 ? 0.0_r : mOne;   // k step 7: rows 30, 31 of M carry no data
+  // P1 with three column tiles (m~ <= 16: trot, flight): 6 output tiles x 8 k steps on four wavefronts = 12 matrix-core instructions each instead of 16 on three --
+  // wavefronts 0..2 stop the lower row tile (rows 16..31) of their column tile after k steps 0..3, wavefront 3 forms k steps 4..7 of all three into Y2, and the
+  // consumers of those rows (P2, P6a) add the two halves.  Its operand offsets, for the column tiles t = 0, 1, 2 and k steps 4..7:
+  constexpr int KS3 = 5;   // first k step of wavefront 3: 8 + 5 = 13 instructions on wavefronts 0..2, 3 x 3 = 9 on wavefront 3 (whose operand set is three times as wide)
+  int w3Off[3][8 - KS3]; real w3One[3], w3Add7[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int jt = t * 16 + l16;
+    const bool jA = jt < 30, jb = jt == 30, jB = jt >= 32;
+    const int off = jA ? OFF_AT + jt : (jb ? OFF_bt : (jB ? OFF_BT + (jt - 32) : 0)), str = jA ? 30 : (jb ? 1 : (jB ? MT : 0));
+#pragma unroll
+    for (int q = 0; q < 8 - KS3; ++q) { const int kk = 4 * (KS3 + q) + h, kc = kk < 30 ? kk : 29; w3Off[t][q] = off + kc * str; QM_KEEP(w3Off[t][q]); }
+    w3One[t] = (jA || jb || jB) ? 1.0_r : 0.0_r; w3Add7[t] = (h == 2 && jb) ? 1.0_r : 0.0_r;
+    QM_KEEP(w3One[t]); QM_KEEP(w3Add7[t]);
+  }
   int ncCur = ncI[N - 1], ncPrev = 0;   // constraint rows of stage k and of stage k + 1; the next one is loaded a stage ahead
   // the staged copy of the next record is shared by wavefronts 1, 3, 2 IN THAT ORDER: the last, partial round of 16-byte units goes to 1 and 3 -- wavefront 2 also
   // runs the deferred gains and is the one closest to the factorisation's length
@@ -346,6 +363,9 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
     QM_TICK(0);
     // ---- P1 + P2: wavefront w owns the 16 columns [16 w, 16 w + 16) of Y and of T
+    const bool splitK = nTiles == 3;                 // (wave uniform, per stage)
+    const real y2On = splitK ? 1.0_r : 0.0_r;        // consumers of Y rows 16..31 add Y2 times this (Y2 always holds finite numbers)
+    real* Y2 = lds + R_Y2;
     if (wave < nTiles) {
       QmAcc c0, c1;
       real a0[8], a1[8], bv[8];   // all operands first: the LDS latency is paid once
@@ -360,10 +380,46 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks) bv[ks] *= mOne;
       bv[7] = bv[7] * m7One + mAdd7;
+      if (splitK) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
+        for (int ks = 0; ks < KS3; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
+#pragma unroll
+        for (int ks = KS3; ks < 8; ++ks) qmMfma(c0, a0[ks], bv[ks], scr);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { qmMfma(c0, a0[ks], bv[ks], scr); qmMfma(c1, a1[ks], bv[ks], scr); }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { Y[(h + 4 * r) * LDS_Y + jc] = c0[r]; Y[(16 + h + 4 * r) * LDS_Y + jc] = c1[r]; }
+    } else if (splitK) {   // wavefront 3: k steps 4..7 of the lower row tile of the three column tiles
+      constexpr int NQ = 8 - KS3;
+      real a1[NQ], bt[3][NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int kk = 4 * (KS3 + q) + h;
+        a1[q] = S[kk * LDS_S + 16 + la];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bt[t][q] = stg[w3Off[t][q]];
+      }
+      QmAcc d[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[t][r] = 0.0_r;
+#pragma unroll
+        for (int q = 0; q < NQ - 1; ++q) bt[t][q] *= w3One[t];
+        bt[t][NQ - 1] = bt[t][NQ - 1] * (h >= 2 ? 0.0_r : w3One[t]) + w3Add7[t];
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) qmMfma(d[t], a1[q], bt[t][q], scr);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y2[(h + 4 * r) * LDS_Y + t * 16 + l16] = d[t][r];
+      }
     }
     QM_TICK(1);
     QM_LDS_BARRIER();
@@ -379,6 +435,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         bv[ks] = Y[kk * LDS_Y + jc];
         a0[ks] = stg[bOffK[ks]];            // B~^T[i][k] = B~[k][i]; columns beyond m~ are zero in the record
       }
+#pragma unroll
+      for (int ks = 4; ks < 8; ++ks) bv[ks] = fma(y2On, Y2[(4 * (ks - 4) + h) * LDS_Y + jc], bv[ks]);   // rows 16..31 of Y: the other half of the k sum (P1)
 #pragma unroll
       for (int r = 0; r < 4; ++r) c0[r] = ci[r] * cOne;
       if (mtTiles == 2) {
@@ -442,6 +500,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
         av[ks] = stg[OFF_AT + kc * 30 + ai]; bw[ks] = Y[kk * LDS_Y + j];   // A~^T[i][k] = A~[k][i]
       }
+#pragma unroll
+      for (int ks = 4; ks < 8; ++ks) bw[ks] = fma(y2On, lds[R_Y2 + (4 * (ks - 4) + h) * LDS_Y + j], bw[ks]);   // rows 16..31 of Y: the other half of the k sum (P1)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         QM_KEEP(qv[r]); QM_KEEP(qq[r]);
