@@ -258,7 +258,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   QM_POISON_LDS(lds, RICCATI_LDS_DOUBLES);
   constexpr int NTHR = NW * 64;
   constexpr int PFB = (OFF_TAIL / 2 + NTHR - 1) / NTHR;
-  constexpr int PFW = (OFF_TAIL / 2 + NTHR - 64 - 1) / (NTHR - 64);   // the same copy by three wavefronts
+  constexpr int NCP = 128;                                      // the same copy during the factorisation: by wavefronts 1 and 3 (wavefront 2 forms a tile AND the deferred gains: it is as long as the factorisation itself)
+  constexpr int PFW = (OFF_TAIL / 2 + NCP - 1) / NCP;
   // forward sweep: only the head of the record (A~ B~ rows 0..11, Px Pu rows 12..29) and b~ q~ r~, Pu rows 0..11, Pe (its tail) are read; Q~ P~ R~ in between are not
   constexpr int FWD_HEAD = OFF_QT, FWD_TAIL0 = OFF_bt;
   static_assert(FWD_HEAD % 2 == 0 && FWD_TAIL0 % 2 == 0, "16-byte units");
@@ -349,10 +350,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QM_KEEP(w3One[t]); QM_KEEP(w3Add7[t]);
   }
   int ncCur = ncI[N - 1], ncPrev = 0;   // constraint rows of stage k and of stage k + 1; the next one is loaded a stage ahead
-  // the staged copy of the next record is shared by wavefronts 1, 3, 2 IN THAT ORDER: the last, partial round of 16-byte units goes to 1 and 3 -- wavefront 2 also
-  // runs the deferred gains and is the one closest to the factorisation's length
-  const int ptid = wave == 1 ? lane : (wave == 3 ? 64 + lane : 128 + lane);
-  const unsigned long long jmW = wave > 0 ? jointRowMask<PFW, NTHR - 64>(ptid) : 0ull;   // which of my units of the staged copy are joint-row entries
+  // the staged copy of the next record is made by wavefronts 1 and 3 (13 units of 16 bytes per thread); wavefront 2 also runs the deferred gains
+  const int ptid = wave == 3 ? 64 + lane : lane;
+  const bool copier = wave == 1 || wave == 3;
+  const unsigned long long jmW = copier ? jointRowMask<PFW, NCP>(ptid) : 0ull;   // which of my units of the staged copy are joint-row entries
 #pragma unroll 1
   for (int k = N - 1; k >= 0; --k) {
     const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
@@ -478,8 +479,8 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     } else {
       // the next stage's blocks HBM -> registers -> LDS by the three wavefronts that are off the critical path here; the other
       // staging buffer was last read before the final barrier of the previous stage
-      StagePrefetch<PFW, NTHR - 64> pf;
-      pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_TAIL, ptid);
+      StagePrefetch<PFW, NCP> pf;
+      if (copier) pf.issue(stagesI + size_t(k > 0 ? k - 1 : 0) * STAGE_DOUBLES, OFF_TAIL, ptid);
       // ---- P6a: [Q~ | q~] + A~^T [S A~ | y] for my tile (independent of the factorisation), symmetrised here: (C + C^T) / 2 on the diagonal
       //      tiles through a scratch square inside the wavefront.  W^T W, subtracted after the factorisation, is symmetric bit for bit
       //      (the same products in the same order on both sides), so S' needs no second pass.  Without the symmetrisation the
@@ -532,7 +533,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       } else if (k + 2 < N) {
         riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
       }
-      pf.commitDynamics(stgNext, OFF_TAIL, ptid, jmW, stg[OFF_DTPREV]);   // stage k - 1 lands in the other buffer, its joint rows as A~ / B~ (its step came with stage k)
+      if (copier) pf.commitDynamics(stgNext, OFF_TAIL, ptid, jmW, stg[OFF_DTPREV]);   // stage k - 1 lands in the other buffer, its joint rows as A~ / B~ (its step came with stage k)
     }
     QM_TICK(5);
     QM_TICK(6);
