@@ -397,6 +397,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   };
   auto pallOp = [&](int ks, int tq) { return pallOpAt(ks, tq * 16 + l16); };    // as a B operand: column of Pall
   auto pallOpT = [&](int ks, int tq) { return pallOpAt(ks, tq * 16 + la); };    // as an A operand (Pall^T): row of Pall^T
+  // The eight operands of one tile column / row at once, held with QM_KEEP: left inside the multiply loops the compiler turned every select above into a
+  // predicated LDS read of its own (s_and_saveexec; ds_read; s_waitcnt lgkmcnt(0)) directly in front of the matrix-core instruction that uses it -- one LDS
+  // round trip per instruction (round 3: 112 of them in the products (2)(3) alone).
+  auto pallOps = [&](real (&o)[8], int tq) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) o[ks] = pallOp(ks, tq);
+#pragma unroll
+    for (int ks = 3; ks < 8; ++ks) QM_KEEP(o[ks]);
+  };
+  auto pallOpsT = [&](real (&o)[8], int tq) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) o[ks] = pallOpT(ks, tq);
+#pragma unroll
+    for (int ks = 3; ks < 8; ++ks) QM_KEEP(o[ks]);
+  };
   {
     int myVr = 0;
 #pragma unroll
@@ -528,12 +543,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const real av = AT[(j < 32 ? j : 0) * LDT + i], bb = bv[i < 30 ? i : 0];
         c1[tn][r] = (i < 12) ? (j < 30 ? av : (j == 30 ? bb : 0.0_r)) : 0.0_r;
       }
+    real ab[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int kk = 4 * ks + h;
-      const real ab = BT[kk * LDT + la];
+    for (int ks = 0; ks < 8; ++ks) ab[ks] = BT[(4 * ks + h) * LDT + la];
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn) { if (tn < nTn) qmMfma(c1[tn], ab, pallOp(ks, tn), red); }
+    for (int tn = 0; tn < 4; ++tn) {
+      if (tn < nTn) {
+        real pb[8];
+        pallOps(pb, tn);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qmMfma(c1[tn], ab[ks], pb[ks], red);
+      }
     }
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
@@ -576,8 +596,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         QmAcc wA, wB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { wA[r] = 0.0_r; wB[r] = 0.0_r; }
+        {
+          real pb[8];
+          pallOps(pb, tn);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { const real pb = pallOp(ks, tn); qmMfma(wA, r0[ks], pb, red); qmMfma(wB, r1[ks], pb, red); }
+          for (int ks = 0; ks < 8; ++ks) { qmMfma(wA, r0[ks], pb[ks], red); qmMfma(wB, r1[ks], pb[ks], red); }
+        }
         QM_WAVE_SYNC();   // the previous tile's readers are done
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int i = h + 4 * r; WT[i * LDW + l16] = wA[r]; WT[(16 + i) * LDW + l16] = wB[r]; }
@@ -601,13 +625,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             qmMfma(g[0], a0, bj, red); qmMfma(g[1], a1, bj, red);
           }
         }
+        real wb[8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const int kk = 4 * ks + h;
-          const real wb = WT[kk * LDW + l16];
-          if (top) { qmMfma(g[0], pallOpT(ks, 0), wb, red); qmMfma(g[1], pallOpT(ks, 1), wb, red); }
-          qmMfma(g[2], pallOpT(ks, 2), wb, red);
-          if (low3) qmMfma(g[3], pallOpT(ks, 3), wb, red);
+        for (int ks = 0; ks < 8; ++ks) wb[ks] = WT[(4 * ks + h) * LDW + l16];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+          if ((tm < 2 && top) || tm == 2 || (tm == 3 && low3)) {
+            real pa[8];
+            pallOpsT(pa, tm);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qmMfma(g[tm], pa[ks], wb[ks], red);
+          }
         }
         const int j = tn * 16 + l16;
 #pragma unroll
