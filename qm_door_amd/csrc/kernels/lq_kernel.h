@@ -502,11 +502,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (lane >= 32 && lane < PAW) {
       const int jj = lane - 32;
       const bool isQ2 = jj >= nStF && jj < nt;
+      real qv[18];   // all reads first (QM_KEEP: otherwise every read is predicated on isQ2 and waited for in front of its two stores)
+#pragma unroll
+      for (int i = 0; i < 18; ++i) qv[i] = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) QM_KEEP(qv[i]);
 #pragma unroll
       for (int i = 0; i < 18; ++i) {
-        const real qv = Qs[i * LDQ + (isQ2 ? nv + (jj - nStF) : 0)];
-        PA[i * PAW + lane] = isQ2 ? qv : 0.0_r;
-        rec[offPuRow(12 + i) + jj] = isQ2 ? qv : 0.0_r;                             // (the B~ area) jj < MT = PAW - 32: zero padding included
+        const real v = isQ2 ? qv[i] : 0.0_r;
+        PA[i * PAW + lane] = v;
+        rec[offPuRow(12 + i) + jj] = v;                                             // (the B~ area) jj < MT = PAW - 32: zero padding included
       }
     }
   }
@@ -588,8 +593,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   {
     fin[lane] = 0.0_r;
     real r0[8], r1[8];   // R operand (symmetric: R[i][k] read as R[k][i]), shared by all tiles
+    // the eight entries (4 ks + h, i) of one operand column at once: all loads (R' from L1, the barrier terms from LDS) before the first use -- written as
+    // rEntry calls each entry waited for its own global load inside a predicated region
+    auto rEntries = [&](real (&o)[8], int i) {
+      const int ic = i < 30 ? i : 0;
+      real raw[8], fbv[8], dvv[8], rkv[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) { const int kk = 4 * ks + h; r0[ks] = rEntry(kk, la); r1[ks] = rEntry(kk, 16 + la); }
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 0;
+        raw[ks] = a.Rw[kc * 30 + ic]; fbv[ks] = fb[(kc < 12 ? kc : 0) * 3 + ic % 3]; dvv[ks] = ddv[kc >= 24 ? kc - 24 : 0]; rkv[ks] = rv[kc];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) { QM_KEEP(raw[ks]); QM_KEEP(fbv[ks]); QM_KEEP(dvv[ks]); QM_KEEP(rkv[ks]); }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 0;
+        const real add = (kc < 12 && ic < 12 && kc / 3 == ic / 3) ? fbv[ks] : ((kc == ic && kc >= 24) ? dvv[ks] : 0.0_r);   // (the two cases exclude each other)
+        const real v = (raw[ks] + add) * dt;
+        o[ks] = kk < 30 ? (i < 30 ? v : (i == 30 ? rkv[ks] : 0.0_r)) : 0.0_r;
+      }
+    };
+    rEntries(r0, la);
+    rEntries(r1, 16 + la);
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       if (tn < nTn) {
@@ -613,16 +638,39 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) g[tm][r] = (tm < 2 && tn < 2) ? sc * qBase(tm * 16 + h + 4 * r, tn * 16 + l16) : 0.0_r;
+          for (int r = 0; r < 4; ++r) g[tm][r] = 0.0_r;
+        if (tn < 2) {   // + sc * (tracking weight + joint-limit barrier): the eight entries of this lane, loads first (as rEntries above)
+          const int j = tn * 16 + l16, jc = j < 30 ? j : 0;
+          real qraw[8], dgv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = (e >> 2) * 16 + h + 4 * (e & 3), ic = i < 30 ? i : 0;
+            qraw[e] = st.Q[ic * 30 + jc]; dgv[e] = ddp[ic >= 24 ? ic - 24 : 0];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { QM_KEEP(qraw[e]); QM_KEEP(dgv[e]); }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = (e >> 2) * 16 + h + 4 * (e & 3), ic = i < 30 ? i : 0;
+            const real v = qraw[e] + ((ic == jc && ic >= 24) ? dgv[e] : 0.0_r);
+            g[e >> 2][e & 3] = (i < 30 && j < 30) ? sc * v : 0.0_r;
+          }
+        }
         if (tn < 2) {   // + J_ee^T diag(mu) J_ee (Gauss-Newton term of the end-effector soft constraints) on the matrix cores: K = 6 error rows in two k steps
+          real ej[2], e0[2], e1[2];
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const int qq = 4 * ks + h;                      // error row this lane supplies
+            const int qq = 4 * ks + h, qc2 = qq < 6 ? qq : 0;     // error row this lane supplies
+            ej[ks] = EEJ[qc2 * 32 + tn * 16 + l16]; e0[ks] = EEJ[qc2 * 32 + la]; e1[ks] = EEJ[qc2 * 32 + 16 + la];
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) { QM_KEEP(ej[ks]); QM_KEEP(e0[ks]); QM_KEEP(e1[ks]); }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int qq = 4 * ks + h;
             const bool on = qq < 6;
             const real wq = on ? sc * (qq < 3 ? muP + muF * Ke * Ke : muO) : 0.0_r;
-            const real bj = on ? EEJ[(on ? qq : 0) * 32 + tn * 16 + l16] : 0.0_r;
-            const real a0 = on ? wq * EEJ[(on ? qq : 0) * 32 + la] : 0.0_r, a1 = on ? wq * EEJ[(on ? qq : 0) * 32 + 16 + la] : 0.0_r;
-            qmMfma(g[0], a0, bj, red); qmMfma(g[1], a1, bj, red);
+            qmMfma(g[0], wq * e0[ks], on ? ej[ks] : 0.0_r, red); qmMfma(g[1], wq * e1[ks], on ? ej[ks] : 0.0_r, red);
           }
         }
         real wb[8];
