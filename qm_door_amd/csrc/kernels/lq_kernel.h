@@ -494,10 +494,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = (t4 >> 1) * 16 + h + 4 * r, j = (t4 & 1) * 16 + l16;   // i: joint-velocity input 12 + i
-        if (i < 18) {
-          PA[i * PAW + j] = j <= 30 ? pc[t4][r] : 0.0_r;
-          if (j < 30) rec[offPxRow(12 + i) + j] = pc[t4][r]; else if (j == 30) rec[OFF_PE + 12 + i] = pc[t4][r];   // Px rows live in the A~ area (layout.h)
-        }
+        const int off = (i < 18 && j <= 30) ? (j < 30 ? offPxRow(12 + i) + j : OFF_PE + 12 + i) : -1;   // Px rows live in the A~ area (layout.h)
+        if (i < 18) PA[i * PAW + j] = j <= 30 ? pc[t4][r] : 0.0_r;
+        if (off >= 0) rec[off] = pc[t4][r];
       }
     if (lane >= 32 && lane < PAW) {
       const int jj = lane - 32;
@@ -565,13 +564,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (tn < nTn) {
         const int j = tn * 16 + l16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 3; ++r) {   // (r = 3: rows 12..15 of the tile do not exist)
           const int i = h + 4 * r;
-          if (i < 12) {
-            if (j < 30) rec[OFF_AT + i * 30 + j] = c1[tn][r];
-            else if (j == 30) rec[OFF_bt + i] = c1[tn][r];
-            else if (j >= 32 && j < 32 + nt) rec[OFF_BT + i * MT + (j - 32)] = c1[tn][r];
-          }
+          // ONE store per accumulator register, its place chosen with selects (nested conditions became nested predicated regions, each with its own branch)
+          const int off = j < 30 ? OFF_AT + i * 30 + j : (j == 30 ? OFF_bt + i : ((j >= 32 && j < 32 + nt) ? OFF_BT + i * MT + (j - 32) : -1));
+          if (off >= 0) rec[off] = c1[tn][r];
         }
       }
     }
@@ -693,15 +690,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int r = 0; r < 4; ++r) {
               const int i = tm * 16 + h + 4 * r;
               const real v = g[tm][r];
-              if (i < 30) {
-                if (j < 30 && !(tm == 1 && tn == 0) && !(tm == tn && j < i)) rec[OFF_QT + i * 30 + j] = v;   // Q~ is symmetric and the backward sweep reads the tile (0,1) and the upper triangles of (0,0), (1,1) only: nothing else is stored
-              } else if (i == 30) {
-                if (j < 30) fin[j] += v;                                   // Pe^T R Px
-              } else if (i >= 32 && i < 32 + nt) {
-                if (j < 30) rec[OFF_PT + (i - 32) * 30 + j] = v;
-                else if (j == 30) fin[i] += v;                             // Pu^T R Pe
-                else if (j >= 32 && j <= i) rec[OFF_RT + (i - 32) * MT + (j - 32)] = v;          // R~: the lower triangle (the backward sweep reads the mirror image for the rest)
-              }
+              // ONE record store per accumulator register, its place chosen with selects (tm, tn, r are compile-time; nested conditions had become nested
+              // predicated regions with a branch each).  Q~ is symmetric and the backward sweep reads the tile (0,1) and the upper triangles of (0,0), (1,1)
+              // only: nothing else is stored; R~: the lower triangle (the backward sweep reads the mirror image for the rest).
+              int off = -1;
+              if (tm < 2) { if (tn < 2 && !(tm == 1 && tn == 0)) off = (i < 30 && j < 30 && !(tm == tn && j < i)) ? OFF_QT + i * 30 + j : -1; }
+              else if (tn < 2) off = (i < 32 + nt && j < 30) ? OFF_PT + (i - 32) * 30 + j : -1;
+              else off = (i < 32 + nt && j <= i) ? OFF_RT + (i - 32) * MT + (j - 32) : -1;
+              if (off >= 0) rec[off] = v;
+              if (tm == 1 && r == 3) { if (i == 30 && j < 30) fin[j] += v; }                        // row 30: Pe^T R Px
+              if (tm >= 2 && tn == 1) { if (j == 30 && i < 32 + nt) fin[i] += v; }                  // column 30: Pu^T R Pe
             }
           }
         }
