@@ -447,7 +447,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = k; i < 18; ++i) { if ((i - k) & 1) sb += v[i] * qcol[i]; else sa += v[i] * qcol[i]; }
         const real sf = (sa + sb) * beta;
 #pragma unroll
-        for (int i = k; i < 18; ++i) qcol[i] = (lane == k) ? (i == k ? alpha : 0.0_r) : qcol[i] - sf * v[i];
+        for (int i = k; i < 18; ++i) qcol[i] -= sf * v[i];
+        qcol[k] = lane == k ? alpha : qcol[k];   // R1[k][k] exactly; the entries below it in lane k (rounding residue instead of zeros) are never read:
+                                                 // R1[r][c], r <= c, lives in lane c register r, later reflectors touch entries >= their own index only
       }
     }
     // Y = R1^-T [C_v | e_v]: forward substitution, R1[k][i] (k <= i) lives in lane i, register k
