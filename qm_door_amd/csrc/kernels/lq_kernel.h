@@ -454,13 +454,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     // Y = R1^-T [C_v | e_v]: forward substitution, R1[k][i] (k <= i) lives in lane i, register k
     real y[NVMAX];
+    real rinv;   // 1 / R1[i][i] in lane i: ONE division for all pivots instead of one on the dependent chain of every row
+    {
+      real mine = 1.0_r;
+#pragma unroll
+      for (int i = 0; i < NVMAX; ++i) mine = (lane == i && i < nv) ? qcol[i] : mine;
+      rinv = 1.0_r / mine;
+    }
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
-      real sacc = ce[i];
+      y[i] = 0.0_r;
+      if (i < nv) {   // (wave uniform: trot has 8 velocity rows, stance 12)
+        real sacc = ce[i];
 #pragma unroll
-      for (int k = 0; k < i; ++k) sacc -= qmReadLane(qcol[k], i, red) * y[k];
-      const real d = qmReadLane(qcol[i], i, red);
-      y[i] = (i < nv) ? sacc / d : 0.0_r;
+        for (int k = 0; k < i; ++k) sacc -= qmReadLane(qcol[k], i, red) * y[k];
+        y[i] = sacc * qmReadLane(rinv, i, red);
+      }
     }
     // publish Y (rows k < 16, my column) and Q_v (lane 16 + c holds row c; rows 18..31 cleared) in region X
     real* Ym = lds + L_YM;
