@@ -65,6 +65,13 @@ __device__ __forceinline__ double qmRsqrtPos(double x) {
   return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
 }
 __device__ __forceinline__ float qmRsqrtPos(float x) { return __builtin_amdgcn_rsqf(x); }
+// 1 / x for a positive, normal x on a dependent chain: v_rcp_f64 and two Newton steps (5 dependent instructions; a full IEEE division is 13 with its scaling)
+__device__ __forceinline__ double qmRcpPos(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+  return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ float qmRcpPos(float x) { return __builtin_amdgcn_rcpf(x); }
 // acc += (bc of lane R of this lane's row of 16 lanes) * m in ONE instruction (DPP row_newbcast, legal on 64-bit operands since gfx90a):
 // the multiplier broadcast of a row operation without the v_readlane pair + wait state + separate multiply-add.  FIRST puts the two wait
 // states a DPP source needs after a VALU write in front (the hazard recogniser does not look into inline assembly).

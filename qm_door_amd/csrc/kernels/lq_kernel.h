@@ -436,12 +436,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         real n2a = 0.0_r, n2b = 0.0_r;
 #pragma unroll
         for (int i = k; i < 18; ++i) { v[i] = qmReadLane(qcol[i], k, red); if ((i - k) & 1) n2b += v[i] * v[i]; else n2a += v[i] * v[i]; }
-        const real dk = v[k], tail2 = (n2a + n2b) - dk * dk;
-        const real nrm = sqrt(n2a + n2b);
+        // reflector v = column - alpha e_k, alpha = -sign(d_k) |column|; beta = 2 / v^T v = 1 / (|column| |v_k|): one reciprocal square root and one
+        // reciprocal on the dependent chain of the step (a square root and an IEEE division before: ~28 dependent instructions)
+        const real dk = v[k], n2 = n2a + n2b;
+        const real rs = n2 > 0.0_r ? qmRsqrtPos(n2) : 0.0_r;
+        const real nrm = n2 * rs;
         const real alpha = dk > 0.0_r ? -nrm : nrm;
         v[k] = dk - alpha;
-        const real vn = tail2 + v[k] * v[k];
-        const real beta = vn > 0.0_r ? 2.0_r / vn : 0.0_r;
+        const real avk = fabs(v[k]);
+        const real beta = avk > 0.0_r ? rs * qmRcpPos(avk) : 0.0_r;
         real sa = 0.0_r, sb = 0.0_r;
 #pragma unroll
         for (int i = k; i < 18; ++i) { if ((i - k) & 1) sb += v[i] * qcol[i]; else sa += v[i] * qcol[i]; }

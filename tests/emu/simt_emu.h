@@ -168,6 +168,8 @@ inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline float qmRsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline double qmRsqrtPos(double x) { return 1.0 / std::sqrt(x); }
 inline float qmRsqrtPos(float x) { return 1.0f / std::sqrt(x); }
+inline double qmRcpPos(double x) { return 1.0 / x; }
+inline float qmRcpPos(float x) { return 1.0f / x; }
 #define QM_KEEP(x) (void)(x)
 #define QM_OPAQUE_LDS(T, name, p) T* name = (p)
 #define QM_LDS_CONST_PTR(T) const T*
