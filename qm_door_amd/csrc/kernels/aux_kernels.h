@@ -41,6 +41,15 @@ __global__ void __launch_bounds__(64) input_weight_kernel(const ProblemR* P, con
     }
     Rw[e] = v;
   }
+  // barrier constants (layout.h: QM_RW_DERIVED): formed with the same value() every node evaluation used to call
+  real* bc = Rw + QM_RW_DERIVED;
+  const SettingsR& st = P->settings;
+  if (lane == 0) { bc[QM_BC_LOGD_POS] = log(st.joint_pos_barrier_delta); bc[QM_BC_LOGD_VEL] = log(st.joint_vel_barrier_delta); bc[QM_BC_LOGD_FRIC] = log(st.friction_barrier_delta); bc[3] = 0.0_r; }
+  if (lane < 6) {
+    const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta}, bv{st.joint_vel_barrier_mu, st.joint_vel_barrier_delta};
+    bc[QM_BC_POS0 + lane] = bp.value(-md.q_lower[12 + lane]) + bp.value(md.q_upper[12 + lane]);
+    bc[QM_BC_VEL0 + lane] = bv.value(-st.arm_vel_lower[lane]) + bv.value(st.arm_vel_upper[lane]);
+  }
 }
 
 struct InitArgs {

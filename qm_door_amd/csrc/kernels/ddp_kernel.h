@@ -95,14 +95,14 @@ __global__ void __launch_bounds__(64) ddp_rollout_kernel(DdpArgs a) {
     }
     for (int i = 0; i < 30; ++i) { Xo[k * 30 + i] = x[i]; Uo[k * 30 + i] = u[i]; }
     real c, d, e;
-    nodePerformance<const real*>(a.P->model, a.P->settings, a.P->settings.Q, a.Rw, 0, sched, tTimes, tStates, contact, a.K, tg[k], a.dtgrid[node], a.nodePhase[node], false, x, u, nullptr, c, d, e, xn);
+    nodePerformance<const real*>(a.P->model, a.P->settings, a.P->settings.Q, a.Rw, 0, a.Rw + QM_RW_DERIVED, sched, tTimes, tStates, contact, a.K, tg[k], a.dtgrid[node], a.nodePhase[node], false, x, u, nullptr, c, d, e, xn);
     merit += c; eqSum += e;
     for (int i = 0; i < 30; ++i) x[i] = xn[i];
   }
   for (int i = 0; i < 30; ++i) Xo[N * 30 + i] = x[i];
   if (!init) {
     real c, d, e;
-    nodePerformance<const real*>(a.P->model, a.P->settings, a.P->settings.Q, a.Rw, 0, sched, tTimes, tStates, contact, a.K, tg[N], 0.0_r, a.nodePhase[size_t(inst) * (N + 1) + N], true, x, u, nullptr, c, d, e);
+    nodePerformance<const real*>(a.P->model, a.P->settings, a.P->settings.Q, a.Rw, 0, a.Rw + QM_RW_DERIVED, sched, tTimes, tStates, contact, a.K, tg[N], 0.0_r, a.nodePhase[size_t(inst) * (N + 1) + N], true, x, u, nullptr, c, d, e);
     merit += c;
     a.merit[size_t(id) * 2] = merit + st.ddp_constraint_penalty * eqSum;
     a.merit[size_t(id) * 2 + 1] = eqSum;

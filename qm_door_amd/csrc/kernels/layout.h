@@ -45,6 +45,11 @@ static_assert(STAGE_DOUBLES % 8 == 0, "stage records stay 64-byte aligned");
 constexpr int OFF_KFB = 0, OFF_kff = MT * 30;
 constexpr int GAIN_DOUBLES = MT * 30 + MT + 2;  // 560
 
+// the input-weight buffer R' [30][30] is followed by constants of the relaxed log barriers that input_weight_kernel derives once per settings update
+// (every node evaluation used to recompute them: two logarithms per barrier value, half of the four values per joint limit):
+//   log(delta) of the joint-position, joint-velocity and friction-cone barrier; value(-lower) + value(upper) per arm joint for positions and velocities
+constexpr int QM_RW_DERIVED = 900, QM_BC_LOGD_POS = 0, QM_BC_LOGD_VEL = 1, QM_BC_LOGD_FRIC = 2, QM_BC_POS0 = 4, QM_BC_VEL0 = 10, QM_RW_DOUBLES = 916;
+
 // per-node metrics: dt*cost, dt*|defect|^2, dt*|eq|^2, armijo contribution (filled by the forward sweep)
 constexpr int NODE_METRICS = 4;
 

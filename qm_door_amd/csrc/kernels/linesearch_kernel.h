@@ -56,7 +56,7 @@ struct DblIn {
 // weightStructure: 0 = Q and R' dense; 1 = Q diagonal and R' = diag (forces 0..11) + dense block (leg joint velocities 12..23, the block QMInterface.cpp:283-296 maps
 // through the foot Jacobian) + diag (arm 24..29) -- what the reference's task.info produces; decided by the caller from the actual values.  The structured forms skip
 // products with exact zeros in the same order of accumulation: bit-identical results.
-template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ModelR& md, const SettingsR& st, WP Qw, WP Rw, int weightStructure, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
+template <class WP> __device__ __attribute__((noinline)) void nodePerformance(const ModelR& md, const SettingsR& st, WP Qw, WP Rw, int weightStructure, const real* bc, const Schedule& sched, const real* tTimes, const real* tStates, const real* contact, int K, real t, real dt, int phase,
                                        bool terminal, const real* x, const real* u, const real* xnext, real& cost, real& dyn, real& eq, real* xnOut = nullptr) {
   QM_TICK_DECL;
   const int mode = sched.modes[phase];
@@ -167,12 +167,13 @@ template <class WP> __device__ __attribute__((noinline)) void nodePerformance(co
   const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta}, bv{st.joint_vel_barrier_mu, st.joint_vel_barrier_delta}, bf{st.friction_barrier_mu, st.friction_barrier_delta};
   for (int i = 0; i < 6; ++i) {
     const real lo = md.q_lower[12 + i], up = md.q_upper[12 + i];
-    c += bp.value(x[24 + i] - lo) + bp.value(up - x[24 + i]) - (bp.value(-lo) + bp.value(up));
-    c += bv.value(u[24 + i] - st.arm_vel_lower[i]) + bv.value(st.arm_vel_upper[i] - u[24 + i]) - (bv.value(-st.arm_vel_lower[i]) + bv.value(st.arm_vel_upper[i]));
+    // (bc: log(delta) of the three barriers and the constant value(-lower) + value(upper) of every limit, formed once by input_weight_kernel, layout.h)
+    c += bp.valueL(x[24 + i] - lo, bc[QM_BC_LOGD_POS]) + bp.valueL(up - x[24 + i], bc[QM_BC_LOGD_POS]) - bc[QM_BC_POS0 + i];
+    c += bv.valueL(u[24 + i] - st.arm_vel_lower[i], bc[QM_BC_LOGD_VEL]) + bv.valueL(st.arm_vel_upper[i] - u[24 + i], bc[QM_BC_LOGD_VEL]) - bc[QM_BC_VEL0 + i];
   }
   for (int cc = 0; cc < 4; ++cc) if (contactOf(mode, cc)) {
     const real fx = u[3 * cc], fy = u[3 * cc + 1], fz = u[3 * cc + 2];
-    c += bf.value(st.friction_coefficient * fz - sqrt(fx * fx + fy * fy + st.friction_regularization));
+    c += bf.valueL(st.friction_coefficient * fz - sqrt(fx * fx + fy * fy + st.friction_regularization), bc[QM_BC_LOGD_FRIC]);
   }
   cost = dt * c; dyn *= dt; eq *= dt;
   QM_TICK(3);
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     for (int k = ltid; k <= N; k += half) {
       real c, d, e;
       const bool term = k == N;
-      nodePerformance(mdS, st, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), weightStructure, sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
+      nodePerformance(mdS, st, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), weightStructure, a.Rw + QM_RW_DERIVED, sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
       cs += c; ds += d; es += e;
     }
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const bool terminal = node == a.N;
   const ModelR& md = a.P->model;
   const SettingsR& st = a.P->settings;
+  const real* bcs = a.Rw + QM_RW_DERIVED;   // barrier constants (layout.h)
 
   real* PA = lds + L_PA; real* CD = lds + L_PA;
   real* AT = lds + L_AT; real* BT = lds + L_BT; real* WT = lds + L_WT;
@@ -198,9 +199,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const Barrier bp{st.joint_pos_barrier_mu, st.joint_pos_barrier_delta};
         const real lo = md.q_lower[c - 12], up = md.q_upper[c - 12];
         const real hl = x[c] - lo, hu = up - x[c];
-        costPart += bp.value(hl) + bp.value(hu) - (bp.value(-lo) + bp.value(up));
-        qc += bp.d1(hl) - bp.d1(hu);
-        dd = bp.d2(hl) + bp.d2(hu);
+        real vl_, gl_, hl2, vu_, gu_, hu2;
+        bp.eval(hl, bcs[QM_BC_LOGD_POS], vl_, gl_, hl2); bp.eval(hu, bcs[QM_BC_LOGD_POS], vu_, gu_, hu2);
+        costPart += vl_ + vu_ - bcs[QM_BC_POS0 + c - 24];
+        qc += gl_ - gu_;
+        dd = hl2 + hu2;
       }
     }
     if (c >= 24 && c < 30) ddp[c - 24] = dd;
@@ -271,9 +274,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const Barrier bvel{st.joint_vel_barrier_mu, st.joint_vel_barrier_delta};
         const int i = c - 24;
         const real vl = u[c] - st.arm_vel_lower[i], vu = st.arm_vel_upper[i] - u[c];
-        costPart += bvel.value(vl) + bvel.value(vu) - (bvel.value(-st.arm_vel_lower[i]) + bvel.value(st.arm_vel_upper[i]));
-        rc += bvel.d1(vl) - bvel.d1(vu);
-        ddv[i] = bvel.d2(vl) + bvel.d2(vu);
+        real va_, ga_, ha_, vb_, gb_, hb_;
+        bvel.eval(vl, bcs[QM_BC_LOGD_VEL], va_, ga_, ha_); bvel.eval(vu, bcs[QM_BC_LOGD_VEL], vb_, gb_, hb_);
+        costPart += va_ + vb_ - bcs[QM_BC_VEL0 + i];
+        rc += ga_ - gb_;
+        ddv[i] = ha_ + hb_;
       }
       if (c < 12) {
         real e0 = 0.0_r, e1 = 0.0_r, e2 = 0.0_r;
@@ -288,8 +293,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           const real hyy = -(fx * fx + st.friction_regularization) / F3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
           const real gac = ac == 0 ? gx : (ac == 1 ? gy : gz);
           const real h0 = ac == 0 ? hxx : (ac == 1 ? hxy : 0.0_r), h1 = ac == 0 ? hxy : (ac == 1 ? hyy : 0.0_r), h2 = ac == 2 ? hzz : 0.0_r;
-          const real p1 = bf.d1(hh), p2 = bf.d2(hh);
-          if (ac == 0) costPart += bf.value(hh);
+          real pv, p1, p2;
+          bf.eval(hh, bcs[QM_BC_LOGD_FRIC], pv, p1, p2);
+          if (ac == 0) costPart += pv;
           rc += p1 * gac;
           e0 = p2 * gx * gac + p1 * h0; e1 = p2 * gy * gac + p1 * h1; e2 = p2 * gz * gac + p1 * h2;
         }

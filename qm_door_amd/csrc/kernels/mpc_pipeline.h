@@ -43,7 +43,7 @@ template <class Alloc> inline void allocateMpcBuffers(MpcBuffers& m, size_t B, s
   auto R = [&](size_t n, bool scratch = true) { return static_cast<real*>(alloc(n, sizeof(real), scratch)); };
   auto I = [&](size_t n) { return static_cast<int*>(alloc(n, sizeof(int), true)); };
   m.dP = static_cast<ProblemR*>(alloc(1, sizeof(ProblemR), false));
-  m.dRw = R(900, false);
+  m.dRw = R(QM_RW_DOUBLES, false);
   m.dZeros = R(64, false);
   m.dTgrid = R(B * N1);
   m.dDtgrid = R(B * N1);

@@ -114,6 +114,17 @@ struct Barrier {
   __device__ __forceinline__ real value(real h) const { const real q = (h - 2.0_r * delta) / delta; return h > delta ? -mu * log(h) : mu * (-log(delta) + 0.5_r * q * q - 0.5_r); }
   __device__ __forceinline__ real d1(real h) const { return h > delta ? -mu / h : mu * ((h - 2.0_r * delta) / (delta * delta)); }
   __device__ __forceinline__ real d2(real h) const { return h > delta ? mu / (h * h) : mu / (delta * delta); }
+  // the same three numbers at once, log(delta) given (layout.h: QM_BC_*): one logarithm and one division in the logarithmic branch (value alone computed two
+  // logarithms and a division, d1 and d2 three more divisions); the quadratic branch is a real branch -- no lane is in it on a healthy iterate
+  __device__ __forceinline__ void eval(real h, real logDelta, real& val, real& g, real& hs) const {
+    if (h > delta) { const real r = 1.0_r / h; val = -mu * log(h); g = -mu * r; hs = mu * r * r; }
+    else { const real q = (h - 2.0_r * delta) / delta; val = mu * (-logDelta + 0.5_r * q * q - 0.5_r); g = mu * ((h - 2.0_r * delta) / (delta * delta)); hs = mu / (delta * delta); }
+  }
+  __device__ __forceinline__ real valueL(real h, real logDelta) const {
+    if (h > delta) return -mu * log(h);
+    const real q = (h - 2.0_r * delta) / delta;
+    return mu * (-logDelta + 0.5_r * q * q - 0.5_r);
+  }
 };
 
 }  // namespace qmk

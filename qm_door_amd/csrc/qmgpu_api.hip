@@ -114,7 +114,7 @@ int qmgpu_create_ex(const qmgpu_problem* problem, int device, int max_batch, int
     auto rawAlloc = [owner](size_t count, size_t elem, bool scratch) { return static_cast<void*>(owner->alloc<char>(count * elem, scratch)); };
     // the fp32 handle keeps the fp64 model / settings / R' (the WBC and the front end read them) but not the fp64 MPC scratch
     if (dtype == QMGPU_F64) allocateMpcBuffers(ctx->m, B, N, rawAlloc);
-    else { ctx->m.dP = ctx->alloc<qmgpu_problem>(1, false); ctx->m.dRw = ctx->alloc<double>(900, false); ctx->m.dZeros = ctx->alloc<double>(64, false); }
+    else { ctx->m.dP = ctx->alloc<qmgpu_problem>(1, false); ctx->m.dRw = ctx->alloc<double>(qmk::QM_RW_DOUBLES, false); ctx->m.dZeros = ctx->alloc<double>(64, false); }
     ctx->dPolX = ctx->alloc<double>(B * 30);
     ctx->dPolU = ctx->alloc<double>(B * 30);
     ctx->dPolMode = ctx->alloc<int>(B);
