@@ -286,11 +286,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           const Barrier bf{st.friction_barrier_mu, st.friction_barrier_delta};
           const int fo = 3 * (c / 3), ac = c % 3;
           const real fx = u[fo], fy = u[fo + 1], fz = u[fo + 2];
-          const real F = sqrt(fx * fx + fy * fy + st.friction_regularization), F3 = F * F * F;
+          // F = sqrt(fx^2 + fy^2 + reg) > 0: 1 / F from the reciprocal square root (gpu_rt.h), F = F^2 / F, 1 / F^3 = (1 / F)^3 -- a square root and five divisions before
+          const real F2 = fx * fx + fy * fy + st.friction_regularization;
+          const real rF = F2 > 0.0_r ? qmRsqrtPos(F2) : 0.0_r, F = F2 * rF, rF3 = rF * rF * rF;
           const real hh = st.friction_coefficient * fz - F;
-          const real gx = -fx / F, gy = -fy / F, gz = st.friction_coefficient;
-          const real hxx = -(fy * fy + st.friction_regularization) / F3 - st.friction_hessian_shift, hxy = fx * fy / F3;
-          const real hyy = -(fx * fx + st.friction_regularization) / F3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
+          const real gx = -fx * rF, gy = -fy * rF, gz = st.friction_coefficient;
+          const real hxx = -(fy * fy + st.friction_regularization) * rF3 - st.friction_hessian_shift, hxy = fx * fy * rF3;
+          const real hyy = -(fx * fx + st.friction_regularization) * rF3 - st.friction_hessian_shift, hzz = -st.friction_hessian_shift;
           const real gac = ac == 0 ? gx : (ac == 1 ? gy : gz);
           const real h0 = ac == 0 ? hxx : (ac == 1 ? hxy : 0.0_r), h1 = ac == 0 ? hxy : (ac == 1 ? hyy : 0.0_r), h2 = ac == 2 ? hzz : 0.0_r;
           real pv, p1, p2;
