@@ -577,8 +577,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (tn < nTn) {
         real pb[8];
         pallOps(pb, tn);
+        // columns 0..15 of the force rows of Pall (k steps 0..2) are zero: Px = 0 there, Pe is column 30, Pu starts at column 32
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qmMfma(c1[tn], ab[ks], pb[ks], red);
+        for (int ks = (tn == 0 ? 3 : 0); ks < 8; ++ks) qmMfma(c1[tn], ab[ks], pb[ks], red);
       }
     }
 #pragma unroll
@@ -644,7 +645,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           real pb[8];
           pallOps(pb, tn);
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) { qmMfma(wA, r0[ks], pb[ks], red); qmMfma(wB, r1[ks], pb[ks], red); }
+          for (int ks = (tn == 0 ? 3 : 0); ks < 8; ++ks) { qmMfma(wA, r0[ks], pb[ks], red); qmMfma(wB, r1[ks], pb[ks], red); }   // (force rows of Pall: zero in columns 0..15)
         }
         QM_WAVE_SYNC();   // the previous tile's readers are done
 #pragma unroll
@@ -700,8 +701,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           if ((tm < 2 && top) || tm == 2 || (tm == 3 && low3)) {
             real pa[8];
             pallOpsT(pa, tm);
+            // rows 0..15 of Pall^T (columns of Px) have no force-row entries: k steps 0..2 multiply zeros
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) qmMfma(g[tm], pa[ks], wb[ks], red);
+            for (int ks = (tm == 0 ? 3 : 0); ks < 8; ++ks) qmMfma(g[tm], pa[ks], wb[ks], red);
           }
         }
         const int j = tn * 16 + l16;
