@@ -442,7 +442,11 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       for (int r = 0; r < 4; ++r) c0[r] = ci[r] * cOne;
       if (mtTiles == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) a1[ks] = stg[bOffK[ks] + (16 + la < MT ? 16 : 0)] * b1One;
+        for (int ks = 0; ks < 8; ++ks) a1[ks] = stg[bOffK[ks] + (16 + la < MT ? 16 : 0)];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) QM_KEEP(a1[ks]);   // all eight reads before the first product (left alone, each read sat with its own wait in front of its instruction)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a1[ks] *= b1One;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c1[r] = ci[4 + r] * cOne;
 #pragma unroll
