@@ -180,6 +180,37 @@ template <class WP> __device__ __attribute__((noinline)) void nodePerformance(co
   QM_TICK_FLUSH(224, blockIdx.x == 0 && threadIdx.x == 5);
 }
 
+// out[e] = x[e] + alpha dx[e] for e = first, first + stride, ... < n, EIGHT elements per pass with all sixteen loads issued before the first store: written as a
+// plain loop every element waited for its own two loads (the compiler may not move a load across the store to a pointer it cannot tell apart), 24-47 memory round
+// trips in a row per trajectory and pass -- two thirds of this kernel's time (round 3)
+__device__ __forceinline__ void axpyStrided(real* out, const real* x, const real* dx, real alpha, int n, int first, int stride) {
+  constexpr int UN = 8;
+  for (int base = first; base < n; base += UN * stride) {
+    real xv[UN], dv[UN];
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * stride, ec = e < n ? e : first; xv[q] = x[ec]; dv[q] = dx[ec]; }
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { QM_KEEP(xv[q]); QM_KEEP(dv[q]); }
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * stride; if (e < n) out[e] = xv[q] + alpha * dv[q]; }
+  }
+}
+// sum of squares of v[first], v[first + stride], ..., eight loads in flight
+__device__ __forceinline__ real sumSquaresStrided(const real* v, int n, int first, int stride) {
+  constexpr int UN = 8;
+  real s = 0.0_r;
+  for (int base = first; base < n; base += UN * stride) {
+    real t[UN];
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * stride; t[q] = v[e < n ? e : first]; }
+#pragma unroll
+    for (int q = 0; q < UN; ++q) QM_KEEP(t[q]);
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * stride; if (e < n) s += t[q] * t[q]; }
+  }
+  return s;
+}
+
 __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   __shared__ real red[3 * 256];
   __shared__ real ctl[8];
@@ -212,12 +243,21 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   // clears the flag (ctl[7], set by thread 0 before this kernel's first barrier... it is initialised below by the thread that owns entry 0)
   {
     bool outside = false;
-    for (int e = tid; e < 900; e += nthr) {
-      const real q = st.Q[e], r = a.Rw[e];
-      wQ[e] = q; wR[e] = r;
-      const int i = e / 30, j = e - 30 * i;
-      const bool legBlock = i >= 12 && i < 24 && j >= 12 && j < 24;
-      outside = outside || (i != j && q != 0.0_r) || (i != j && !legBlock && r != 0.0_r);
+    real qv[4], rv4[4];   // (900 = 3.5 x 256: four entries per thread, all eight loads first)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) { const int e = tid + q4 * nthr, ec = e < 900 ? e : tid; qv[q4] = st.Q[ec]; rv4[q4] = a.Rw[ec]; }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) { QM_KEEP(qv[q4]); QM_KEEP(rv4[q4]); }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int e = tid + q4 * nthr;
+      if (e < 900) {
+        const real q = qv[q4], r = rv4[q4];
+        wQ[e] = q; wR[e] = r;
+        const int i = e / 30, j = e - 30 * i;
+        const bool legBlock = i >= 12 && i < 24 && j >= 12 && j < 24;
+        outside = outside || (i != j && q != 0.0_r) || (i != j && !legBlock && r != 0.0_r);
+      }
     }
     structVotes[tid] = outside ? 1 : 0;
   }
@@ -247,8 +287,8 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
 #pragma unroll 1
   for (int trial = 0; trial < (ricStatus == 0.0_r ? 64 : 0); ++trial) {
     const real alphaMine = myTr ? alpha * st.alpha_decay : alpha;
-    for (int e = ltid; e < (N + 1) * 30; e += half) Xt[e] = X[e] + alphaMine * dX[e];
-    for (int e = ltid; e < N * 30; e += half) Ut[e] = U[e] + alphaMine * dU[e];
+    axpyStrided(Xt, X, dX, alphaMine, (N + 1) * 30, ltid, half);
+    axpyStrided(Ut, U, dU, alphaMine, N * 30, ltid, half);
     __syncthreads();
     real cs = 0.0_r, ds = 0.0_r, es = 0.0_r;
     for (int k = ltid; k <= N; k += half) {
@@ -290,13 +330,11 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   if (!accepted) { alpha = 0.0_r; stepType = 4; merit1 = merit0; viol1 = viol0; }
   // ---- write the new iterate
   real* oX = a.outX + size_t(inst) * (N + 1) * 30; real* oU = a.outU + size_t(inst) * N * 30;
-  for (int e = tid; e < (N + 1) * 30; e += nthr) oX[e] = X[e] + alpha * dX[e];
-  for (int e = tid; e < N * 30; e += nthr) oU[e] = U[e] + alpha * dU[e];
+  axpyStrided(oX, X, dX, alpha, (N + 1) * 30, tid, nthr);
+  axpyStrided(oU, U, dU, alpha, N * 30, tid, nthr);
   for (int k = tid; k <= N; k += nthr) { a.outT[size_t(inst) * (N + 1) + k] = tg[k]; a.outMode[size_t(inst) * (N + 1) + k] = a.nodeMode[size_t(inst) * (N + 1) + k]; }
   // ---- upstream SqpSolver::checkConvergence: iteration limit, step size, metrics, primal step (l2 norms over the whole horizon)
-  real sx = 0.0_r, su = 0.0_r;
-  for (int e = tid; e < (N + 1) * 30; e += nthr) sx += dX[e] * dX[e];
-  for (int e = tid; e < N * 30; e += nthr) su += dU[e] * dU[e];
+  const real sx = sumSquaresStrided(dX, (N + 1) * 30, tid, nthr), su = sumSquaresStrided(dU, N * 30, tid, nthr);
   __syncthreads();
   red[tid] = sx; red[256 + tid] = su;
   __syncthreads();
