@@ -87,21 +87,36 @@ __global__ void mpc_init_kernel(InitArgs a) {
   __syncthreads();   // the node phases written above are read below (same workgroup)
   // initial trajectories, one element per thread (a thread per node wrote 60 scattered values: 14 us for the launch)
   const size_t xb = size_t(inst) * (a.N + 1) * 30, ub = size_t(inst) * a.N * 30;
-  for (int e = threadIdx.x; e < (a.N + 1) * 30; e += blockDim.x) {
-    const int k = e / 30, i = e - 30 * k;
-    a.X[xb + e] = (a.warmX && k > 0) ? a.warmX[xb + e] : a.x0[size_t(inst) * 30 + i];
-  }
-  for (int e = threadIdx.x; e < a.N * 30; e += blockDim.x) {
-    const int k = e / 30, i = e - 30 * k;
-    real v;
-    if (a.warmU) v = a.warmU[ub + e];
-    else {
-      const int mode = modes[a.nodePhase[size_t(inst) * (a.N + 1) + k]];
-      int n = 0;
-      for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
-      v = (i < 12 && (i % 3) == 2 && n > 0 && contactOf(mode, i / 3)) ? a.P->model.total_mass * st.gravity / n : 0.0_r;
+  for (int base = threadIdx.x; base < (a.N + 1) * 30; base += 8 * blockDim.x) {   // eight loads in flight per thread, then the stores
+    real v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = base + q * blockDim.x, ec = e < (a.N + 1) * 30 ? e : threadIdx.x, k = ec / 30, i = ec - 30 * k;
+      v[q] = (a.warmX && k > 0) ? a.warmX[xb + ec] : a.x0[size_t(inst) * 30 + i];
     }
-    a.U[ub + e] = v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) QM_KEEP(v[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int e = base + q * blockDim.x; if (e < (a.N + 1) * 30) a.X[xb + e] = v[q]; }
+  }
+  const real weight = a.P->model.total_mass * st.gravity;
+  for (int base = threadIdx.x; base < a.N * 30; base += 8 * blockDim.x) {
+    real v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = base + q * blockDim.x, ec = e < a.N * 30 ? e : threadIdx.x, k = ec / 30, i = ec - 30 * k;
+      if (a.warmU) v[q] = a.warmU[ub + ec];
+      else {   // weight-compensating normal forces for the contact flags of the node (QMInitializer.cpp:33-41)
+        const int mode = modes[a.nodePhase[size_t(inst) * (a.N + 1) + k]];
+        int n = 0;
+        for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
+        v[q] = (i < 12 && (i % 3) == 2 && n > 0 && contactOf(mode, i / 3)) ? weight / n : 0.0_r;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) QM_KEEP(v[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int e = base + q * blockDim.x; if (e < a.N * 30) a.U[ub + e] = v[q]; }
   }
 }
 

@@ -281,7 +281,16 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // ---- terminal value function S_N = Q_N, s_N = q_N (zero padded), and the first stage to process
   {
     const real* rec = stagesI + size_t(N) * STAGE_DOUBLES;
-    for (int e = tid; e < 32 * LDS_S; e += NTHR) { const int i = e / LDS_S, j = e % LDS_S; S[e] = (i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
+    {   // all of a thread's loads before its first LDS store (a load may not pass the store in front of it: seven memory round trips in a row otherwise)
+      constexpr int NS = (32 * LDS_S + NTHR - 1) / NTHR;
+      real sv[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { const int e = tid + q * NTHR, i = e / LDS_S, j = e % LDS_S; sv[q] = (e < 32 * LDS_S && i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
+#pragma unroll
+      for (int q = 0; q < NS; ++q) QM_KEEP(sv[q]);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { const int e = tid + q * NTHR; if (e < 32 * LDS_S) S[e] = sv[q]; }
+    }
     __syncthreads();
     if (tid < 30) S[30 * LDS_S + tid] = rec[OFF_qt + tid];        // s: row 30 of S (the B operands carry a unit entry at (30, 30))
     for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES + 2 * GAIN_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;   // W, L, gains images of both parities (contiguous)
