@@ -83,40 +83,22 @@ __global__ void mpc_init_kernel(InitArgs a) {
     a.tgrid[size_t(inst) * (a.N + 1) + k] = real(tD);
     a.dtgrid[size_t(inst) * (a.N + 1) + k] = k < a.N ? real(timeOf(k + 1) - tD) : 0.0_r;
     a.nodePhase[size_t(inst) * (a.N + 1) + k] = phase;
-  }
-  __syncthreads();   // the node phases written above are read below (same workgroup)
-  // initial trajectories, one element per thread (a thread per node wrote 60 scattered values: 14 us for the launch)
-  const size_t xb = size_t(inst) * (a.N + 1) * 30, ub = size_t(inst) * a.N * 30;
-  for (int base = threadIdx.x; base < (a.N + 1) * 30; base += 8 * blockDim.x) {   // eight loads in flight per thread, then the stores
-    real v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = base + q * blockDim.x, ec = e < (a.N + 1) * 30 ? e : threadIdx.x, k = ec / 30, i = ec - 30 * k;
-      v[q] = (a.warmX && k > 0) ? a.warmX[xb + ec] : a.x0[size_t(inst) * 30 + i];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) QM_KEEP(v[q]);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int e = base + q * blockDim.x; if (e < (a.N + 1) * 30) a.X[xb + e] = v[q]; }
-  }
-  const real weight = a.P->model.total_mass * st.gravity;
-  for (int base = threadIdx.x; base < a.N * 30; base += 8 * blockDim.x) {
-    real v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = base + q * blockDim.x, ec = e < a.N * 30 ? e : threadIdx.x, k = ec / 30, i = ec - 30 * k;
-      if (a.warmU) v[q] = a.warmU[ub + ec];
-      else {   // weight-compensating normal forces for the contact flags of the node (QMInitializer.cpp:33-41)
-        const int mode = modes[a.nodePhase[size_t(inst) * (a.N + 1) + k]];
+    real* x = a.X + (size_t(inst) * (a.N + 1) + k) * 30;
+    const real* src = (a.warmX && k > 0) ? a.warmX + (size_t(inst) * (a.N + 1) + k) * 30 : a.x0 + size_t(inst) * 30;
+    for (int i = 0; i < 30; ++i) x[i] = src[i];
+    if (k < a.N) {
+      real* u = a.U + (size_t(inst) * a.N + k) * 30;
+      if (a.warmU) {
+        const real* su = a.warmU + (size_t(inst) * a.N + k) * 30;
+        for (int i = 0; i < 30; ++i) u[i] = su[i];
+      } else {
+        const int mode = modes[phase];
         int n = 0;
         for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
-        v[q] = (i < 12 && (i % 3) == 2 && n > 0 && contactOf(mode, i / 3)) ? weight / n : 0.0_r;
+        for (int i = 0; i < 30; ++i) u[i] = 0.0_r;
+        if (n > 0) for (int c = 0; c < 4; ++c) if (contactOf(mode, c)) u[3 * c + 2] = a.P->model.total_mass * st.gravity / n;
       }
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) QM_KEEP(v[q]);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int e = base + q * blockDim.x; if (e < a.N * 30) a.U[ub + e] = v[q]; }
   }
 }
 
