@@ -374,6 +374,9 @@ def main():
                          "note": "algorithmic dense-contraction FLOPs of SURVEY.md 8(d) per launch / HIP-event kernel time; fp64 matrix peak is the public spec; "
                                  "the path is latency bound, not MFMA bound (DESIGN.md)",
                          "kernel_ms": dict(zip(names + ["whole_call"], kernel_ms)),
+                         # launches within 5 % of the longest one: since round 3 the three FLOP-carrying kernels take 0.45-0.47 ms each, so which of them is
+                         # "the dominant kernel" (the longest; `kernel`, `frac` above) changes from run to run -- their fractions are all in kernel_frac
+                         "dominant_within_5pct": [k for k in flops if kernel_ms[names.index(k)] >= 0.95 * kernel_ms[names.index(roof_kernel)]],
                          "kernel_frac": {k: (tf(flops[k], kernel_ms[names.index(k)]) or 0.0) / FP64_MFMA_PEAK_TFLOPS for k in flops},
                          "path_achieved": tf(path_flops, kernel_ms[5]), "path_frac": (tf(path_flops, kernel_ms[5]) or 0.0) / FP64_MFMA_PEAK_TFLOPS},
         }
