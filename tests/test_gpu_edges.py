@@ -196,3 +196,29 @@ def test_horizon_beyond_the_line_search_lds_budget(interface, oracle):
     assert np.array_equal(r32["mode"], r["mode"]) and (r32["stats"][:, 4] == r["stats"][:, 4]).all()
     assert np.abs(r32["X"] - r["X"]).max() <= 1e-4 * max(1.0, np.abs(r["X"]).max())
     assert np.abs(r32["U"] - r["U"]).max() <= 1e-4 * max(1.0, np.abs(r["U"]).max())
+
+
+def test_barrier_constants_follow_a_settings_update(interface, oracle):
+    """The relaxed-barrier constants that input_weight_kernel derives once per settings update (log delta, value(-lower) + value(upper) per arm joint; layout.h:
+    QM_RW_DERIVED) must be re-derived by qmgpu_update_settings: the next MPC solve is the oracle's solve WITH the new barrier parameters, and differs from the old."""
+    import gpu_harness as G
+    from qm_door_amd import abi
+    B, N = 2, 8
+    sol = G.make_solver(interface, B, N)
+    mb, (x0, tt, ts, nev, ev, md) = _batch(G, interface, oracle, B, N, seed=11)
+    sol.mpc(mb.args)
+    before = {k: v.copy() for k, v in mb.results().items()}
+    P2 = type(interface.problem).from_buffer_copy(interface.problem)
+    P2.settings.joint_vel_barrier_delta *= 3.0; P2.settings.joint_pos_barrier_mu *= 4.0
+    P2.settings.friction_barrier_delta *= 0.5; P2.settings.friction_barrier_mu *= 2.0
+    abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(P2.settings)))
+    sol.mpc(mb.args)
+    after = mb.results()
+    assert np.abs(after["U"] - before["U"]).max() > 1e-6
+    o2 = S.Oracle(P2)
+    for i in range(B):
+        ref = o2.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert np.array_equal(after["mode"][i], ref["mode"])
+        assert np.abs(after["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(after["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
+    abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(interface.problem.settings)))   # (handles are per test, but leave it as found)
