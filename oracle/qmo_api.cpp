@@ -160,7 +160,8 @@ static void policyEval(int N, const double* tg, const double* X, const double* U
 // Per-instance inputs: t0 [B] (null: 0), x0 [B][30], target knots [B][K] / [B][K][37], contact reference [B][K][6] or null, mode schedule
 // nEv [B] / ev [B][QMGPU_MAX_EVENTS] / modes [B][QMGPU_MAX_EVENTS + 1]; tEval / period / time [B], rbd [B][55], inputLast [B][30] (in / out),
 // eeForce [B][3] or null.  Returns the number of instances whose Riccati factorisation or WBC reported a failure.
-int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int threads, const double* t0, const double* x0, const double* ttimes, const double* tstates,
+int qmo_cycle_batch_warm_mt(const qmgpu_problem* P, int batch, int N, int K, int threads, const double* t0, const double* x0, const double* timeGrid /*[B][N+1] or null*/,
+                            const double* warmX /*[B][N+1][30] or null*/, const double* warmU /*[B][N][30] or null*/, const double* ttimes, const double* tstates,
                        const double* contactRef, const int32_t* nEv, const double* ev, const int32_t* modes, int lineSearch, const double* tEval, const double* rbd,
                        const double* period, const double* time, double* inputLast, const double* eeForce, int variant, double* outX, double* outU,
                        int32_t* outMode, double* outStats, double* outPolicy /*[B][60] or null*/, int32_t* outPolicyMode /*[B] or null*/, double* outWbc /*[B][54]*/,
@@ -175,9 +176,10 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
       for (int i = t; i < batch; i += threads) {
         double* Xi = outX + size_t(i) * (N + 1) * 30; double* Ui = outU + size_t(i) * N * 30; int32_t* Mi = outMode + size_t(i) * (N + 1);
         double* Si = outStats + size_t(i) * QMGPU_NSTATS;
-        const int rc = mpcSolveImpl(P, N, t0 ? t0[i] : 0.0, x0 + size_t(i) * 30, nullptr, K, ttimes + size_t(i) * K, tstates + size_t(i) * K * 37,
+        const int rc = mpcSolveImpl(P, N, t0 ? t0[i] : 0.0, x0 + size_t(i) * 30, timeGrid ? timeGrid + size_t(i) * (N + 1) : nullptr, K, ttimes + size_t(i) * K, tstates + size_t(i) * K * 37,
                                     contactRef ? contactRef + size_t(i) * K * 6 : nullptr, nEv[i], ev + size_t(i) * QMGPU_MAX_EVENTS,
-                                    modes + size_t(i) * (QMGPU_MAX_EVENTS + 1), nullptr, nullptr, lineSearch, T.data(), Xi, Ui, Mi, Si);
+                                    modes + size_t(i) * (QMGPU_MAX_EVENTS + 1), warmX ? warmX + size_t(i) * (N + 1) * 30 : nullptr, warmU ? warmU + size_t(i) * N * 30 : nullptr,
+                                    lineSearch, T.data(), Xi, Ui, Mi, Si);
         int bad = rc != 0;
         if (rbd) {
           double xd[30], ud[30]; int32_t md;
@@ -196,6 +198,58 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
   int n = 0;
   for (int v : failed) n += v;
   return n;
+}
+
+int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int threads, const double* t0, const double* x0, const double* ttimes, const double* tstates,
+                       const double* contactRef, const int32_t* nEv, const double* ev, const int32_t* modes, int lineSearch, const double* tEval, const double* rbd,
+                       const double* period, const double* time, double* inputLast, const double* eeForce, int variant, double* outX, double* outU,
+                       int32_t* outMode, double* outStats, double* outPolicy, int32_t* outPolicyMode, double* outWbc, int32_t* outWbcStatus) {
+  return qmo_cycle_batch_warm_mt(P, batch, N, K, threads, t0, x0, nullptr, nullptr, nullptr, ttimes, tstates, contactRef, nEv, ev, modes, lineSearch, tEval, rbd, period, time,
+                                 inputLast, eeForce, variant, outX, outU, outMode, outStats, outPolicy, outPolicyMode, outWbc, outWbcStatus);
+}
+
+// WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],
+// mode / period / time [B], inputLast [B][30] in / out, eeForce [B][3] or null, out [B][54], status [B].  Returns the number of non-zero status words.
+int qmo_wbc_batch_mt(const qmgpu_problem* P, int batch, int threads, int variant, const double* xDes, const double* uDes, const double* rbd, const int32_t* mode,
+                     const double* period, const double* time, double* inputLast, const double* eeForce, double* out, int32_t* status) {
+  if (threads < 1) threads = 1;
+  mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20);
+  std::vector<int> failed(threads, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t)
+    pool.emplace_back([=, &failed]() {
+      for (int i = t; i < batch; i += threads) {
+        status[i] = wbcUpdate(*P, variant, xDes + size_t(i) * 30, uDes + size_t(i) * 30, rbd + size_t(i) * 55, mode[i], period[i], time[i], inputLast + size_t(i) * 30,
+                              out + size_t(i) * 54, nullptr, eeForce ? eeForce + size_t(i) * 3 : nullptr);
+        failed[t] += status[i] != 0;
+      }
+    });
+  for (auto& th : pool) th.join();
+  int n = 0;
+  for (int v : failed) n += v;
+  return n;
+}
+
+// Initial guess of the next solve from the previous solution (what upstream's SqpSolver::runImpl takes from its PrimalSolution; the counterpart of
+// qmgpu_warm_start_batch): (X, U) of the previous grid evaluated at every node of the new grid with the policy-evaluation rule (end values held; the input
+// trajectory has one entry less and holds its last value), x[0] replaced by x0.
+void qmo_warm_start_batch(int batch, int Np, const double* gridP, const double* Xp, const double* Up, int Nn, const double* gridN, const double* x0, double* warmX,
+                          double* warmU) {
+  std::vector<int32_t> noModes(Np + 1, 0);
+  for (int i = 0; i < batch; ++i)
+    for (int k = 0; k <= Nn; ++k) {
+      double x[30], u[30]; int32_t md;
+      policyEval(Np, gridP + size_t(i) * (Np + 1), Xp + size_t(i) * (Np + 1) * 30, Up + size_t(i) * Np * 30, noModes.data(), gridN[size_t(i) * (Nn + 1) + k], x, u, &md);
+      for (int j = 0; j < 30; ++j) warmX[(size_t(i) * (Nn + 1) + k) * 30 + j] = (k == 0 && x0) ? x0[size_t(i) * 30 + j] : x[j];
+      if (k < Nn) for (int j = 0; j < 30; ++j) warmU[(size_t(i) * Nn + k) * 30 + j] = u[j];
+    }
+}
+
+// policy evaluation of a batch (MPC_MRT_Interface::evaluatePolicy, see policyEval): T [B][N+1], X [B][N+1][30], U [B][N][30], modes [B][N+1], t [B] -> xu [B][60], mode [B]
+void qmo_policy_eval_batch(int batch, int N, const double* T, const double* X, const double* U, const int32_t* modes, const double* t, double* xu, int32_t* modeOut) {
+  for (int i = 0; i < batch; ++i)
+    policyEval(N, T + size_t(i) * (N + 1), X + size_t(i) * (N + 1) * 30, U + size_t(i) * N * 30, modes + size_t(i) * (N + 1), t[i], xu + size_t(i) * 60, xu + size_t(i) * 60 + 30,
+               modeOut + i);
 }
 
 // DDP variant (ddpIteration): warmU [N][30] or null -> the initializer's inputs; warmX [N+1][30] or null -> open-loop rollout of the inputs

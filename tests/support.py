@@ -224,7 +224,7 @@ class Oracle:
         return x0, tt, ts, le
 
     def cycle_batch(self, N, x0, ttimes, tstates, nev, ev, modes, t0=None, contact=None, line_search=True, t_eval=None, rbd=None, period=None, time=None,
-                    input_last=None, ee_force=None, variant=0, threads=None):
+                    input_last=None, ee_force=None, variant=0, threads=None, time_grid=None, warm=None):
         """qmo_cycle_batch_mt: the whole control cycle (MPC solve -> policy evaluation at t_eval -> WBC update) of EVERY instance of a batch on
         `threads` host threads (default: the CPUs this process may use).  Shapes as the C ABI: x0 [B][30], ttimes [B][K], tstates [B][K][37],
         nev [B] (or a scalar), ev [B][MAX_EVENTS] / modes [B][MAX_EVENTS + 1] (or one schedule for all).  rbd None: MPC only."""
@@ -245,23 +245,59 @@ class Oracle:
             period = f64(np.broadcast_to(0.002 if period is None else period, (B,))); time = f64(np.broadcast_to(20.0 if time is None else time, (B,)))
             il = np.zeros((B, 30)) if input_last is None else np.array(input_last, dtype=np.float64)
             ee_force = None if ee_force is None else f64(ee_force)
-        if threads is None:
-            threads = len(os.sched_getaffinity(0))
-            try:   # a cgroup quota below the visible CPU count (the GPU boxes: 256 hardware threads, 16 CPUs granted)
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-                if q != "max":
-                    threads = max(1, min(threads, int(np.ceil(int(q) / int(per)))))
-            except (OSError, ValueError):
-                pass
-        fn = self.lib.qmo_cycle_batch_mt
+        threads = host_threads() if threads is None else threads
+        time_grid = None if time_grid is None else f64(np.broadcast_to(time_grid, (B, N + 1)))
+        wx = None if warm is None else f64(warm[0]); wu = None if warm is None else f64(warm[1])
+        assert warm is None or (wx.shape == (B, N + 1, 30) and wu.shape == (B, N, 30))
+        fn = self.lib.qmo_cycle_batch_warm_mt
         fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 8
-        bad = fn(C.byref(self.P), B, N, K, int(threads), p(t0), p(x0), p(ttimes), p(tstates), p(contact), p(nev), p(ev), p(modes), int(line_search), p(t_eval), p(rbd),
-                 p(period), p(time), p(il), p(ee_force), int(variant), p(X), p(U), p(M), p(st), p(pol), p(pm), p(wout), p(wst))
-        out = dict(X=X, U=U, mode=M, stats=st, failed=bad)
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 11 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 8
+        bad = fn(C.byref(self.P), B, N, K, int(threads), p(t0), p(x0), p(time_grid), p(wx), p(wu), p(ttimes), p(tstates), p(contact), p(nev), p(ev), p(modes), int(line_search),
+                 p(t_eval), p(rbd), p(period), p(time), p(il), p(ee_force), int(variant), p(X), p(U), p(M), p(st), p(pol), p(pm), p(wout), p(wst))
+        T = time_grid if time_grid is not None else (np.zeros(B) if t0 is None else t0)[:, None] + self.P.settings.dt * np.arange(N + 1)[None, :]
+        out = dict(X=X, U=U, mode=M, stats=st, failed=bad, T=T)
         if rbd is not None:
             out.update(x_des=pol[:, :30], u_des=pol[:, 30:], policy_mode=pm, out=wout, status=wst, input_last=il)
         return out
+
+    def wbc_batch(self, x_des, u_des, rbd, mode, period, time, input_last, variant=0, ee_force=None, threads=None):
+        """qmo_wbc_batch_mt: the WBC update of EVERY instance of a batch on `threads` host threads; returns out [B][54], status [B], input_last [B][30] (updated)"""
+        B = rbd.shape[0]
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        x_des, u_des, rbd = f64(x_des), f64(u_des), f64(rbd)
+        mode = np.ascontiguousarray(np.broadcast_to(mode, (B,)), dtype=np.int32)
+        period = f64(np.broadcast_to(period, (B,))); time = f64(np.broadcast_to(time, (B,)))
+        il = np.array(input_last, dtype=np.float64)
+        ee_force = None if ee_force is None else f64(ee_force)
+        out, st = np.zeros((B, 54)), np.zeros(B, dtype=np.int32)
+        fn = self.lib.qmo_wbc_batch_mt
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
+        fn(C.byref(self.P), B, int(host_threads() if threads is None else threads), int(variant), p(x_des), p(u_des), p(rbd), p(mode), p(period), p(time), p(il), p(ee_force),
+           p(out), p(st))
+        return dict(out=out, status=st, input_last=il)
+
+    def warm_start_batch(self, T, X, U, new_grid, x0):
+        """previous solutions (T [B][Np+1], X, U) resampled on new_grid [B][Nn+1], x[0] = x0: the oracle's counterpart of qmgpu_warm_start_batch"""
+        B, Np, Nn = U.shape[0], U.shape[1], new_grid.shape[1] - 1
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        wx, wu = np.zeros((B, Nn + 1, 30)), np.zeros((B, Nn, 30))
+        fn = self.lib.qmo_warm_start_batch
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn(B, Np, p(f64(T)), p(f64(X)), p(f64(U)), Nn, p(f64(new_grid)), p(f64(x0)), p(wx), p(wu))
+        return wx, wu
+
+    def policy_eval_batch(self, T, X, U, modes, t):
+        """MPC_MRT_Interface::evaluatePolicy for every instance: (x_des [B][30], u_des [B][30], planned mode [B]) at the times t [B]"""
+        B, N = U.shape[0], U.shape[1]
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        xu, md = np.zeros((B, 60)), np.zeros(B, dtype=np.int32)
+        fn = self.lib.qmo_policy_eval_batch
+        fn.restype = None
+        fn.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7
+        fn(B, N, p(f64(T)), p(f64(X)), p(f64(U)), p(np.ascontiguousarray(modes, dtype=np.int32)), p(f64(np.broadcast_to(t, (B,)))), p(xu), p(md))
+        return xu[:, :30].copy(), xu[:, 30:].copy(), md
 
     def time_cycles_node_threads(self, count, N, x0s, ttimes, tstates, nev, ev, modes, rbds, node_threads=3, line_search=True):
         """Seconds for `count` MPC+WBC cycles, one instance at a time, `node_threads` workers over the shooting nodes (task.info:78)."""
@@ -276,6 +312,18 @@ class Oracle:
         self.lib.qmo_time_cycles_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                 C.c_int]
         return self.lib.qmo_time_cycles_mt(C.byref(self.P), count, N, p(x0s), len(ttimes), p(ttimes), p(tstates), nev, p(ev), p(modes), p(rbds), int(line_search), int(threads))
+
+
+def host_threads():
+    """CPUs this process may keep busy: the affinity mask capped by a cgroup quota (the GPU boxes: 256 hardware threads, 16 CPUs granted)"""
+    threads = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            threads = max(1, min(threads, int(np.ceil(int(q) / int(per)))))
+    except (OSError, ValueError):
+        pass
+    return threads
 
 
 def load_problem(lib):
@@ -320,6 +368,28 @@ def rbd_from_state(oracle, x, v=None):
     _, _, ee, eq, _ = oracle.kinematics(x, np.zeros(30))
     r[48:51] = ee; r[51:55] = eq
     return r
+
+
+def moving_inputs(oracle, x0, dt, seed=11, t0=0.0):
+    """A batch of robots IN MOTION on an arbitrary tick of the controller (the whole-batch comparisons used to run the WBC on
+    robots standing still at t = 20 s on their first tick).  For every instance: a seeded measured twist + joint rates (rbd[24:48] != 0, so Jdot v, the
+    Coriolis part of nle, Adot_G v and the Euler-rate maps of WbcBase.cpp:154-155,180-202,279-299 contribute), the centroidal momentum of x0 replaced by
+    A(q) v / m of that measurement (the observation QMController.cpp:239-244 would hand the MPC), a non-zero inputLast_ (WbcBase.cpp:224-225), controller
+    times on both sides of the start-up branch (t < 10, HierarchicalWbc.cpp:23) and a policy-evaluation time strictly between shooting nodes.
+    Returns dict(x0, rbd, input_last, time, t_eval)."""
+    rng = np.random.default_rng(seed)
+    B = x0.shape[0]
+    v = np.c_[rng.uniform(-0.3, 0.3, (B, 3)), rng.uniform(-0.3, 0.3, (B, 3)), rng.uniform(-0.5, 0.5, (B, 18))]
+    rbd = np.zeros((B, 55)); x0m = np.array(x0, dtype=np.float64)
+    for i in range(B):
+        rbd[i] = rbd_from_state(oracle, x0[i], v[i])
+        x0m[i, :6] = oracle.frontend(rbd[i], 0.0, 0, np.zeros(7), rbd[i, 48:55])[0][:6]
+    il = np.zeros((B, 30))
+    il[:, 2:12:3] = 9.81 * 7.0 + rng.uniform(-5, 5, (B, 4))                 # never read by the update (only the joint part is), non-zero all the same
+    il[:, 12:] = v[:, 6:] + rng.uniform(-1, 1, (B, 18)) * 0.02
+    time = np.where(rng.uniform(size=B) < 0.25, rng.uniform(0.5, 9.5, B), rng.uniform(10.5, 30.0, B))
+    t_eval = t0 + (rng.integers(0, 4, B) + rng.uniform(0.1, 0.9, B)) * dt
+    return dict(x0=x0m, rbd=rbd, input_last=il, time=time, t_eval=t_eval, v=v)
 
 
 # ------------------------------------------------------------------------------------------------ force tracking (BASELINE.json configs[3], own formulation)

@@ -1,0 +1,60 @@
+"""Closed loop, GPU vs oracle: a batch of robots through 100 warm-started MPC cycles at 100 Hz with ten 1 kHz WBC ticks each -- inputLast_
+carried from tick to tick, the measured state following each backend's OWN plan plus a seeded disturbance, the start-up branch of the WBC (t < 10 s) ending
+half way -- compared cycle by cycle.  Line-search step lengths are discrete decisions: one flipped alpha would be an O(1) divergence, so they must agree on
+every instance of every cycle (tests/closed_loop.py has the loop; what the reference runs: qm_controllers/src/QMController.cpp:116-157,316-327)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import closed_loop as CL
+import support as S
+
+
+def _summary(rows):
+    return dict(cycles=len(rows), X_max=max(r["X"] for r in rows), U_max=max(r["U"] for r in rows), x0_max=max(r["x0"] for r in rows), tau_max=max(r["tau"] for r in rows),
+                xacc_max=max(r["xacc"] for r in rows), alpha_differs=sum(r["alpha_differs"] for r in rows), step_type_differs=sum(r["step_type_differs"] for r in rows),
+                modes_equal=all(r["modes_equal"] for r in rows), policy_mode_differs=sum(r["policy_mode_differs"] for r in rows),
+                riccati_status=[sum(r["riccati_status"][0] for r in rows), sum(r["riccati_status"][1] for r in rows)],
+                wbc_status=[sum(r["wbc_status"][0] for r in rows), sum(r["wbc_status"][1] for r in rows)], alpha_min=min(r["alpha_min"] for r in rows),
+                nodes=sorted({r["N"] for r in rows}))
+
+
+def _check(rows, tol=1e-6):
+    s = _summary(rows)
+    assert s["modes_equal"] and s["policy_mode_differs"] == 0, s
+    assert s["alpha_differs"] == 0 and s["step_type_differs"] == 0, s
+    assert s["riccati_status"] == [0, 0] and s["wbc_status"] == [0, 0], s
+    assert max(s["X_max"], s["U_max"], s["x0_max"], s["tau_max"]) <= tol, s
+    return s
+
+
+def test_closed_loop_on_the_emulation_path(oracle):
+    """CPU: the loop itself (front end -> warm start -> MPC -> policy -> WBC, twice over) on the host-emulated kernels at a toy size; the full-size run is the -m gpu test below."""
+    import gpu_harness as G
+    from qm_door_amd import abi, api
+    itf = api.QMInterface(lib=abi.load_library(S.build_emu()))
+    old = G.DEVICE
+    G.DEVICE = "cpu"
+    try:
+        # the emulated WBC costs ~7 s per instance and tick: one robot, three cycles of two ticks; t crosses 10 s, the horizon holds a mode switch
+        sc = CL.Scenario(itf, 1, cycles=3, t_start=9.995, gait_start=0.03, horizon=0.09, max_nodes=12)
+        rows = CL.run_lockstep(sc, CL.GpuBackend(itf, sc), CL.OracleBackend(S.Oracle(itf.problem), sc), ticks=2)
+    finally:
+        G.DEVICE = old
+    _check(rows, tol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0])
+def test_closed_loop_256_instances_100_cycles(interface, variant):
+    B, cycles = 256, 100
+    sc = CL.Scenario(interface, B, cycles=cycles)
+    rows = CL.run_lockstep(sc, CL.GpuBackend(interface, sc, variant), CL.OracleBackend(S.Oracle(interface.problem, fast=True), sc, variant), ticks=10)
+    s = _summary(rows)
+    path = os.path.join(S.ROOT, "gpurun_out", "closed_loop.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(dict(instances=B, ticks_per_cycle=10, t_start=sc.t_start, summary=s, per_cycle=rows), open(path, "w"), indent=1)
+    assert 66 <= min(s["nodes"]) and max(s["nodes"]) <= 72                     # the plugin's operating point: ~67 nodes + the mode switches inside the horizon
+    _check(rows)

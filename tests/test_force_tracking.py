@@ -126,22 +126,25 @@ def test_config4_force_tracking_n100_batch1024():
     nev = np.where(trot, nev_t, nev_s).astype(np.int32)
     ev = np.where(trot[:, None], ev_t[None, :], ev_s[None, :]); md = np.where(trot[:, None], md_t[None, :], md_s[None, :]).astype(np.int32)
     sol = G.make_solver(itf, B, N)
-    mb = G.MpcBatch(x0, tt, ts, nev, ev, md, N)
     cdev = G.dev(contact, torch.float64)
+    # robots in motion (support.moving_inputs): measured twist / joint rates, momentum-consistent x0, non-zero inputLast_, t < 10 and t >= 10, t_eval between nodes
+    mv = S.moving_inputs(orc, x0, dt, seed=23)
+    x0, rbd = mv["x0"], mv["rbd"]
+    mb = G.MpcBatch(x0, tt, ts, nev, ev, md, N)
     mb.args.ee_contact_ref = cdev.data_ptr()
-    rbd = np.array([S.rbd_from_state(orc, x0[i]) for i in range(B)])
     fe = np.array([S.ee_contact_force(orc, x0[i], contact[i, 0]) for i in range(B)])
-    wb = G.WbcBatch(rbd, np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
+    wb = G.WbcBatch(rbd, np.full(B, 0.002), mv["time"], mv["input_last"])
     fdev = G.dev(fe, torch.float64)
     wb.args.ee_force = fdev.data_ptr()
     sol.debug_poison()
-    sol.cycle(mb.args, G.dev(np.zeros(B), torch.float64), wb.args)
+    sol.cycle(mb.args, G.dev(mv["t_eval"], torch.float64), wb.args)
     r, w = mb.results(), wb.results()
     assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(w["out"]).all()
     assert (r["stats"][:, 7] == 0).all() and (w["status"] == 0).all()
     r.update(w)
-    ref = S.Oracle(itf.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, contact=contact, rbd=rbd, ee_force=fe)   # all 1024 instances
-    S.assert_parity(S.parity_report("configs3_force_tracking_1024xN100", r, ref))
+    ref = S.Oracle(itf.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, contact=contact, rbd=rbd, ee_force=fe, t_eval=mv["t_eval"], time=mv["time"],
+                                                       input_last=mv["input_last"])   # all 1024 instances
+    S.assert_parity(S.parity_report("configs3_force_tracking_1024xN100_moving", r, ref))
     # the force soft constraint does its job: at the end of the horizon the planned contact force is closer to the reference than without it
     from numpy.linalg import norm
     k_end = N

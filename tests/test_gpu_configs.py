@@ -68,16 +68,22 @@ def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
     sc = bench.build_config3(interface)        # the ONE global batch `bench.py --gpus 8` shards (seed 1), here all of it on one GPU
     x0, tt, ts, nev, ev, md, rbd = sc["x0"], sc["tt"], sc["ts"], sc["nev"], sc["ev"], sc["md"], sc["rbd"]
     assert x0.shape == (B, 30) and np.abs(x0[:, 6:8]).max() <= 0.5 and np.abs(x0[:, 9]).max() <= 0.5
+    # the same 2048 poses and targets with the robots in motion (support.moving_inputs: measured twist / joint rates, momentum-consistent x0, non-zero
+    # inputLast_, controller times on both sides of the start-up branch, the policy evaluated between nodes)
+    mv = S.moving_inputs(oracle, x0, interface.problem.settings.dt, seed=22)
+    x0, rbd = mv["x0"], mv["rbd"]
     sol = G.make_solver(interface, B, N)
     mb = G.MpcBatch(x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1)), N)
-    wb = G.WbcBatch(rbd, np.full(B, 0.002), np.full(B, 20.0), np.zeros((B, 30)))
-    sol.cycle(mb.args, G.dev(np.zeros(B), torch.float64), wb.args)
+    wb = G.WbcBatch(rbd, np.full(B, 0.002), mv["time"], mv["input_last"])
+    sol.cycle(mb.args, G.dev(mv["t_eval"], torch.float64), wb.args)
     r, w = mb.results(), wb.results()
     assert np.isfinite(r["X"]).all() and np.isfinite(r["U"]).all() and np.isfinite(w["out"]).all()
     assert (r["stats"][:, 7] == 0).all() and (w["status"] == 0).all()
     r.update(w)
-    ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, rbd=rbd)     # all 2048 instances, MPC + policy + WBC
-    S.assert_parity(S.parity_report("configs2_2048xN100_random_pose", r, ref))
+    ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, rbd=rbd, t_eval=mv["t_eval"], time=mv["time"],
+                                                             input_last=mv["input_last"])     # all 2048 instances, MPC + policy + WBC
+    S.assert_parity(S.parity_report("configs2_2048xN100_random_pose_moving", r, ref))
+    assert np.array_equal(r["input_last"], ref["input_last"])
 
 
 def test_config5_fp32_vs_fp64_sweep(interface, oracle):
