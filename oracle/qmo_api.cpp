@@ -209,9 +209,9 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
 }
 
 // WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],
-// mode / period / time [B], inputLast [B][30] in / out, eeForce [B][3] or null, out [B][54], status [B].  Returns the number of non-zero status words.
+// mode / period / time [B], inputLast [B][30] in / out, eeForce [B][3] or null, out [B][54], status [B], diag [B][8] or null (per level 0..3: re-solve attempts, interior-point iterations).  Returns the number of non-zero status words.
 int qmo_wbc_batch_mt(const qmgpu_problem* P, int batch, int threads, int variant, const double* xDes, const double* uDes, const double* rbd, const int32_t* mode,
-                     const double* period, const double* time, double* inputLast, const double* eeForce, double* out, int32_t* status) {
+                     const double* period, const double* time, double* inputLast, const double* eeForce, double* out, int32_t* status, int32_t* diag /*[B][8] or null*/) {
   if (threads < 1) threads = 1;
   mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 16 << 20);
   std::vector<int> failed(threads, 0);
@@ -220,7 +220,7 @@ int qmo_wbc_batch_mt(const qmgpu_problem* P, int batch, int threads, int variant
     pool.emplace_back([=, &failed]() {
       for (int i = t; i < batch; i += threads) {
         status[i] = wbcUpdate(*P, variant, xDes + size_t(i) * 30, uDes + size_t(i) * 30, rbd + size_t(i) * 55, mode[i], period[i], time[i], inputLast + size_t(i) * 30,
-                              out + size_t(i) * 54, nullptr, eeForce ? eeForce + size_t(i) * 3 : nullptr);
+                              out + size_t(i) * 54, nullptr, eeForce ? eeForce + size_t(i) * 3 : nullptr, diag ? diag + size_t(i) * 8 : nullptr);
         failed[t] += status[i] != 0;
       }
     });

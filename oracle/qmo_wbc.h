@@ -329,6 +329,8 @@ inline bool choleskyFloored(Mat& A, double floorv) {
 // 256 bench instances: 45 -> 31 iterations per update; mean 32.8 -> 24.2).  A constant, so that both implementations start identically
 // whatever null-space basis they use; <= 0 selects sqrt(scale) (second / third attempts, see HoQp).
 constexpr double kLowerLevelStart = 300.0;
+// diagnostics of the last solveQpIpm call of this thread: 1 = the returned point is a polished (exact) vertex, 0 = the interior-point iterate stands
+static thread_local int g_ipmPolished = 0;
 inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, double sigma0 = 1.0,
                       bool activeSetCorrection = false) {
   const int n = H.r;
@@ -365,23 +367,29 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     std::vector<int> act;
     for (int i = 0; i < m; ++i) if (lam[i] > s[i]) act.push_back(i);
     double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
-    const double rho = 1e6 * std::max(1.0, hmax);
+    static const double rhoRel = getenv("QMO_RHO") ? atof(getenv("QMO_RHO")) : 1e6;
+    const double rho = rhoRel * std::max(1.0, hmax);
     for (int released = 0;; ) {
       Mat K = H;
       for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
+      { static const double proxRel = getenv("QMO_PROX") ? atof(getenv("QMO_PROX")) : 0.0; for (int i = 0; i < n; ++i) K(i, i) += proxRel * std::max(1.0, hmax); }
       if (!choleskyFloored(K, pivotFloor)) return false;
       Vec zp = z, lp(m, 0.0);
       for (int r : act) lp[r] = lam[r];
-      bool again = false;
-      for (int step = 0; step < 3; ++step) {
+      bool again = false, converged = false;
+      static const int polishSteps = getenv("QMO_PSTEPS") ? atoi(getenv("QMO_PSTEPS")) : 3;
+      static const double convTol = getenv("QMO_PCONV") ? atof(getenv("QMO_PCONV")) : 0.0;   // 0: no convergence requirement (round-3 behaviour)
+      for (int step = 0; step < polishSteps; ++step) {
         const Vec Dz = D * zp;
         Vec t(m, 0.0);
         for (int r : act) t[r] = lp[r] + rho * (Dz[r] - f[r]);
         Vec dz = -1.0 * (H * zp + c + tmul(D, t));
         cholSolve(K, dz);
         for (int i = 0; i < n; ++i) zp[i] += dz[i];
+        { const Vec Hdz = H * dz; double dn = 0; for (int i = 0; i < n; ++i) dn = std::max(dn, std::fabs(Hdz[i])); converged = dn <= convTol * scale; }
         const Vec Dz2 = D * zp;
         for (int r : act) lp[r] += rho * (Dz2[r] - f[r]);
+        if (convTol > 0.0 && converged && step >= 1) break;
         if (activeSetCorrection && step == 0) {
           double viol = -1e300, lmin = 0.0;
           for (int i = 0; i < m; ++i) viol = std::max(viol, Dz2[i] - f[i]);
@@ -392,16 +400,22 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
             act.swap(kept); released = 1; again = true;
             break;
           }
-          if (!(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) return false;
+          if (convTol > 0.0) { /* decided after convergence */ } else
+          if (!(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) { if (getenv("QMO_DEBUG_POLISH")) fprintf(stderr, "POLISH reject step0 n %d m %d act %zu released %d viol/scale %.3e lmin/scale %.3e mu/scale %.3e\n", n, m, act.size(), released, viol / scale, lmin / scale, dot(s, lam) / m / scale); return false; }
         }
       }
       if (again) continue;
       const Vec Dz = D * zp;
-      bool ok = true;
+      bool ok = convTol > 0.0 ? converged : true;
       for (int i = 0; i < m; ++i) if (!(Dz[i] - f[i] <= 1e-9 * scale)) ok = false;
       for (int r : act) if (!(lp[r] >= -1e-9 * scale)) ok = false;
       for (double v : zp) if (!(v == v)) ok = false;
+      if (getenv("QMO_DEBUG_POLISH")) { Vec t(m, 0.0); for (int r : act) t[r] = lp[r]; const Vec g = H * zp + c + tmul(D, t); double gn = 0; for (double v : g) gn = std::max(gn, std::fabs(v));
+        auto objf = [&](const Vec& v) { const Vec Hv = H * v; return 0.5 * dot(v, Hv) + dot(c, v); }; double lmin = 0; for (int r : act) lmin = std::min(lmin, lp[r]);
+        fprintf(stderr, "POLISH %s n %d m %d act %zu released %d obj ipm %.10e polished %.10e stationarity %.3e lmin %.3e scale %.3e\n", ok ? "accept" : "REJECT", n, m, act.size(), released, objf(z), objf(zp), gn, lmin, scale); }
       if (ok) { z = zp; return true; }
+      if (getenv("QMO_DEBUG_POLISH")) { double viol = -1e300, lmin = 0; for (int i = 0; i < m; ++i) viol = std::max(viol, Dz[i] - f[i]); for (int r : act) lmin = std::min(lmin, lp[r]);
+        fprintf(stderr, "POLISH reject final n %d m %d act %zu released %d viol/scale %.3e lmin/scale %.3e\n", n, m, act.size(), released, viol / scale, lmin / scale); }
       return false;
     }
   };
@@ -425,17 +439,19 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     }
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
     // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
-    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
+    static const double nrdTol = getenv("QMO_NRD") ? atof(getenv("QMO_NRD")) : 1e-7;
+    if (nrd <= nrdTol * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
     // the polish is first tried as soon as the active set can plausibly be read off (mu <= 1e-6 scale; at most twice, the second time
     // only after the complementarity has dropped another 100x): an accepted vertex is exact whatever iterate it started from; a
     // rejected one leaves z, s, lam untouched and the interior point goes on
     if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) {
       ++earlyTries; lastTryMu = mu;
-      if (tryPolish()) return it;
+      if (tryPolish()) { g_ipmPolished = 1; return it; }
     }
     // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
     // here instead of iterating into the divergence that follows; the polish finishes the job
-    if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) break;
+    static const double stagMu = getenv("QMO_STAG") ? atof(getenv("QMO_STAG")) : 1e-10;
+    if (it > 0 && mu > 0.5 * muPrev && mu <= stagMu * scale && nrp <= 1e-9 * scale && nrd <= nrdTol * scale) break;
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = H;
     for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
@@ -464,7 +480,7 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     for (int i = 0; i < m; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
   }
   if (it >= maxIter) return -4;   // iteration cap: a failure like the others (HoQp retries from a different starting point)
-  tryPolish();
+  g_ipmPolished = tryPolish() ? 1 : 0;
   return it;
 }
 
@@ -476,7 +492,7 @@ struct HoQp {
   int numSlack = 0, numDec = 0, numPrevSlack = 0;
   Mat Zprev, Z, Hm, Dm;
   Vec slackPrev, xPrev, cv, fv, stackedSlack, slackSol, decSol;
-  int qpIters = 0;
+  int qpIters = 0, attempts = 0, polished = 0;   // attempts: 0 = the first solve converged, 1 / 2 = the relaxed re-solves, 3 = level skipped
 
   HoQp(const Task& t, const HoQp* higher) : task(t) {
     // initVars
@@ -520,14 +536,19 @@ struct HoQp {
     // 100x that, and the iteration starts from slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the
     // higher priorities' solution) and the failure is reported.  2 x 2048 random configurations: 6 second attempts, no skip.
     if (nz > 0) {
-      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? kLowerLevelStart : 1.0, numSlack == 0);
+      g_ipmPolished = 0;
+      static const double sig0 = getenv("QMO_SIGMA0") ? atof(getenv("QMO_SIGMA0")) : kLowerLevelStart;
+      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? sig0 : 1.0, numSlack == 0);
       for (int attempt = 1; attempt <= 2 && qpIters < 0; ++attempt) {
         Vec fr = fv;
         const double margin = attempt == 1 ? kInheritedMargin : 100.0 * kInheritedMargin;   // 1e-5, then 1e-3
         for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(margin, fr[numSlack + i]);
+        g_ipmPolished = 0;
         qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 40, nullptr, -1.0, numSlack == 0);
+        attempts = attempt;
       }
-      if (qpIters < 0) sol.assign(nz, 0.0);
+      if (qpIters < 0) { sol.assign(nz, 0.0); attempts = 3; }
+      polished = g_ipmPolished;
     } else sol.clear();
     decSol = Vec(sol.begin(), sol.begin() + numDec); slackSol = Vec(sol.begin() + numDec, sol.end());
     // An interior point method leaves the slacks of inactive rows at O(sqrt(mu)) (v = 0 and its multiplier = 0 is a degenerate
@@ -548,7 +569,7 @@ struct HoQp {
 
 // HierarchicalWbc::update (variant 0) / HierarchicalMpcWbc::update (variant 1); returns [x(36); tau(18)]
 inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
-                     double* inputLast, double out[54], WbcModel* modelOut = nullptr, const double* eeForce = nullptr) {
+                     double* inputLast, double out[54], WbcModel* modelOut = nullptr, const double* eeForce = nullptr, int32_t* diag /*[8]: attempts, iterations per level*/ = nullptr) {
   WbcModel w;
   std::unique_ptr<PhaseTimer> phase(new PhaseTimer(PH_WBC_MODEL));
   wbcUpdateMeasured(P, rbd, w);
@@ -566,20 +587,29 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
     task1 = tk.baseHeight() + tk.baseAngular() + tk.baseLinear() + tk.swingLeg() * 100.0;
     task2 = tk.contactForce(uDes);
   }
+  // EXPERIMENT: force variables in units of sF newtons
+  static const double sF = getenv("QMO_SF") ? atof(getenv("QMO_SF")) : 1.0;
+  auto scaleTask = [&](Task& t) { for (int i = 0; i < t.a.r; ++i) for (int j = NV; j < 36; ++j) t.a(i, j) *= sF; for (int i = 0; i < t.d.r; ++i) for (int j = NV; j < 36; ++j) t.d(i, j) *= sF; };
+  Task task0s = task0; scaleTask(task0s); scaleTask(task1); scaleTask(task2);
   phase.reset(); phase.reset(new PhaseTimer(PH_WBC_QP));
-  HoQp h0(task0, nullptr);
+  HoQp h0(task0s, nullptr);
   HoQp h1(task1, &h0);
   Vec x;
   int status = (h0.qpIters < 0 || h0.qpIters >= 60 ? 1 : 0) | (h1.qpIters < 0 || h1.qpIters >= 60 ? 2 : 0);
+  if (diag) { for (int i = 0; i < 8; ++i) diag[i] = 0; diag[0] = h0.attempts + 10 * h0.polished; diag[1] = h1.attempts + 10 * h1.polished; diag[4] = h0.qpIters; diag[5] = h1.qpIters; }
   if (h1.Z.c > 0) {
     HoQp h2(task2, &h1); x = h2.solution(); status |= (h2.qpIters < 0 || h2.qpIters >= 60 ? 4 : 0);
+    if (diag) { diag[2] = h2.attempts + 10 * h2.polished; diag[6] = h2.qpIters; }
     if (h2.Z.c > 0) {
       // Directions no task sees (the arm accelerations of HierarchicalMpcWbc) are fixed in the reference only by HoQp's 1e-12
       // regulariser and qpOASES' internal regularisation, i.e. "small".  Defined here as the minimum-norm completion: one more
       // level with the task x = 0.
-      HoQp h3(Task(Mat::identity(36), Vec(36, 0.0), Mat(), Vec()), &h2); x = h3.solution(); status |= (h3.qpIters < 0 || h3.qpIters >= 60 ? 8 : 0);
+      Task t3(Mat::identity(36), Vec(36, 0.0), Mat(), Vec()); scaleTask(t3);
+      HoQp h3(t3, &h2); x = h3.solution(); status |= (h3.qpIters < 0 || h3.qpIters >= 60 ? 8 : 0);
+      if (diag) { diag[3] = h3.attempts + 10 * h3.polished; diag[7] = h3.qpIters; }
     }
   } else x = h1.solution();  // FLY: level 2 has no decision variables left -> skip
+  for (int j = NV; j < 36; ++j) x[j] *= sF;
   // updateCmd (WbcBase.cpp:580-595)
   for (int i = 0; i < 36; ++i) out[i] = x[i];
   for (int i = 0; i < NJ; ++i) {

@@ -37,6 +37,9 @@ class GpuWbc : public WbcBase {
     ros::NodeHandle nhGains(nh, "wbc_gpu");
     dynamicSrv_ = std::make_shared<dynamic_reconfigure::Server<qm_wbc::WbcWeightConfig>>(nhGains);
     dynamicSrv_->setCallback([this](qm_wbc::WbcWeightConfig& c, uint32_t) { stageGains(c); });
+    // Launch files and rqt layouts written for the reference point at <controller>/wbc: say once, loudly, that it no longer does anything here.
+    ROS_WARN_STREAM("[GpuWbc] WBC gains are served on " << nhGains.getNamespace() << " (dynamic_reconfigure); the base-class server " << nh.getNamespace()
+                    << "/wbc stays advertised but edits members the GPU path never reads: requests sent there have NO effect");
   }
   ~GpuWbc() {   // (the reference's WbcBase declares no virtual destructor; the controller's shared_ptr was made from this type)
     qmgpu_set_stream(h_, nullptr);

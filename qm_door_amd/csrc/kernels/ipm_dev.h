@@ -15,6 +15,14 @@
 
 namespace qmk {
 
+// Stagnation exit of the interior point (complementarity no longer halves): only once mu <= this x scale.  Round 3 used 1e-6: with robots in motion
+// 14-28 % of the level-1 problems took this exit after ONE slow iteration at mu ~ 1e-6 scale, an unconverged iterate whose active set cannot be read
+// (polish rejected) and whose dual residual (<= 1e-7 scale, scale = |c|max ~ 6e4 with the x100 swing weight) leaves the weakly weighted task directions
+// (singular values 0.02 .. 60 of A Z) off by O(1) -- the source of GPU / oracle torque deviations of 1e-5 .. 1e-1 (profiles/r04_notes.md section 1).
+#ifndef QM_IPM_STAGNATION_MU
+#define QM_IPM_STAGNATION_MU 1e-10
+#endif
+
 struct IpmIo {
   const double* G;      // [36][ldk], zero outside n x n
   const double* g;      // [36]
@@ -280,7 +288,7 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
       else if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) { done = true; early = true; ++earlyTries; lastTryMu = mu; }
       // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
       // stop here instead of iterating into the divergence that follows; the polish finishes the job
-      else if (it > 0 && mu > 0.5 * muPrev && mu <= 1e-6 * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
+      else if (it > 0 && mu > 0.5 * muPrev && mu <= QM_IPM_STAGNATION_MU * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
       if (it >= 39 && !done) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
       if (done) {
         itOut = it;

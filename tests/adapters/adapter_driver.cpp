@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <thread>
 #include <iostream>
@@ -14,9 +15,10 @@
 #include "QMGpuController.h"
 
 namespace {
-struct Harness : qm::QMGpuController {
-  using qm::QMGpuController::setupMpc;
-  using qm::QMGpuController::setupWbc;
+template <class Ctl>
+struct Harness : Ctl {
+  using Ctl::setupMpc;
+  using Ctl::setupWbc;
   using qm::QMController::mpc_;
   using qm::QMController::qmInterface_;
   using qm::QMController::wbc_;
@@ -31,14 +33,121 @@ ocs2::vector_t readVec(std::istream& in, int n) { ocs2::vector_t v(n); for (int 
 void writeVec(std::ostream& out, const ocs2::vector_t& v) { out.precision(17); for (long i = 0; i < v.size(); ++i) out << v[i] << (i + 1 < v.size() ? ' ' : '\n'); }
 }  // namespace
 
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Latency at the plugin's operating point: ONE robot, the reference's own instrumentation points -- mpcTimer_ around advanceMpc
+// (QMController.cpp:322-324) and wbcTimer_ around wbc_->update (QMController.cpp:146-148), printed as max / average (QMController.cpp:348-355).
+// timeHorizon 1.0 s, dt 0.015, trot: ~67 nodes + the mode switches inside the horizon, warm start from the previous solution, 100 Hz; ten 1 kHz WBC
+// ticks per MPC run on the plan just computed.  Wall clock per call = pinned staging + H2D + the batch-1 launch chain + D2H + one stream synchronisation.
+struct Stat { std::vector<double> ms; void add(double v) { ms.push_back(v); }
+  void write(std::ostream& o) const { std::vector<double> s = ms; std::sort(s.begin(), s.end()); double sum = 0; for (double v : s) sum += v;
+    o << "{\"calls\": " << s.size() << ", \"avg_ms\": " << sum / s.size() << ", \"max_ms\": " << s.back() << ", \"min_ms\": " << s.front() << ", \"median_ms\": " << s[s.size() / 2]
+      << ", \"p99_ms\": " << s[std::min(s.size() - 1, size_t(0.99 * s.size()))] << "}"; } };
+
+void interpPlan(const ocs2::PrimalSolution& p, double t, ocs2::vector_t& x, ocs2::vector_t& u) {
+  const auto& T = p.timeTrajectory_;
+  size_t k = 0;
+  while (k + 2 < T.size() && T[k + 1] < t) ++k;
+  const double len = T[k + 1] - T[k], a = len > 1e-12 ? std::min(1.0, std::max(0.0, (T[k + 1] - t) / len)) : 1.0;
+  x.resize(30); u.resize(30);
+  for (int i = 0; i < 30; ++i) { x[i] = a * p.stateTrajectory_[k][i] + (1.0 - a) * p.stateTrajectory_[k + 1][i]; u[i] = a * p.inputTrajectory_[k][i] + (1.0 - a) * p.inputTrajectory_[k + 1][i]; }
+}
+
+template <class Ctl>
+int runLatency(const char* outPath, int runs, int ticksPerRun) {
+  Harness<Ctl> ctl;
+  ros::NodeHandle nh;
+  std::string task; ros::param::get("/taskFile", task);
+  qmgpu_problem P{};
+  { std::string urdf, ref; ros::param::get("/urdfFile", urdf); ros::param::get("/referenceFile", ref);
+    if (qmgpu_load_problem(task.c_str(), urdf.c_str(), ref.c_str(), nullptr, &P) != QMGPU_OK) throw std::runtime_error(qmgpu_last_error()); }
+  auto& rm = *ctl.qmInterface_->referenceManagerPtr_;
+  // stance for 0.2 s, then the trot of gait.info (0.35 s per phase) past the last horizon; hold-pose target (StartingPosition.h:13-15 offsets)
+  const double tEnd = runs * 0.01 + 1.6;
+  rm.modeSchedule.eventTimes.clear(); rm.modeSchedule.modeSequence = {15};
+  for (double t = 0.2; t < tEnd; t += 0.35) { rm.modeSchedule.eventTimes.push_back(t); rm.modeSchedule.modeSequence.push_back(rm.modeSchedule.modeSequence.size() % 2 ? 9 : 6); }
+  ocs2::vector_t x0(30); for (int i = 0; i < 30; ++i) x0[i] = P.settings.initial_state[i];
+  ocs2::vector_t tgt(37); for (int i = 0; i < 30; ++i) tgt[i] = x0[i];
+  tgt[30] = x0[6] + 0.6; tgt[31] = x0[7]; tgt[32] = x0[8] + 0.036; tgt[33] = 0; tgt[34] = 0; tgt[35] = 0; tgt[36] = 1;
+  rm.targetTrajectories.timeTrajectory = {0.0}; rm.targetTrajectories.stateTrajectory = {tgt}; rm.targetTrajectories.inputTrajectory = {ocs2::vector_t(30)};
+  ctl.qmInterface_->mpcSettings_.timeHorizon_ = 1.0;
+  ctl.setupMpc(nh); ctl.setupWbc(nh, task);
+  std::ofstream out(outPath);
+  out.precision(6);
+  out << "{\"controller\": \"" << (Ctl::kWbcVariant ? "qm/QMGpuMpcController" : "qm/QMGpuController") << "\", \"wbc_variant\": " << Ctl::kWbcVariant;
+  for (int pass = 0; pass < 2; ++pass) {       // pass 0: wall clock only; pass 1: the same loop with HIP-event kernel timing on both handles
+    qmgpu_enable_timing(ctl.mpcHandle(), pass); qmgpu_enable_timing(ctl.wbcHandle(), pass);
+    ctl.mpc_->reset();
+    Stat mpc, wbc; double nodes = 0; int wbcStatus = 0;
+    ocs2::vector_t x = x0, xd, ud;
+    ocs2::PrimalSolution plan;
+    for (int r = -5; r < runs; ++r) {            // five untimed warm-up cycles (first launches, lazy module load)
+      const double t0 = std::max(r, 0) * 0.01;
+      if (r > 0) { interpPlan(plan, t0, x, ud); }
+      auto a = std::chrono::steady_clock::now();
+      ctl.mpc_->run(t0, x);
+      auto b = std::chrono::steady_clock::now();
+      ctl.mpc_->getSolverPtr()->getPrimalSolution(t0 + 1.0, &plan);
+      if (r >= 0) { mpc.add(std::chrono::duration<double, std::milli>(b - a).count()); nodes += double(plan.timeTrajectory_.size() - 1); }
+      for (int j = 0; j < ticksPerRun; ++j) {
+        const double t = t0 + j * 0.001;
+        interpPlan(plan, t, xd, ud);
+        ocs2::vector_t xh, uh; interpPlan(plan, t + 0.001, xh, uh);
+        ocs2::vector_t rbd(55);
+        for (int i = 0; i < 3; ++i) { rbd[i] = xd[9 + i]; rbd[3 + i] = xd[6 + i]; rbd[27 + i] = (xh[6 + i] - xd[6 + i]) / 0.001; rbd[24 + i] = (xh[11 - i] - xd[11 - i]) / 0.001; }
+        for (int i = 0; i < 18; ++i) { rbd[6 + i] = xd[12 + i]; rbd[30 + i] = ud[12 + i]; }
+        rbd[54] = 1.0;
+        size_t k = 0; while (k + 2 < plan.timeTrajectory_.size() && plan.timeTrajectory_[k + 1] < t) ++k;
+        const size_t mode = plan.modeSchedule_.modeAtTime(plan.timeTrajectory_[k]);
+        auto c = std::chrono::steady_clock::now();
+        (void)ctl.wbc_->update(xd, ud, rbd, mode, 0.001, 20.0 + t);
+        auto d = std::chrono::steady_clock::now();
+        if (r >= 0) { wbc.add(std::chrono::duration<double, std::milli>(d - c).count()); wbcStatus += dynamic_cast<qm::GpuWbc*>(ctl.wbc_.get())->lastStatus() != 0; }
+      }
+    }
+    out << ", \"" << (pass ? "with_kernel_timing" : "wall_clock") << "\": {\"mpc_run\": "; mpc.write(out); out << ", \"wbc_update\": "; wbc.write(out);
+    out << ", \"mean_nodes\": " << nodes / runs << ", \"wbc_status_nonzero\": " << wbcStatus;
+    if (pass) {
+      double m[6] = {0}, w[6] = {0};
+      qmgpu_kernel_ms_mean(ctl.mpcHandle(), std::min(runs, 64), m); qmgpu_kernel_ms_mean(ctl.wbcHandle(), std::min(runs * ticksPerRun, 64), w);
+      out << ", \"kernel_ms_mean\": {\"ad_node\": " << m[0] << ", \"lq_node\": " << m[1] << ", \"riccati\": " << m[2] << ", \"linesearch\": " << m[3] << ", \"mpc_launch_chain\": " << m[5]
+          << ", \"wbc\": " << w[4] << "}";
+    }
+    out << "}";
+  }
+  out << "}\n";
+  return 0;
+}
+
+template <class Ctl> int runDriver(int argc, char** argv);
+}  // namespace
+
 int main(int argc, char** argv) {
-  if (argc != 6) { std::fprintf(stderr, "usage: adapter_driver task.info robot.urdf reference.info inputs.txt outputs.txt\n"); return 2; }
+  // adapter_driver task.info robot.urdf reference.info inputs.txt outputs.txt [variant]      parity run (tests/test_adapters.py)
+  // adapter_driver task.info robot.urdf reference.info --latency out.json [variant] [runs] [ticks per run]
+  if (argc < 6) { std::fprintf(stderr, "usage: adapter_driver task.info robot.urdf reference.info (inputs.txt outputs.txt | --latency out.json) [variant 0|1] [runs] [ticks]\n"); return 2; }
+  const int variant = argc > 6 ? std::atoi(argv[6]) : 0;
   try {
     ros::param::store()["/taskFile"] = argv[1]; ros::param::store()["/urdfFile"] = argv[2]; ros::param::store()["/referenceFile"] = argv[3];
+    if (std::string(argv[4]) == "--latency") {
+      const int runs = argc > 7 ? std::atoi(argv[7]) : 200, ticks = argc > 8 ? std::atoi(argv[8]) : 10;
+      return variant ? runLatency<qm::QMGpuMpcController>(argv[5], runs, ticks) : runLatency<qm::QMGpuController>(argv[5], runs, ticks);
+    }
+    return variant ? runDriver<qm::QMGpuMpcController>(argc, argv) : runDriver<qm::QMGpuController>(argc, argv);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "adapter_driver: %s\n", e.what());
+    return 1;
+  }
+}
+
+namespace {
+template <class Ctl>
+int runDriver(int /*argc*/, char** argv) {
+  {
     std::ifstream in(argv[4]);
     if (!in) throw std::runtime_error("cannot open inputs");
     std::ofstream out(argv[5]);
-    Harness ctl;
+    Harness<Ctl> ctl;
     // reference manager contents: what the gait receiver and the target subscriber would have installed before the solver runs
     auto& rm = *ctl.qmInterface_->referenceManagerPtr_;
     int nev = 0, K = 0, runs = 0;
@@ -133,11 +242,12 @@ int main(int argc, char** argv) {
       while (ctl.mrtRuns_ < 3) std::this_thread::sleep_for(std::chrono::milliseconds(1));
       out << "mrt " << ctl.mrtRuns_ << '\n';
     }
+    // which controller class ran, which WBC task set its hook selected, whether the reference's own (private) QMMpcController::setupWbc was bypassed, and
+    // the warning about the inert base-class gain server
+    out << "class " << Ctl::kWbcVariant << ' ' << ros::warnings().size() << '\n';
     out << "done\n";
     out.flush();
-  } catch (const std::exception& e) {
-    std::fprintf(stderr, "adapter_driver: %s\n", e.what());
-    return 1;
   }
   return 0;
 }
+}  // namespace

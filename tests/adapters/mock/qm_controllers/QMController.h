@@ -46,4 +46,14 @@ class QMController {
   std::shared_ptr<WbcBase> wbc_;
   ros::Publisher observationPublisher_, eeStatePublisher_;
 };
+// qm_controllers/include/qm_controllers/QMController.h:95-110: the separated-system controller overrides setupWbc PRIVATELY (building HierarchicalMpcWbc,
+// QMController.cpp:411-415) together with the arm position-interface hooks; a class derived from it can still override the virtual.
+class QMMpcController : public QMController {
+ public:
+  QMMpcController() = default;
+  ~QMMpcController() = default;
+  bool baseWbcHookRan_ = false;
+ private:
+  void setupWbc(ros::NodeHandle& controller_nh, const std::string& taskFile) { (void)controller_nh; (void)taskFile; baseWbcHookRan_ = true; }
+};
 }  // namespace qm

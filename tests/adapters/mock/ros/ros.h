@@ -3,7 +3,11 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <cstdio>
+#define ROS_WARN_STREAM(msg) do { ros::warnings().push_back([&]() { std::ostringstream os_; os_ << msg; return os_.str(); }()); } while (0)
+#include <sstream>
 namespace ros {
+inline std::vector<std::string>& warnings() { static std::vector<std::string> w; return w; }   // test hook: what rosconsole would have printed
 class Publisher {};
 class NodeHandle {
  public:

@@ -269,13 +269,13 @@ class Oracle:
         period = f64(np.broadcast_to(period, (B,))); time = f64(np.broadcast_to(time, (B,)))
         il = np.array(input_last, dtype=np.float64)
         ee_force = None if ee_force is None else f64(ee_force)
-        out, st = np.zeros((B, 54)), np.zeros(B, dtype=np.int32)
+        out, st, diag = np.zeros((B, 54)), np.zeros(B, dtype=np.int32), np.zeros((B, 8), dtype=np.int32)
         fn = self.lib.qmo_wbc_batch_mt
         fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 11
         fn(C.byref(self.P), B, int(host_threads() if threads is None else threads), int(variant), p(x_des), p(u_des), p(rbd), p(mode), p(period), p(time), p(il), p(ee_force),
-           p(out), p(st))
-        return dict(out=out, status=st, input_last=il)
+           p(out), p(st), p(diag))
+        return dict(out=out, status=st, input_last=il, attempts=diag[:, :4] % 10, polished=diag[:, :4] // 10, iterations=diag[:, 4:])
 
     def warm_start_batch(self, T, X, U, new_grid, x0):
         """previous solutions (T [B][Np+1], X, U) resampled on new_grid [B][Nn+1], x[0] = x0: the oracle's counterpart of qmgpu_warm_start_batch"""
@@ -442,6 +442,8 @@ def parity_report(name, got, ref, keys=("X", "U"), tau=True, record=True):
         e = rel_inf(got[k], ref[k])
         rep[k] = {"max": float(e.max()), "p99": float(np.percentile(e, 99)), "median": float(np.median(e)), "argmax": int(e.argmax())}
     if tau and "out" in ref:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", f"wbc_{name}.npz"), gpu=got["out"], oracle=ref["out"])     # scratch, for offline analysis
         e = rel_inf(got["out"][:, 36:], ref["out"][:, 36:])
         rep["tau"] = {"max": float(e.max()), "p99": float(np.percentile(e, 99)), "median": float(np.median(e)), "argmax": int(e.argmax())}
         rep["wbc_status_nonzero"] = [int((got["status"] != 0).sum()), int((ref["status"] != 0).sum())]

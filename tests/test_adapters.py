@@ -21,6 +21,18 @@ def test_adapter_header_compiles_against_the_stand_ins(header):
     assert err == "", err
 
 
+def test_both_plugin_classes_come_from_one_template():
+    """qm::QMGpuController derives from qm::QMController, qm::QMGpuMpcController from qm::QMMpcController (the reference's second exported class,
+    qm_controllers/src/QMController.cpp:450-451); the WBC variant follows the base."""
+    src = """#include "QMGpuController.h"
+static_assert(std::is_base_of<qm::QMController, qm::QMGpuController>::value && !std::is_base_of<qm::QMMpcController, qm::QMGpuController>::value, "");
+static_assert(std::is_base_of<qm::QMMpcController, qm::QMGpuMpcController>::value, "");
+static_assert(qm::QMGpuController::kWbcVariant == 0 && qm::QMGpuMpcController::kWbcVariant == 1, "");
+"""
+    r = subprocess.run(["g++", *BD.FLAGS, *BD.INCLUDES, "-fsyntax-only", "-x", "c++", "-"], input=src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_every_declared_adapter_member_is_defined():
     """Linking the driver fails on any member that is declared and used but not defined (the round-1 stageAndSolve / finishMpcSetup)."""
     exe = BD.build_driver(force=True)
@@ -61,13 +73,18 @@ def _read_outputs(path):
             extra["gains"] = [float(t) for t in toks[i + 1:i + 5]]; i += 5
         elif toks[i] == "mrt":
             extra["mrt_runs"] = int(toks[i + 1]); i += 2
+        elif toks[i] == "class":
+            extra["wbc_variant"], extra["warnings"] = int(toks[i + 1]), int(toks[i + 2]); i += 3
         else:
             raise AssertionError(f"unexpected token {toks[i]}")
     return runs, wbc, extra
 
 
 @pytest.mark.gpu
-def test_adapters_reproduce_the_direct_c_abi_solves(interface, oracle):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_adapters_reproduce_the_direct_c_abi_solves(interface, oracle, variant):
+    """variant 0: qm/QMGpuController (derived from qm::QMController, HierarchicalWbc task set); variant 1: qm/QMGpuMpcController (derived from
+    qm::QMMpcController, whose own setupWbc -- private in the reference, QMController.h:104 -- builds HierarchicalMpcWbc).  One template, both classes."""
     import torch
     import gpu_harness as G
     from qm_door_amd import abi, api
@@ -99,7 +116,7 @@ def test_adapters_reproduce_the_direct_c_abi_solves(interface, oracle):
     ticks = [(r1["X"][0][0], r1["U"][0][0], rbd, int(r1["mode"][0][0]), 0.002, 20.0), (r1["X"][0][1], r1["U"][0][1], rbd, int(r1["mode"][0][1]), 0.002, 20.002)]
     wb_outs, il = [], np.zeros((1, 30))
     for xd, ud, rb, mode, period, time in ticks:
-        wb = G.WbcBatch(rb[None], np.array([period]), np.array([time]), il, state_desired=xd[None], input_desired=ud[None], mode=np.array([mode], dtype=np.int32))
+        wb = G.WbcBatch(rb[None], np.array([period]), np.array([time]), il, state_desired=xd[None], input_desired=ud[None], mode=np.array([mode], dtype=np.int32), variant=variant)
         sol.wbc(wb.args)
         res = wb.results()
         wb_outs.append(res["out"][0]); il = res["input_last"]
@@ -109,10 +126,12 @@ def test_adapters_reproduce_the_direct_c_abi_solves(interface, oracle):
         fin, fout = os.path.join(tmp, "in.txt"), os.path.join(tmp, "out.txt")
         _write_inputs(fin, nev, ev, md, tt, ts, horizon, [(0.0, x0), (dt, x1)], ticks)
         d = abi.DATA_DIR
-        p = subprocess.run([exe, f"{d}/task.info", f"{d}/aliengo_z1.urdf", f"{d}/reference.info", fin, fout], capture_output=True, text=True, timeout=300)
+        p = subprocess.run([exe, f"{d}/task.info", f"{d}/aliengo_z1.urdf", f"{d}/reference.info", fin, fout, str(variant)], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr       # (a crash while the controller is torn down with its MPC thread running would show here)
         runs, wbc, extra = _read_outputs(fout)
     assert len(runs) == 2 and len(wbc) == 2
+    # the hook of the class that was loaded selected its base's WBC task set, and said (once per GpuWbc) that the base-class gain server is inert
+    assert extra["wbc_variant"] == variant and extra["warnings"] >= 1
     # gains through the dynamic_reconfigure stand-in on another thread: identical gains change nothing, a doubled base-height gain is applied by the
     # next update() and moves the torques; the MPC thread made >= 3 solves before the controller was destroyed under it
     d_same, d_changed, ratio, out_len = extra["gains"]

@@ -83,7 +83,7 @@ def test_config3_randomised_pose_and_targets_batch2048(interface, oracle):
     ref = S.Oracle(interface.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, rbd=rbd, t_eval=mv["t_eval"], time=mv["time"],
                                                              input_last=mv["input_last"])     # all 2048 instances, MPC + policy + WBC
     S.assert_parity(S.parity_report("configs2_2048xN100_random_pose_moving", r, ref))
-    assert np.array_equal(r["input_last"], ref["input_last"])
+    assert S.rel_inf(r["input_last"], ref["input_last"]).max() <= 1e-9            # inputLast_ <- the evaluated policy input
 
 
 def test_config5_fp32_vs_fp64_sweep(interface, oracle):

@@ -76,12 +76,9 @@ def test_cycle_matches_oracle(interface, oracle):
         assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-def test_wbc_stress_all_modes_converge(interface, oracle, variant):
-    """2048 random instances over every contact mode of gait.info: all three levels converge everywhere; 48 samples vs the oracle."""
-    import gpu_harness as G
+def stress_batch(interface, variant, B=2048):
+    """2048 random (NOT MPC-consistent) instances over every contact mode of gait.info, robots in motion, non-zero inputLast_, 20 % on the start-up branch"""
     rng = np.random.default_rng(17 + variant)
-    B = 2048
     x_nom, m = interface.initial_state, interface.robot_mass
     modes_all = np.array([15, 9, 6, 0, 10, 5, 13, 7, 14, 11], dtype=np.int32)
     mode = modes_all[rng.integers(0, len(modes_all), B)]
@@ -100,21 +97,73 @@ def test_wbc_stress_all_modes_converge(interface, oracle, variant):
     t = np.where(rng.uniform(size=B) < 0.2, 5.0, 20.0)
     rbd = np.zeros((B, 55))
     rbd[:, 0:3] = xm[:, 9:12]; rbd[:, 3:6] = xm[:, 6:9]; rbd[:, 6:24] = xm[:, 12:30]; rbd[:, 24:48] = vm
+    return dict(xd=xd, u=u, rbd=rbd, mode=mode, t=t, il=il)
+
+
+def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=3, seed=5):
+    """How far the ORACLE's own torques move when the instance's desired state / measurement are perturbed by eps (relative to their scale, a few seeded
+    directions): max over the draws of ||d tau||_inf / max(1, ||tau||_inf), per instance of idx.  An instance whose level-2 problem is a nearly degenerate
+    LP moves by many orders of magnitude more than eps; GPU-oracle agreement there cannot be better than the rounding noise times this amplification."""
+    rng = np.random.default_rng(seed)
+    base = orc.wbc_batch(c["xd"][idx], c["u"][idx], c["rbd"][idx], c["mode"][idx], 0.002, c["t"][idx], c["il"][idx], variant)["out"][:, 36:]
+    worst = np.zeros(len(idx))
+    for _ in range(draws):
+        xd = c["xd"][idx] * (1 + eps * rng.uniform(-1, 1, (len(idx), 30))); rbd = c["rbd"][idx].copy()
+        rbd[:, :48] *= 1 + eps * rng.uniform(-1, 1, (len(idx), 48))
+        o = orc.wbc_batch(xd, c["u"][idx], rbd, c["mode"][idx], 0.002, c["t"][idx], c["il"][idx], variant)["out"][:, 36:]
+        worst = np.maximum(worst, S.rel_inf(o, base))
+    return worst
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wbc_stress_all_modes_converge(interface, variant):
+    """2048 random instances over every contact mode of gait.info, robots in motion: all three levels converge everywhere, and EVERY instance is
+    compared with the (multi-threaded) oracle -- no sampling.  The distribution goes to gpurun_out/parity.json.  Stated bound: tau within 1e-6 rel-inf on
+    every instance that is not ill-conditioned, where ill-conditioned is MEASURED, not assumed: the oracle's own torques move by more than 1e-3 rel-inf under
+    a 1e-9 relative perturbation of the instance's inputs (an amplification >= 1e6: the nearly degenerate low-priority LPs of DESIGN.md section 5 that random,
+    not MPC-consistent, desired states produce); on those the deviation must stay below the oracle's own movement under that perturbation x 10."""
+    import json
+    import os
+    import gpu_harness as G
+    B = 2048
+    os.makedirs(os.path.join(S.ROOT, "gpurun_out"), exist_ok=True)
+    c = stress_batch(interface, variant, B)
     sol = G.make_solver(interface, B, 4)
-    wb = G.WbcBatch(rbd, np.full(B, 0.002), t, il, xd, u, mode, variant)
+    wb = G.WbcBatch(c["rbd"], np.full(B, 0.002), c["t"], c["il"], c["xd"], c["u"], c["mode"], variant)
     sol.debug_poison()
     sol.wbc(wb.args)
     r = wb.results()
     assert np.isfinite(r["out"]).all()
     assert (r["status"] == 0).all(), (np.nonzero(r["status"])[0][:10], r["status"][np.nonzero(r["status"])[0][:10]])
-    errs = []
-    for i in rng.choice(B, 48, replace=False):
-        st, ref, _ = oracle.wbc_update(xd[i], u[i], rbd[i], int(mode[i]), 0.002, float(t[i]), il[i], variant)
-        assert st == 0
-        errs.append(np.abs(r["out"][i][36:] - ref[36:]).max() / max(1.0, np.abs(ref[36:]).max()))
-    # Random (not MPC-consistent) desired states make some lowest-priority levels nearly degenerate LPs whose minimiser moves by 1e-2
-    # when an inherited bound moves by 1e-5; the 1e-6 bar is asserted on the MPC-driven workloads (test_gpu_fullsize, test_gpu_configs).
-    assert np.median(errs) <= 1e-8 and np.quantile(errs, 0.85) <= 1e-6 and max(errs) <= 1e-4, np.sort(errs)[-8:]
+    orc = S.Oracle(interface.problem, fast=True)
+    ref = orc.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], 0.002, c["t"], c["il"], variant)
+    assert (ref["status"] == 0).all()
+    assert np.array_equal(r["input_last"], ref["input_last"])
+    err = S.rel_inf(r["out"][:, 36:], ref["out"][:, 36:])
+    errx = S.rel_inf(r["out"][:, :36], ref["out"][:, :36])
+    np.savez(os.path.join(S.ROOT, "gpurun_out", f"wbc_stress_v{variant}.npz"), gpu=r["out"], oracle=ref["out"], attempts=ref["attempts"], iterations=ref["iterations"])   # scratch, for offline analysis
+    above = np.nonzero(err > 1e-6)[0]
+    sens = oracle_sensitivity(orc, c, above, variant) if len(above) else np.zeros(0)
+    rep = {"instances": B, "tau": {"max": float(err.max()), "p99": float(np.percentile(err, 99)), "p90": float(np.percentile(err, 90)), "median": float(np.median(err))},
+           "x": {"max": float(errx.max()), "p99": float(np.percentile(errx, 99)), "median": float(np.median(errx))},
+           "count_above_1e-6": int(len(above)), "count_above_1e-8": int((err > 1e-8).sum()),
+           "oracle_relaxed_resolves_per_level": [int((ref["attempts"][:, l] > 0).sum()) for l in range(4)],
+           "oracle_iterations_mean_max_per_level": [[float(ref["iterations"][:, l].mean()), int(ref["iterations"][:, l].max())] for l in range(4)],
+           "above_1e-6": [{"instance": int(i), "mode": int(c["mode"][i]), "time": float(c["t"][i]), "tau_dev": float(err[i]), "x_dev": float(errx[i]),
+                           "oracle_attempts": ref["attempts"][i].tolist(), "oracle_iterations": ref["iterations"][i].tolist(),
+                           "oracle_tau_move_under_1e-9_input_perturbation": float(sens[k])} for k, i in enumerate(above)]}
+    path = os.path.join(S.ROOT, "gpurun_out", "parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        allrep = json.load(open(path))
+    except (OSError, ValueError):
+        allrep = {}
+    allrep[f"wbc_stress_2048_all_modes_variant{variant}"] = rep
+    json.dump(allrep, open(path, "w"), indent=1)
+    assert np.median(err) <= 1e-9, rep["tau"]
+    for k, i in enumerate(above):
+        assert sens[k] > 1e-3 and err[i] <= 10 * sens[k], rep["above_1e-6"][k]
+    assert len(above) <= B // 100, rep["count_above_1e-6"]          # the ill-conditioned class is rare: at most 1 % of random instances
 
 
 def test_settings_update_and_dtype_handles(interface, oracle):
