@@ -85,6 +85,101 @@ def build_config3(itf, total=CONFIG3_GLOBAL_BATCH, seed=1):
     return dict(x0=x0, tt=tt, ts=ts, nev=nev, ev=ev, md=md, rbd=rbd)
 
 
+def steady_state(itf, sc, steps, warmup, emulate=False):
+    """config.steady_state: what the controller does between the first tick and shutdown -- the SAME 256 instances in a receding
+    horizon: every step shifts the horizon by one MPC period (10 ms, mpcDesiredFrequency task.info:147), resamples the previous solution on the shifted grid
+    ON THE DEVICE as the initial guess (qmgpu_warm_start_batch; coldStart false, task.info:143), solves, evaluates the policy between two nodes and runs the
+    WBC on a robot IN MOTION: the measured state follows the instance's own plan plus a seeded disturbance (tests/closed_loop.py: measurement), inputLast_
+    is carried from step to step, the centroidal observation comes from qmgpu_frontend_batch.
+    The measurements depend on the plans, so the sequence is produced once, untimed (record pass: plan -> host -> measurement -> device), and then REPLAYED
+    from device-resident inputs with nothing but qmgpu_warm_start_batch + qmgpu_cycle_batch per step inside the timed region; the replay must reproduce the
+    recorded trajectories bit for bit (checked)."""
+    import torch
+    import closed_loop as CL
+    import gpu_harness as G
+    from qm_door_amd import abi, api
+    f64 = torch.float64
+    B, N = len(sc["x0"]), HORIZON_N
+    dt = itf.problem.settings.dt
+    total = warmup + steps
+    dist_ = CL.Disturbance(B, np.random.default_rng(5))
+    sol = G.make_solver(itf, B, N)
+    z = lambda *shape, dtype=f64: torch.zeros(shape, dtype=dtype, device=G.DEVICE)  # noqa: E731
+    sets = [dict(T=z(B, N + 1), X=z(B, N + 1, 30), U=z(B, N, 30), M=z(B, N + 1, dtype=torch.int32), S=z(B, abi.NSTATS)) for _ in range(2)]
+    wx, wu = z(B, N + 1, 30), z(B, N, 30)
+    tt, ts = G.dev(sc["tt"], f64), G.dev(sc["ts"], f64)
+    sn, se, sm = G.dev(np.full(B, sc["nev"], dtype=np.int32), torch.int32), G.dev(np.tile(sc["ev"], (B, 1)), f64), G.dev(np.tile(sc["md"], (B, 1)), torch.int32)
+    kind, cmd, lastee, ftt, fts = z(B, dtype=torch.int32), z(B, 7), z(B, 7), z(B, 2), z(B, 2, 37)
+    il0 = np.zeros((B, 30)); il0[:, 12:] = 0.0
+    out, status, period = z(B, 54), z(B, dtype=torch.int32), G.dev(np.full(B, 0.001), f64)
+    rec = []          # per step: device-resident inputs of the replay
+    sync = (lambda: None) if emulate else torch.cuda.synchronize
+
+    def run_step(k, r, il, timed_outputs=None):
+        cur, prev = sets[k & 1], sets[(k & 1) ^ 1]
+        if k > 0:
+            sol.warm_start(B, N, prev["T"], prev["X"], prev["U"], N, r["grid"], r["x0"], wx, wu)
+        a = api.GpuSolver.mpc_args(B, N, r["x0"], tt, ts, sn, se, sm, cur["T"], cur["X"], cur["U"], cur["M"], cur["S"], t0=r["t0"], time_grid=r["grid"],
+                                   warm_x=wx if k > 0 else None, warm_u=wu if k > 0 else None)
+        w = api.GpuSolver.wbc_args(B, r["rbd"], period, r["time"], il, out, status)
+        sol.cycle(a, r["t_eval"], w)
+        return cur
+
+    # ---- record pass (untimed)
+    v0 = np.c_[np.random.default_rng(6).uniform(-0.1, 0.1, (B, 6)), np.random.default_rng(7).uniform(-0.2, 0.2, (B, 18))]
+    q0 = sc["x0"][:, 6:30]
+    rbd = CL.pack_rbd(q0 + dist_.dq(0.0), v0 + dist_.dv(0.0))
+    il = G.dev(il0, f64)
+    plan = None
+    for k in range(total):
+        t0 = k * CL.MPC_PERIOD
+        if k > 0:
+            rbd = CL.measurement(dist_, plan, t0)
+        r = dict(rbd=G.dev(rbd, f64), x0=z(B, 30), grid=G.dev(np.tile(t0 + dt * np.arange(N + 1), (B, 1)), f64), t0=G.dev(np.full(B, t0), f64),
+                 t_eval=G.dev(np.full(B, t0 + 0.3 * CL.WBC_PERIOD), f64), time=G.dev(np.full(B, 20.0 + t0), f64))
+        sol.frontend(sol.frontend_args(B, r["rbd"], r["t0"], kind, cmd, lastee, r["x0"], ftt, fts))
+        cur = run_step(k, r, il)
+        sync()
+        plan = dict(T=cur["T"].cpu().numpy(), X=cur["X"].cpu().numpy(), U=cur["U"].cpu().numpy())
+        rec.append(r)
+    rec_last = dict(X=plan["X"], out=out.cpu().numpy(), status=status.cpu().numpy(), stats=cur["S"].cpu().numpy())
+    # ---- replay: the first `warmup` steps untimed (step 0 is the cold start), then `steps` steps timed
+    il = G.dev(il0, f64)
+    for k in range(warmup):
+        run_step(k, rec[k], il)
+    sol.enable_timing(True)
+    sync()
+    t_begin = time.perf_counter()
+    for k in range(warmup, total):
+        cur = run_step(k, rec[k], il)
+    sync()
+    elapsed = time.perf_counter() - t_begin
+    kms = sol.kernel_ms_mean(steps)
+    sol.enable_timing(False)
+    same = bool(np.array_equal(cur["X"].cpu().numpy(), rec_last["X"]) and np.array_equal(out.cpu().numpy(), rec_last["out"]))
+    speed = np.abs(np.concatenate([r["rbd"].cpu().numpy()[:, 24:48] for r in rec[warmup:]])).mean(axis=0)
+    res = {"value": B * steps / elapsed, "unit": "cycles/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+           "what": "receding horizon: shifted grid (10 ms per step), device-resampled warm start of every solve (qmgpu_warm_start_batch inside the timed region), policy evaluated between "
+                   "nodes, WBC on robots in motion (plan-following measurement + seeded disturbance, inputLast_ carried); replay of a recorded input sequence, inputs resident",
+           "kernel_ms": dict(zip(["ad", "lq", "riccati", "linesearch", "wbc", "whole"], kms)),
+           "replay_reproduces_the_recorded_run_bit_for_bit": same,
+           "results_finite_and_converged": bool(np.isfinite(rec_last["X"]).all() and np.isfinite(rec_last["out"]).all() and (rec_last["stats"][:, 7] == 0).all() and (rec_last["status"] == 0).all()),
+           "line_search_full_steps_last_solve": int((rec_last["stats"][:, 4] == 1.0).sum()),
+           "mean_abs_measured_velocity": {"base_angular": float(speed[0:3].mean()), "base_linear": float(speed[3:6].mean()), "joints": float(speed[6:].mean())}}
+    sol.close()
+    return res
+
+
+def device_for_rank(local_rank, device_count, visible=None):
+    """LOCAL_RANK -> device index of THIS process.  torch.cuda.device_count() already honours HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES: a launcher that
+    starts more ranks than the process can see devices (e.g. 8 ranks under HIP_VISIBLE_DEVICES=0,1) is a configuration error, reported here instead of as
+    an 'invalid device ordinal' from the first allocation."""
+    if not 0 <= local_rank < device_count:
+        raise SystemExit(f"[bench] LOCAL_RANK {local_rank} has no GPU: this process sees {device_count} device(s)"
+                         + (f" (HIP_VISIBLE_DEVICES={visible})" if visible else "") + "; start at most that many ranks per node")
+    return local_rank
+
+
 def shard_of(sc, lo, hi):
     return dict(x0=sc["x0"][lo:hi], tt=sc["tt"][lo:hi], ts=sc["ts"][lo:hi], nev=sc["nev"], ev=sc["ev"], md=sc["md"], rbd=sc["rbd"][lo:hi])
 
@@ -176,8 +271,9 @@ def cpu_baseline(itf, sc, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps; the default makes the timed region >= 0.2 s at 1.9 ms per step")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-steady-state", action="store_true", help="skip config.steady_state (the receding-horizon leg, N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="single process: run the N > 1 code path (pack -> RCCL all_gather_into_tensor -> unpack) on a 1-rank nccl group and verify it")
@@ -207,7 +303,7 @@ def main():
         G.DEVICE = "cpu"
         lib = abi.load_library(S.build_emu())
     else:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device_for_rank(local_rank, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")))
         lib = abi.load_library()
     collective = world > 1 or args.force_collective
     if collective:
@@ -215,10 +311,15 @@ def main():
         if world == 1:   # --force-collective without a launcher: a 1-rank group on the loopback address
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        # a rank that never arrives must not hold the others for the default 30 minutes (under torch.distributed.run the agent also tears the job down
+        # as soon as one worker exits non-zero; the timeout covers launchers that do not)
         if args.emulate:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
+    if os.environ.get("QM_BENCH_FAIL_RANK") == str(rank):     # tests/test_bench_contract.py: one rank fails before the first barrier
+        raise RuntimeError("injected failure (QM_BENCH_FAIL_RANK)")
 
     itf = api.QMInterface(lib=lib)
     B, N = args.batch_per_gpu, args.nodes
@@ -361,7 +462,9 @@ def main():
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": world * B, "horizon_nodes": N, "gait": "trot", "seed": 0 if world == 1 else 1, "results_finite_and_converged": ok,
                        "collective": ("all_gather(X,U,tau,mode) over " + ("gloo (emulation)" if args.emulate else "RCCL")) if collective else "none",
-                       "per_rank_value": rank_values, "gathered_bytes_per_step": int(world * B * sharding.pack_len(N) * 8) if collective else 0,
+                       "per_rank_value": rank_values, "per_rank_value_min": min(rank_values), "per_rank_value_max": max(rank_values),
+                       "slowest_rank_over_fastest": min(rank_values) / max(rank_values),
+                       "gathered_bytes_per_step": int(world * B * sharding.pack_len(N) * 8) if collective else 0,
                        "gather_matches_local_results": gather_ok},
             "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved is not None else None,
@@ -382,6 +485,12 @@ def main():
         }
         if batch_sweep is not None:
             out["config"]["batch_sweep"] = batch_sweep
+        if world == 1 and not args.no_steady_state and not args.emulate:
+            from qm_door_amd import api as _api
+            sc_ss = dict(sc)
+            t_end = (args.steps + args.warmup) * 0.01 + N * itf.problem.settings.dt + 0.5
+            sc_ss["nev"], sc_ss["ev"], sc_ss["md"] = _api.GaitSchedule(lib=itf.lib).mode_schedule("trot", 0.0, 0.0, t_end)
+            out["config"]["steady_state"] = steady_state(itf, sc_ss, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline and not args.emulate:
             out["cpu_baseline"] = cpu_baseline(itf, sc)
         print(json.dumps(out), flush=True)
@@ -390,4 +499,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001 -- say WHICH rank failed, then exit non-zero at once: the launcher tears the other ranks down
+        import traceback
+        traceback.print_exc()
+        print(f"[bench] rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        os._exit(1)

@@ -208,6 +208,11 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
                                  inputLast, eeForce, variant, outX, outU, outMode, outStats, outPolicy, outPolicyMode, outWbc, outWbcStatus);
 }
 
+// experiment knobs of the WBC restatement (qmo_wbc.h): key 0 = starting value of the lower levels' interior point (default 300), key 1 = orthonormal null-space basis (0 / 1)
+void qmo_set_experiment(int key, double value) {
+  if (key == 0) g_expLowerLevelStart = value; else if (key == 1) g_expOrthonormalNullSpace = value != 0.0;
+}
+
 // WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],
 // mode / period / time [B], inputLast [B][30] in / out, eeForce [B][3] or null, out [B][54], status [B], diag [B][8] or null (per level 0..3: re-solve attempts, interior-point iterations).  Returns the number of non-zero status words.
 int qmo_wbc_batch_mt(const qmgpu_problem* P, int batch, int threads, int variant, const double* xDes, const double* uDes, const double* rbd, const int32_t* mode,

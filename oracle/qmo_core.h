@@ -189,7 +189,9 @@ inline void householderQR(const Mat& A, Mat& Q, Mat& Rout) {
 
 // Null-space basis of A (r x c) by full-pivot LU, the construction of Eigen's FullPivLU::kernel()
 // (reference call site: qm_wbc/src/HoQp.cpp:129).  Returns c x (c - rank).
-inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr) {
+// (no fused multiply-add in the elimination, in EITHER build of the oracle: the pivot search compares the updated entries for equality of magnitude --
+// the level tasks carry unit rows, exact ties are the rule -- and the kernels' wbc_kernel.h takes the same decisions with the same roundings)
+__attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr) {
   Mat A = Ain;
   const int rows = A.r, cols = A.c, size = std::min(rows, cols);
   std::vector<int> colPerm(cols);

@@ -329,8 +329,18 @@ inline bool choleskyFloored(Mat& A, double floorv) {
 // 256 bench instances: 45 -> 31 iterations per update; mean 32.8 -> 24.2).  A constant, so that both implementations start identically
 // whatever null-space basis they use; <= 0 selects sqrt(scale) (second / third attempts, see HoQp).
 constexpr double kLowerLevelStart = 300.0;
+constexpr double kStagnationMu = 1e-10;
+constexpr bool kPolishAdd = false;       // adding violated rows to the guess (ipm_dev.h: QM_IPM_POLISH_ADD)
+constexpr int kPolishCorrections = 4;    // releases + additions per polish attempt (ipm_dev.h: QM_IPM_POLISH_CORRECTIONS)   // = QM_IPM_STAGNATION_MU of the kernels (ipm_dev.h)
 // diagnostics of the last solveQpIpm call of this thread: 1 = the returned point is a polished (exact) vertex, 0 = the interior-point iterate stands
 static thread_local int g_ipmPolished = 0;
+static thread_local int g_ipmExit = 0; static thread_local double g_ipmExitMu = 0, g_ipmExitNrd = 0;   // TEMP diagnostics
+// Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  lowerLevelStart: the interior point's starting slacks / multipliers below the
+// top level -- a second value gives the ALGORITHMIC sensitivity of an instance (how far the oracle's own torques move when only the path of the
+// interior point changes; tests/test_gpu_wbc.py).  orthonormalNullSpace: Gram-Schmidt on the kernel basis, the round-3 kernels' basis, which
+// reproduces their round-4 failures inside the oracle (profiles/r04_notes.md section 1).
+static double g_expLowerLevelStart = kLowerLevelStart;
+static int g_expOrthonormalNullSpace = 0;
 inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, double sigma0 = 1.0,
                       bool activeSetCorrection = false) {
   const int n = H.r;
@@ -363,59 +373,59 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   // if the guess is still wrong after that the attempt is abandoned at once instead of after two more steps and the check.  On the
   // bench set the slowest instance read one weakly active row too many at both early attempts and went on for five more interior-point
   // iterations (12 + three polishes = 24 passes of its second level; now 14).
-  auto tryPolish = [&]() -> bool {
+  auto tryPolish = [&](bool early) -> bool {
     std::vector<int> act;
     for (int i = 0; i < m; ++i) if (lam[i] > s[i]) act.push_back(i);
     double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
-    static const double rhoRel = getenv("QMO_RHO") ? atof(getenv("QMO_RHO")) : 1e6;
-    const double rho = rhoRel * std::max(1.0, hmax);
-    for (int released = 0;; ) {
+    const double rho = 1e6 * std::max(1.0, hmax);
+    // Active-set correction loop (levels without slack variables of their own): the estimates after the FIRST step of an attempt decide.  Negative
+    // multipliers at a feasible point -> those rows are released; rows outside the guess that the step violates (weakly active rows whose slack and
+    // multiplier both vanish: the interior point cannot classify them) -> they are added; either way the polish starts again from the interior-point
+    // iterate, at most kPolishCorrections times per attempt (round 3: one release, no add -- with robots in motion 14-28 % of the level-1 polishes
+    // were then rejected and the interior-point iterate, accurate to its tolerances only, stood).
+    for (int corrections = 0;; ) {
       Mat K = H;
       for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
-      { static const double proxRel = getenv("QMO_PROX") ? atof(getenv("QMO_PROX")) : 0.0; for (int i = 0; i < n; ++i) K(i, i) += proxRel * std::max(1.0, hmax); }
       if (!choleskyFloored(K, pivotFloor)) return false;
       Vec zp = z, lp(m, 0.0);
       for (int r : act) lp[r] = lam[r];
-      bool again = false, converged = false;
-      static const int polishSteps = getenv("QMO_PSTEPS") ? atoi(getenv("QMO_PSTEPS")) : 3;
-      static const double convTol = getenv("QMO_PCONV") ? atof(getenv("QMO_PCONV")) : 0.0;   // 0: no convergence requirement (round-3 behaviour)
-      for (int step = 0; step < polishSteps; ++step) {
+      bool again = false;
+      for (int step = 0; step < 3; ++step) {
         const Vec Dz = D * zp;
         Vec t(m, 0.0);
         for (int r : act) t[r] = lp[r] + rho * (Dz[r] - f[r]);
         Vec dz = -1.0 * (H * zp + c + tmul(D, t));
         cholSolve(K, dz);
         for (int i = 0; i < n; ++i) zp[i] += dz[i];
-        { const Vec Hdz = H * dz; double dn = 0; for (int i = 0; i < n; ++i) dn = std::max(dn, std::fabs(Hdz[i])); converged = dn <= convTol * scale; }
         const Vec Dz2 = D * zp;
         for (int r : act) lp[r] += rho * (Dz2[r] - f[r]);
-        if (convTol > 0.0 && converged && step >= 1) break;
         if (activeSetCorrection && step == 0) {
           double viol = -1e300, lmin = 0.0;
           for (int i = 0; i < m; ++i) viol = std::max(viol, Dz2[i] - f[i]);
           for (int r : act) lmin = std::min(lmin, lp[r]);
-          if (released == 0 && lmin < -1e-9 * scale && viol <= 1e-6 * scale) {
+          if (corrections < kPolishCorrections && lmin < -1e-9 * scale && viol <= 1e-6 * scale) {
             std::vector<int> kept;
             for (int r : act) if (!(lp[r] < 0.0)) kept.push_back(r);
-            act.swap(kept); released = 1; again = true;
+            act.swap(kept); ++corrections; again = true;
             break;
           }
-          if (convTol > 0.0) { /* decided after convergence */ } else
-          if (!(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) { if (getenv("QMO_DEBUG_POLISH")) fprintf(stderr, "POLISH reject step0 n %d m %d act %zu released %d viol/scale %.3e lmin/scale %.3e mu/scale %.3e\n", n, m, act.size(), released, viol / scale, lmin / scale, dot(s, lam) / m / scale); return false; }
+          if (kPolishAdd && !early && corrections < kPolishCorrections && viol > 1e-8 * scale && viol <= 0.1 * scale) {   // (only once the interior point has converged)
+            std::vector<char> in(m, 0); for (int r : act) in[r] = 1;
+            for (int i = 0; i < m; ++i) if (!in[i] && Dz2[i] - f[i] > 1e-9 * scale) in[i] = 1;
+            act.clear(); for (int i = 0; i < m; ++i) if (in[i]) act.push_back(i);
+            ++corrections; again = true;
+            break;
+          }
+          if (!(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) return false;
         }
       }
       if (again) continue;
       const Vec Dz = D * zp;
-      bool ok = convTol > 0.0 ? converged : true;
+      bool ok = true;
       for (int i = 0; i < m; ++i) if (!(Dz[i] - f[i] <= 1e-9 * scale)) ok = false;
       for (int r : act) if (!(lp[r] >= -1e-9 * scale)) ok = false;
       for (double v : zp) if (!(v == v)) ok = false;
-      if (getenv("QMO_DEBUG_POLISH")) { Vec t(m, 0.0); for (int r : act) t[r] = lp[r]; const Vec g = H * zp + c + tmul(D, t); double gn = 0; for (double v : g) gn = std::max(gn, std::fabs(v));
-        auto objf = [&](const Vec& v) { const Vec Hv = H * v; return 0.5 * dot(v, Hv) + dot(c, v); }; double lmin = 0; for (int r : act) lmin = std::min(lmin, lp[r]);
-        fprintf(stderr, "POLISH %s n %d m %d act %zu released %d obj ipm %.10e polished %.10e stationarity %.3e lmin %.3e scale %.3e\n", ok ? "accept" : "REJECT", n, m, act.size(), released, objf(z), objf(zp), gn, lmin, scale); }
       if (ok) { z = zp; return true; }
-      if (getenv("QMO_DEBUG_POLISH")) { double viol = -1e300, lmin = 0; for (int i = 0; i < m; ++i) viol = std::max(viol, Dz[i] - f[i]); for (int r : act) lmin = std::min(lmin, lp[r]);
-        fprintf(stderr, "POLISH reject final n %d m %d act %zu released %d viol/scale %.3e lmin/scale %.3e\n", n, m, act.size(), released, viol / scale, lmin / scale); }
       return false;
     }
   };
@@ -435,23 +445,24 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
       z = zPrev; s = sPrev; lam = lamPrev;
       if (kktRes) *kktRes = std::max(nrdPrev, muPrev);
       if (!(muPrev <= 1e-8 * scale)) return -3;
+      g_ipmExit = 3; g_ipmExitMu = muPrev / scale; g_ipmExitNrd = nrdPrev / scale;
       break;   // accepted as converged: polished below like any other final iterate
     }
     if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
     // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
-    static const double nrdTol = getenv("QMO_NRD") ? atof(getenv("QMO_NRD")) : 1e-7;
-    if (nrd <= nrdTol * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) break;
+    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) { g_ipmExit = 1; g_ipmExitMu = mu / scale; g_ipmExitNrd = nrd / scale; break; }
     // the polish is first tried as soon as the active set can plausibly be read off (mu <= 1e-6 scale; at most twice, the second time
     // only after the complementarity has dropped another 100x): an accepted vertex is exact whatever iterate it started from; a
     // rejected one leaves z, s, lam untouched and the interior point goes on
     if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) {
       ++earlyTries; lastTryMu = mu;
-      if (tryPolish()) { g_ipmPolished = 1; return it; }
+      if (tryPolish(true)) { g_ipmPolished = 1; return it; }
     }
     // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
     // here instead of iterating into the divergence that follows; the polish finishes the job
-    static const double stagMu = getenv("QMO_STAG") ? atof(getenv("QMO_STAG")) : 1e-10;
-    if (it > 0 && mu > 0.5 * muPrev && mu <= stagMu * scale && nrp <= 1e-9 * scale && nrd <= nrdTol * scale) break;
+    // (1e-10: round 3 stopped at mu <= 1e-6 * scale, i.e. after one slow iteration at an iterate whose active set cannot be read yet -- with robots in
+    //  motion 14-28 % of the level-1 solves left that way, unpolished, 1e-5 .. 1e-1 off in the weakly weighted task directions)
+    if (it > 0 && mu > 0.5 * muPrev && mu <= kStagnationMu * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) { g_ipmExit = 2; g_ipmExitMu = mu / scale; g_ipmExitNrd = nrd / scale; break; }
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = H;
     for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
@@ -480,7 +491,8 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     for (int i = 0; i < m; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
   }
   if (it >= maxIter) return -4;   // iteration cap: a failure like the others (HoQp retries from a different starting point)
-  g_ipmPolished = tryPolish() ? 1 : 0;
+  g_ipmPolished = tryPolish(false) ? 1 : 0;
+  if (!g_ipmPolished && getenv("QMO_DEBUG_EXIT")) fprintf(stderr, "UNPOLISHED n %d exit %d mu/s %.1e nrd/s %.1e it %d\n", n, g_ipmExit, g_ipmExitMu, g_ipmExitNrd, it);
   return it;
 }
 
@@ -537,8 +549,7 @@ struct HoQp {
     // higher priorities' solution) and the failure is reported.  2 x 2048 random configurations: 6 second attempts, no skip.
     if (nz > 0) {
       g_ipmPolished = 0;
-      static const double sig0 = getenv("QMO_SIGMA0") ? atof(getenv("QMO_SIGMA0")) : kLowerLevelStart;
-      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? sig0 : 1.0, numSlack == 0);
+      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? g_expLowerLevelStart : 1.0, numSlack == 0);
       for (int attempt = 1; attempt <= 2 && qpIters < 0; ++attempt) {
         Vec fr = fv;
         const double margin = attempt == 1 ? kInheritedMargin : 100.0 * kInheritedMargin;   // 1e-5, then 1e-3
@@ -561,6 +572,13 @@ struct HoQp {
     }
     // buildZMatrix
     if (hasEq) Z = Zprev * kernelFullPivLU(aZ); else Z = Zprev;
+    if (g_expOrthonormalNullSpace && Z.c > 0) {   // EXPERIMENT: orthonormal columns (modified Gram-Schmidt, twice)
+      for (int pass = 0; pass < 2; ++pass)
+        for (int j = 0; j < Z.c; ++j) {
+          for (int k = 0; k < j; ++k) { double d = 0; for (int i = 0; i < Z.r; ++i) d += Z(i, k) * Z(i, j); for (int i = 0; i < Z.r; ++i) Z(i, j) -= d * Z(i, k); }
+          double nn = 0; for (int i = 0; i < Z.r; ++i) nn += Z(i, j) * Z(i, j); nn = std::sqrt(nn); for (int i = 0; i < Z.r; ++i) Z(i, j) /= nn;
+        }
+    }
     // stackSlackSolutions
     stackedSlack = higher ? vcat(higher->stackedSlack, slackSol) : slackSol;
   }
@@ -587,12 +605,8 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
     task1 = tk.baseHeight() + tk.baseAngular() + tk.baseLinear() + tk.swingLeg() * 100.0;
     task2 = tk.contactForce(uDes);
   }
-  // EXPERIMENT: force variables in units of sF newtons
-  static const double sF = getenv("QMO_SF") ? atof(getenv("QMO_SF")) : 1.0;
-  auto scaleTask = [&](Task& t) { for (int i = 0; i < t.a.r; ++i) for (int j = NV; j < 36; ++j) t.a(i, j) *= sF; for (int i = 0; i < t.d.r; ++i) for (int j = NV; j < 36; ++j) t.d(i, j) *= sF; };
-  Task task0s = task0; scaleTask(task0s); scaleTask(task1); scaleTask(task2);
   phase.reset(); phase.reset(new PhaseTimer(PH_WBC_QP));
-  HoQp h0(task0s, nullptr);
+  HoQp h0(task0, nullptr);
   HoQp h1(task1, &h0);
   Vec x;
   int status = (h0.qpIters < 0 || h0.qpIters >= 60 ? 1 : 0) | (h1.qpIters < 0 || h1.qpIters >= 60 ? 2 : 0);
@@ -604,12 +618,10 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
       // Directions no task sees (the arm accelerations of HierarchicalMpcWbc) are fixed in the reference only by HoQp's 1e-12
       // regulariser and qpOASES' internal regularisation, i.e. "small".  Defined here as the minimum-norm completion: one more
       // level with the task x = 0.
-      Task t3(Mat::identity(36), Vec(36, 0.0), Mat(), Vec()); scaleTask(t3);
-      HoQp h3(t3, &h2); x = h3.solution(); status |= (h3.qpIters < 0 || h3.qpIters >= 60 ? 8 : 0);
+      HoQp h3(Task(Mat::identity(36), Vec(36, 0.0), Mat(), Vec()), &h2); x = h3.solution(); status |= (h3.qpIters < 0 || h3.qpIters >= 60 ? 8 : 0);
       if (diag) { diag[3] = h3.attempts + 10 * h3.polished; diag[7] = h3.qpIters; }
     }
   } else x = h1.solution();  // FLY: level 2 has no decision variables left -> skip
-  for (int j = NV; j < 36; ++j) x[j] *= sF;
   // updateCmd (WbcBase.cpp:580-595)
   for (int i = 0; i < 36; ++i) out[i] = x[i];
   for (int i = 0; i < NJ; ++i) {

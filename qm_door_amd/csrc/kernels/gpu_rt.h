@@ -57,6 +57,9 @@ __device__ __forceinline__ void qmMfma(QmAccF& c, float a, float b, float* = nul
 __device__ __forceinline__ constexpr int qmARow(int p) { return sizeof(real) == 8 ? p : (p >> 2) + 4 * (p & 3); }
 __device__ __forceinline__ double qmRsqrt(double x) { return rsqrt(x); }
 __device__ __forceinline__ float qmRsqrt(float x) { return rsqrtf(x); }
+// a * b and a - b rounded on their own: the optimiser may not fuse them into one multiply-add (results that feed exact comparisons shared with the host oracle)
+__device__ __forceinline__ double qmMulNoFma(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double qmSubNoFma(double a, double b) { return __dsub_rn(a, b); }
 // 1 / sqrt(x) for a positive, normal x on a dependent chain: v_rsq_f64 (~2^-26) and one third-order correction -- the arithmetic of the
 // library routine without its scaling of denormals and its special-case selects (5 dependent instructions instead of 9)
 __device__ __forceinline__ double qmRsqrtPos(double x) {

@@ -22,6 +22,12 @@ namespace qmk {
 #ifndef QM_IPM_STAGNATION_MU
 #define QM_IPM_STAGNATION_MU 1e-10
 #endif
+#ifndef QM_IPM_POLISH_ADD
+#define QM_IPM_POLISH_ADD 0               // = kPolishAdd of the oracle
+#endif
+#ifndef QM_IPM_POLISH_CORRECTIONS
+#define QM_IPM_POLISH_CORRECTIONS 4       // = kPolishCorrections of the oracle
+#endif
 
 struct IpmIo {
   const double* G;      // [36][ldk], zero outside n x n
@@ -191,7 +197,7 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
     return false;
   };
   int polish = 0;                       // 0 interior point; 1..3 polish step; 4 final check
-  bool released = false;                // this polish attempt has already dropped the rows with negative multiplier estimates once
+  int corrections = 0;                  // releases + additions of this polish attempt so far
   // the polish is first tried as soon as the active set can plausibly be read (mu <= 1e-6 scale, at most twice): an accepted
                                             // vertex is exact whatever iterate it started from, a rejected one resumes the interior point
   bool isE = false, isV = false;        // my row: pinned (equality) / violated soft row of this level (exact quadratic)
@@ -241,15 +247,20 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
       break;
     }
     if (polish == 2 && !own) {
-      // active-set correction (the oracle's solveQpIpm, activeSetCorrection): the multiplier estimates after the first step already
-      // tell whether the active set was read correctly.  Negative ones at a feasible point: release those rows and start the polish
-      // again from the interior-point iterate (once); still wrong: abandon the attempt now, not after two more steps and the check
+      // active-set correction loop (the oracle's solveQpIpm, activeSetCorrection): the estimates after the first step of an attempt already tell
+      // whether the active set was read correctly.  Negative multipliers at a feasible point: release those rows; rows outside the guess that the step
+      // violates (weakly active rows whose slack and multiplier both vanish -- the interior point cannot classify them): add them; either way the
+      // polish starts again from the interior-point iterate, at most QM_IPM_POLISH_CORRECTIONS times per attempt.  Still wrong: abandon the attempt
+      // now, not after two more steps and the check
       const double viol = allMax(rowActive ? rRow : -1e300);
       const double lmin = allMin((rowActive && isE) ? lamE : 0.0);
-      const bool release = !released && lmin < -1e-9 * scale && viol <= 1e-6 * scale;
-      if (release || !(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) {
+      const bool canFix = corrections < QM_IPM_POLISH_CORRECTIONS;
+      const bool release = canFix && lmin < -1e-9 * scale && viol <= 1e-6 * scale;
+      const bool add = QM_IPM_POLISH_ADD && canFix && !early && !release && viol > 1e-8 * scale && viol <= 0.1 * scale;   // (only once the interior point has converged: an early guess at mu ~ 1e-7 scale that needs rows added is abandoned instead)
+      if (release || add || !(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) {
         zc = zIpm;
-        if (release) { released = true; isE = isE && !(lamE < 0.0); lamE = isE ? l1 : 0.0; polish = 1; continue; }
+        if (release) { ++corrections; isE = isE && !(lamE < 0.0); lamE = isE ? l1 : 0.0; polish = 1; continue; }
+        if (add) { ++corrections; isE = isE || (rowActive && rRow > 1e-9 * scale); lamE = isE ? l1 : 0.0; polish = 1; continue; }
         if (early) { early = false; polish = 0; continue; }
         break;
       }
@@ -278,6 +289,9 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
     // A late Newton step of a degenerate problem can lose all accuracy (barrier weights ~1e18).  As in the oracle's
     // solveQpIpm: a step that blows the dual residual up or yields NaN is rejected and the previous iterate returned --
     // as converged if its complementarity was already <= 1e-8 * scale, flagged (it = 60) otherwise.
+#ifdef QMGPU_EMU_DEBUG
+    if (lane == 0) printf("EMU ipm NP %d n %d it %d attempt %d polish %d mu/s %.3e nrd/s %.3e nrp/s %.3e scale %.3e\n", NP, n, it, attempt, polish, mu / scale, nrd / scale, nrp / scale, scale);
+#endif
     if (!polish) {
       bool done = false;
       if (it > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) {
@@ -294,7 +308,7 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
         itOut = it;
         const bool c1 = rowActive && l1 > s1, c2 = rowActive && own && l2 > s2;
         isE = c1 && (!own || c2); isV = c1 && own && !c2;
-        lamE = isE ? l1 : 0.0; zIpm = zc; polish = 1; released = false;
+        lamE = isE ? l1 : 0.0; zIpm = zc; polish = 1; corrections = 0;
         continue;                                                    // residuals again, now in polish form (zc may have been restored)
       }
       zcPrev = zc; s1p = s1; l1p = l1; s2p = s2; l2p = l2; vp = v; nrdPrev = nrd; muPrev = mu;

@@ -781,123 +781,124 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     if (level == numLevels - 1) break;
 
     QM_TICK(8);
-    // ---- Z <- Z null(A Z) (HoQp.cpp:126-133): Householder QR of (A Z)^T with dependent columns skipped.  The columns live in registers,
-    //      NL = 8 / 20 / 36 entries (the current null-space dimension n padded, as the interior point's NP): entries >= n are zero
-    auto nullSpace = [&](auto NLc) {
-      constexpr int NL = decltype(NLc)::value;
-      QM_OPAQUE_LDS(double, VhL, Vh);   // one address register + immediate offsets for the reflector table
-      double dcol[NL];
+    // ---- Z <- Z kernel(A Z) (HoQp.cpp:126-133): the reference takes Eigen's FullPivLU::kernel() of A Z, i.e. the basis [-U11^-1 U12; I] in the column
+    //      order full pivoting leaves -- NOT an orthonormal one.  Round 4: the kernels do the same (as the oracle does on the host).  Until
+    //      round 3 a Householder QR gave an orthonormal basis here; the projected optimum is the same, the conditioning of the NEXT level's interior
+    //      point is not: in the LU basis every null vector carries a 1 on one original coordinate, the inherited cone / limit rows stay nearly
+    //      axis-aligned and the normal equations G + (DZ)' W (DZ) keep their accuracy when W reaches 1e14; in the rotated basis the same rows spread
+    //      over all coordinates and the Newton steps lose 5-7 digits (dual residual 1e-8 instead of 1e-15 at mu = 1e-8: start-up branch + trot
+    //      failed all three attempts on the GPU AND in the oracle once it was given an orthonormal basis; profiles/r04_notes.md section 1).
+    //      With the same construction both implementations also solve numerically the SAME level problems (same z coordinates up to rounding).
+    //      Lane i < r owns row i of A Z in LDS (destroyed here); columns are swapped physically, rows stay where they are (rowPos = their
+    //      permuted position).  U row k = the pivot row of step k, entries at column positions >= k.
+    {
+      int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
+      int* colPerm = ip; int* rowOf = ip + 40; int* pivOk = ip + 64; int* freePos = ip + 96;
+      const int size = r < n ? r : n;
+      if (lane < n) colPerm[lane] = lane;
+      QM_WAVE_SYNC();
+      int rowPos = lane;
+      double maxPivot = 0.0;
+      int nonzero = 0;
+      double* row = AZ + (lane < r ? lane : 0) * LDZ;
+      // largest entry of this lane's row over the column positions >= k, first one on ties (the oracle scans positions in increasing order).  Loads in
+      // batches of eight before any store: a store to LDS between two loads of the same array serialises them (the compiler cannot tell the rows apart)
+      double best = -1.0; int bj = 0;
+      if (lane < r) {
+#pragma unroll 1
+        for (int j0 = 0; j0 < n; j0 += 8) {
+          double v[8];
 #pragma unroll
-      for (int i = 0; i < NL; ++i) dcol[i] = (lane < r && i < n) ? AZ[lane * LDZ + i] : 0.0;
-      double n2 = 0.0;
+          for (int q = 0; q < 8; ++q) v[q] = fabs(row[j0 + q < n ? j0 + q : 0]);
 #pragma unroll
-      for (int i = 0; i < NL; ++i) n2 += dcol[i] * dcol[i];
-      const double tol2 = 1e-20 * wbcMax(red, lane, lane < r ? n2 : 0.0);
-      int kk = 0, j0 = 0;
-      // As long as every column so far was independent the rank kk equals the column index j: the steps are unrolled with j as a
-      // compile-time constant, so the entries i < j drop out of every loop instead of being masked one by one against the runtime rank
-      // (a reflector cost ~650 instructions in the generic loop below, which takes over at the first dependent column).
-      bool fast = true;
-#pragma unroll
-      for (int j = 0; j < MAXR; ++j) {
-        if (j < NL && fast && j < r && j < n) {   // wave-uniform
-          if (lane == j) {
-            // This block runs on ONE lane while the wavefront waits: the norm in four partial sums, the scale 2 / v^T v = 1 / (|column| |v_j|) from a reciprocal
-            // square root and a Newton reciprocal (gpu_rt.h) -- before: two dependent sums of NL - j terms, a square root and a division, ~800 cycles per reflector
-            double ma = 0.0, mb = 0.0, mc = 0.0, me = 0.0;
-#pragma unroll
-            for (int i = j; i < NL; ++i) { const double t = dcol[i] * dcol[i]; if (((i - j) & 3) == 0) ma += t; else if (((i - j) & 3) == 1) mb += t; else if (((i - j) & 3) == 2) mc += t; else me += t; }
-            const double m2 = (ma + mb) + (mc + me);
-            ctl[0] = m2;
-            if (m2 > tol2) {
-              const double dk = dcol[j < NL ? j : 0];
-              const double rs = qmRsqrtPos(m2), nrm = m2 * rs, alpha = dk > 0.0 ? -nrm : nrm, vk = dk - alpha;
-#pragma unroll
-              for (int i = 0; i < NL; ++i) VhL[j * 40 + i] = (i > j) ? dcol[i] : ((i == j) ? vk : 0.0);
-              VhL[j * 40 + 36] = rs * qmRcpPos(fabs(vk));
-            }
-          }
-          QM_WAVE_SYNC();
-          const bool indep = ctl[0] > tol2;
-          if (indep) {
-            if (lane > j && lane < r) {
-              double sdot = 0.0;
-#pragma unroll
-              for (int i = j; i < NL; ++i) sdot += VhL[j * 40 + i] * dcol[i];
-              sdot *= VhL[j * 40 + 36];
-#pragma unroll
-              for (int i = j; i < NL; ++i) dcol[i] -= sdot * VhL[j * 40 + i];
-            }
-            kk = j + 1; j0 = j + 1;
-#ifdef QM_RICCATI_TIMING
-            qmTs[19] += 1;
-#endif
-          } else {
-            fast = false; j0 = j;
-          }
-          QM_WAVE_SYNC();
+          for (int q = 0; q < 8; ++q) if (j0 + q < n && v[q] > best) { best = v[q]; bj = j0 + q; }
         }
       }
 #pragma unroll 1
-      for (int j = j0; j < r && kk < n; ++j) {
-#ifdef QM_RICCATI_TIMING
-        qmTs[18] += 1;
-#endif
-        if (lane == j) {
-          double m2 = 0.0, dk = 0.0;
+      for (int k = 0; k < size; ++k) {
+        const bool mine = lane < r && rowPos >= k;
+        const double gmax = qmAllMax(mine ? best : -1.0, red);
+        if (!(gmax > 0.0)) break;
+        // ties between rows: the smallest row position (the oracle's outer scan index)
+        const double key = (mine && best == gmax) ? double(rowPos * 64 + lane) : 1e9;
+        const int kmin = int(qmAllMin(key, red));
+        const int Lp = kmin & 63, pr = kmin >> 6;
+        if (lane == Lp) ctl[0] = double(bj);
+        QM_WAVE_SYNC();
+        const int pc = int(ctl[0]);
+        maxPivot = fmax(maxPivot, gmax);
+        if (lane < r) { if (lane == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
+        if (pc != k && lane < r) { const double t = row[k]; row[k] = row[pc]; row[pc] = t; }
+        if (lane == 0) { const int t = colPerm[k]; colPerm[k] = colPerm[pc]; colPerm[pc] = t; rowOf[k] = Lp; }
+        QM_WAVE_SYNC();
+        // elimination of the rows still below the pivot; the largest entry of the updated row (positions > k) is found on the way: the next step's candidate
+        const double* prow = AZ + Lp * LDZ;
+        best = -1.0; bj = k + 1;
+        if (lane < r && rowPos > k) {
+          const double f = row[k] / prow[k];
+#pragma unroll 1
+          for (int j0 = k + 1; j0 < n; j0 += 8) {
+            double a[8], pv[8];
 #pragma unroll
-          for (int i = 0; i < NL; ++i) { if (i >= kk) m2 += dcol[i] * dcol[i]; if (i == kk) dk = dcol[i]; }
-          ctl[0] = m2;
-          if (m2 > tol2) {
-            const double rs = qmRsqrtPos(m2), nrm = m2 * rs, alpha = dk > 0.0 ? -nrm : nrm, vk = dk - alpha;
+            for (int q = 0; q < 8; ++q) { const int j = j0 + q < n ? j0 + q : k + 1; a[q] = row[j]; pv[q] = prow[j]; }
+            // product and difference rounded separately (no fused multiply-add): the pivot search compares these numbers for EQUALITY of magnitude with
+            // entries of other rows (the level tasks carry unit rows, so exact ties are the rule, not the exception) and must take the decisions the
+            // oracle's kernelFullPivLU takes on the host
 #pragma unroll
-            for (int i = 0; i < NL; ++i) VhL[kk * 40 + i] = (i > kk) ? dcol[i] : ((i == kk) ? vk : 0.0);
-            VhL[kk * 40 + 36] = rs * qmRcpPos(fabs(vk));
+            for (int q = 0; q < 8; ++q) a[q] = qmSubNoFma(a[q], qmMulNoFma(f, pv[q]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (j0 + q < n) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
           }
         }
+        ++nonzero;
         QM_WAVE_SYNC();
-        const bool indep = ctl[0] > tol2;
-        if (indep && lane > j && lane < r) {
-          double s = 0.0;
-#pragma unroll
-          for (int i = 0; i < NL; ++i) s += VhL[kk * 40 + i] * dcol[i];
-          s *= VhL[kk * 40 + 36];
-#pragma unroll
-          for (int i = 0; i < NL; ++i) dcol[i] -= s * VhL[kk * 40 + i];
-        }
-        QM_WAVE_SYNC();
-        if (indep) ++kk;
       }
+      // rank: pivots above Eigen's default threshold eps * size * max pivot; the others' columns count as free
+      const double thresh = maxPivot * 2.220446049250313e-16 * double(size);
+      if (lane < nonzero) pivOk[lane] = fabs(AZ[rowOf[lane] * LDZ + lane]) > thresh ? 1 : 0;
+      QM_WAVE_SYNC();
+      int rank = 0;
+      for (int k = 0; k < nonzero; ++k) rank += pivOk[k];
+      const int nNew = n - rank;
+      if (lane == 0) { int q = 0; for (int pos = 0; pos < n; ++pos) if (!(pos < nonzero && pivOk[pos])) freePos[q++] = pos; }
+      for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;      // N (n x nNew), one kernel vector per lane / column
+      QM_WAVE_SYNC();
       QM_TICK(15);
-      const int rank = kk, nNew = n - rank;
-      // null vectors: Q e_{rank + lane}
-      double nv[NL];
+      {
+        // U11 X = -U12 for this lane's free column: back substitution over the accepted pivots, X(:, lane) in registers (fully unrolled: compile-time
+        // indices), the U entries as wave-uniform LDS reads; the results leave for LDS after the loop (no store between the loads)
+        const int fp = lane < nNew ? freePos[lane] : 0;
+        double xk[MAXR];
 #pragma unroll
-      for (int i = 0; i < NL; ++i) nv[i] = (i == rank + lane && lane < nNew) ? 1.0 : 0.0;
-#pragma unroll 1
-      for (int k = rank - 1; k >= 0; --k) {
-        double s = 0.0;
+        for (int k = MAXR - 1; k >= 0; --k) {
+          xk[k] = 0.0;
+          if (k < nonzero && pivOk[k]) {   // wave-uniform
+            const double* urow = AZ + rowOf[k] * LDZ;
+            double u[MAXR];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) s += VhL[k * 40 + i] * nv[i];
-        s *= VhL[k * 40 + 36];
+            for (int k2 = k + 1; k2 < MAXR; ++k2) u[k2] = urow[k2 < n ? k2 : 0];
+            double sacc = fp >= k ? -urow[fp] : 0.0;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) nv[i] -= s * VhL[k * 40 + i];
-      }
-      QM_TICK(16);
-      // Z N on the matrix cores: the null vectors (one per lane) pass through LDS (the K scratch is free here)
-      if (lane < nNew) {
+            for (int k2 = k + 1; k2 < MAXR; ++k2) sacc -= (k2 < nonzero ? u[k2] : 0.0) * xk[k2];
+            xk[k] = sacc / urow[k];
+          }
+        }
+        if (lane < nNew) {
 #pragma unroll
-        for (int q = 0; q < NL; ++q) K[q * LDK + lane] = nv[q];
+          for (int k = 0; k < MAXR; ++k) if (k < nonzero && pivOk[k]) K[colPerm[k] * LDK + lane] = xk[k];
+          K[colPerm[fp] * LDK + lane] = 1.0;
+        }
       }
       QM_WAVE_SYNC();
-      forkGemm(false, Z, LDZ, K, LDK, ND, nNew, NL, Zn, LDZ, 0.0);   // columns >= n of Z are zero: NL terms
+      QM_TICK(16);
+      // Z N on the matrix cores (columns >= n of Z are zero, rows >= n of N too)
+      forkGemm(false, Z, LDZ, K, LDK, ND, nNew, n, Zn, LDZ, 0.0);
       QM_WAVE_SYNC();
       for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
       n = nNew;
       QM_WAVE_SYNC();
       QM_TICK(17);
-    };
-    if (n <= 8) nullSpace(std::integral_constant<int, 8>{}); else if (n <= 20) nullSpace(std::integral_constant<int, 20>{}); else nullSpace(std::integral_constant<int, ND>{});
+    }
     if (level == 0) QM_WBC_CHECKPOINT(5);   // Z after the first null space
     if (level == 1) QM_WBC_CHECKPOINT(6);
   }

@@ -19,7 +19,23 @@ WBC_PERIOD = 0.001       # ros_control update rate of the controller (1 kHz)
 HORIZON = 1.0            # timeHorizon (task.info:141)
 
 
-class Scenario:
+class Disturbance:
+    """a sin(w t + phi) per instance and coordinate on the measured configuration / velocities (smooth, so that the measurement of a plan follower stays
+    differentiable); amplitudes 2-4 mm / mrad and 2-4 cm/s / crad/s"""
+
+    def __init__(self, batch, rng):
+        self.amp_q = np.c_[np.full((batch, 3), 0.002), np.full((batch, 3), 0.003), np.full((batch, 18), 0.004)] * rng.uniform(0.3, 1.0, (batch, 24))
+        self.amp_v = np.c_[np.full((batch, 3), 0.02), np.full((batch, 3), 0.02), np.full((batch, 18), 0.04)] * rng.uniform(0.3, 1.0, (batch, 24))
+        self.om = rng.uniform(2.0, 9.0, (batch, 24)); self.ph_q = rng.uniform(0, 2 * np.pi, (batch, 24)); self.ph_v = rng.uniform(0, 2 * np.pi, (batch, 24))
+
+    def dq(self, t):
+        return self.amp_q * np.sin(self.om * t + self.ph_q)
+
+    def dv(self, t):
+        return self.amp_v * np.sin(self.om * t + self.ph_v)
+
+
+class Scenario(Disturbance):
     """Seeded batch: initial poses (xy, yaw, joints perturbed), two target knots spanning the run (base + end-effector displaced), stance then trot,
     a start time just before the WBC's start-up branch ends (t = 10 s, HierarchicalWbc.cpp:23), smooth per-coordinate disturbances."""
 
@@ -52,22 +68,13 @@ class Scenario:
         ev = np.array(ev); md = np.array(md, dtype=np.int32)
         assert md[0] == 15 and nev <= abi.MAX_EVENTS          # the tiler puts the default STANCE mode in front of the template's first phase
         self.nev, self.ev, self.md = int(nev), ev, md
-        # disturbances: a sin(w t + phi) per instance and coordinate (smooth, so that a finite-difference velocity of the measurement stays small)
-        self.amp_q = np.c_[np.full((batch, 3), 0.002), np.full((batch, 3), 0.003), np.full((batch, 18), 0.004)] * rng.uniform(0.3, 1.0, (batch, 24))
-        self.amp_v = np.c_[np.full((batch, 3), 0.02), np.full((batch, 3), 0.02), np.full((batch, 18), 0.04)] * rng.uniform(0.3, 1.0, (batch, 24))
-        self.om = rng.uniform(2.0, 9.0, (batch, 24)); self.ph_q = rng.uniform(0, 2 * np.pi, (batch, 24)); self.ph_v = rng.uniform(0, 2 * np.pi, (batch, 24))
+        Disturbance.__init__(self, batch, rng)
         self.lib = itf.lib
 
     def grid(self, t0):
         """event-aligned shooting grid of one MPC cycle (the same for every instance: they share the gait): (N, grid[N + 1])"""
         from qm_door_amd import api
         return api.time_grid_with_events(t0, t0 + self.horizon, self.dt, self.ev[:self.nev], max_nodes=self.max_nodes, lib=self.lib)
-
-    def dq(self, t):
-        return self.amp_q * np.sin(self.om * t + self.ph_q)
-
-    def dv(self, t):
-        return self.amp_v * np.sin(self.om * t + self.ph_v)
 
     def first_measurement(self):
         return pack_rbd(self.q0 + self.dq(self.t_start), self.v0 + self.dv(self.t_start))
@@ -216,12 +223,14 @@ class OracleBackend:
         xd, ud, md = self.o.policy_eval_batch(self.plan["T"], self.plan["X"], self.plan["U"], self.plan["mode"], t)
         w = self.o.wbc_batch(xd, ud, rbd, md, WBC_PERIOD, time, self.il, self.variant)
         self.il = w["input_last"]
-        return dict(out=w["out"], status=w["status"], mode=md, input_last=self.il)
+        return dict(out=w["out"], status=w["status"], mode=md, input_last=self.il, attempts=w["attempts"], polished=w["polished"], iterations=w["iterations"])
 
 
-def run_lockstep(sc, a, b, ticks=10, on_cycle=None):
+def run_lockstep(sc, a, b, ticks=10, on_cycle=None, offenders=None, tol=1e-6):
     """Both backends through sc.cycles MPC cycles x `ticks` WBC ticks, each on its OWN plan and measurements; returns per-cycle deviations (rel-inf per
-    instance, worst over the batch) and the agreement of the discrete outcomes."""
+    instance, worst over the batch) and the agreement of the discrete outcomes.  `offenders` (a list) receives one record per (cycle, tick, instance)
+    whose torques deviate by more than `tol` or whose WBC status words are non-zero / differ, with the second backend's diagnostics when it has any
+    (the oracle's re-solve attempts, polish flags and iteration counts per level)."""
     from support import rel_inf
     rows = []
     rbd = [sc.first_measurement(), sc.first_measurement()]
@@ -249,6 +258,14 @@ def run_lockstep(sc, a, b, ticks=10, on_cycle=None):
             row["xacc"] = max(row["xacc"], float(rel_inf(wa["out"][:, :36], wb["out"][:, :36]).max()))
             row["wbc_status"] = [row["wbc_status"][0] + int((wa["status"] != 0).sum()), row["wbc_status"][1] + int((wb["status"] != 0).sum())]
             row["policy_mode_differs"] += int((wa["mode"] != wb["mode"]).sum())
+            if offenders is not None:
+                e = rel_inf(wa["out"][:, 36:], wb["out"][:, 36:])
+                for i in np.nonzero((e > tol) | (wa["status"] != 0) | (wb["status"] != 0))[0]:
+                    rec = dict(cycle=k, tick=j, instance=int(i), time=float(t), tau_dev=float(e[i]), status=[int(wa["status"][i]), int(wb["status"][i])], mode=int(wb["mode"][i]))
+                    for key in ("attempts", "polished", "iterations"):
+                        if key in wb:
+                            rec[key] = wb[key][i].tolist()
+                    offenders.append(rec)
         # the measurement the next cycle starts from: each loop's own plan at the next MPC time
         for s in range(2):
             rbd[s] = measurement(sc, plans[s], t0 + MPC_PERIOD)

@@ -167,6 +167,8 @@ inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 
 inline double qmRsqrt(double x) { return 1.0 / std::sqrt(x); }
 inline float qmRsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline double qmRsqrtPos(double x) { return 1.0 / std::sqrt(x); }
+inline double qmMulNoFma(double a, double b) { volatile double p = a * b; return p; }
+inline double qmSubNoFma(double a, double b) { volatile double d = a - b; return d; }
 inline float qmRsqrtPos(float x) { return 1.0f / std::sqrt(x); }
 inline double qmRcpPos(double x) { return 1.0 / x; }
 inline float qmRcpPos(float x) { return 1.0f / x; }
