@@ -357,6 +357,9 @@ int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transiti
       ev.push_back(t);
     }
   }
+  // a truncated tiling that did not overflow is a template without mode changes (every cycle merged away): the default final phase still starts at
+  // the end of the last WHOLE cycle at or after t_end, not where the bounded loop happened to stop (a one-mode non-stance template with a short period)
+  if (truncated && t < t_end) { t += std::ceil((t_end - t) / period) * period; ev.back() = t; }
   md.push_back(15);  // default final phase
   // merge equal neighbouring modes (e.g. a pure stance template)
   std::vector<double> ev2;
@@ -367,7 +370,6 @@ int qmgpu_switch_gait(const qmgpu_gait* gait, int32_t prev_mode, double transiti
     md2.push_back(md[i + 1]);
   }
   if (int(ev2.size()) > QMGPU_MAX_EVENTS) return setError(QMGPU_ERR_CAPACITY, "mode schedule needs more than QMGPU_MAX_EVENTS events");
-  (void)truncated;   // a truncated tiling that did not overflow is a template without mode changes: complete as it is
   *num_events = int(ev2.size());
   for (size_t i = 0; i < ev2.size(); ++i) event_times[i] = ev2[i];
   for (size_t i = 0; i < md2.size(); ++i) modes[i] = md2[i];

@@ -190,6 +190,8 @@ __global__ void __launch_bounds__(64) gait_schedule_kernel(GaitArgs a) {
       evTime = t;
     }
   }
+  // bounded loop ended before tEnd without overflowing: a template without mode changes -- the final phase starts after the last WHOLE cycle (host_config.cpp)
+  if (t < tEnd && !overflow) { const double period = g.switching_times[g.num_modes] - g.switching_times[0]; evTime = t + ceil((tEnd - t) / period) * period; }
   push(evTime, 15);   // default final phase
   if (overflow) { stanceOnly(QMGPU_ERR_CAPACITY); return; }
   a.numEvents[i] = n;

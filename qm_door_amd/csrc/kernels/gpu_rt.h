@@ -39,6 +39,7 @@ __device__ __forceinline__ real qmReadLane(real v, int src, real* = nullptr) {
   const int hi = sizeof(real) == 8 ? __builtin_amdgcn_readlane(qmHiWord(v), src) : 0;
   return qmFromWords(lo, hi, real());
 }
+__device__ __forceinline__ int qmReadLaneInt(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 // One 16x16x4 matrix-core instruction: C[16x16] += A[16x4] B[4x16]  (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).
 // Operand layout (both types; measured on gfx950 for fp64, tools/probe_mfma.hip): lane l supplies a = A[l % 16][l / 16] and
 // b = B[l / 16][l % 16].  The accumulators differ: register r of lane l is

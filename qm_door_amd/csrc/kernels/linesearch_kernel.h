@@ -192,7 +192,8 @@ __device__ __forceinline__ void axpyStrided(real* out, const real* x, const real
 #pragma unroll
     for (int q = 0; q < UN; ++q) { QM_KEEP(xv[q]); QM_KEEP(dv[q]); }
 #pragma unroll
-    for (int q = 0; q < UN; ++q) { const int e = base + q * stride; if (e < n) out[e] = xv[q] + alpha * dv[q]; }
+    // alpha == 0 (no trial accepted, or a failed factorisation: the direction may hold Inf / NaN from pivots replaced by 1): the iterate itself, not x + 0 * dx
+    for (int q = 0; q < UN; ++q) { const int e = base + q * stride; if (e < n) out[e] = alpha == 0.0_r ? xv[q] : xv[q] + alpha * dv[q]; }
   }
 }
 // sum of squares of v[first], v[first + stride], ..., eight loads in flight
@@ -239,8 +240,8 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   real* Xt = a.trialInLds ? trialLds + size_t(myTr) * (2 * N + 1) * 30 : a.Xt + (size_t(inst) * 2 + myTr) * (N + 1) * 30;
   real* Ut = a.trialInLds ? Xt + (N + 1) * 30 : a.Ut + (size_t(inst) * 2 + myTr) * N * 30;
 
-  // the weights into LDS; while copying, every thread checks its entries against the structured pattern (nodePerformance: weightStructure): any entry outside it
-  // clears the flag (ctl[7], set by thread 0 before this kernel's first barrier... it is initialised below by the thread that owns entry 0)
+  // the weights into LDS; while copying, every thread checks its entries against the structured pattern (nodePerformance: weightStructure) and records a vote
+  // (structVotes[tid] = 1: an entry outside the pattern); thread 0 combines the votes below, after the barrier, into ctl[7] = 1 (structured) / 0 (dense forms)
   {
     bool outside = false;
     real qv[4], rv4[4];   // (900 = 3.5 x 256: four entries per thread, all eight loads first)

@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       else cdv[r] = ad[AD_CD + (r < nc ? r : firstStored) * 64 + lane];     // (rows >= nc re-read a row that exists; their values are never used)
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) eev[q] = (lane < 30 || lane >= 48) ? ad[AD_EE + q * 64 + lane] : 0.0_r;   // columns 30..59 of a state-only row are zero and not stored (ad_kernel.h: putGlobal): lanes 48..59 fetch the line of the value column and are ignored
+    for (int q = 0; q < 6; ++q) eev[q] = (lane < 30 || lane >= 60) ? ad[AD_EE + q * 64 + lane] : 0.0_r;   // columns 30..59 of a state-only row are zero and NOT stored (ad_kernel.h: putGlobal): those words of the buffer are undefined and are not loaded
     // [C | D_v]: state columns from lanes 0..29, joint-velocity columns (inputs 12..29) from lanes 42..59, e from lane 60.  The
     // force columns of D are not kept: a zero-force row is a unit vector there, a velocity row is zero (see the projection below).
 #pragma unroll

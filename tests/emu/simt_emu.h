@@ -95,6 +95,7 @@ template <int G, class T> inline T qmReplicateRow(T v, T* = nullptr) {   // ds_b
 }
 template <class T> inline T qmReplicateRow0(T v, T* s = nullptr) { return qmReplicateRow<0>(v, s); }
 template <class T> inline T qmHalfXor32(T v, bool) { return qmShflXor(v, 32); }   // v_permlane32_swap
+inline int qmReadLaneInt(int v, int src);
 template <class T> inline T qmRowXor16(T v, bool) { return qmShflXor(v, 16); }    // v_permlane16_swap
 
 template <class T> inline T qmReadLane(T v, int src, T* scratch = nullptr) {
@@ -104,6 +105,7 @@ template <class T> inline T qmReadLane(T v, int src, T* scratch = nullptr) {
   QM_WAVE_SYNC();
   return T(buf[unsigned(src) & 63u]);
 }
+inline int qmReadLaneInt(int v, int src) { return qmReadLane<int>(v, src); }
 
 template <class T> struct QmGatherT {
   T vals[64];

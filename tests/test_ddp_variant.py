@@ -79,9 +79,9 @@ def test_gpu_ddp_matches_oracle_n100(interface, oracle):
     for i in range(B):     # every instance.  An open-loop rollout that leaves the neighbourhood of the nominal posture has amplified the rounding
         ref = oracle.ddp_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)   # differences of the two implementations: |x| <= 3 is held to the
         top = np.abs(ref["X"]).max()                                         # north_star 1e-6, 3 < |x| <= 30 to 1e-3, and a rollout that has blown up
-        if top > 30.0:                                                       # (|x| in the hundreds) only to step length / trial count / status
-            blown += 1
-            assert np.array_equal(r["mode"][i], ref["mode"]) and r["stats"][i][4] == ref["stats"][4] and r["stats"][i][5] == ref["stats"][5] and r["stats"][i][7] == 0
+        if top > 30.0:                                                       # (|x| in the hundreds) to step length / trial count / status and, RELATIVE to
+            blown += 1                                                       # its own size, to 1e-3 (_check's tolerances scale with max |x|): no instance goes unchecked
+            _check(r, i, ref, 1e-3)
             continue
         diverging += top > 3.0
         _check(r, i, ref, 1e-3 if top > 3.0 else 1e-6)

@@ -66,6 +66,25 @@ def test_emu_gait_schedule_matches_host_tiler():
     _check(gs, names, idx, t_phase0, t_begin, t_end, n, ev, md, st, np.full(B, 15), trans)
 
 
+def test_one_mode_non_stance_template_with_a_short_period_keeps_its_mode_until_t_end():
+    """a template whose modes are all equal but not STANCE, tiled over more than MAX_EVENTS + 2 periods: the bounded loop stops early without
+    overflowing (every cycle merges away); the default final STANCE must still begin at the end of the last whole cycle at or after t_end -- not where the
+    loop stopped, which would put a spurious switch to STANCE inside the horizon.  Host and device tilers, bit-identical."""
+    lib = abi.load_library(S.build_emu())
+    itf = api.QMInterface(lib=lib)
+    g = api.GaitSchedule(lib=lib).template("trot")
+    g.num_modes = 2; g.modes[0] = 9; g.modes[1] = 9
+    g.switching_times[0] = 0.0; g.switching_times[1] = 0.01; g.switching_times[2] = 0.02          # period 0.02: 500 periods in 10 s
+    n = abi.i32(0); ev = (abi.d * abi.MAX_EVENTS)(); md = (abi.i32 * (abi.MAX_EVENTS + 1))()
+    abi.check(lib, lib.qmgpu_tile_gait(C.byref(g), 1.0, 1.0, 11.0, C.byref(n), ev, md))
+    assert n.value == 2 and list(md[:3]) == [15, 9, 15] and ev[0] == 1.0
+    assert 11.0 <= ev[1] <= 11.0 + 0.02 + 1e-12                     # the one switch back to STANCE lies at / after t_end
+    sol = api.GpuSolver(itf, max_batch=4, max_nodes=4)
+    nn, e2, m2, st = np.zeros(1, dtype=np.int32), np.zeros((1, abi.MAX_EVENTS)), np.zeros((1, abi.MAX_EVENTS + 1), dtype=np.int32), np.zeros(1, dtype=np.int32)
+    sol.gait_schedule([g], np.zeros(1, dtype=np.int32), np.array([1.0]), np.array([1.0]), np.array([11.0]), nn, e2, m2, st)
+    assert st[0] == 0 and nn[0] == 2 and np.array_equal(e2[0], np.array(ev[:])) and np.array_equal(m2[0], np.array(md[:], dtype=np.int32))
+
+
 def test_gait_switch_inserts_the_transition_stance():
     """Hand-checked: a trot command arriving during RF_LH (6): STANCE for phaseTransitionStanceTime, then LF_RH / RF_LH cycles; arriving during
     LF_RH (9, the template's first mode) or during STANCE: no transition phase (upstream GaitSchedule::insertModeSequenceTemplate)."""

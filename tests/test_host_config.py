@@ -163,3 +163,29 @@ def test_bench_cpu_baseline_leg_runs(interface):
         bench.HORIZON_N = saved
     assert out["kind"] == "port" and out["unit"] == "cycles/s" and np.isfinite(out["value"]) and out["value"] > 0 and out["cores"] >= 1
     assert out["one_thread"] > 0 and out["three_threads_over_nodes"] > 0 and abs(sum(out["one_thread_split_percent"].values()) - 100.0) < 0.1
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "qm_controllers", "config")), reason="the reference tree is not mounted (GPU boxes)")
+def test_loader_reads_the_reference_own_files_into_the_same_problem(hip_lib):
+    """the oracle receives its problem through the product's loader, and the product ships values DISTILLED from the reference's files
+    (tools/distill_reference_config.py).  Where the reference tree is mounted, qmgpu_load_problem on the maintainer's ORIGINAL task.info / robot.urdf /
+    reference.info (gains NULL: the task file carries them) must produce, byte for byte, the qmgpu_problem it produces from qm_door_amd/data/."""
+    import glob
+    cfg = os.path.join(REFERENCE, "qm_controllers", "config")
+    task, ref = os.path.join(cfg, "task.info"), os.path.join(cfg, "reference.info")
+    urdfs = [p for p in glob.glob(os.path.join(REFERENCE, "**", "*.urdf"), recursive=True) if "robot" in os.path.basename(p) or "aliengo" in os.path.basename(p).lower()]
+    assert os.path.exists(task) and os.path.exists(ref) and urdfs, (task, ref, urdfs)
+    d = abi.DATA_DIR.encode()
+    ours = abi.Problem()
+    assert hip_lib.qmgpu_load_problem(d + b"/task.info", d + b"/aliengo_z1.urdf", d + b"/reference.info", None, C.byref(ours)) == 0, hip_lib.qmgpu_last_error()
+    matched = []
+    for urdf in urdfs:
+        theirs = abi.Problem()
+        if hip_lib.qmgpu_load_problem(task.encode(), urdf.encode(), ref.encode(), None, C.byref(theirs)) != 0:
+            continue
+        if bytes(theirs) == bytes(ours):
+            matched.append(urdf)
+    assert matched, ("no URDF of the reference tree reproduces the shipped problem", urdfs)

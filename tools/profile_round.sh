@@ -8,10 +8,10 @@ set -u
 tag=$1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/pmc_${tag}_sq -o pmc -- python $R/bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch -o pmc -- python $R/bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write -o pmc -- python $R/bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench -- python $R/bench.py --no-cpu-baseline --no-steady-state > $R/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/pmc_${tag}_sq -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 5 > /dev/null 2>&1
 cd $R
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 tail -1 gpurun_out/bench_$tag.json
