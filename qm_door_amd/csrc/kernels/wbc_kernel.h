@@ -789,28 +789,31 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     //      over all coordinates and the Newton steps lose 5-7 digits (dual residual 1e-8 instead of 1e-15 at mu = 1e-8: start-up branch + trot
     //      failed all three attempts on the GPU AND in the oracle once it was given an orthonormal basis; profiles/r04_notes.md section 1).
     //      With the same construction both implementations also solve numerically the SAME level problems (same z coordinates up to rounding).
-    //      Rows stay in their lanes (rowPos = their permuted position), columns are swapped physically.
-    auto nullSpaceLU = [&](auto NLc) {
-      // NL = the null-space dimension n padded (8 / 20 / 36, as the interior point's NP): lane i < r keeps row i of A Z in NL registers; columns are
-      // swapped physically (selects on the wave-uniform indices), the pivot row of a step reaches the other lanes by v_readlane -- no LDS on the
-      // dependent chain of a step except the two all-reduces.  U row k = the registers of lane rowOf[k], columns >= k.
-      constexpr int NL = decltype(NLc)::value;
-      constexpr int NR = NL < MAXR ? NL : MAXR;      // pivots: at most min(r, n)
-      int* ip = reinterpret_cast<int*>(Vh);          // colPerm[36] | rowOf[MAXR]  (the reflector table of round 3: free here)
-      int* colPerm = ip; int* rowOf = ip + 40;
+    //      Lane i < r owns row i of A Z in LDS (destroyed here); columns are swapped physically, rows stay where they are (rowPos = their
+    //      permuted position).  U row k = the pivot row of step k, entries at column positions >= k.
+    {
+      int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
+      int* colPerm = ip; int* rowOf = ip + 40; int* pivOk = ip + 64; int* freePos = ip + 96;
       const int size = r < n ? r : n;
       if (lane < n) colPerm[lane] = lane;
-      double av[NL];
-#pragma unroll
-      for (int j = 0; j < NL; ++j) av[j] = (lane < r && j < n) ? AZ[lane * LDZ + j] : 0.0;
       QM_WAVE_SYNC();
       int rowPos = lane;
       double maxPivot = 0.0;
       int nonzero = 0;
-      // largest entry of this lane's row over the column positions >= k, first one on ties (the oracle scans positions in increasing order)
+      double* row = AZ + (lane < r ? lane : 0) * LDZ;
+      // largest entry of this lane's row over the column positions >= k, first one on ties (the oracle scans positions in increasing order).  Loads in
+      // batches of eight before any store: a store to LDS between two loads of the same array serialises them (the compiler cannot tell the rows apart)
       double best = -1.0; int bj = 0;
+      if (lane < r) {
+#pragma unroll 1
+        for (int j0 = 0; j0 < n; j0 += 8) {
+          double v[8];
 #pragma unroll
-      for (int j = 0; j < NL; ++j) { const double v = fabs(av[j]); if (j < n && v > best) { best = v; bj = j; } }
+          for (int q = 0; q < 8; ++q) v[q] = fabs(row[j0 + q < n ? j0 + q : 0]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (j0 + q < n && v[q] > best) { best = v[q]; bj = j0 + q; }
+        }
+      }
 #pragma unroll 1
       for (int k = 0; k < size; ++k) {
         const bool mine = lane < r && rowPos >= k;
@@ -820,73 +823,69 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         const double key = (mine && best == gmax) ? double(rowPos * 64 + lane) : 1e9;
         const int kmin = int(qmAllMin(key, red));
         const int Lp = kmin & 63, pr = kmin >> 6;
-        const int pc = qmReadLaneInt(bj, Lp);
+        if (lane == Lp) ctl[0] = double(bj);
+        QM_WAVE_SYNC();
+        const int pc = int(ctl[0]);
         maxPivot = fmax(maxPivot, gmax);
-        if (lane == Lp) rowPos = k; else if (rowPos == k) rowPos = pr;
+        if (lane < r) { if (lane == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
+        if (pc != k && lane < r) { const double t = row[k]; row[k] = row[pc]; row[pc] = t; }
         if (lane == 0) { const int t = colPerm[k]; colPerm[k] = colPerm[pc]; colPerm[pc] = t; rowOf[k] = Lp; }
-        // column swap k <-> pc in every row (finished rows too: they are the U rows)
-        double ak = 0.0, apc = 0.0;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) { if (j == k) ak = av[j]; if (j == pc) apc = av[j]; }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) av[j] = (j == k) ? apc : ((j == pc) ? ak : av[j]);
-        // the pivot row, wave-uniform
-        double pv[NL], pk = 1.0;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) { pv[j] = qmReadLane(av[j], Lp, red); if (j == k) pk = pv[j]; }
-        // elimination of the rows still below the pivot; the largest entry of the updated row (positions > k) is found on the way: the next step's
-        // candidate.  Product and difference rounded separately (no fused multiply-add): the pivot search compares these numbers for EQUALITY of
-        // magnitude with entries of other rows (the level tasks carry unit rows: exact ties are the rule) and must take the oracle's decisions
+        QM_WAVE_SYNC();
+        // elimination of the rows still below the pivot; the largest entry of the updated row (positions > k) is found on the way: the next step's candidate
+        const double* prow = AZ + Lp * LDZ;
         best = -1.0; bj = k + 1;
         if (lane < r && rowPos > k) {
-          const double f = apc / pk;
+          const double f = row[k] / prow[k];
+#pragma unroll 1
+          for (int j0 = k + 1; j0 < n; j0 += 8) {
+            double a[8], pv[8];
 #pragma unroll
-          for (int j = 0; j < NL; ++j) {
-            const double t = qmSubNoFma(av[j], qmMulNoFma(f, pv[j]));
-            if (j > k && j < n) { av[j] = t; const double v = fabs(t); if (v > best) { best = v; bj = j; } }
+            for (int q = 0; q < 8; ++q) { const int j = j0 + q < n ? j0 + q : k + 1; a[q] = row[j]; pv[q] = prow[j]; }
+            // product and difference rounded separately (no fused multiply-add): the pivot search compares these numbers for EQUALITY of magnitude with
+            // entries of other rows (the level tasks carry unit rows, so exact ties are the rule, not the exception) and must take the decisions the
+            // oracle's kernelFullPivLU takes on the host
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = qmSubNoFma(a[q], qmMulNoFma(f, pv[q]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (j0 + q < n) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
           }
         }
         ++nonzero;
+        QM_WAVE_SYNC();
       }
-      QM_WAVE_SYNC();
       // rank: pivots above Eigen's default threshold eps * size * max pivot; the others' columns count as free
       const double thresh = maxPivot * 2.220446049250313e-16 * double(size);
-      unsigned okMask = 0u;
+      if (lane < nonzero) pivOk[lane] = fabs(AZ[rowOf[lane] * LDZ + lane]) > thresh ? 1 : 0;
+      QM_WAVE_SYNC();
       int rank = 0;
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        if (k < nonzero) {   // wave-uniform
-          const double d = qmReadLane(av[k], rowOf[k], red);
-          if (fabs(d) > thresh) { okMask |= 1u << k; ++rank; }
-        }
-      }
+      for (int k = 0; k < nonzero; ++k) rank += pivOk[k];
       const int nNew = n - rank;
-      int fp = 0;
-      { int cnt = 0; for (int pos = 0; pos < n; ++pos) { const bool isP = pos < nonzero && ((okMask >> pos) & 1u); if (!isP) { if (cnt == lane) fp = pos; ++cnt; } } }
+      if (lane == 0) { int q = 0; for (int pos = 0; pos < n; ++pos) if (!(pos < nonzero && pivOk[pos])) freePos[q++] = pos; }
       for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;      // N (n x nNew), one kernel vector per lane / column
       QM_WAVE_SYNC();
       QM_TICK(15);
       {
-        // U11 X = -U12 for this lane's free column fp: back substitution over the accepted pivots, X(:, lane) in registers; row k of U arrives by v_readlane
-        double xk[NR];
+        // U11 X = -U12 for this lane's free column: back substitution over the accepted pivots, X(:, lane) in registers (fully unrolled: compile-time
+        // indices), the U entries as wave-uniform LDS reads; the results leave for LDS after the loop (no store between the loads)
+        const int fp = lane < nNew ? freePos[lane] : 0;
+        double xk[MAXR];
 #pragma unroll
-        for (int k = NR - 1; k >= 0; --k) {
+        for (int k = MAXR - 1; k >= 0; --k) {
           xk[k] = 0.0;
-          if (k < nonzero && ((okMask >> k) & 1u)) {   // wave-uniform
-            const int rk = rowOf[k];
-            double u12 = 0.0, ukk = 1.0, sacc = 0.0;
+          if (k < nonzero && pivOk[k]) {   // wave-uniform
+            const double* urow = AZ + rowOf[k] * LDZ;
+            double u[MAXR];
 #pragma unroll
-            for (int j = k; j < NL; ++j) {
-              const double t = qmReadLane(av[j], rk, red);
-              if (j == k) ukk = t;
-              else { if (j == fp) u12 = t; if (j < NR) sacc += t * xk[j]; }
-            }
-            xk[k] = (-u12 - sacc) / ukk;
+            for (int k2 = k + 1; k2 < MAXR; ++k2) u[k2] = urow[k2 < n ? k2 : 0];
+            double sacc = fp >= k ? -urow[fp] : 0.0;
+#pragma unroll
+            for (int k2 = k + 1; k2 < MAXR; ++k2) sacc -= (k2 < nonzero ? u[k2] : 0.0) * xk[k2];
+            xk[k] = sacc / urow[k];
           }
         }
         if (lane < nNew) {
 #pragma unroll
-          for (int k = 0; k < NR; ++k) if (k < nonzero && ((okMask >> k) & 1u)) K[colPerm[k] * LDK + lane] = xk[k];
+          for (int k = 0; k < MAXR; ++k) if (k < nonzero && pivOk[k]) K[colPerm[k] * LDK + lane] = xk[k];
           K[colPerm[fp] * LDK + lane] = 1.0;
         }
       }
@@ -899,8 +898,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       n = nNew;
       QM_WAVE_SYNC();
       QM_TICK(17);
-    };
-    if (n <= 8) nullSpaceLU(std::integral_constant<int, 8>{}); else if (n <= 20) nullSpaceLU(std::integral_constant<int, 20>{}); else nullSpaceLU(std::integral_constant<int, ND>{});
+    }
     if (level == 0) QM_WBC_CHECKPOINT(5);   // Z after the first null space
     if (level == 1) QM_WBC_CHECKPOINT(6);
   }

@@ -471,7 +471,7 @@ def parity_report(name, got, ref, keys=("X", "U"), tau=True, record=True):
 
 def assert_parity(rep, tol=1e-6, tau_tol=1e-6, tau_outliers=0, tau_outlier_tol=1e-4):
     """north_star bar: X, U, tau within 1e-6 rel-inf on EVERY instance, modes / step lengths / step types exact.  `tau_outliers`: how many instances
-    may exceed tau_tol (never tau_outlier_tol) -- only the moving-robot force-tracking batch uses it (one instance of 1024 whose level-1 QP ends unpolished
+    may exceed tau_tol (never tau_outlier_tol) -- only the moving-robot force-tracking batch uses it (at most two instances of 1024 whose level-1 QP ends unpolished
     on both sides: its weakly weighted base rows, singular value 0.02 of A Z against 60 for the x100 swing rows, amplify the interior point's 1e-13 * scale
     dual residual to ~1e-6 in the torques)."""
     B = rep["instances"]
