@@ -87,7 +87,8 @@ constexpr int ADL_X2 = ADL_XU + AD_NODES * 64;         // [3][12]  x + dt k1, mo
 constexpr int ADL_A2 = ADL_X2 + AD_NODES * 12;         // [3][12][16] J2[:, 0:12] (operand of the chain-rule product), columns 12..15 zero
 constexpr int ADL_PARK = ADL_A2 + AD_NODES * 12 * 16;  // feet of the first stage [4][15][64]  /  J1 then J1 + J2 + ... [3][12][64]
 constexpr int AD_PARK_DOUBLES = 4 * 15 * 64;
-constexpr int AD_LDS_DOUBLES = ADL_PARK + AD_PARK_DOUBLES;
+constexpr int ADL_PUB = ADL_PARK + AD_PARK_DOUBLES;    // [3][119] primal composites of the five kinematic chains of each node (sweep_dev.h: centroidalSweepOwnChain)
+constexpr int AD_LDS_DOUBLES = ADL_PUB + AD_NODES * SWEEP_PUB_NODE;
 static_assert(AD_NODES * 12 * 64 <= AD_PARK_DOUBLES, "the Jacobian rows reuse the parking area");
 static_assert(AD_LDS_DOUBLES * sizeof(real) <= 40960, "four wavefronts per CU");
 
@@ -173,8 +174,9 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
     const AdIn in{x, u, stage ? x2 : x, dd, stage ? dt : 0.0_r};
     FlowOut<Du, Du3, Du3> f;
     BaseMotion2<Du, Du3> bm;
-    centroidalSweep2<Du, Du3, Du3>(
-        md, st.gravity, in,
+    QM_WAVE_SYNC();   // (the published composites of the previous stage have been read by every lane)
+    centroidalSweepOwnChain(
+        md, st.gravity, in, dd, lds + ADL_PUB + grp * SWEEP_PUB_NODE,
         [&](int c, Vec3<Du> r, Vec3<Du3> v) {
           QM_TICK(stage ? 3 : 1);
           if (stage == 0) {

@@ -174,6 +174,120 @@ __device__ __forceinline__ void centroidalSweep2(const ModelR& md, real gravity,
   for (int i = 0; i < 6; ++i) hn[i] = in.hn(i);
   closeSweep2<P, V, F>(md, gravity, acc, hn, fsum, tsum, sz, cz, sy, cy, f, bm);
 }
+// ---- the sweep of ad_node_kernel, round 4: every lane walks ONLY the kinematic chain of its own direction -------------------------------------
+// A joint tangent is non-zero in its own chain only (the chains are accumulated in the base frame; the base Euler angles enter afterwards through R0), so of
+// the 18 joint crossings centroidalSweep2 makes in every lane, 15 (leg lanes) or 12 (arm lanes) multiply zero tangents, and the three base-angle lanes need no
+// chain tangent at all.  Here the arm lanes (dd 15..20) walk the arm, every other lane ONE leg ((dd - 3) / 3; the base-angle lanes leg 0, as passengers): two
+// divergent regions of 6 and 3 crossings instead of 18 in every lane.  The PRIMAL composites of the five chains are published through LDS by one lane each
+// (`pub`: this node's 4 x 22 + 31 doubles; the publishing lane executes the same instruction stream on the same inputs as every other lane of its chain, so the
+// published values are the ones those lanes hold) and the totals are the published primal parts plus the lane's own tangents.
+constexpr int SWEEP_PUB_LEG = 22, SWEEP_PUB_ARM = 31, SWEEP_PUB_NODE = 4 * SWEEP_PUB_LEG + SWEEP_PUB_ARM;
+template <class In, class FootFn, class EeFn>
+__device__ __forceinline__ void centroidalSweepOwnChain(const ModelR& md, real gravity, const In& in, int dd, real* pub, FootFn&& onFoot, EeFn&& onEE, FlowOut<Du, Du3, Du3>& f,
+                                                        BaseMotion2<Du, Du3>& bm) {
+  using P = Du; using V = Du3;
+  P sz, cz, sy, cy;
+  Mat3<P> R0;
+  baseRotation(in.euler(0), in.euler(1), in.euler(2), R0, sz, cz, sy, cy);
+  const bool isArm = dd >= 15, isLeg = dd >= 3 && dd < 15;
+  const int myLeg = isLeg ? (dd - 3) / 3 : 0;
+  ChainAcc<P, V> c;
+  c.M = 0.0_r;
+  Mat3<P> Re;
+  Re.c0 = Vec3<P>(P(1.0_r), P(0.0_r), P(0.0_r)); Re.c1 = Vec3<P>(P(0.0_r), P(1.0_r), P(0.0_r)); Re.c2 = Vec3<P>(P(0.0_r), P(0.0_r), P(1.0_r));
+  int cftMine = 0;
+  if (isArm) {
+    c.p = Vec3<P>(P(md.ee_offset[0]), P(md.ee_offset[1]), P(md.ee_offset[2]));
+#pragma unroll
+    for (int a = 5; a >= 0; --a) {
+      addBody(md, 13 + a, c);
+      crossJoint(md, 13 + a, ARM_AXIS[a], in.q(12 + a), in.qd(12 + a), c, [&](int axis, P cs, P sn) { rotAxis(axis, cs, sn, Re.c0); rotAxis(axis, cs, sn, Re.c1); rotAxis(axis, cs, sn, Re.c2); });
+    }
+  } else {
+    for (int k = 1; k < 4; ++k) if (md.foot_body[k] == 3 + 3 * myLeg) cftMine = k;
+    c.p = Vec3<P>(P(md.foot_offset[cftMine][0]), P(md.foot_offset[cftMine][1]), P(md.foot_offset[cftMine][2]));
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+      addBody(md, 1 + 3 * myLeg + j, c);
+      crossJoint(md, 1 + 3 * myLeg + j, LEG_AXIS[j], in.q(3 * myLeg + j), in.qd(3 * myLeg + j), c, [](int, P, P) {});
+    }
+  }
+  // publish the primal composites: the first lane of each chain (legs dd = 3 + 3 leg, arm dd = 15)
+  if ((isLeg && dd == 3 + 3 * myLeg) || dd == 15) {
+    real* p = pub + (isArm ? 4 * SWEEP_PUB_LEG : myLeg * SWEEP_PUB_LEG);
+    p[0] = c.M; p[1] = c.h.x.v; p[2] = c.h.y.v; p[3] = c.h.z.v;
+    p[4] = c.I.xx.v; p[5] = c.I.xy.v; p[6] = c.I.xz.v; p[7] = c.I.yy.v; p[8] = c.I.yz.v; p[9] = c.I.zz.v;
+    p[10] = c.l.x.v; p[11] = c.l.y.v; p[12] = c.l.z.v; p[13] = c.k.x.v; p[14] = c.k.y.v; p[15] = c.k.z.v;
+    p[16] = c.p.x.v; p[17] = c.p.y.v; p[18] = c.p.z.v; p[19] = c.vf.x.v; p[20] = c.vf.y.v; p[21] = c.vf.z.v;
+    if (isArm) { p[22] = Re.c0.x.v; p[23] = Re.c0.y.v; p[24] = Re.c0.z.v; p[25] = Re.c1.x.v; p[26] = Re.c1.y.v; p[27] = Re.c1.z.v; p[28] = Re.c2.x.v; p[29] = Re.c2.y.v; p[30] = Re.c2.z.v; }
+  }
+  QM_WAVE_SYNC();
+  // the lane's own tangents (zero for the base-angle lanes: their chain carried none)
+  const real on = (isArm || isLeg) ? 1.0_r : 0.0_r;
+  // totals in the base frame, about the base origin: the base body + the five published chains (values) + this lane's tangents
+  ChainAcc<P, V> tot;
+  tot.M = 0.0_r;
+  addBody(md, 0, tot);
+  {
+    real s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.0_r;
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch) {
+      const real* p = pub + ch * SWEEP_PUB_LEG;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] += p[i];
+    }
+    tot.M += s[0];
+    tot.h = tot.h + Vec3<P>(P(s[1], on * c.h.x.d), P(s[2], on * c.h.y.d), P(s[3], on * c.h.z.d));
+    tot.I.xx = tot.I.xx + P(s[4], on * c.I.xx.d); tot.I.xy = tot.I.xy + P(s[5], on * c.I.xy.d); tot.I.xz = tot.I.xz + P(s[6], on * c.I.xz.d);
+    tot.I.yy = tot.I.yy + P(s[7], on * c.I.yy.d); tot.I.yz = tot.I.yz + P(s[8], on * c.I.yz.d); tot.I.zz = tot.I.zz + P(s[9], on * c.I.zz.d);
+    tot.l = tot.l + Vec3<V>(V(s[10], on * c.l.x.d, on * c.l.x.e), V(s[11], on * c.l.y.d, on * c.l.y.e), V(s[12], on * c.l.z.d, on * c.l.z.e));
+    tot.k = tot.k + Vec3<V>(V(s[13], on * c.k.x.d, on * c.k.x.e), V(s[14], on * c.k.y.d, on * c.k.y.e), V(s[15], on * c.k.z.d, on * c.k.z.e));
+  }
+  Vec3<Du3> fsum;
+  Vec3<Du3> tsum;
+  {  // arm tip = end-effector frame
+    const real* p = pub + 4 * SWEEP_PUB_LEG;
+    const real oa = isArm ? 1.0_r : 0.0_r;
+    const Vec3<P> pe(P(p[16], oa * c.p.x.d), P(p[17], oa * c.p.y.d), P(p[18], oa * c.p.z.d));
+    Mat3<P> Rl;
+    Rl.c0 = Vec3<P>(P(p[22], oa * Re.c0.x.d), P(p[23], oa * Re.c0.y.d), P(p[24], oa * Re.c0.z.d));
+    Rl.c1 = Vec3<P>(P(p[25], oa * Re.c1.x.d), P(p[26], oa * Re.c1.y.d), P(p[27], oa * Re.c1.z.d));
+    Rl.c2 = Vec3<P>(P(p[28], oa * Re.c2.x.d), P(p[29], oa * Re.c2.y.d), P(p[30], oa * Re.c2.z.d));
+    Mat3<P> Rw;
+    Rw.c0 = mul(R0, Rl.c0); Rw.c1 = mul(R0, Rl.c1); Rw.c2 = mul(R0, Rl.c2);
+    const Vec3<P> rEE = mul(R0, pe);
+    const Vec3<Du3> fe = onEE(rEE, Rw);
+    fsum = fe;
+    tsum = cross(rEE, fe);
+  }
+#pragma unroll 1
+  for (int leg = 0; leg < 4; ++leg) {
+    int cft = 0;
+    for (int k = 1; k < 4; ++k) if (md.foot_body[k] == 3 + 3 * leg) cft = k;
+    const real* p = pub + leg * SWEEP_PUB_LEG;
+    const real ol = (isLeg && myLeg == leg) ? 1.0_r : 0.0_r;
+    const Vec3<P> pf(P(p[16], ol * c.p.x.d), P(p[17], ol * c.p.y.d), P(p[18], ol * c.p.z.d));
+    const Vec3<V> vl(V(p[19], ol * c.vf.x.d, ol * c.vf.x.e), V(p[20], ol * c.vf.y.d, ol * c.vf.y.e), V(p[21], ol * c.vf.z.d, ol * c.vf.z.e));
+    const Vec3<P> r = mul(R0, pf);
+    const Vec3<V> v = mul(R0, vl);
+    const Vec3<Du3> Fc = in.force(cft);
+    fsum = fsum + Fc;
+    tsum = tsum + cross(r, Fc);
+    onFoot(cft, r, v);
+  }
+  Accum2<P, V> acc;
+  acc.M1 = mul(R0, tot.h);
+  acc.hl = mul(R0, tot.l);
+  acc.ha = mul(R0, tot.k);
+  acc.Io = similarity(R0, tot.I);
+  V hn[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) hn[i] = in.hn(i);
+  closeSweep2<P, V, Du3>(md, gravity, acc, hn, fsum, tsum, sz, cz, sy, cy, f, bm);
+}
+
 // single scalar type (plain evaluation with T = double; T = Du differentiates along one direction per lane through everything)
 template <class T, class In, class FootFn, class EeFn>
 __device__ __forceinline__ void centroidalSweep(const ModelR& md, real gravity, const In& in, FootFn&& onFoot, EeFn&& onEE, T f[12], BaseMotion<T>& bm) {
