@@ -175,8 +175,7 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
     FlowOut<Du, Du3, Du3> f;
     BaseMotion2<Du, Du3> bm;
     QM_WAVE_SYNC();   // (the published composites of the previous stage have been read by every lane)
-    centroidalSweepOwnChain(
-        md, st.gravity, in, dd, lds + ADL_PUB + grp * SWEEP_PUB_NODE,
+    auto footCb =
         [&](int c, Vec3<Du> r, Vec3<Du3> v) {
           QM_TICK(stage ? 3 : 1);
           if (stage == 0) {
@@ -185,7 +184,8 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
             p[384] = v.x.v; p[448] = v.x.d; p[512] = v.x.e; p[576] = v.y.v; p[640] = v.y.d; p[704] = v.y.e; p[768] = v.z.v; p[832] = v.z.d; p[896] = v.z.e;
           }
           QM_TICK(7);
-        },
+        };
+    auto eeCb =
         [&](Vec3<Du> r, const Mat3<Du>& R) {
           // external force of the compliant contact: linear in the base position (force-type slot of lanes 3..5), configuration tangent -K dr
           QM_TICK(stage ? 3 : 1);
@@ -193,9 +193,24 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
           const Vec3<Du3> fe(Du3(-Ke * (xs[6] + r.x.v - pEnv[0]), -Ke * r.x.d, dd == 3 ? -Ke : 0.0_r), Du3(-Ke * (xs[7] + r.y.v - pEnv[1]), -Ke * r.y.d, dd == 4 ? -Ke : 0.0_r),
                              Du3(-Ke * (xs[8] + r.z.v - pEnv[2]), -Ke * r.z.d, dd == 5 ? -Ke : 0.0_r));
           if (stage == 0) {  // end-effector pose error (EndEffectorConstraint.cpp:36-78): no velocity / force dependence, d/dp = identity
-            Du qee[4];
-            matrixToQuaternion(R, qee);
-            const Vec3<Du> od = quaternionDistance(qee, eeQuatRef);
+            // orientation error and its tangent in closed form: the quaternion of the PRIMAL rotation (one square root, one division, in plain arithmetic), and for
+            // the tangent the world-frame rotation increment  [dtheta]x = dR R^T  of the lane's direction: dq = 1/2 (dtheta, 0) (x) q, and quaternionDistance is
+            // linear in q.  (Until round 4 the whole chain matrix -> quaternion -> distance ran in dual arithmetic: a dual square root and two dual divisions per lane.)
+            Mat3<real> Rp;
+            Rp.c0 = Vec3<real>(R.c0.x.v, R.c0.y.v, R.c0.z.v); Rp.c1 = Vec3<real>(R.c1.x.v, R.c1.y.v, R.c1.z.v); Rp.c2 = Vec3<real>(R.c2.x.v, R.c2.y.v, R.c2.z.v);
+            real qp[4];
+            matrixToQuaternion(Rp, qp);
+            const Vec3<real> odp = quaternionDistance(qp, eeQuatRef);
+            const real thx = R.c0.z.d * R.c0.y.v + R.c1.z.d * R.c1.y.v + R.c2.z.d * R.c2.y.v;   // (dR R^T)[2][1]
+            const real thy = R.c0.x.d * R.c0.z.v + R.c1.x.d * R.c1.z.v + R.c2.x.d * R.c2.z.v;   // (dR R^T)[0][2]
+            const real thz = R.c0.y.d * R.c0.x.v + R.c1.y.d * R.c1.x.v + R.c2.y.d * R.c2.x.v;   // (dR R^T)[1][0]
+            real dq[4];
+            dq[0] = 0.5_r * (thx * qp[3] + thy * qp[2] - thz * qp[1]);
+            dq[1] = 0.5_r * (thy * qp[3] + thz * qp[0] - thx * qp[2]);
+            dq[2] = 0.5_r * (thz * qp[3] + thx * qp[1] - thy * qp[0]);
+            dq[3] = -0.5_r * (thx * qp[0] + thy * qp[1] + thz * qp[2]);
+            const Vec3<real> odd = quaternionDistance(dq, eeQuatRef);
+            const Vec3<Du> od(Du(odp.x, odd.x), Du(odp.y, odd.y), Du(odp.z, odd.z));
             const Du hq[6] = {x[6] + r.x - eePosRef[0], x[7] + r.y - eePosRef[1], x[8] + r.z - eePosRef[2], od.x, od.y, od.z};
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
@@ -206,8 +221,9 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
           }
           QM_TICK(8);
           return fe;
-        },
-        f, bm);
+        };
+    real* pubN = lds + ADL_PUB + grp * SWEEP_PUB_NODE;
+    centroidalSweepOwnChain(md, st.gravity, in, dd, pubN, footCb, eeCb, f, bm);
     QM_TICK(stage ? 3 : 1);
     if (stage == 0) {
       // ---- equality constraints in the insertion order of QMInterface.cpp:116-131

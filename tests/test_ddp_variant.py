@@ -23,7 +23,7 @@ def _check(r, i, ref, tolx):
     assert r["stats"][i][4] == ref["stats"][4] and r["stats"][i][5] == ref["stats"][5] and r["stats"][i][7] == 0      # step length, trials evaluated, status
     assert np.abs(r["X"][i] - ref["X"]).max() <= tolx * max(1.0, np.abs(ref["X"]).max())
     assert np.abs(r["U"][i] - ref["U"]).max() <= tolx * max(1.0, np.abs(ref["U"]).max())
-    assert np.allclose(r["stats"][i][[0, 2]], ref["stats"][[0, 2]], rtol=1e-7 if tolx <= 1e-6 else (1e-3 if tolx <= 1e-3 else 0.2))
+    assert np.allclose(r["stats"][i][[0, 2]], ref["stats"][[0, 2]], rtol=1e-7 if tolx <= 1e-6 else 1e-3)
 
 
 def test_oracle_ddp_iteration_properties(interface, oracle):
@@ -79,9 +79,11 @@ def test_gpu_ddp_matches_oracle_n100(interface, oracle):
     for i in range(B):     # every instance.  An open-loop rollout that leaves the neighbourhood of the nominal posture has amplified the rounding
         ref = oracle.ddp_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)   # differences of the two implementations: |x| <= 3 is held to the
         top = np.abs(ref["X"]).max()                                         # north_star 1e-6, 3 < |x| <= 30 to 1e-3, and a rollout that has blown up
-        if top > 30.0:                                                       # (|x| in the hundreds) to step length / trial count / status and, RELATIVE to
-            blown += 1                                                       # its own size, to 5e-2 (_check's tolerances scale with max |x|): no instance goes unchecked
-            _check(r, i, ref, 5e-2)
+        if top > 30.0:                                                       # (|x| in the hundreds) to step length / trial count / status -- and the part of the
+            blown += 1                                                       # trajectory BEFORE it leaves |x| <= 30 to 1e-3 (no instance goes unchecked)
+            assert np.array_equal(r["mode"][i], ref["mode"]) and r["stats"][i][4] == ref["stats"][4] and r["stats"][i][5] == ref["stats"][5] and r["stats"][i][7] == 0
+            k = int(np.argmax(np.abs(ref["X"]).max(axis=1) > 30.0))          # first node beyond the bound
+            assert k >= 1 and np.abs(r["X"][i][:k] - ref["X"][:k]).max() <= 1e-3 * max(1.0, np.abs(ref["X"][:k]).max()), (i, k)
             continue
         diverging += top > 3.0
         _check(r, i, ref, 1e-3 if top > 3.0 else 1e-6)
