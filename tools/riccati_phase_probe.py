@@ -99,3 +99,23 @@ print("  workgroups in flight every 20 us:", run)
 full = max(run)
 tail = sum(1 for r in run if r < 0.5 * full) * 20.0
 print("  peak %d in flight (1024 SIMDs x 1 wavefront); time below half of the peak: %.0f us of %.0f us" % (full, tail, en_us.max()))
+
+# ---- the same per-instance picture of wbc_kernel on robots IN MOTION (tests/support.py: moving_inputs; main branch t >= 10 s, policy evaluated between nodes): the launch lasts as long
+#      as its slowest instance, and the steady state of bench.py (config.steady_state) pays for the longer tail of interior-point iterations
+import support as S
+orc = S.Oracle(itf.problem)
+mv = S.moving_inputs(orc, sc["x0"], itf.problem.settings.dt, seed=21)
+mb2 = G.MpcBatch(mv["x0"], sc["tt"], sc["ts"], np.full(B, sc["nev"], dtype=np.int32), np.tile(sc["ev"], (B, 1)), np.tile(sc["md"], (B, 1)), N)
+wb2 = G.WbcBatch(mv["rbd"], np.full(B, 0.002), np.full(B, 20.0), mv["input_last"])
+te2 = G.dev(mv["t_eval"], torch.float64)
+for _ in range(3): sol.cycle(mb2.args, te2, wb2.args)
+torch.cuda.synchronize()
+ms2 = sol.kernel_ms_mean(3)
+assert lib.qmgpu_debug_riccati_ticks(buf, 0) == 0
+pi = np.array(buf[512:512 + 4 * B], dtype=np.float64).reshape(B, 4)
+tk, its = pi[:, 0], pi[:, 1:]
+print("wbc_kernel per instance, robots in motion (kernel %.4f ms): ticks mean %.0f  median %.0f  p90 %.0f  max %.0f  => max/mean %.3f; iterations per level mean %s max %s; total mean %.1f max %d"
+      % (ms2[4], tk.mean(), np.median(tk), np.percentile(tk, 90), tk.max(), tk.max() / tk.mean(), np.round(its.mean(0), 2).tolist(), its.max(0).astype(int).tolist(), its.sum(1).mean(), int(its.sum(1).max())))
+worst = np.argsort(-tk)[:8]
+print("  slowest instances:", [(int(i), int(tk[i]), its[i].astype(int).tolist()) for i in worst])
+print("  histogram of total iterations:", np.bincount(its.sum(1).astype(int)).tolist())
