@@ -331,6 +331,7 @@ inline bool choleskyFloored(Mat& A, double floorv) {
 constexpr double kLowerLevelStart = 300.0;
 constexpr double kStagnationMu = 1e-10;
 constexpr bool kPolishAdd = false;       // adding violated rows to the guess (ipm_dev.h: QM_IPM_POLISH_ADD)
+constexpr int kEarlyTriesOwn = 4; constexpr double kEarlyMuOwn = 1e-2, kEarlyNrpOwn = 1e-2, kEarlyNrdOwn = 1e-1, kEarlyDropOwn = 0.1;   // = QM_IPM_EARLY_*_OWN (ipm_dev.h)
 constexpr int kPolishCorrections = 4;    // releases + additions per polish attempt (ipm_dev.h: QM_IPM_POLISH_CORRECTIONS)   // = QM_IPM_STAGNATION_MU of the kernels (ipm_dev.h)
 // diagnostics of the last solveQpIpm call of this thread: 1 = the returned point is a polished (exact) vertex, 0 = the interior-point iterate stands
 static thread_local int g_ipmPolished = 0;
@@ -454,7 +455,13 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
     // the polish is first tried as soon as the active set can plausibly be read off (mu <= 1e-6 scale; at most twice, the second time
     // only after the complementarity has dropped another 100x): an accepted vertex is exact whatever iterate it started from; a
     // rejected one leaves z, s, lam untouched and the interior point goes on
-    if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) {
+    // A level WITH slack variables of its own (the first one: torque limits and friction cones soften the equations of motion, and away from the limits
+    // no row is active) is tried much earlier: from mu <= 1e-2 scale, up to four times, after every 10x drop.  Measured on the four parity sets
+    // (profiles/r04_notes.md section 7): the first attempt, after two interior-point iterations instead of four, is accepted in every instance of
+    // the bench and closed-loop sets and in 86 % of the stress instances (2.5 iterations on average instead of 3.9).
+    const bool ownSlack = !activeSetCorrection;
+    if (earlyTries < (ownSlack ? kEarlyTriesOwn : 2) && nrd <= (ownSlack ? kEarlyNrdOwn : 1e-4) * scale && nrp <= (ownSlack ? kEarlyNrpOwn : 1e-6) * scale &&
+        mu <= (ownSlack ? kEarlyMuOwn : 1e-6) * scale && mu <= (ownSlack ? kEarlyDropOwn : 0.01) * lastTryMu) {
       ++earlyTries; lastTryMu = mu;
       if (tryPolish(true)) { g_ipmPolished = 1; return it; }
     }

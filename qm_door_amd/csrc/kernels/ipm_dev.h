@@ -28,6 +28,12 @@ namespace qmk {
 #ifndef QM_IPM_POLISH_CORRECTIONS
 #define QM_IPM_POLISH_CORRECTIONS 4       // = kPolishCorrections of the oracle
 #endif
+// early polish attempts of a level with slack variables of its own (= kEarly*Own of the oracle)
+#define QM_IPM_EARLY_TRIES_OWN 4
+#define QM_IPM_EARLY_MU_OWN 1e-2
+#define QM_IPM_EARLY_NRP_OWN 1e-2
+#define QM_IPM_EARLY_NRD_OWN 1e-1
+#define QM_IPM_EARLY_DROP_OWN 0.1
 
 struct IpmIo {
   const double* G;      // [36][ldk], zero outside n x n
@@ -299,7 +305,9 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
         if (!(muPrev <= 1e-8 * scale)) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
         done = true;
       } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
-      else if (earlyTries < 2 && nrd <= 1e-4 * scale && nrp <= 1e-6 * scale && mu <= 1e-6 * scale && mu <= 0.01 * lastTryMu) { done = true; early = true; ++earlyTries; lastTryMu = mu; }
+      // (a level with slack variables of its own -- the first -- is tried from mu <= 1e-2 scale on, up to four times: oracle/qmo_wbc.h: solveQpIpm, kEarly*Own)
+      else if (earlyTries < (own ? QM_IPM_EARLY_TRIES_OWN : 2) && nrd <= (own ? QM_IPM_EARLY_NRD_OWN : 1e-4) * scale && nrp <= (own ? QM_IPM_EARLY_NRP_OWN : 1e-6) * scale &&
+               mu <= (own ? QM_IPM_EARLY_MU_OWN : 1e-6) * scale && mu <= (own ? QM_IPM_EARLY_DROP_OWN : 0.01) * lastTryMu) { done = true; early = true; ++earlyTries; lastTryMu = mu; }
       // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
       // stop here instead of iterating into the divergence that follows; the polish finishes the job
       else if (it > 0 && mu > 0.5 * muPrev && mu <= QM_IPM_STAGNATION_MU * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) done = true;
