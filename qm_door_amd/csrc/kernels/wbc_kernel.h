@@ -795,9 +795,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
       int* colPerm = ip; int* rowOf = ip + 40; int* pivOk = ip + 64; int* freePos = ip + 96;
       const int size = r < n ? r : n;
-      if (lane < n) colPerm[lane] = lane;
-      QM_WAVE_SYNC();
       int rowPos = lane;
+      int colPermReg = lane;     // lane j: the original column at position j (swapped between lanes with v_readlane; LDS copy after the loop)
+      int rowOfReg = 0;          // lane k: the row that gave pivot k
       double maxPivot = 0.0;
       int nonzero = 0;
       double* row = AZ + (lane < r ? lane : 0) * LDZ;
@@ -814,28 +814,37 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
           for (int q = 0; q < 8; ++q) if (j0 + q < n && v[q] > best) { best = v[q]; bj = j0 + q; }
         }
       }
+      // One step = one dependent chain; what is on it besides the elimination itself is kept in registers: the pivot's lane from a ballot (the
+      // smallest-row-position rule needs a second reduction only when two rows tie), its column and value by v_readlane, the permutations in lanes.
 #pragma unroll 1
       for (int k = 0; k < size; ++k) {
+        QM_TICK(15);
         const bool mine = lane < r && rowPos >= k;
         const double gmax = qmAllMax(mine ? best : -1.0, red);
         if (!(gmax > 0.0)) break;
-        // ties between rows: the smallest row position (the oracle's outer scan index)
-        const double key = (mine && best == gmax) ? double(rowPos * 64 + lane) : 1e9;
-        const int kmin = int(qmAllMin(key, red));
-        const int Lp = kmin & 63, pr = kmin >> 6;
-        if (lane == Lp) ctl[0] = double(bj);
-        QM_WAVE_SYNC();
-        const int pc = int(ctl[0]);
+        QM_TICK(18);
+        const bool cand = mine && best == gmax;
+        const unsigned long long tied = qmBallot(cand);
+        int Lp;
+        if ((tied & (tied - 1)) == 0) Lp = qmFirstBit(tied);
+        else Lp = int(qmAllMin(cand ? double(rowPos * 64 + lane) : 1e9, red)) & 63;   // ties between rows: the smallest row position (the oracle's outer scan index)
+        const int pr = qmReadLaneInt(rowPos, Lp), pc = qmReadLaneInt(bj, Lp);
         maxPivot = fmax(maxPivot, gmax);
         if (lane < r) { if (lane == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
-        if (pc != k && lane < r) { const double t = row[k]; row[k] = row[pc]; row[pc] = t; }
-        if (lane == 0) { const int t = colPerm[k]; colPerm[k] = colPerm[pc]; colPerm[pc] = t; rowOf[k] = Lp; }
+        { const int ck = qmReadLaneInt(colPermReg, k), cp = qmReadLaneInt(colPermReg, pc); if (lane == k) colPermReg = cp; else if (lane == pc) colPermReg = ck; }
+        if (lane == k) rowOfReg = Lp;
+        QM_TICK(19);
+        double vk = 0.0, vpc = 0.0;
+        if (lane < r) { vk = row[k]; vpc = row[pc]; }
+        if (pc != k && lane < r) { row[k] = vpc; row[pc] = vk; }
+        const double pivot = qmReadLane(vpc, Lp);
         QM_WAVE_SYNC();
+        QM_TICK(20);
         // elimination of the rows still below the pivot; the largest entry of the updated row (positions > k) is found on the way: the next step's candidate
         const double* prow = AZ + Lp * LDZ;
         best = -1.0; bj = k + 1;
         if (lane < r && rowPos > k) {
-          const double f = row[k] / prow[k];
+          const double f = vpc / pivot;
 #pragma unroll 1
           for (int j0 = k + 1; j0 < n; j0 += 8) {
             double a[8], pv[8];
@@ -852,7 +861,11 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         }
         ++nonzero;
         QM_WAVE_SYNC();
+        QM_TICK(21);
       }
+      if (lane < n) colPerm[lane] = colPermReg;
+      if (lane < nonzero) rowOf[lane] = rowOfReg;
+      QM_WAVE_SYNC();
       // rank: pivots above Eigen's default threshold eps * size * max pivot; the others' columns count as free
       const double thresh = maxPivot * 2.220446049250313e-16 * double(size);
       if (lane < nonzero) pivOk[lane] = fabs(AZ[rowOf[lane] * LDZ + lane]) > thresh ? 1 : 0;

@@ -106,6 +106,15 @@ template <class T> inline T qmReadLane(T v, int src, T* scratch = nullptr) {
   return T(buf[unsigned(src) & 63u]);
 }
 inline int qmReadLaneInt(int v, int src) { return qmReadLane<int>(v, src); }
+inline unsigned long long qmBallot(bool p) {
+  double* buf = emuXchgBuf(nullptr);
+  buf[threadIdx.x & 63u] = p ? 1.0 : 0.0;
+  QM_WAVE_SYNC();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; ++i) if (buf[i] != 0.0) m |= 1ull << i;
+  return m;
+}
+inline int qmFirstBit(unsigned long long m) { return __builtin_ctzll(m); }
 
 template <class T> struct QmGatherT {
   T vals[64];

@@ -60,7 +60,7 @@ for base, name in ((160, "NP = 36"), (256, "NP = 20"), (288, "NP = 8")):
         print("wbc interior point, %s, instance 0: total %d ticks of %.0f (kernel %.4f ms)" % (name, v.sum(), ms[4] * tot / ms[2] if ms[2] else 0, ms[4]))
         for n_, x in zip(IPM, v): print("  %-40s %9.0f  %4.1f %%" % (n_, x, 100 * x / v.sum()))
 
-WBC = ["S1-S2 inputs, coordinates", "S3 measured pass", "S4 nle, M, Jacobians", "S5 desired pass", "task 0 inequality rows + level-loop re-entry (null space of the previous level ends here)", "assemble level task", "reduced data", "interior point", "x update", "(after the last null space)", "torques", "  reduced data: A Z", "  reduced data: zero + D Z", "  reduced data: A x - b, margins", "  reduced data: zero + (A Z)^T A Z", "  null space: full-pivot LU of A Z", "  null space: kernel vectors (back substitution)", "  null space: Z N, copy"]   # (g and the vanishing-row test are what is left in "reduced data" above)
+WBC = ["S1-S2 inputs, coordinates", "S3 measured pass", "S4 nle, M, Jacobians", "S5 desired pass", "task 0 inequality rows + level-loop re-entry (null space of the previous level ends here)", "assemble level task", "reduced data", "interior point", "x update", "(after the last null space)", "torques", "  reduced data: A Z", "  reduced data: zero + D Z", "  reduced data: A x - b, margins", "  reduced data: zero + (A Z)^T A Z", "  null space: full-pivot LU of A Z", "  null space: kernel vectors (back substitution)", "  null space: Z N, copy", "    LU: max reduction", "    LU: pivot lane, permutations", "    LU: swap, pivot broadcast", "    LU: elimination"]   # (g and the vanishing-row test are what is left in "reduced data" above)
 v = raw[192:192 + len(WBC)]
 print("wbc_kernel, instance 0: total %d ticks (kernel %.4f ms)" % (v.sum(), ms[4]))
 for n_, x in zip(WBC, v): print("  %-60s %9.0f  %4.1f %%" % (n_[:60], x, 100 * x / v.sum()))
