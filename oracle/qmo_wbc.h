@@ -332,6 +332,7 @@ constexpr double kLowerLevelStart = 300.0;
 constexpr double kStagnationMu = 1e-10;
 constexpr bool kPolishAdd = false;       // adding violated rows to the guess (ipm_dev.h: QM_IPM_POLISH_ADD)
 constexpr int kEarlyTriesOwn = 4; constexpr double kEarlyMuOwn = 1e-2, kEarlyNrpOwn = 1e-2, kEarlyNrdOwn = 1e-1, kEarlyDropOwn = 0.1;   // = QM_IPM_EARLY_*_OWN (ipm_dev.h)
+constexpr bool kZeroTryOwn = true;       // = QM_IPM_ZERO_TRY_OWN of the kernels (ipm_dev.h)
 constexpr int kPolishCorrections = 4;    // releases + additions per polish attempt (ipm_dev.h: QM_IPM_POLISH_CORRECTIONS)   // = QM_IPM_STAGNATION_MU of the kernels (ipm_dev.h)
 // diagnostics of the last solveQpIpm call of this thread: 1 = the returned point is a polished (exact) vertex, 0 = the interior-point iterate stands
 static thread_local int g_ipmPolished = 0;
@@ -374,9 +375,12 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   // if the guess is still wrong after that the attempt is abandoned at once instead of after two more steps and the check.  On the
   // bench set the slowest instance read one weakly active row too many at both early attempts and went on for five more interior-point
   // iterations (12 + three polishes = 24 passes of its second level; now 14).
-  auto tryPolish = [&](bool early) -> bool {
+  // zero = the try BEFORE the first interior-point iteration (a level with slack variables of its own, kZeroTryOwn below): the guess is "no limit binds" --
+  // the working set holds the rows with a zero right-hand side only (v >= 0 of every slack variable, and the friction rows of a swing leg, 0 <= 0), the
+  // multiplier estimates start from zero.
+  auto tryPolish = [&](bool early, bool zero = false) -> bool {
     std::vector<int> act;
-    for (int i = 0; i < m; ++i) if (lam[i] > s[i]) act.push_back(i);
+    for (int i = 0; i < m; ++i) if (zero ? (f[i] <= 1e-9 * scale) : (lam[i] > s[i])) act.push_back(i);
     double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
     const double rho = 1e6 * std::max(1.0, hmax);
     // Active-set correction loop (levels without slack variables of their own): the estimates after the FIRST step of an attempt decide.  Negative
@@ -389,7 +393,7 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
       for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
       if (!choleskyFloored(K, pivotFloor)) return false;
       Vec zp = z, lp(m, 0.0);
-      for (int r : act) lp[r] = lam[r];
+      for (int r : act) lp[r] = zero ? 0.0 : lam[r];
       bool again = false;
       for (int step = 0; step < 3; ++step) {
         const Vec Dz = D * zp;
@@ -430,6 +434,11 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
       return false;
     }
   };
+  // The first level (equations of motion, torque limits, friction cones; slack variables of its own): away from the limits NO inequality row is active and
+  // the level is an equality-constrained least-squares problem -- one factorisation instead of two interior-point iterations and a polish.  Tried first;
+  // accepted (all rows feasible, all multipliers of the working set >= -1e-9 scale: then it IS the solution of the strictly convex QP) in every instance of
+  // the bench, moving, closed-loop and 2 x 2048 stress sets (profiles/r04_notes.md section 7); a rejected try leaves z, s, lam untouched.
+  if (kZeroTryOwn && !activeSetCorrection && tryPolish(true, true)) { g_ipmPolished = 1; return 0; }
   int it = 0;
   int earlyTries = 0; double lastTryMu = 1e300;
   Vec zPrev = z, sPrev = s, lamPrev = lam;

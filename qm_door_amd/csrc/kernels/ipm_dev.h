@@ -34,6 +34,13 @@ namespace qmk {
 #define QM_IPM_EARLY_NRP_OWN 1e-2
 #define QM_IPM_EARLY_NRD_OWN 1e-1
 #define QM_IPM_EARLY_DROP_OWN 0.1
+// A level with slack variables of its own (the first: equations of motion, torque limits, friction cones) first tries the active-set polish BEFORE any
+// interior-point iteration with the guess "no limit binds" (= kZeroTryOwn of the CPU restatement's solveQpIpm): pinned are only the rows with a
+// zero right-hand side (the friction rows of a swing leg, 0 <= 0), every slack variable is zero.  Away from the limits that IS the solution -- one
+// factorisation instead of two interior-point iterations and a polish; a rejected try leaves the interior point's starting point untouched.
+#ifndef QM_IPM_ZERO_TRY_OWN
+#define QM_IPM_ZERO_TRY_OWN 1
+#endif
 
 struct IpmIo {
   const double* G;      // [36][ldk], zero outside n x n
@@ -210,6 +217,11 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
   double lamE = 0.0, zIpm = 0.0;
   const double rho = 1e6 * fmax(1.0, pivotFloor * 1e13);
   int it = 0, itOut = 0;
+  bool zeroTry = false;
+  if (QM_IPM_ZERO_TRY_OWN && own) {
+    zeroTry = true; early = true;
+    isE = rowActive && fl <= 1e-9 * scale; isV = false; lamE = 0.0; zIpm = zc; polish = 1; corrections = 0;
+  }
   double kc[NP], uc[NP], myInv = 1.0;   // factor of the current K (row c of L, row c of L^T): survives across the polish steps, whose K is constant
 #pragma unroll
   for (int r = 0; r < NP; ++r) { kc[r] = 0.0; uc[r] = 0.0; }
@@ -243,12 +255,13 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
     if (polish == 4) {                                               // keep the polished point only if it is a valid vertex
       bool bad = false;
       if (rowActive) {
-        if (isE) bad = !(lamE >= -1e-9 * scale) || !(fabs(rRow) <= 1e-9 * scale);
+        if (isE) bad = !(lamE >= -1e-9 * scale) || !(fabs(rRow) <= 1e-9 * scale) || (zeroTry && !(lamE <= 1e-9 * scale));   // (zero try: the row's slack variable is pinned at 0 as well, its multiplier is -lamE)
         else if (isV) bad = !(rRow >= -1e-9 * scale);
         else bad = !(rRow <= 1e-9 * scale);
       }
       const bool rejected = allMax((bad || !(zc == zc)) ? 1.0 : 0.0) > 0.0;
       if (rejected) zc = zIpm;
+      if (rejected && zeroTry) { zeroTry = false; early = false; polish = 0; it = -1; continue; }   // the interior point starts as if nothing had happened
       if (rejected && early) { early = false; polish = 0; continue; }   // back to the interior point (its slacks / multipliers were not touched)
       break;
     }
@@ -305,7 +318,7 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
         if (!(muPrev <= 1e-8 * scale)) { if (restartOrGiveUp()) { it = -1; continue; } itOut = 60; break; }
         done = true;
       } else if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) done = true;  // same tolerances as the oracle's solveQpIpm
-      // (a level with slack variables of its own -- the first -- is tried from mu <= 1e-2 scale on, up to four times: oracle/qmo_wbc.h: solveQpIpm, kEarly*Own)
+      // (a level with slack variables of its own -- the first -- is tried from mu <= 1e-2 scale on, up to four times: kEarly*Own of the CPU restatement)
       else if (earlyTries < (own ? QM_IPM_EARLY_TRIES_OWN : 2) && nrd <= (own ? QM_IPM_EARLY_NRD_OWN : 1e-4) * scale && nrp <= (own ? QM_IPM_EARLY_NRP_OWN : 1e-6) * scale &&
                mu <= (own ? QM_IPM_EARLY_MU_OWN : 1e-6) * scale && mu <= (own ? QM_IPM_EARLY_DROP_OWN : 0.01) * lastTryMu) { done = true; early = true; ++earlyTries; lastTryMu = mu; }
       // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) --
