@@ -395,7 +395,12 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
       Vec zp = z, lp(m, 0.0);
       for (int r : act) lp[r] = zero ? 0.0 : lam[r];
       bool again = false;
-      for (int step = 0; step < 3; ++step) {
+      // zero try with nothing pinned but simple bounds (v_i >= 0: rows with a single entry, decoupled from everything else as long as no constraint row is in the
+      // working set): the first Newton step on the quadratic is the minimiser, the further steps would only repeat it
+      bool boundsOnly = zero;
+      if (zero) for (int r : act) { int nnz = 0; for (int j = 0; j < n; ++j) nnz += D(r, j) != 0.0; if (nnz > 1) { boundsOnly = false; break; } }
+      const int nSteps = boundsOnly ? 1 : 3;
+      for (int step = 0; step < nSteps; ++step) {
         const Vec Dz = D * zp;
         Vec t(m, 0.0);
         for (int r : act) t[r] = lp[r] + rho * (Dz[r] - f[r]);

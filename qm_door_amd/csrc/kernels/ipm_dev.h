@@ -217,10 +217,11 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
   double lamE = 0.0, zIpm = 0.0;
   const double rho = 1e6 * fmax(1.0, pivotFloor * 1e13);
   int it = 0, itOut = 0;
-  bool zeroTry = false;
+  bool zeroTry = false, zeroPinned = false;
   if (QM_IPM_ZERO_TRY_OWN && own) {
     zeroTry = true; early = true;
     isE = rowActive && fl <= 1e-9 * scale; isV = false; lamE = 0.0; zIpm = zc; polish = 1; corrections = 0;
+    zeroPinned = allMax(isE ? 1.0 : 0.0) > 0.0;   // nothing pinned: the first Newton step is the minimiser of the quadratic, the check follows at once
   }
   double kc[NP], uc[NP], myInv = 1.0;   // factor of the current K (row c of L, row c of L^T): survives across the polish steps, whose K is constant
 #pragma unroll
@@ -252,6 +253,7 @@ __device__ __attribute__((noinline)) IpmResult ipmSolve(IpmOff off, int n, int m
     const double rdv = (rowActive && own) ? (v - l1 - l2) : 0.0;
     const double rRow = Dz - fl;
     if (polish > 1 && isE) lamE += rho * rRow;                       // multiplier update of the previous polish step
+    if (zeroTry && polish == 2 && !zeroPinned) polish = 4;
     if (polish == 4) {                                               // keep the polished point only if it is a valid vertex
       bool bad = false;
       if (rowActive) {
