@@ -210,7 +210,7 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
 
 // experiment knobs of the WBC restatement (qmo_wbc.h): key 0 = starting value of the lower levels' interior point (default 300), key 1 = orthonormal null-space basis (0 / 1)
 void qmo_set_experiment(int key, double value) {
-  if (key == 0) g_expLowerLevelStart = value; else if (key == 1) g_expOrthonormalNullSpace = value != 0.0;
+  if (key == 0) g_expLowerLevelStart = value; else if (key == 1) g_expOrthonormalNullSpace = value != 0.0; else if (key == 2) g_expNoZeroTry = value != 0.0;
 }
 
 // WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],

@@ -343,6 +343,7 @@ static thread_local int g_ipmExit = 0; static thread_local double g_ipmExitMu = 
 // reproduces their round-4 failures inside the oracle (profiles/r04_notes.md section 1).
 static double g_expLowerLevelStart = kLowerLevelStart;
 static int g_expOrthonormalNullSpace = 0;
+static int g_expNoZeroTry = 0;   // the first level without its zero try (tests: the shortcut must not change the result)
 inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, double sigma0 = 1.0,
                       bool activeSetCorrection = false) {
   const int n = H.r;
@@ -443,7 +444,7 @@ inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin
   // the level is an equality-constrained least-squares problem -- one factorisation instead of two interior-point iterations and a polish.  Tried first;
   // accepted (all rows feasible, all multipliers of the working set >= -1e-9 scale: then it IS the solution of the strictly convex QP) in every instance of
   // the bench, moving, closed-loop and 2 x 2048 stress sets (profiles/r04_notes.md section 7); a rejected try leaves z, s, lam untouched.
-  if (kZeroTryOwn && !activeSetCorrection && tryPolish(true, true)) { g_ipmPolished = 1; return 0; }
+  if (kZeroTryOwn && !g_expNoZeroTry && !activeSetCorrection && tryPolish(true, true)) { g_ipmPolished = 1; return 0; }
   int it = 0;
   int earlyTries = 0; double lastTryMu = 1e300;
   Vec zPrev = z, sPrev = s, lamPrev = lam;

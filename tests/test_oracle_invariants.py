@@ -409,3 +409,36 @@ def test_full_size_hoqp_levels_against_a_primal_active_set_method(interface, ora
                 assert np.abs(z[:nd] - lv["sol"][:nd]).max() <= 1e-5 * max(1.0, np.abs(lv["sol"][:nd]).max()), (mode, level)
             checked += 1
     assert checked >= 25 and undecided <= 3
+
+
+def test_zero_try_of_the_first_level_does_not_change_the_result(interface, oracle):
+    """The first HoQP level tries "no limit binds" before any interior-point iteration (oracle/qmo_wbc.h kZeroTryOwn = QM_IPM_ZERO_TRY_OWN of the kernels).
+    An accepted try must be THE solution of the level: 512 random instances over every contact mode, robots in motion, with the try and without it
+    (qmo_set_experiment 2).  Bound on the torques: 1e-6 (the tolerance the path is held to) unless the instance is path sensitive with EITHER algorithm -- it moves
+    as much when nothing but the starting value of the lower levels changes: a level-1 problem that ends unpolished on one of the two paths keeps the interior
+    point's own accuracy, ~4e-6 in the weakly weighted directions --, and no more such instances with the try than without."""
+    import test_gpu_wbc as TW
+    for variant in (0, 1):
+        B = 512
+        c = TW.stress_batch(interface, variant, B)
+        per = np.full(B, 0.002)
+
+        def run(**kw):
+            try:
+                oracle.set_experiment(**kw)
+                return oracle.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], per, c["t"], c["il"].copy(), variant=variant)
+            finally:
+                oracle.set_experiment()
+        ref, ref_alt = run(no_zero_try=True), run(no_zero_try=True, lower_level_start=100.0)
+        got, got_alt = run(), run(lower_level_start=100.0)
+        assert (ref["iterations"][:, 0] >= 1).all() and (got["iterations"][:, 0] == 0).mean() >= 0.95     # the try is accepted (0 iterations) almost always
+        assert (got["status"] != 0).sum() <= (ref["status"] != 0).sum()
+        tau = lambda r: r["out"][:, 36:]  # noqa: E731
+        dev = S.rel_inf(tau(got), tau(ref))
+        sens_old, sens_new = S.rel_inf(tau(ref_alt), tau(ref)), S.rel_inf(tau(got_alt), tau(got))
+        bad = dev > np.maximum(1e-6, 10.0 * np.maximum(sens_old, sens_new))
+        print("zero try vs interior point, variant", variant, "max", dev.max(), "p99", np.percentile(dev, 99), "above 1e-7:", int((dev > 1e-7).sum()),
+              "path sensitive (> 1e-7) without / with the try:", int((sens_old > 1e-7).sum()), int((sens_new > 1e-7).sum()))
+        assert bad.sum() == 0, (variant, np.nonzero(bad)[0][:8], dev[bad][:8], sens_old[bad][:8], sens_new[bad][:8])
+        assert np.median(dev) <= 1e-8 and (dev > 1e-7).sum() <= max(2, (sens_old > 1e-7).sum())
+        assert (sens_new > 1e-7).sum() <= (sens_old > 1e-7).sum() + 3
