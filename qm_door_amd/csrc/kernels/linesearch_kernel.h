@@ -212,7 +212,16 @@ __device__ __forceinline__ real sumSquaresStrided(const real* v, int n, int firs
   return s;
 }
 
+// section clocks of the kernel itself in the profiling build (tools/riccati_phase_probe.py; thread 0 of instance 0 -> slots 240..247); nothing in the product build
+#ifdef QM_RICCATI_TIMING
+#define QM_LS_CLOCK(slot) do { const unsigned long long n_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) qmk::qmRiccatiTicks[240 + (slot)] += n_ - lsClk; lsClk = n_; } while (0)
+#else
+#define QM_LS_CLOCK(slot)
+#endif
 __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
+#ifdef QM_RICCATI_TIMING
+  unsigned long long lsClk = clock64();
+#endif
   __shared__ real red[3 * 256];
   __shared__ real ctl[8];
   __shared__ int structVotes[256];   // per thread: one of my weight entries lies outside the structured pattern
@@ -275,6 +284,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     ctl[0] = s0; ctl[1] = sqrt(s1 + s2); ctl[7] = dense ? 0.0_r : 1.0_r;
   }
   __syncthreads();
+  QM_LS_CLOCK(0);
   const real merit0 = ctl[0], viol0 = ctl[1];
   const int weightStructure = int(ctl[7]);
   const real armijo = a.instStats[size_t(inst) * 4 + 0];
@@ -291,6 +301,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     axpyStrided(Xt, X, dX, alphaMine, (N + 1) * 30, ltid, half);
     axpyStrided(Ut, U, dU, alphaMine, N * 30, ltid, half);
     __syncthreads();
+    QM_LS_CLOCK(1);
     real cs = 0.0_r, ds = 0.0_r, es = 0.0_r;
     for (int k = ltid; k <= N; k += half) {
       real c, d, e;
@@ -298,8 +309,10 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
       nodePerformance(mdS, st, QM_TO_LDS_PTR(real, wQ), QM_TO_LDS_PTR(real, wR), weightStructure, a.Rw + QM_RW_DERIVED, sched, tTimes, tStates, a.eeContact ? a.eeContact + size_t(inst) * a.K * 6 : nullptr, a.K, tg[k], a.dtgrid[size_t(inst) * (N + 1) + k], a.nodePhase[size_t(inst) * (N + 1) + k], term, Xt + k * 30, term ? Ut : Ut + k * 30, term ? Xt + k * 30 : Xt + (k + 1) * 30, c, d, e);
       cs += c; ds += d; es += e;
     }
+    QM_LS_CLOCK(2);
     red[tid] = cs; red[256 + tid] = ds; red[512 + tid] = es;
     __syncthreads();
+    QM_LS_CLOCK(3);
     if (tid == 0) {
       real acc = 0.0_r, accAlpha = alpha, m1 = merit0, v1 = viol0; int type = 0;
       for (int tr = 0; tr < nTr && acc == 0.0_r; ++tr) {
@@ -320,6 +333,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
       ctl[2] = m1; ctl[3] = v1; ctl[4] = acc; ctl[5] = real(type); ctl[6] = accAlpha;
     }
     __syncthreads();
+    QM_LS_CLOCK(4);
     merit1 = ctl[2]; viol1 = ctl[3]; stepType = int(ctl[5]);
     accepted = ctl[4] != 0.0_r;
     const real lastAlpha = ctl[6];
@@ -334,6 +348,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   axpyStrided(oX, X, dX, alpha, (N + 1) * 30, tid, nthr);
   axpyStrided(oU, U, dU, alpha, N * 30, tid, nthr);
   for (int k = tid; k <= N; k += nthr) { a.outT[size_t(inst) * (N + 1) + k] = tg[k]; a.outMode[size_t(inst) * (N + 1) + k] = a.nodeMode[size_t(inst) * (N + 1) + k]; }
+  QM_LS_CLOCK(5);
   // ---- upstream SqpSolver::checkConvergence: iteration limit, step size, metrics, primal step (l2 norms over the whole horizon)
   const real sx = sumSquaresStrided(dX, (N + 1) * 30, tid, nthr), su = sumSquaresStrided(dU, N * 30, tid, nthr);
   __syncthreads();
@@ -355,6 +370,7 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
       s[8] = real(a.iteration + 1); s[9] = real(conv);
     }
   }
+  QM_LS_CLOCK(6);
 }
 
 }  // namespace qmk

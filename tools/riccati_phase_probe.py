@@ -70,6 +70,9 @@ v = raw[224:224 + len(LS)]
 print("linesearch nodePerformance, node 5 of instance 0 (all calls of a launch): total %d ticks (kernel %.4f ms)" % (v.sum(), ms[3]))
 for n_, x in zip(LS, v): print("  %-50s %9.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
 
+v = raw[240:247]
+print("linesearch_kernel, thread 0 of instance 0: sections in ticks (total %d)" % v.sum())
+for n_, x in zip(["weights / model into LDS, baseline sums", "trial iterates (axpy) + barrier", "node evaluations (nodePerformance)", "partial sums + barrier", "filter decision (thread 0) + barrier", "new iterate out", "step norms, convergence, statistics"], v): print("  %-50s %8.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
 # per-instance totals of the last wbc launch (not sums): ticks, interior-point iterations of the three levels
 pi = np.array(buf[512:512 + 4 * B], dtype=np.float64).reshape(B, 4)
 tk, its = pi[:, 0], pi[:, 1:]
