@@ -44,6 +44,10 @@ VARIANTS["x_inline"] = ((*_OPQ, "-DQM_WBC_EXP=2"), False, "failing combination, 
 VARIANTS["x_wave2"] = ((*_OPQ, "-DQM_WBC_EXP=3"), False, "failing combination, desired pass on helper wavefront 2: fails too (the failure follows the call)")
 VARIANTS["x_drain"] = ((*_OPQ, "-DQM_WBC_EXP=4"), False, "failing combination, s_waitcnt vmcnt(0) lgkmcnt(0) before the fork-join loop: still fails (not memory ordering)")
 VARIANTS["x_sleep"] = ((*_OPQ, "-DQM_WBC_EXP=5"), False, "failing combination, helpers sleep before the fork-join loop: still fails (not timing)")
+# timing experiments (tools/variant_timing.py): the instruction scheduler's strategy for the whole translation unit
+VARIANTS["s_maxilp"] = (("-mllvm", "-amdgpu-sched-strategy=max-ilp"), False, "LLVM's max-ILP scheduling strategy (timing experiment)")
+VARIANTS["s_iterilp"] = (("-mllvm", "-amdgpu-sched-strategy=iterative-ilp"), False, "LLVM's iterative ILP scheduling strategy (timing experiment)")
+VARIANTS["s_maxmem"] = (("-mllvm", "-amdgpu-sched-strategy=max-memory-clause"), False, "LLVM's max-memory-clause scheduling strategy (timing experiment)")
 VARIANTS["dump"] = (("-DQM_WBC_DUMP",), False, "product + LDS dump checkpoints of instance 0")
 VARIANTS["dump_opq"] = (("-DQM_WBC_DUMP", "-DQM_WBC_OPAQUE_MASK=511", "-mllvm", "-enable-ipra=1"), False, "failing combination + LDS dump checkpoints (the instrumentation of the helper loop hides the failure)")
 
