@@ -218,6 +218,13 @@ __device__ __forceinline__ real sumSquaresStrided(const real* v, int n, int firs
 #else
 #define QM_LS_CLOCK(slot)
 #endif
+// QM_LS_EXTERN (the product build of qmgpu_api.hip, qm_door_amd/build.py): the kernel is only declared here and DEFINED in qmgpu_ls.hip, a translation unit of its own
+// that is compiled with LLVM's interprocedural register allocation ON.  The rest of the library needs it off (wbc_kernel), and without it
+// the called node evaluation saves and restores 156 callee-saved registers per lane through scratch memory -- 1,248 B per lane, 0.16 GB of HBM traffic per step and
+// 14 % of this kernel's time (profiles/r04h_variant_timing.txt: 0.109 -> 0.095 ms).  The profiling build keeps one translation unit (its clocks live in one device symbol).
+#if defined(QM_LS_EXTERN) && !defined(QM_RICCATI_TIMING)
+__global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a);
+#else
 __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
 #ifdef QM_RICCATI_TIMING
   unsigned long long lsClk = clock64();
@@ -372,5 +379,6 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   }
   QM_LS_CLOCK(6);
 }
+#endif   // QM_LS_EXTERN
 
 }  // namespace qmk
