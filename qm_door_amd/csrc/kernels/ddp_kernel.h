@@ -43,6 +43,11 @@ __device__ __forceinline__ real ddpStepLength(const SettingsR& st, int trial) {
   return a;
 }
 
+// as linesearch_kernel: only declared in the product build of qmgpu_api.hip, defined in qmgpu_ls.hip (interprocedural register allocation on: the called node
+// evaluation no longer saves its callee-saved registers through scratch)
+#if defined(QM_LS_EXTERN) && !defined(QM_RICCATI_TIMING)
+__global__ void __launch_bounds__(64) ddp_rollout_kernel(DdpArgs a);
+#else
 __global__ void __launch_bounds__(64) ddp_rollout_kernel(DdpArgs a) {
   const int id = blockIdx.x * 64 + threadIdx.x;
   const bool init = a.trials == 0;
@@ -108,6 +113,7 @@ __global__ void __launch_bounds__(64) ddp_rollout_kernel(DdpArgs a) {
     a.merit[size_t(id) * 2 + 1] = eqSum;
   }
 }
+#endif   // QM_LS_EXTERN
 
 struct DdpSelectArgs {
   const ProblemR* P;
@@ -121,6 +127,7 @@ struct DdpSelectArgs {
   int* done;
 };
 
+#ifndef QM_LS_UNIT   // (qmgpu_ls.hip includes this file for ddp_rollout_kernel only)
 __global__ void __launch_bounds__(256) ddp_select_kernel(DdpSelectArgs a) {
   __shared__ real red[2 * 256];
   __shared__ int pick;
@@ -164,5 +171,6 @@ __global__ void __launch_bounds__(256) ddp_select_kernel(DdpSelectArgs a) {
   for (int e = tid; e < N * 30; e += nthr) oU[e] = Us[e];
   for (int k = tid; k <= N; k += nthr) { a.outT[size_t(inst) * (N + 1) + k] = a.tgrid[size_t(inst) * (N + 1) + k]; a.outMode[size_t(inst) * (N + 1) + k] = a.nodeMode[size_t(inst) * (N + 1) + k]; }
 }
+#endif
 
 }  // namespace qmk
