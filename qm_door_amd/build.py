@@ -40,7 +40,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, obj_dir=
         return OUT
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    api_o, mpc32_o, host_o, ls_o = os.path.join(OBJ, "qmgpu_api.o"), os.path.join(OBJ, "qmgpu_mpc32.o"), os.path.join(OBJ, "host_config.o"), os.path.join(OBJ, "qmgpu_ls.o")
+    api_o, mpc32_o, host_o, ls_o, lq_o = (os.path.join(OBJ, n) for n in ("qmgpu_api.o", "qmgpu_mpc32.o", "host_config.o", "qmgpu_ls.o", "qmgpu_lq.o"))
     # -enable-ipra=0: LLVM's interprocedural register allocation (on by default for AMDGPU) miscompiles a call on wbc_kernel's helper wavefront path in
     # some build variants of these sources (reproducer tools/wbc_variants.py --run opq x_noipra); with it off every variant
     # computes the same cycle.  a variant switches it back on with extra_flags = (-mllvm, -enable-ipra=1).
@@ -52,19 +52,24 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None, obj_dir=
     # switch itself, or the profiling build (one device symbol for all clocks), keeps the single translation unit
     split_ls = bool(ipra) and "-DQM_RICCATI_TIMING" not in extra_flags
     base_flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *extra_flags]
+    # lq_node_kernel lives in a translation unit of its own (qmgpu_lq.hip) compiled at -O2: measured 2.7 % faster than at -O3 (0.456 -> 0.443 ms, profiles/r04i_variant_timing.txt),
+    # bit-identical results; the profiling build keeps the single translation unit
+    split_lq = "-DQM_RICCATI_TIMING" not in extra_flags
     cmds = [
-        [hipcc, *hip_flags, *(["-DQM_LS_EXTERN"] if split_ls else []), "-c", os.path.join(CSRC, "qmgpu_api.hip"), "-o", api_o],
+        [hipcc, *hip_flags, *(["-DQM_LS_EXTERN"] if split_ls else []), *(["-DQM_LQ_EXTERN"] if split_lq else []), "-c", os.path.join(CSRC, "qmgpu_api.hip"), "-o", api_o],
         [hipcc, *hip_flags, "-DQM_REAL=float", "-Dqmk=qmk32", "-c", os.path.join(CSRC, "qmgpu_mpc32.hip"), "-o", mpc32_o],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, "host", "host_config.cpp"), "-o", host_o],
     ]
     if split_ls:
         cmds.append([hipcc, *base_flags, "-mllvm", "-enable-ipra=1", "-c", os.path.join(CSRC, "qmgpu_ls.hip"), "-o", ls_o])
+    if split_lq:
+        cmds.append([hipcc, *[("-O2" if f == "-O3" else f) for f in hip_flags], "-c", os.path.join(CSRC, "qmgpu_lq.hip"), "-o", lq_o])
     # Inside this repository the process already holds PyTorch's bundled HIP runtime, so link against that one first; a catkin
     # workspace without PyTorch sets QMGPU_HIP_LIBDIR=/opt/rocm/lib.
     override = os.environ.get("QMGPU_HIP_LIBDIR")
     tl = None if override else _torch_lib_dir()
     libdirs = [override] if override else (([tl] if tl else []) + ["/opt/rocm/lib"])
-    link = ["g++", "-shared", "-o", OUT, api_o, mpc32_o, host_o] + ([ls_o] if split_ls else [])
+    link = ["g++", "-shared", "-o", OUT, api_o, mpc32_o, host_o] + ([ls_o] if split_ls else []) + ([lq_o] if split_lq else [])
     for d in libdirs:
         link += [f"-L{d}", f"-Wl,-rpath,{d}"]
     link += ["-lamdhip64", "-lstdc++", "-lm"]

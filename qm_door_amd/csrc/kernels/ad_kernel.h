@@ -92,6 +92,7 @@ constexpr int AD_LDS_DOUBLES = ADL_PUB + AD_NODES * SWEEP_PUB_NODE;
 static_assert(AD_NODES * 12 * 64 <= AD_PARK_DOUBLES, "the Jacobian rows reuse the parking area");
 static_assert(AD_LDS_DOUBLES * sizeof(real) <= 40960, "four wavefronts per CU");
 
+#ifndef QM_LQ_UNIT   // (qmgpu_lq.hip includes this file for LqArgs and the row layout only)
 __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs a) {
   __shared__ real lds[AD_LDS_DOUBLES];
   QM_POISON_LDS(lds, AD_LDS_DOUBLES);
@@ -360,5 +361,6 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
   if (lane == 0 && blockIdx.x < QM_AD_WG_CLOCKS) { qmk::qmAdWgClock[2 * blockIdx.x] = qmWgStart; qmk::qmAdWgClock[2 * blockIdx.x + 1] = wall_clock64(); }
 #endif
 }
+#endif   // QM_LQ_UNIT
 
 }  // namespace qmk
