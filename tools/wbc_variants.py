@@ -48,6 +48,12 @@ VARIANTS["x_sleep"] = ((*_OPQ, "-DQM_WBC_EXP=5"), False, "failing combination, h
 VARIANTS["s_maxilp"] = (("-mllvm", "-amdgpu-sched-strategy=max-ilp"), False, "LLVM's max-ILP scheduling strategy (timing experiment)")
 VARIANTS["s_iterilp"] = (("-mllvm", "-amdgpu-sched-strategy=iterative-ilp"), False, "LLVM's iterative ILP scheduling strategy (timing experiment)")
 VARIANTS["s_maxmem"] = (("-mllvm", "-amdgpu-sched-strategy=max-memory-clause"), False, "LLVM's max-memory-clause scheduling strategy (timing experiment)")
+VARIANTS["s_track"] = (("-mllvm", "-amdgpu-use-amdgpu-trackers"), False, "AMDGPU register-pressure trackers in the scheduler (timing experiment)")
+VARIANTS["s_bias0"] = (("-mllvm", "-amdgpu-schedule-metric-bias=0"), False, "scheduler metric bias 0: latency over occupancy (timing experiment)")
+VARIANTS["s_bias100"] = (("-mllvm", "-amdgpu-schedule-metric-bias=100"), False, "scheduler metric bias 100: occupancy only (timing experiment)")
+VARIANTS["s_relax"] = (("-mllvm", "-amdgpu-schedule-relaxed-occupancy"), False, "relaxed occupancy targets (timing experiment)")
+VARIANTS["s_nopost"] = (("-mllvm", "-enable-post-misched=0"), False, "no post-RA machine scheduler (timing experiment)")
+VARIANTS["s_nounroll"] = (("-fno-unroll-loops",), False, "no loop unrolling beyond the pragmas (timing experiment)")
 VARIANTS["dump"] = (("-DQM_WBC_DUMP",), False, "product + LDS dump checkpoints of instance 0")
 VARIANTS["dump_opq"] = (("-DQM_WBC_DUMP", "-DQM_WBC_OPAQUE_MASK=511", "-mllvm", "-enable-ipra=1"), False, "failing combination + LDS dump checkpoints (the instrumentation of the helper loop hides the failure)")
 
