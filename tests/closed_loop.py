@@ -39,7 +39,7 @@ class Scenario(Disturbance):
     """Seeded batch: initial poses (xy, yaw, joints perturbed), two target knots spanning the run (base + end-effector displaced), stance then trot,
     a start time just before the WBC's start-up branch ends (t = 10 s, HierarchicalWbc.cpp:23), smooth per-coordinate disturbances."""
 
-    def __init__(self, itf, batch, seed=31, t_start=9.5, cycles=100, gait_start=0.12, max_nodes=96, horizon=HORIZON):
+    def __init__(self, itf, batch, seed=31, t_start=9.5, cycles=100, gait_start=0.12, max_nodes=96, horizon=HORIZON, gait="trot"):
         from qm_door_amd import abi, api
         rng = np.random.default_rng(seed)
         self.B, self.t_start, self.cycles, self.max_nodes, self.horizon = batch, t_start, cycles, max_nodes, horizon
@@ -64,7 +64,7 @@ class Scenario(Disturbance):
         self.tt, self.ts = tt, ts
         # stance until t_start + gait_start, then trot (gait.info) tiled past the last horizon
         g = api.GaitSchedule(lib=itf.lib)
-        nev, ev, md = g.mode_schedule("trot", t_start + gait_start, t_start + gait_start, t_end)
+        nev, ev, md = g.mode_schedule(gait, t_start + gait_start, t_start + gait_start, t_end)
         ev = np.array(ev); md = np.array(md, dtype=np.int32)
         assert md[0] == 15 and nev <= abi.MAX_EVENTS          # the tiler puts the default STANCE mode in front of the template's first phase
         self.nev, self.ev, self.md = int(nev), ev, md

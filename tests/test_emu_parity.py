@@ -3,6 +3,7 @@ oracle.  This validates the kernels' lane roles, LDS hand-offs and index math wi
 comparison on the real hipcc build.  The emulation library is test infrastructure and is never loaded by qm_door_amd."""
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 
@@ -80,6 +81,20 @@ def test_emu_wbc(emu):
         assert s == 0
         assert np.abs(out[i] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
         assert np.array_equal(il[i], il_ref)
+
+
+def test_emu_wbc_on_the_degenerate_stance_tick(emu):
+    """tests/golden/wbc_degenerate_stance_tick.npz (test_oracle_invariants.py says what it is): on the SAME inputs kernel and oracle take the same path"""
+    itf, orc = emu
+    c = np.load(os.path.join(S.ROOT, "tests", "golden", "wbc_degenerate_stance_tick.npz"))
+    sol = api.GpuSolver(itf, max_batch=1, max_nodes=4)
+    out, st = np.zeros((1, 54)), np.zeros(1, dtype=np.int32)
+    il = c["il"][None].copy()
+    a = sol.wbc_args(1, c["rbd"][None], np.full(1, 0.001), np.array([float(c["t"])]), il, out, st, c["xd"][None], c["ud"][None], np.array([int(c["mode"])], dtype=np.int32), 0)
+    sol.wbc(a)
+    s, ref, il_ref = orc.wbc_update(c["xd"], c["ud"], c["rbd"], int(c["mode"]), 0.001, float(c["t"]), c["il"].copy())
+    assert s == 0 and st[0] == 0
+    assert np.abs(out[0] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
 
 
 def test_emu_mixed_modes_and_event_grid(emu):

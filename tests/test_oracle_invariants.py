@@ -1,3 +1,4 @@
+import os
 """Pins the CPU oracle (PARITY UNPINNED: the reference ships no golden vectors) by the invariant suite of SURVEY.md 8(c):
 model identities, finite-difference checks of every derivative, rigid-body dynamics identities, QP optimality (KKT),
 hierarchy properties of the HoQP cascade, bit-exact mode tables, swing-spline boundary conditions, SQP convergence."""
@@ -442,3 +443,33 @@ def test_zero_try_of_the_first_level_does_not_change_the_result(interface, oracl
         assert bad.sum() == 0, (variant, np.nonzero(bad)[0][:8], dev[bad][:8], sens_old[bad][:8], sens_new[bad][:8])
         assert np.median(dev) <= 1e-8 and (dev > 1e-7).sum() <= max(2, (sens_old > 1e-7).sum())
         assert (sens_new > 1e-7).sum() <= (sens_old > 1e-7).sum() + 3
+
+
+def test_degenerate_lowest_level_is_bistable_in_the_oracle_itself(interface, oracle):
+    """tests/golden/wbc_degenerate_stance_tick.npz: the WBC inputs of ONE tick of the static-walk closed loop (tests/test_closed_loop.py, instance 72, t = 10.501 s, full
+    stance) on which the GPU loop and the oracle loop -- each fed by its own plan, inputs 1e-11 apart -- returned torques 12 % apart.  This pins what that is: not a kernel
+    defect (the emulated kernel reproduces the oracle on these inputs, test_emu_parity / 2e-14 on the GPU) but the degenerate class of DESIGN.md section 5.  The contact-force
+    level inherits rows with zero margin that leave it no interior: its exact solution is z = 0; the relaxed re-solve (every inherited margin >= 1e-5, HoQp's fallback when the
+    first attempt does not converge) moves the level by O(10) for a violation of 1e-5.  Which of the two the SAME implementation returns depends on the path of its interior
+    point: here the oracle with lower-level starting values 300 (product) and 100."""
+    c = np.load(os.path.join(S.ROOT, "tests", "golden", "wbc_degenerate_stance_tick.npz"))
+    args = (c["xd"], c["ud"], c["rbd"], int(c["mode"]), 0.001, float(c["t"]))
+    try:
+        sa, out_a, _ = oracle.wbc_update(*args, c["il"].copy())
+        lv_a = oracle.wbc_level(2, *args, c["il"].copy())
+        oracle.set_experiment(lower_level_start=100.0)
+        sb, out_b, _ = oracle.wbc_update(*args, c["il"].copy())
+        lv_b = oracle.wbc_level(2, *args, c["il"].copy())
+    finally:
+        oracle.set_experiment()
+    assert sa == 0 and sb == 0
+    assert np.abs(lv_a["H"] - lv_b["H"]).max() <= 1e-9 and np.abs(lv_a["D"] - lv_b["D"]).max() <= 1e-9      # the same level-2 problem on both paths (levels 0 and 1 agree to 1e-12)
+    H, cc, D, f = lv_a["H"], lv_a["c"], lv_a["D"], lv_a["f"]
+    za, zb = lv_a["sol"], lv_b["sol"]
+    obj = lambda v: 0.5 * v @ H @ v + cc @ v  # noqa: E731
+    small, large = (za, zb) if np.abs(za).max() < np.abs(zb).max() else (zb, za)
+    assert np.abs(small).max() <= 1e-9 and (D @ small - f).max() <= 1e-9                 # the exact problem: nothing to gain inside the inherited rows
+    assert np.abs(large).max() >= 1.0 and 1e-7 <= (D @ large - f).max() <= 1.01e-5      # the relaxed problem: a large step for a violation of the 1e-5 margin
+    assert obj(large) < obj(small) - 1.0
+    dev = np.abs(out_a[36:] - out_b[36:]).max() / max(1.0, np.abs(out_a[36:]).max())
+    assert 1e-2 <= dev <= 1.0, dev                                                        # what the torques make of it
