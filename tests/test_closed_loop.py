@@ -104,3 +104,19 @@ def test_closed_loop_static_walk_three_leg_stances(interface):
     # its first attempt does not converge) the level moves by 16 and the torques by 12 %; which of the two an implementation returns flips under input perturbations of
     # 1e-13 in the ORACLE ITSELF, and the two loops here feed their own plans back (inputs 1e-11 apart).  With the oracle's inputs the kernels return the oracle's torques to 2e-14.
     _check(rows, offenders=offenders, ticks=B * cycles * 10, loose_per=10000, gross_per=25000, loose_max=1e-3)
+
+
+@pytest.mark.gpu
+def test_closed_loop_flying_trot_flight_phases(interface):
+    """The same loop on flying_trot (gait.info: LF_RH, FLY, RF_LH, FLY): flight phases -- no contact, sixteen equality rows per node in the MPC, a WBC whose lowest level has
+    no decision variable left -- alternate with two-leg stances.  64 robots x 50 MPC cycles x 10 WBC ticks, HierarchicalWbc."""
+    B, cycles = 64, 50
+    sc = CL.Scenario(interface, B, cycles=cycles, t_start=10.5, gait_start=0.05, gait="flying_trot", seed=41)
+    offenders = []
+    rows = CL.run_lockstep(sc, CL.GpuBackend(interface, sc, 0), CL.OracleBackend(S.Oracle(interface.problem, fast=True), sc, 0), ticks=10, offenders=offenders)
+    s = _summary(rows)
+    path = os.path.join(S.ROOT, "gpurun_out", "closed_loop_flying_trot.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(dict(instances=B, ticks_per_cycle=10, t_start=sc.t_start, gait="flying_trot", summary=s, offenders=offenders, per_cycle=rows), open(path, "w"), indent=1)
+    assert 0 in set(int(m) for m in sc.md[1:sc.nev])          # flight phases inside the run
+    _check(rows, offenders=offenders, ticks=B * cycles * 10, loose_per=10000, gross_per=25000, loose_max=1e-3)
