@@ -795,16 +795,25 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
       int* colPerm = ip; int* rowOf = ip + 40; int* pivOk = ip + 64; int* freePos = ip + 96;
       const int size = r < n ? r : n;
-      int rowPos = lane;
+      // Lanes: row i of A Z is worked on by up to three lanes, i, r + i and 2 r + i ("chunks"), each eliminating a contiguous third of the column positions behind the pivot
+      // (r <= 21: three chunks, 22: two) -- with one lane per row only r of the 64 lanes worked and a step was 35 dependent LDS round trips long.  Same arithmetic per
+      // entry, same decisions: the chunks' column ranges are in increasing order, so "largest magnitude, first position on ties" of a row is the best of chunk 0, else 1,
+      // else 2; the per-row state (rowPos, best, bj) is kept identical in the lanes of a row, the pivot's row is chosen among the chunk-0 lanes (lane = row index) as before.
+      const int nChunk = 3 * r <= 64 ? 3 : (2 * r <= 64 ? 2 : 1);
+      const int chunk = (lane >= r ? 1 : 0) + (lane >= 2 * r ? 1 : 0);
+      const bool active = lane < nChunk * r;
+      const int rowIdx = active ? lane - chunk * r : 0;
+      double* xchgV = Vh + 128; int* xchgJ = reinterpret_cast<int*>(Vh + 192);   // exchange of the chunks' candidates (64 doubles, 64 ints; beyond the index tables)
+      int rowPos = rowIdx;
       int colPermReg = lane;     // lane j: the original column at position j (swapped between lanes with v_readlane; LDS copy after the loop)
       int rowOfReg = 0;          // lane k: the row that gave pivot k
       double maxPivot = 0.0;
       int nonzero = 0;
-      double* row = AZ + (lane < r ? lane : 0) * LDZ;
+      double* row = AZ + rowIdx * LDZ;
       // largest entry of this lane's row over the column positions >= k, first one on ties (the oracle scans positions in increasing order).  Loads in
       // batches of eight before any store: a store to LDS between two loads of the same array serialises them (the compiler cannot tell the rows apart)
       double best = -1.0; int bj = 0;
-      if (lane < r) {
+      if (active) {
 #pragma unroll 1
         for (int j0 = 0; j0 < n; j0 += 8) {
           double v[8];
@@ -830,33 +839,50 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         else Lp = int(qmAllMin(cand ? double(rowPos * 64 + lane) : 1e9, red)) & 63;   // ties between rows: the smallest row position (the oracle's outer scan index)
         const int pr = qmReadLaneInt(rowPos, Lp), pc = qmReadLaneInt(bj, Lp);
         maxPivot = fmax(maxPivot, gmax);
-        if (lane < r) { if (lane == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
+        if (active) { if (rowIdx == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
         { const int ck = qmReadLaneInt(colPermReg, k), cp = qmReadLaneInt(colPermReg, pc); if (lane == k) colPermReg = cp; else if (lane == pc) colPermReg = ck; }
         if (lane == k) rowOfReg = Lp;
         QM_TICK(19);
         double vk = 0.0, vpc = 0.0;
-        if (lane < r) { vk = row[k]; vpc = row[pc]; }
+        if (active) { vk = row[k]; vpc = row[pc]; }
+        QM_WAVE_SYNC();
         if (pc != k && lane < r) { row[k] = vpc; row[pc] = vk; }
         const double pivot = qmReadLane(vpc, Lp);
         QM_WAVE_SYNC();
         QM_TICK(20);
-        // elimination of the rows still below the pivot; the largest entry of the updated row (positions > k) is found on the way: the next step's candidate
+        // elimination of the rows still below the pivot, this lane's share of the column positions; the largest entry of the updated row (positions > k) is found on
+        // the way: the next step's candidate
         const double* prow = AZ + Lp * LDZ;
         best = -1.0; bj = k + 1;
-        if (lane < r && rowPos > k) {
+        const int len = n - k - 1, per = (len + nChunk - 1) / nChunk;
+        const int jLo = k + 1 + chunk * per, jHi = (jLo + per < n) ? jLo + per : n;
+        if (active && rowPos > k) {
           const double f = vpc / pivot;
 #pragma unroll 1
-          for (int j0 = k + 1; j0 < n; j0 += 8) {
+          for (int j0 = jLo; j0 < jHi; j0 += 8) {
             double a[8], pv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int j = j0 + q < n ? j0 + q : k + 1; a[q] = row[j]; pv[q] = prow[j]; }
+            for (int q = 0; q < 8; ++q) { const int j = j0 + q < jHi ? j0 + q : jLo; a[q] = row[j]; pv[q] = prow[j]; }
             // product and difference rounded separately (no fused multiply-add): the pivot search compares these numbers for EQUALITY of magnitude with
             // entries of other rows (the level tasks carry unit rows, so exact ties are the rule, not the exception) and must take the decisions the
             // oracle's kernelFullPivLU takes on the host
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[q] = qmSubNoFma(a[q], qmMulNoFma(f, pv[q]));
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (j0 + q < n) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
+            for (int q = 0; q < 8; ++q) if (j0 + q < jHi) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
+          }
+        }
+        if (nChunk > 1) {   // the row's candidate: the chunks' candidates in the order of their column ranges (strictly larger wins: first position on ties)
+          QM_WAVE_SYNC();
+          xchgV[lane] = best; xchgJ[lane] = bj;
+          QM_WAVE_SYNC();
+          if (active) {
+            double b0 = xchgV[rowIdx]; int j0 = xchgJ[rowIdx];
+            const double b1 = xchgV[rowIdx + r]; const int j1 = xchgJ[rowIdx + r];
+            const double b2 = nChunk > 2 ? xchgV[rowIdx + 2 * r] : -1.0; const int j2 = nChunk > 2 ? xchgJ[rowIdx + 2 * r] : 0;
+            if (b1 > b0) { b0 = b1; j0 = j1; }
+            if (b2 > b0) { b0 = b2; j0 = j2; }
+            best = b0; bj = j0;
           }
         }
         ++nonzero;
