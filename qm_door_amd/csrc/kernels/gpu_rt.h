@@ -43,6 +43,7 @@ __device__ __forceinline__ int qmReadLaneInt(int v, int src) { return __builtin_
 // the lanes of the wavefront where `p` holds, as a mask (v_cmp into a scalar pair), and the lowest set bit of such a mask (s_ff1)
 __device__ __forceinline__ unsigned long long qmBallot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int qmFirstBit(unsigned long long m) { return __builtin_ctzll(m); }
+__device__ __forceinline__ int qmPopCount(unsigned long long m) { return __builtin_popcountll(m); }
 // One 16x16x4 matrix-core instruction: C[16x16] += A[16x4] B[4x16]  (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).
 // Operand layout (both types; measured on gfx950 for fp64, tools/probe_mfma.hip): lane l supplies a = A[l % 16][l / 16] and
 // b = B[l / 16][l % 16].  The accumulators differ: register r of lane l is

@@ -894,12 +894,14 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       QM_WAVE_SYNC();
       // rank: pivots above Eigen's default threshold eps * size * max pivot; the others' columns count as free
       const double thresh = maxPivot * 2.220446049250313e-16 * double(size);
-      if (lane < nonzero) pivOk[lane] = fabs(AZ[rowOf[lane] * LDZ + lane]) > thresh ? 1 : 0;
-      QM_WAVE_SYNC();
-      int rank = 0;
-      for (int k = 0; k < nonzero; ++k) rank += pivOk[k];
+      // (rank and the list of free column positions from two ballots: as loops over the LDS table -- one of them on lane 0 alone -- they were 36 + 18 dependent LDS round trips)
+      const bool okReg = lane < nonzero && fabs(AZ[rowOfReg * LDZ + lane]) > thresh;
+      if (lane < nonzero) pivOk[lane] = okReg ? 1 : 0;
+      const int rank = qmPopCount(qmBallot(okReg));
       const int nNew = n - rank;
-      if (lane == 0) { int q = 0; for (int pos = 0; pos < n; ++pos) if (!(pos < nonzero && pivOk[pos])) freePos[q++] = pos; }
+      const bool freeReg = lane < n && !okReg;
+      const unsigned long long freeMask = qmBallot(freeReg);
+      if (freeReg) freePos[qmPopCount(freeMask & ((1ull << lane) - 1ull))] = lane;
       for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;      // N (n x nNew), one kernel vector per lane / column
       QM_WAVE_SYNC();
       QM_TICK(15);
@@ -933,7 +935,21 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       // Z N on the matrix cores (columns >= n of Z are zero, rows >= n of N too)
       forkGemm(false, Z, LDZ, K, LDK, ND, nNew, n, Zn, LDZ, 0.0);
       QM_WAVE_SYNC();
-      for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e % LDZ) < nNew) ? Zn[e] : 0.0;
+      {   // Z <- Z N with the columns >= nNew cleared: all loads first (a store between two loads of LDS serialises them), the column index carried along instead of e % LDZ
+        constexpr int NIT = (ND * LDZ + 63) / 64;
+        double t[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) { const int e = lane + 64 * i; t[i] = Zn[e < ND * LDZ ? e : 0]; }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) QM_KEEP(t[i]);
+        int col = lane >= LDZ ? lane - LDZ : lane;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int e = lane + 64 * i;
+          if (e < ND * LDZ) Z[e] = col < nNew ? t[i] : 0.0;
+          col += 64 - LDZ; if (col >= LDZ) col -= LDZ;
+        }
+      }
       n = nNew;
       QM_WAVE_SYNC();
       QM_TICK(17);

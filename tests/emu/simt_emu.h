@@ -115,6 +115,7 @@ inline unsigned long long qmBallot(bool p) {
   return m;
 }
 inline int qmFirstBit(unsigned long long m) { return __builtin_ctzll(m); }
+inline int qmPopCount(unsigned long long m) { return __builtin_popcountll(m); }
 
 template <class T> struct QmGatherT {
   T vals[64];
