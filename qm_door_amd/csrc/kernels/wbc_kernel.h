@@ -702,13 +702,29 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     const int mOwn = (level == 0) ? m0 : 0, mPrev = (level == 0) ? 0 : m0;
     const int mRows = mOwn + mPrev;  // <= 56, one row per lane
     const double* AZp = AZ;
+    // row-major copy (stride ND -> stride LDZ) of `rows` rows: what the products with Z = I of the first level are, entry for entry (x * 1 + 0 + ... is exact)
+    auto copyRows = [&](const double* src, double* dst, int rows) {
+#pragma unroll 1
+      for (int e0 = 0; e0 < rows * ND; e0 += 8 * 64) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + 64 * q + lane; t[q] = src[e < rows * ND ? e : 0]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) QM_KEEP(t[q]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + 64 * q + lane; if (e < rows * ND) dst[(e / ND) * LDZ + (e % ND)] = t[q]; }
+      }
+    };
     if (level == 3) AZp = Z;  // A = I  =>  A Z = Z
+    else if (level == 0) copyRows(A, AZ, r);   // Z = I (n = ND)
     else forkGemm(false, A, ND, Z, LDZ, r, n, ND, AZ, LDZ, 0.0);
     QM_TICK(11);
     // D Z on the matrix cores; columns >= n stay zero padding (the interior point always spans whole tiles)
     for (int e = lane; e < m0 * LDZ; e += 64) DZ[e] = 0.0;
     QM_WAVE_SYNC();
-    forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0);
+    if (level == 0) copyRows(D0, DZ, m0);
+    else forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0);
+    QM_WAVE_SYNC();
     QM_TICK(12);
     if (lane < r) {  // A x_prev - b (temporarily in tzv)
       double s;
@@ -909,12 +925,16 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         // U11 X = -U12 for this lane's free column: back substitution over the accepted pivots, X(:, lane) in registers (fully unrolled: compile-time
         // indices), the U entries as wave-uniform LDS reads; the results leave for LDS after the loop (no store between the loads)
         const int fp = lane < nNew ? freePos[lane] : 0;
+        // (which pivots count and where their rows are: read once, all loads in flight together, instead of one LDS round trip in front of every step)
+        bool okk[MAXR]; int rb[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) { const int ok = pivOk[k < nonzero ? k : 0], ro = rowOf[k < nonzero ? k : 0]; okk[k] = k < nonzero && ok != 0; rb[k] = ro * LDZ; }
         double xk[MAXR];
 #pragma unroll
         for (int k = MAXR - 1; k >= 0; --k) {
           xk[k] = 0.0;
-          if (k < nonzero && pivOk[k]) {   // wave-uniform
-            const double* urow = AZ + rowOf[k] * LDZ;
+          if (okk[k]) {   // wave-uniform
+            const double* urow = AZ + rb[k];
             double u[MAXR];
 #pragma unroll
             for (int k2 = k + 1; k2 < MAXR; ++k2) u[k2] = urow[k2 < n ? k2 : 0];
@@ -926,7 +946,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         }
         if (lane < nNew) {
 #pragma unroll
-          for (int k = 0; k < MAXR; ++k) if (k < nonzero && pivOk[k]) K[colPerm[k] * LDK + lane] = xk[k];
+          for (int k = 0; k < MAXR; ++k) if (okk[k]) K[colPerm[k] * LDK + lane] = xk[k];
           K[colPerm[fp] * LDK + lane] = 1.0;
         }
       }
