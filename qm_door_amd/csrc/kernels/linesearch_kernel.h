@@ -32,11 +32,18 @@ struct LsArgs {
 
 // dynamic LDS of a line-search launch that keeps the trial trajectories on chip: 0 if they do not fit beside the static arrays
 constexpr int LS_STATIC_LDS_BYTES = (3 * 256 + 8 + 1800) * int(sizeof(real)) + int(sizeof(ModelR)) + 256 * 4 + 256;
-inline int lsTrialLdsBytes(int N) {
-  const int trials = (N + 1 <= 128) ? 2 : 1;
+inline int lsTrialLdsBytes(int N, int threads = 256) {
+  const int trials = (N + 1 <= threads / 2) ? 2 : 1;
   const long long need = (long long)trials * (2 * N + 1) * 30 * (long long)sizeof(real);
   return need + LS_STATIC_LDS_BYTES <= 160 * 1024 ? int(need) : 0;
 }
+// Threads per workgroup of a line-search launch.  256 = two trial steps side by side (the kernel comment): right while every instance has a CU of its own, where
+// the launch lasts as long as its slowest instance.  With more instances than CUs the launch is a queue, throughput counts, and the speculative second trial (wasted
+// in every instance that accepts the full step: all of them in the bench sets) is better spent on a second INSTANCE: 128 threads evaluate one trial at a time with
+// the same node-to-thread assignment and the same order of summation (64 < N + 1 <= 128: half = 128 either way; N + 1 <= 64: one node per thread either way --
+// merit, violation, alpha, step type and the iterate are bit-identical),
+// one trial's trajectories in LDS (48 KB at N = 100 instead of 96), so two workgroups share a CU.
+inline int lsThreads(int B, int N, int cus) { return (B > cus && N + 1 <= 128) ? 128 : 256; }
 
 struct DblIn {
   const real* x; const real* u; real dtS; const real* k1;
@@ -275,6 +282,13 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
         const bool legBlock = i >= 12 && i < 24 && j >= 12 && j < 24;
         outside = outside || (i != j && q != 0.0_r) || (i != j && !legBlock && r != 0.0_r);
       }
+    }
+    for (int e = tid + 4 * nthr; e < 900; e += nthr) {   // a 128-thread launch (lsThreads): the rest of the 900 entries; no iteration at 256 threads
+      const real q = st.Q[e], r = a.Rw[e];
+      wQ[e] = q; wR[e] = r;
+      const int i = e / 30, j = e - 30 * i;
+      const bool legBlock = i >= 12 && i < 24 && j >= 12 && j < 24;
+      outside = outside || (i != j && q != 0.0_r) || (i != j && !legBlock && r != 0.0_r);
     }
     structVotes[tid] = outside ? 1 : 0;
   }

@@ -22,6 +22,7 @@ struct MpcBuffers {
   real *dXt = nullptr, *dUt = nullptr, *dInstStats = nullptr, *dDebug = nullptr;
   int *dStageNc = nullptr, *dNodeMode = nullptr, *dNodePhase = nullptr, *dDone = nullptr;
   real *dDdpX = nullptr, *dDdpU = nullptr, *dDdpMerit = nullptr;   // DDP variant: trial trajectories / merits, allocated on first use
+  int cus = 256;                                                   // compute units of the device the buffers live on (allocateMpcBuffers): launch shapes that depend on batch > CUs
 };
 
 // the arguments of one call (qmgpu_mpc_args) as `real` device arrays
@@ -62,6 +63,8 @@ template <class Alloc> inline void allocateMpcBuffers(MpcBuffers& m, size_t B, s
   m.dStageNc = I(B * N1);
   m.dNodeMode = I(B * N1);
   m.dDone = I(B);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) m.cus = cus;
 }
 
 template <class Alloc> inline void ensureDdpBuffers(MpcBuffers& m, size_t B, size_t N, Alloc&& alloc) {
@@ -97,8 +100,8 @@ inline void enqueueMpcKernels(hipStream_t s, const MpcBuffers& m, const MpcIo& i
     QM_LAUNCH_DYN(riccati_kernel<RICCATI_WAVES>, B, RICCATI_WAVES * 64, RICCATI_LDS_BYTES, s, ra);
     if (ev) (void)hipEventRecord(ev[2], s);
     LsArgs ls{m.dP, m.dRw, B, N, io.K, io.lineSearch, io.eeContact, m.dTgrid, m.dDtgrid, m.dNodePhase, m.dX, m.dU, m.ddX, m.ddU, io.targetTimes, io.targetStates, io.schedNum,
-              io.schedTimes, io.schedModes, m.dMetrics, m.dInstStats, m.dNodeMode, m.dXt, m.dUt, io.outT, io.outX, io.outU, io.outMode, io.outStats, it, lsTrialLdsBytes(N) > 0, m.dDone};
-    QM_LAUNCH_DYN(linesearch_kernel, B, 256, lsTrialLdsBytes(N), s, ls);
+              io.schedTimes, io.schedModes, m.dMetrics, m.dInstStats, m.dNodeMode, m.dXt, m.dUt, io.outT, io.outX, io.outU, io.outMode, io.outStats, it, lsTrialLdsBytes(N, lsThreads(B, N, m.cus)) > 0, m.dDone};
+    QM_LAUNCH_DYN(linesearch_kernel, B, lsThreads(B, N, m.cus), lsTrialLdsBytes(N, lsThreads(B, N, m.cus)), s, ls);
     if (ev) (void)hipEventRecord(ev[3], s);
   }
 }

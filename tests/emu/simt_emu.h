@@ -229,6 +229,9 @@ inline const char* hipGetErrorString(hipError_t) { return "emulation"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+// compute units of the emulated device: QMGPU_EMU_CUS (default 256) -- a test sets it below its batch to reach the launch shapes chosen for batch > CUs
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { const char* e = std::getenv("QMGPU_EMU_CUS"); *v = e ? std::atoi(e) : 256; return 0; }
 // device memory is not zeroed by the driver: the emulation fills it with 0xFF (NaN as double, -1 as int32) so that reads of scratch
 // that no kernel wrote show up in the results
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (*p) std::memset(*p, 0xFF, n ? n : 1); return *p ? 0 : 1; }

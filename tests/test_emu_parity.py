@@ -53,6 +53,31 @@ def test_emu_lq_and_sqp_iteration(emu):
         assert np.allclose(oS[inst][:7], ref["stats"][:7], rtol=1e-8, atol=1e-10)
 
 
+def test_emu_line_search_launch_shape_for_batches_beyond_the_cus(emu):
+    """linesearch_kernel runs 128 threads per instance when the batch exceeds the device's CUs (lsThreads, linesearch_kernel.h): same results, bit for bit,
+    as the 256-thread launch -- iterate, merit, violation, alpha, step type.  The emulated device's CU count is QMGPU_EMU_CUS (simt_emu.h)."""
+    itf, orc = emu
+    B, N = 3, 7
+    x0 = S.perturbed_states(itf.initial_state, B, seed=11)
+    tgt = S.nominal_target(orc, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.03)
+    res = {}
+    for cus in ("256", "2"):
+        os.environ["QMGPU_EMU_CUS"] = cus
+        try:
+            sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+        finally:
+            del os.environ["QMGPU_EMU_CUS"]
+        oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+        a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B))
+        sol.mpc(a)
+        res[cus] = (oX.copy(), oU.copy(), oS.copy(), oM.copy())
+    for a_, b_ in zip(res["256"], res["2"]):
+        assert np.array_equal(a_, b_)
+    assert np.isfinite(res["2"][0]).all() and (res["2"][2][:, 4] > 0).all()   # a step was taken in every instance
+
+
 def test_emu_wbc(emu):
     itf, orc = emu
     rng = np.random.default_rng(3)
