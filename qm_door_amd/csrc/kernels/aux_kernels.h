@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) warm_start_kernel(int batch, int Np, cons
   for (int k = wave; k <= Nn; k += nw) {
     const real t = gridN[size_t(inst) * (Nn + 1) + k];
     int idx; real alpha;
-    timeSegment(tg, Np + 1, t, idx, alpha);
+    timeSegmentWave(tg, Np + 1, t, lane, idx, alpha);
     if (lane < 30) {
       const real* xl = Xp + (size_t(inst) * (Np + 1) + idx) * 30;
       const real v = alpha * xl[lane] + (1.0_r - alpha) * xl[30 + lane];
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64) policy_eval_kernel(int batch, int N, const
   const real* tg = tgrid + size_t(inst) * (N + 1);
   const real t = tEval[inst];
   int idx; real alpha;
-  timeSegment(tg, N + 1, t, idx, alpha);
+  timeSegmentWave(tg, N + 1, t, lane, idx, alpha);
   if (lane < 30) {
     const real* xl = X + (size_t(inst) * (N + 1) + idx) * 30;
     xOut[size_t(inst) * 30 + lane] = alpha * xl[lane] + (1.0_r - alpha) * xl[30 + lane];

@@ -70,6 +70,29 @@ __device__ __forceinline__ void timeSegment(const real* times, int K, real t, in
   }
 }
 
+// The same for a WHOLE WAVEFRONT and a wavefront-uniform t: the lower bound is the number of entries below t (the grid is non-decreasing), counted with one
+// ballot per 64 entries instead of the dependent chain of loads of the scan above (one memory round trip per entry: a resampling pass over a 100-node
+// horizon walked ~50 entries per node).  Index and alpha as timeSegment, bit for bit.
+__device__ __forceinline__ void timeSegmentWave(const real* times, int K, real t, int lane, int& index, real& alpha) {
+  if (K <= 1) { index = 0; alpha = 1.0_r; return; }
+  int lb = 0;
+  for (int base = 0; base < K; base += 64) {
+    const int i = base + lane;
+    const bool below = i < K && times[i < K ? i : 0] < t;
+    const unsigned long long m = qmBallot(below);
+    lb += qmPopCount(m);
+    if (m != ~0ull) break;   // a non-decreasing grid: nothing below t behind the first entry that is not
+  }
+  const int interval = lb - 1, last = K - 1;
+  if (interval < 0) { index = 0; alpha = 1.0_r; }
+  else if (interval >= last) { index = max(last - 1, 0); alpha = 0.0_r; }
+  else {
+    const real len = times[interval + 1] - times[interval];
+    index = interval;
+    alpha = (len > 2.0_r * REAL_EPS) ? (times[interval + 1] - t) / len : 1.0_r;
+  }
+}
+
 // End-effector reference pose at t: position lerp, Eigen-style slerp from the left knot by (1 - alpha).
 __device__ inline void eeReference(const real* times, const real* states, int K, real t, real pos[3], real quat[4]) {
   int idx; real alpha;
