@@ -83,44 +83,103 @@ __global__ void mpc_init_kernel(InitArgs a) {
     a.tgrid[size_t(inst) * (a.N + 1) + k] = real(tD);
     a.dtgrid[size_t(inst) * (a.N + 1) + k] = k < a.N ? real(timeOf(k + 1) - tD) : 0.0_r;
     a.nodePhase[size_t(inst) * (a.N + 1) + k] = phase;
-    real* x = a.X + (size_t(inst) * (a.N + 1) + k) * 30;
-    const real* src = (a.warmX && k > 0) ? a.warmX + (size_t(inst) * (a.N + 1) + k) * 30 : a.x0 + size_t(inst) * 30;
-    for (int i = 0; i < 30; ++i) x[i] = src[i];
-    if (k < a.N) {
-      real* u = a.U + (size_t(inst) * a.N + k) * 30;
-      if (a.warmU) {
-        const real* su = a.warmU + (size_t(inst) * a.N + k) * 30;
-        for (int i = 0; i < 30; ++i) u[i] = su[i];
-      } else {
-        const int mode = modes[phase];
+  }
+  __syncthreads();   // the phases written above are read below by other threads of the workgroup
+  // The trajectories as flat copies, consecutive threads consecutive entries, eight entries per thread and pass with all loads in front of the first store (a
+  // thread per node wrote its 30 + 30 entries one by one, 240 bytes apart from its neighbour's, each load behind the previous store: 13.7 us per launch).
+  constexpr int UN = 8;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  const int nX = (a.N + 1) * 30, nU = a.N * 30;
+  real* Xi = a.X + size_t(inst) * nX;
+  const real* wX = a.warmX ? a.warmX + size_t(inst) * nX : nullptr;
+  const real* x0 = a.x0 + size_t(inst) * 30;
+  for (int base = tid; base < nX; base += UN * nthr) {
+    real v[UN];
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * nthr, ec = e < nX ? e : tid; v[q] = (wX && ec >= 30) ? wX[ec] : x0[ec % 30]; }
+#pragma unroll
+    for (int q = 0; q < UN; ++q) QM_KEEP(v[q]);
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * nthr; if (e < nX) Xi[e] = v[q]; }
+  }
+  real* Ui = a.U + size_t(inst) * nU;
+  const real* wU = a.warmU ? a.warmU + size_t(inst) * nU : nullptr;
+  const int* phI = a.nodePhase + size_t(inst) * (a.N + 1);
+  for (int base = tid; base < nU; base += UN * nthr) {
+    real v[UN];
+#pragma unroll
+    for (int q = 0; q < UN; ++q) {
+      const int e = base + q * nthr, ec = e < nU ? e : tid;
+      if (wU) v[q] = wU[ec];
+      else {   // QMInitializer: the weight shared by the feet in contact at the node's time, nothing else
+        const int k = ec / 30, i = ec - 30 * k, mode = modes[phI[k]];
         int n = 0;
         for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
-        for (int i = 0; i < 30; ++i) u[i] = 0.0_r;
-        if (n > 0) for (int c = 0; c < 4; ++c) if (contactOf(mode, c)) u[3 * c + 2] = a.P->model.total_mass * st.gravity / n;
+        const bool fz = i < 12 && i % 3 == 2 && n > 0 && contactOf(mode, i / 3);
+        v[q] = fz ? a.P->model.total_mass * st.gravity / (n > 0 ? n : 1) : 0.0_r;
       }
     }
+#pragma unroll
+    for (int q = 0; q < UN; ++q) QM_KEEP(v[q]);
+#pragma unroll
+    for (int q = 0; q < UN; ++q) { const int e = base + q * nthr; if (e < nU) Ui[e] = v[q]; }
   }
 }
 
-// Warm start of the next solve: the previous solution resampled on the new grid.  One workgroup per instance, one new node per wavefront
-// pass (lanes 0..29 the state, 32..61 the input); the input trajectory has one entry less than the grid and holds its last value.
+// Warm start of the next solve: the previous solution resampled on the new grid.  One workgroup per instance; a wavefront takes FOUR new nodes per pass (lanes
+// 0..29 the state, 32..61 the input; the input trajectory has one entry less than the grid and holds its last value) so that the passes' memory round trips
+// are shared: the four times, then the grid (each lane its entries, the interval of every time = the number of entries below it, from ballots: timeSegmentWave's
+// rule without its early exit), then the interval ends, then the eight trajectory rows, then the stores.  One node per pass cost four dependent round trips per
+// node, 25 nodes per wavefront: 35 us per launch.  Index and alpha as timeSegment (schedule_dev.h), bit for bit.
 __global__ void __launch_bounds__(256) warm_start_kernel(int batch, int Np, const real* gridP, const real* Xp, const real* Up, int Nn, const real* gridN,
                                                          const real* x0, real* warmX, real* warmU) {
   const int inst = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if (inst >= batch) return;
+  constexpr int NB = 4;
   const real* tg = gridP + size_t(inst) * (Np + 1);
-  for (int k = wave; k <= Nn; k += nw) {
-    const real t = gridN[size_t(inst) * (Nn + 1) + k];
-    int idx; real alpha;
-    timeSegmentWave(tg, Np + 1, t, lane, idx, alpha);
-    if (lane < 30) {
-      const real* xl = Xp + (size_t(inst) * (Np + 1) + idx) * 30;
-      const real v = alpha * xl[lane] + (1.0_r - alpha) * xl[30 + lane];
-      warmX[(size_t(inst) * (Nn + 1) + k) * 30 + lane] = (k == 0 && x0) ? x0[size_t(inst) * 30 + lane] : v;
-    } else if (lane >= 32 && lane < 62 && k < Nn) {
-      const int i = lane - 32, iu0 = min(idx, Np - 1), iu1 = min(idx + 1, Np - 1);
-      const real* ul = Up + (size_t(inst) * Np + iu0) * 30; const real* ur = Up + (size_t(inst) * Np + iu1) * 30;
-      warmU[(size_t(inst) * Nn + k) * 30 + i] = alpha * ul[i] + (1.0_r - alpha) * ur[i];
+  const int K = Np + 1, last = K - 1;
+  for (int k0 = wave * NB; k0 <= Nn; k0 += nw * NB) {
+    real t[NB]; int lb[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { t[q] = gridN[size_t(inst) * (Nn + 1) + min(k0 + q, Nn)]; lb[q] = 0; }
+    for (int base = 0; base < K; base += 64) {
+      const int i = base + lane;
+      const real g = tg[i < K ? i : 0];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) lb[q] += qmPopCount(qmBallot(i < K && g < t[q]));
+    }
+    real ta[NB], tb[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { const int ic = max(0, min(lb[q] - 1, K - 2)); ta[q] = tg[ic]; tb[q] = tg[min(ic + 1, last)]; }
+    int idx[NB]; real alpha[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int interval = lb[q] - 1;
+      const real len = tb[q] - ta[q];
+      const real a = (len > 2.0_r * REAL_EPS) ? (tb[q] - t[q]) / len : 1.0_r;
+      const bool before = interval < 0 || K <= 1, after = !before && interval >= last;
+      idx[q] = before ? 0 : (after ? max(last - 1, 0) : interval);
+      alpha[q] = before ? 1.0_r : (after ? 0.0_r : a);
+    }
+    const bool isX = lane < 30, isU = lane >= 32 && lane < 62;
+    const int c = isX ? lane : (isU ? lane - 32 : 0);
+    real l[NB], r[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int iu0 = min(idx[q], Np - 1), iu1 = min(idx[q] + 1, Np - 1);
+      const real* pl = isU ? Up + (size_t(inst) * Np + iu0) * 30 : Xp + (size_t(inst) * (Np + 1) + idx[q]) * 30;
+      const real* pr = isU ? Up + (size_t(inst) * Np + iu1) * 30 : Xp + (size_t(inst) * (Np + 1) + min(idx[q] + 1, last)) * 30;
+      l[q] = pl[c]; r[q] = pr[c];
+    }
+    const real x0v = (x0 && isX) ? x0[size_t(inst) * 30 + c] : 0.0_r;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { QM_KEEP(l[q]); QM_KEEP(r[q]); }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int k = k0 + q;
+      const real v = alpha[q] * l[q] + (1.0_r - alpha[q]) * r[q];
+      if (k <= Nn && isX) warmX[(size_t(inst) * (Nn + 1) + k) * 30 + c] = (k == 0 && x0) ? x0v : v;
+      else if (k < Nn && isU) warmU[(size_t(inst) * Nn + k) * 30 + c] = v;
     }
   }
 }
