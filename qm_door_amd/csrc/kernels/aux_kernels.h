@@ -83,10 +83,18 @@ __global__ void mpc_init_kernel(InitArgs a) {
     a.tgrid[size_t(inst) * (a.N + 1) + k] = real(tD);
     a.dtgrid[size_t(inst) * (a.N + 1) + k] = k < a.N ? real(timeOf(k + 1) - tD) : 0.0_r;
     a.nodePhase[size_t(inst) * (a.N + 1) + k] = phase;
+    if (k < a.N && !a.warmU) {   // QMInitializer: the weight shared by the feet in contact at the node's time, nothing else -- stores only, nothing to wait for
+      real* u = a.U + (size_t(inst) * a.N + k) * 30;
+      const int mode = modes[phase];
+      int n = 0;
+      for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
+      const real w = n > 0 ? a.P->model.total_mass * st.gravity / n : 0.0_r;
+      for (int i = 0; i < 30; ++i) u[i] = (i < 12 && i % 3 == 2 && contactOf(mode, i / 3)) ? w : 0.0_r;
+    }
   }
-  __syncthreads();   // the phases written above are read below by other threads of the workgroup
-  // The trajectories as flat copies, consecutive threads consecutive entries, eight entries per thread and pass with all loads in front of the first store (a
-  // thread per node wrote its 30 + 30 entries one by one, 240 bytes apart from its neighbour's, each load behind the previous store: 13.7 us per launch).
+  // The copied trajectories (x0 / warm states, warm inputs) as flat copies, consecutive threads consecutive entries, eight entries per thread and pass with all
+  // loads in front of the first store (a thread per node copied its 30 + 30 entries one by one, 240 bytes apart from its neighbour's, each load behind the
+  // previous store).
   constexpr int UN = 8;
   const int nthr = blockDim.x, tid = threadIdx.x;
   const int nX = (a.N + 1) * 30, nU = a.N * 30;
@@ -102,27 +110,18 @@ __global__ void mpc_init_kernel(InitArgs a) {
 #pragma unroll
     for (int q = 0; q < UN; ++q) { const int e = base + q * nthr; if (e < nX) Xi[e] = v[q]; }
   }
-  real* Ui = a.U + size_t(inst) * nU;
-  const real* wU = a.warmU ? a.warmU + size_t(inst) * nU : nullptr;
-  const int* phI = a.nodePhase + size_t(inst) * (a.N + 1);
-  for (int base = tid; base < nU; base += UN * nthr) {
-    real v[UN];
+  if (a.warmU) {
+    real* Ui = a.U + size_t(inst) * nU;
+    const real* wU = a.warmU + size_t(inst) * nU;
+    for (int base = tid; base < nU; base += UN * nthr) {
+      real v[UN];
 #pragma unroll
-    for (int q = 0; q < UN; ++q) {
-      const int e = base + q * nthr, ec = e < nU ? e : tid;
-      if (wU) v[q] = wU[ec];
-      else {   // QMInitializer: the weight shared by the feet in contact at the node's time, nothing else
-        const int k = ec / 30, i = ec - 30 * k, mode = modes[phI[k]];
-        int n = 0;
-        for (int c = 0; c < 4; ++c) n += contactOf(mode, c) ? 1 : 0;
-        const bool fz = i < 12 && i % 3 == 2 && n > 0 && contactOf(mode, i / 3);
-        v[q] = fz ? a.P->model.total_mass * st.gravity / (n > 0 ? n : 1) : 0.0_r;
-      }
+      for (int q = 0; q < UN; ++q) { const int e = base + q * nthr; v[q] = wU[e < nU ? e : tid]; }
+#pragma unroll
+      for (int q = 0; q < UN; ++q) QM_KEEP(v[q]);
+#pragma unroll
+      for (int q = 0; q < UN; ++q) { const int e = base + q * nthr; if (e < nU) Ui[e] = v[q]; }
     }
-#pragma unroll
-    for (int q = 0; q < UN; ++q) QM_KEEP(v[q]);
-#pragma unroll
-    for (int q = 0; q < UN; ++q) { const int e = base + q * nthr; if (e < nU) Ui[e] = v[q]; }
   }
 }
 
