@@ -221,10 +221,20 @@ def test_emu_warm_start_resamples_the_previous_solution(emu):
     """qmgpu_warm_start_batch: previous (grid, X, U) -> initial guess on a shifted / non-uniform grid, against numpy interpolation."""
     itf, orc = emu
     rng = np.random.default_rng(3)
-    B, Np, Nn = 2, 9, 12
-    gp = np.cumsum(np.concatenate([np.zeros((B, 1)), rng.uniform(0.01, 0.02, (B, Np))], axis=1), axis=1)
+    _warm_start_case(itf, orc, rng, 2, 9, 12, event_pair=False)
+    # a previous grid longer than two wavefronts' worth of entries (the interval search counts the entries below t with one ballot per 64) that holds an
+    # event's (pre, post) pair of equal times; the new nodes run four to a wavefront pass with a ragged last pass (142 = 35 x 4 + 2)
+    _warm_start_case(itf, orc, rng, 3, 150, 141, event_pair=True)
+
+
+def _warm_start_case(itf, orc, rng, B, Np, Nn, event_pair):
+    steps = rng.uniform(0.01, 0.02, (B, Np))
+    if event_pair:
+        steps[:, 70] = 0.0
+    gp = np.cumsum(np.concatenate([np.zeros((B, 1)), steps], axis=1), axis=1)
     Xp = rng.normal(size=(B, Np + 1, 30)); Up = rng.normal(size=(B, Np, 30))
-    gn = 0.013 + np.cumsum(np.concatenate([np.zeros((B, 1)), rng.uniform(0.008, 0.02, (B, Nn))], axis=1), axis=1)   # starts later, ends past the old horizon
+    gn = 0.013 + np.cumsum(np.concatenate([np.zeros((B, 1)), rng.uniform(0.008, 0.02, (B, Nn)) * (1.3 if Nn > 100 else 1.0)], axis=1), axis=1)   # starts later, ends past the old horizon
+    assert (gn[:, -1] > gp[:, -1]).all()
     x0 = rng.normal(size=(B, 30))
     wx, wu = np.zeros((B, Nn + 1, 30)), np.zeros((B, Nn, 30))
     sol = api.GpuSolver(itf, max_batch=B, max_nodes=Nn)
