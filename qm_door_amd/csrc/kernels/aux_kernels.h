@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(64) policy_eval_kernel(int batch, int N, const
   const real t = tEval[inst];
   int idx; real alpha;
   timeSegmentWave(tg, N + 1, t, lane, idx, alpha);
+  const int kMode = gridCountBelow(tg + 1, N, t, lane);   // node interval containing t (lower_bound convention of the grid): the leading entries of t_1 .. t_N below t
   if (lane < 30) {
     const real* xl = X + (size_t(inst) * (N + 1) + idx) * 30;
     xOut[size_t(inst) * 30 + lane] = alpha * xl[lane] + (1.0_r - alpha) * xl[30 + lane];
@@ -203,9 +204,7 @@ __global__ void __launch_bounds__(64) policy_eval_kernel(int batch, int N, const
     uOut[size_t(inst) * 30 + i] = alpha * ul[i] + (1.0_r - alpha) * ur[i];
   } else if (lane == 63) {
     // mode of the node interval containing t (lower_bound convention of the grid)
-    int k = 0;
-    while (k < N && tg[k + 1] < t) ++k;
-    modeOut[inst] = modes[size_t(inst) * (N + 1) + k];
+    modeOut[inst] = modes[size_t(inst) * (N + 1) + kMode];
   }
 }
 

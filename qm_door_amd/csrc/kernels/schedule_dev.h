@@ -73,16 +73,20 @@ __device__ __forceinline__ void timeSegment(const real* times, int K, real t, in
 // The same for a WHOLE WAVEFRONT and a wavefront-uniform t: the lower bound is the number of entries below t (the grid is non-decreasing), counted with one
 // ballot per 64 entries instead of the dependent chain of loads of the scan above (one memory round trip per entry: a resampling pass over a 100-node
 // horizon walked ~50 entries per node).  Index and alpha as timeSegment, bit for bit.
-__device__ __forceinline__ void timeSegmentWave(const real* times, int K, real t, int lane, int& index, real& alpha) {
-  if (K <= 1) { index = 0; alpha = 1.0_r; return; }
+__device__ __forceinline__ int gridCountBelow(const real* times, int K, real t, int lane) {   // entries of a non-decreasing grid below t (a whole wavefront, t uniform)
   int lb = 0;
   for (int base = 0; base < K; base += 64) {
     const int i = base + lane;
     const bool below = i < K && times[i < K ? i : 0] < t;
     const unsigned long long m = qmBallot(below);
     lb += qmPopCount(m);
-    if (m != ~0ull) break;   // a non-decreasing grid: nothing below t behind the first entry that is not
+    if (m != ~0ull) break;   // nothing below t behind the first entry that is not
   }
+  return lb;
+}
+__device__ __forceinline__ void timeSegmentWave(const real* times, int K, real t, int lane, int& index, real& alpha) {
+  if (K <= 1) { index = 0; alpha = 1.0_r; return; }
+  const int lb = gridCountBelow(times, K, t, lane);
   const int interval = lb - 1, last = K - 1;
   if (interval < 0) { index = 0; alpha = 1.0_r; }
   else if (interval >= last) { index = max(last - 1, 0); alpha = 0.0_r; }

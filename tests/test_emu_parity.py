@@ -251,6 +251,27 @@ def _warm_start_case(itf, orc, rng, B, Np, Nn, event_pair):
     assert sol.lib.qmgpu_warm_start_batch(sol.handle, B, Np, None, None, None, Nn, None, None, None, None) == 1
 
 
+def test_emu_policy_evaluation_over_the_whole_horizon(emu):
+    """qmgpu_policy_eval_batch against the oracle (MPC_MRT_Interface::evaluatePolicy, QMController.cpp:134-142) for evaluation times before the first node, on
+    nodes, between nodes far into a 150-node horizon (the interval and the mode come from ballots over the grid: more than two wavefronts' worth of entries),
+    on an event's pair of equal times and past the end: state, input and planned mode bit for bit."""
+    itf, orc = emu
+    rng = np.random.default_rng(17)
+    N = 150
+    steps = rng.uniform(0.005, 0.02, N); steps[40] = 0.0; steps[97] = 0.0
+    grid = 0.3 + np.r_[0.0, np.cumsum(steps)]
+    te = np.r_[grid[0] - 0.01, grid[0], grid[1], grid[40], grid[41], grid[64], grid[65], grid[128], grid[-1], grid[-1] + 0.02,
+               rng.uniform(grid[0], grid[-1], 22)]
+    B = len(te)
+    T = np.tile(grid, (B, 1)); X = rng.normal(size=(B, N + 1, 30)); U = rng.normal(size=(B, N, 30))
+    M = rng.integers(0, 16, (B, N + 1)).astype(np.int32)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+    xo, uo, mo = np.zeros((B, 30)), np.zeros((B, 30)), np.zeros(B, dtype=np.int32)
+    sol.policy_eval(B, N, T, X, U, M, te, xo, uo, mo)
+    xr, ur, mr = orc.policy_eval_batch(T, X, U, M, te)
+    assert np.array_equal(xo, xr) and np.array_equal(uo, ur) and np.array_equal(mo, mr)
+
+
 def test_emu_fp32_build_of_the_mpc_chain(emu):
     """The fp32 build (qmgpu_mpc32.hip: the same kernel sources with real = float, namespace qmk32) on the CPU tier.  The emulation reproduces the
     hardware's fp32 accumulator map (row 4 (l / 16) + r instead of fp64's l / 16 + 4 r), so the permutation of the A-operand rows that keeps the kernels'

@@ -222,3 +222,33 @@ def test_barrier_constants_follow_a_settings_update(interface, oracle):
         assert np.abs(after["X"][i] - ref["X"]).max() <= 1e-6 * max(1.0, np.abs(ref["X"]).max())
         assert np.abs(after["U"][i] - ref["U"]).max() <= 1e-6 * max(1.0, np.abs(ref["U"]).max())
     abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(interface.problem.settings)))   # (handles are per test, but leave it as found)
+
+
+def test_policy_evaluation_and_warm_start_over_long_grids(interface, oracle):
+    """qmgpu_policy_eval_batch / qmgpu_warm_start_batch on a 150-node grid holding two events' pairs of equal times (their grid intervals come from ballots
+    over the grid, schedule_dev.h: timeSegmentWave): evaluation times before the first node, on nodes, far into the horizon, past the end; new grids that
+    start later and end past the old horizon.  Against the oracle: planned modes exact, interpolated values to 1e-12 (fused multiply-adds differ between the builds)."""
+    import torch
+    import gpu_harness as G
+    rng = np.random.default_rng(17)
+    N = 150
+    steps = rng.uniform(0.005, 0.02, N); steps[40] = 0.0; steps[97] = 0.0
+    grid = 0.3 + np.r_[0.0, np.cumsum(steps)]
+    te = np.r_[grid[0] - 0.01, grid[0], grid[1], grid[40], grid[41], grid[64], grid[65], grid[128], grid[-1], grid[-1] + 0.02, rng.uniform(grid[0], grid[-1], 54)]
+    B = len(te)
+    T = np.tile(grid, (B, 1)); X = rng.normal(size=(B, N + 1, 30)); U = rng.normal(size=(B, N, 30))
+    M = rng.integers(0, 16, (B, N + 1)).astype(np.int32)
+    sol = G.make_solver(interface, B, N)
+    f64 = torch.float64
+    dT, dX, dU, dM = G.dev(T, f64), G.dev(X, f64), G.dev(U, f64), G.dev(M, torch.int32)
+    xo, uo, mo = G.dev(np.zeros((B, 30)), f64), G.dev(np.zeros((B, 30)), f64), G.dev(np.zeros(B), torch.int32)
+    sol.policy_eval(B, N, dT, dX, dU, dM, G.dev(te, f64), xo, uo, mo)
+    xr, ur, mr = oracle.policy_eval_batch(T, X, U, M, te)
+    assert np.abs(xo.cpu().numpy() - xr).max() <= 1e-12 and np.abs(uo.cpu().numpy() - ur).max() <= 1e-12 and np.array_equal(mo.cpu().numpy(), mr)
+    Nn = 141
+    gn = te[:, None] * 0.0 + grid[0] + rng.uniform(0.0, 0.05, (B, 1)) + np.cumsum(np.concatenate([np.zeros((B, 1)), rng.uniform(0.008, 0.02, (B, Nn)) * 1.3], axis=1), axis=1)
+    x0 = rng.normal(size=(B, 30))
+    wx, wu = G.dev(np.zeros((B, Nn + 1, 30)), f64), G.dev(np.zeros((B, Nn, 30)), f64)
+    sol.warm_start(B, N, dT, dX, dU, Nn, G.dev(gn, f64), G.dev(x0, f64), wx, wu)
+    rx, ru = oracle.warm_start_batch(T, X, U, gn, x0)
+    assert np.abs(wx.cpu().numpy() - rx).max() <= 1e-12 and np.abs(wu.cpu().numpy() - ru).max() <= 1e-12
