@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
   if (tid == 0) {
     real s0 = 0, s1 = 0, s2 = 0;
     int dense = 0;
-    for (int i = 0; i < nthr; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; dense |= structVotes[i]; }
+    const int nSum = N + 1 < nthr ? N + 1 : nthr;   // threads beyond the last node hold exact zeros: the sum over the nodes, in node order, is the same number
+    for (int i = 0; i < nSum; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; }
+    for (int i = 0; i < nthr; ++i) dense |= structVotes[i];
     ctl[0] = s0; ctl[1] = sqrt(s1 + s2); ctl[7] = dense ? 0.0_r : 1.0_r;
   }
   __syncthreads();
@@ -340,7 +342,8 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
         const real al = tr ? alpha * st.alpha_decay : alpha;
         if (tr && al < st.alpha_min) break;        // the sequential loop would have stopped before this trial
         real s0 = 0, s1 = 0, s2 = 0;
-        for (int i = tr * half; i < (tr + 1) * half; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; }
+        const int nTrial = N + 1 < half ? N + 1 : half;   // as above: the threads of the trial beyond its last node hold zeros
+        for (int i = tr * half; i < tr * half + nTrial; ++i) { s0 += red[i]; s1 += red[256 + i]; s2 += red[512 + i]; }
         m1 = s0; v1 = sqrt(s1 + s2);
         bool ok;
         // upstream FilterLinesearch::acceptStep
