@@ -281,24 +281,30 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
   // ---- terminal value function S_N = Q_N, s_N = q_N (zero padded), and the first stage to process
   {
     const real* rec = stagesI + size_t(N) * STAGE_DOUBLES;
+    // ONE memory round trip for the whole prologue: the record of stage N - 1 is requested first, the terminal Q_N with s_N = q_N as its row 30 (the B operands
+    // carry a unit entry at (30, 30)) behind it, and nothing is waited for before all of them are on their way (were three round trips and a barrier in a row: Q_N,
+    // then q_N into the row the first pass had zeroed, then the record)
+    StagePrefetch<PFB, NTHR> pf;
+    pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_TAIL, tid);
+    const real dtLast = dtI[N - 1];
     {   // all of a thread's loads before its first LDS store (a load may not pass the store in front of it: seven memory round trips in a row otherwise)
       constexpr int NS = (32 * LDS_S + NTHR - 1) / NTHR;
       real sv[NS];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) { const int e = tid + q * NTHR, i = e / LDS_S, j = e % LDS_S; sv[q] = (e < 32 * LDS_S && i < 30 && j < 30) ? rec[OFF_QT + i * 30 + j] : 0.0_r; }
+      for (int q = 0; q < NS; ++q) {
+        const int e = tid + q * NTHR, i = e / LDS_S, j = e % LDS_S;
+        const bool inQ = e < 32 * LDS_S && i < 30 && j < 30, inq = e < 32 * LDS_S && i == 30 && j < 30;
+        sv[q] = (inQ || inq) ? rec[inq ? OFF_qt + j : OFF_QT + i * 30 + j] : 0.0_r;
+      }
 #pragma unroll
       for (int q = 0; q < NS; ++q) QM_KEEP(sv[q]);
 #pragma unroll
       for (int q = 0; q < NS; ++q) { const int e = tid + q * NTHR; if (e < 32 * LDS_S) S[e] = sv[q]; }
     }
-    __syncthreads();
-    if (tid < 30) S[30 * LDS_S + tid] = rec[OFF_qt + tid];        // s: row 30 of S (the B operands carry a unit entry at (30, 30))
     for (int e = tid; e < 2 * W_DOUBLES + 2 * LT_DOUBLES + 2 * GAIN_DOUBLES; e += NTHR) lds[R_W + e] = 0.0_r;   // W, L, gains images of both parities (contiguous)
     for (int e = tid; e < 2 * 32 * LDS_Y; e += NTHR) Y[e] = 0.0_r;        // Y, T (contiguous)
     for (int e = tid; e < 16 * LDS_Y; e += NTHR) lds[R_Y2 + e] = 0.0_r;
-    StagePrefetch<PFB, NTHR> pf;
-    pf.issue(stagesI + size_t(N - 1) * STAGE_DOUBLES, OFF_TAIL, tid);
-    pf.commitDynamics(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_TAIL, tid, jointRowMask<PFB, NTHR>(tid), dtI[N - 1]);
+    pf.commitDynamics(lds + R_STG + ((N - 1) & 1) * STG_B, OFF_TAIL, tid, jointRowMask<PFB, NTHR>(tid), dtLast);
   }
   __syncthreads();
   QM_TICK_DECL;
