@@ -265,13 +265,29 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
 
   // the weights into LDS; while copying, every thread checks its entries against the structured pattern (nodePerformance: weightStructure) and records a vote
   // (structVotes[tid] = 1: an entry outside the pattern); thread 0 combines the votes below, after the barrier, into ctl[7] = 1 (structured) / 0 (dense forms)
+  // the model constants and the baseline node metrics are requested together with the weights: ONE memory round trip for the prologue (were three in a row)
+  constexpr int MDW = (int(sizeof(ModelR) / 4) + 255) / 256;   // 32-bit words of the model per thread of a 256-thread launch
+  int mdw[2 * MDW];                                            // (a 128-thread launch takes twice as many)
+  const int mdPer = nthr >= 256 ? MDW : 2 * MDW;
+  real m0 = 0.0_r, d0 = 0.0_r, e0 = 0.0_r;
   {
     bool outside = false;
     real qv[4], rv4[4];   // (900 = 3.5 x 256: four entries per thread, all eight loads first)
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) { const int e = tid + q4 * nthr, ec = e < 900 ? e : tid; qv[q4] = st.Q[ec]; rv4[q4] = a.Rw[ec]; }
+    {
+      const int* src = reinterpret_cast<const int*>(&a.P->model);
+#pragma unroll
+      for (int w = 0; w < 2 * MDW; ++w) { const int e = tid + w * nthr; mdw[w] = (w < mdPer && e < int(sizeof(ModelR) / 4)) ? src[e] : 0; }
+    }
+    real mk[3] = {0.0_r, 0.0_r, 0.0_r};
+    if (tid <= N) { const real* m = a.metrics + (size_t(inst) * (N + 1) + tid) * NODE_METRICS; mk[0] = m[0]; mk[1] = m[1]; mk[2] = m[2]; }
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) { QM_KEEP(qv[q4]); QM_KEEP(rv4[q4]); }
+#pragma unroll
+    for (int w = 0; w < 2 * MDW; ++w) QM_KEEP(mdw[w]);
+    QM_KEEP(mk[0]); QM_KEEP(mk[1]); QM_KEEP(mk[2]);
+    if (tid <= N) { m0 = mk[0]; d0 = mk[1]; e0 = mk[2]; }
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int e = tid + q4 * nthr;
@@ -292,10 +308,13 @@ __global__ void __launch_bounds__(256) linesearch_kernel(LsArgs a) {
     }
     structVotes[tid] = outside ? 1 : 0;
   }
-  { const int* src = reinterpret_cast<const int*>(&a.P->model); int* dst = reinterpret_cast<int*>(&mdS); for (int e = tid; e < int(sizeof(ModelR) / 4); e += nthr) dst[e] = src[e]; }
-  // baseline performance (sum of the LQ kernel's node metrics)
-  real m0 = 0.0_r, d0 = 0.0_r, e0 = 0.0_r;
-  for (int k = tid; k <= N; k += nthr) { const real* m = a.metrics + (size_t(inst) * (N + 1) + k) * NODE_METRICS; m0 += m[0]; d0 += m[1]; e0 += m[2]; }
+  {
+    int* dst = reinterpret_cast<int*>(&mdS);
+#pragma unroll
+    for (int w = 0; w < 2 * MDW; ++w) { const int e = tid + w * nthr; if (w < mdPer && e < int(sizeof(ModelR) / 4)) dst[e] = mdw[w]; }
+  }
+  // baseline performance (sum of the LQ kernel's node metrics): the first node of every thread came with the prologue's loads, the others (horizons beyond the thread count) here
+  for (int k = tid + nthr; k <= N; k += nthr) { const real* m = a.metrics + (size_t(inst) * (N + 1) + k) * NODE_METRICS; m0 += m[0]; d0 += m[1]; e0 += m[2]; }
   red[tid] = m0; red[256 + tid] = d0; red[512 + tid] = e0;
   __syncthreads();
   if (tid == 0) {
