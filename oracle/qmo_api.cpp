@@ -208,9 +208,11 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
                                  inputLast, eeForce, variant, outX, outU, outMode, outStats, outPolicy, outPolicyMode, outWbc, outWbcStatus);
 }
 
-// experiment knobs of the WBC restatement (qmo_wbc.h): key 0 = starting value of the lower levels' interior point (default 300), key 1 = orthonormal null-space basis (0 / 1)
+// experiment knobs of the WBC restatement (qmo_wbc.h; defaults = the product's algorithm): key 0 = starting value of the interior point that runs in front of the active-set method
+// (default 300), key 3 = no interior point at all (the active-set method cold from z = 0 on every level), key 9 = per-iteration trace on stderr.  Both change the PATH to the
+// vertex only: the tests use them to check that the result does not.
 void qmo_set_experiment(int key, double value) {
-  if (key == 0) g_expLowerLevelStart = value; else if (key == 1) g_expOrthonormalNullSpace = value != 0.0; else if (key == 2) g_expNoZeroTry = value != 0.0;
+  if (key == 0) g_expLowerLevelStart = value; else if (key == 3) g_expNoInteriorPoint = value != 0.0; else if (key == 9) g_expTrace = int(value);
 }
 
 // WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],
@@ -310,7 +312,9 @@ int qmo_wbc_update(const qmgpu_problem* P, int variant, const double* xDes, cons
 int qmo_qp_solve(int n, int m, const double* H, const double* c, const double* D, const double* f, double* z, double* kktRes) {
   Mat Hm = Mat::from(H, n, n), Dm = m > 0 ? Mat::from(D, m, n) : Mat(0, n);
   Vec cv(c, c + n), fv(f, f + m), zv;
-  const int it = solveQpIpm(Hm, cv, Dm, fv, zv, 40, kktRes);
+  const QpStats st = solveQpGeneric(Hm, cv, Dm, fv, zv);
+  const int it = st.status ? -st.status : st.ipmIterations + st.iterations;
+  if (kktRes) *kktRes = 0.0;
   for (int i = 0; i < n; ++i) z[i] = zv[i];
   return it;
 }

@@ -188,10 +188,13 @@ inline void householderQR(const Mat& A, Mat& Q, Mat& Rout) {
 }
 
 // Null-space basis of A (r x c) by full-pivot LU, the construction of Eigen's FullPivLU::kernel()
-// (reference call site: qm_wbc/src/HoQp.cpp:129).  Returns c x (c - rank).
+// (reference call site: qm_wbc/src/HoQp.cpp:129).  Returns c x (c - rank); freeOut: the column of A each kernel vector carries its 1 on.
+// Pivot search as Eigen 3.3's (upstream: FullPivLU::computeInPlace takes bottomRightCorner(...).cwiseAbs().maxCoeff(&row, &col), a scalar visitor that walks the
+// column-major corner column by column and keeps the FIRST strict maximum): ties go to the smallest column position, then the smallest row position.  The level
+// tasks carry unit rows, exact ties are the rule; the basis, and with it the coordinates the minimum-norm completion is taken in, depends on this order.
 // (no fused multiply-add in the elimination, in EITHER build of the oracle: the pivot search compares the updated entries for equality of magnitude --
 // the level tasks carry unit rows, exact ties are the rule -- and the kernels' wbc_kernel.h takes the same decisions with the same roundings)
-__attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr) {
+__attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr, std::vector<int>* freeOut = nullptr) {
   Mat A = Ain;
   const int rows = A.r, cols = A.c, size = std::min(rows, cols);
   std::vector<int> colPerm(cols);
@@ -201,7 +204,7 @@ __attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivL
   int nonzero = 0;
   for (int k = 0; k < size; ++k) {
     int pr = k, pc = k; double best = 0.0;
-    for (int i = k; i < rows; ++i) for (int j = k; j < cols; ++j) if (std::fabs(A(i, j)) > best) { best = std::fabs(A(i, j)); pr = i; pc = j; }
+    for (int j = k; j < cols; ++j) for (int i = k; i < rows; ++i) if (std::fabs(A(i, j)) > best) { best = std::fabs(A(i, j)); pr = i; pc = j; }
     if (best == 0.0) break;
     maxPivot = std::max(maxPivot, best);
     if (pr != k) for (int j = 0; j < cols; ++j) std::swap(A(k, j), A(pr, j));
@@ -216,6 +219,7 @@ __attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivL
   if (rankOut) *rankOut = rank;
   const int dimker = cols - rank;
   Mat ker(cols, std::max(dimker, 0));
+  if (freeOut) freeOut->clear();
   if (dimker <= 0) return ker;
   // collect pivot columns (in the permuted ordering) that pass the threshold
   std::vector<int> piv;
@@ -234,6 +238,7 @@ __attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivL
   for (int j = 0; j < dimker; ++j) {
     for (int i = 0; i < rank; ++i) ker(colPerm[piv[i]], j) = X(i, j);
     ker(colPerm[freeCols[j]], j) = 1.0;
+    if (freeOut) freeOut->push_back(colPerm[freeCols[j]]);
   }
   return ker;
 }

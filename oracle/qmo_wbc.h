@@ -305,15 +305,43 @@ struct WbcTasks {
   }
 };
 
-// Cholesky with a pivot floor (1e-13 x the largest diagonal entry of the cost Hessian, NOT of the barrier-weighted matrix): directions no task and no inequality row touches have (numerically) zero curvature;
-// flooring the pivot leaves them where they are (their right-hand side is zero) instead of dividing by roundoff.
-inline bool choleskyFloored(Mat& A, double floorv) {
+// ================================================================================================ the QP of one HoQp level (HoQp.cpp:60-150)
+// The reference hands   min 1/2 [z;v]' blkdiag(AZ'AZ + 1e-12 I, I) [z;v] + c'[z;v]   s.t.  D_inh Z z <= f_inh - D_inh x_prev + v_prev,  D_own Z z - v <= f_own - D_own x_prev,  v >= 0
+// to qpOASES (an online active-set method: cold start, nWSR = 100, HoQp.cpp:136-149; un-vendored).  Restated here with the slack block eliminated,
+//   min 1/2 z'G z + g'z + 1/2 sum_{i own} max(0, D_i z - f_i)^2     s.t.   D_i z <= f_i  (i inherited; f_i >= 0: z = 0 is feasible),
+// which is exact (v = max(0, D z - f) at the optimum), and solved by a method of the same class as the reference's:
+//   a PRIMAL ACTIVE-SET method ends every level -- a working set, one row changes per iteration, the iterate stays feasible, and the point returned satisfies the KKT
+//   conditions on its working set: THE minimiser (unique up to the directions neither a task nor a pinned row sees, which the next level decides);
+//   an INTERIOR POINT (Mehrotra) runs in front of it on the levels with inherited rows, only to hand it a starting point and a working set that are usually
+//   right already (one active-set iteration then ends the level; cold, from z = 0, it would take one iteration per active row and a zero-length step per
+//   zero-margin row the first direction happens to cross -- up to 55 on three-leg stances).  Nothing the interior point returns is final.
+// Rows a higher level left STRONGLY active are equalities for every level below (see eliminateImpliedEqualities): they are removed from the problem exactly,
+// by a change of variables, before anything else -- the "cone without interior" a low level inherits is solved on its face.
+constexpr double kLowerLevelStart = 300.0;   // starting slacks / multipliers of the interior point (a unit start spends up to fifteen iterations on steps of a few per cent)
+constexpr double kStagnationMu = 1e-10;
+constexpr double kEps = 2.220446049250313e-16;
+constexpr double kAsRho = 1e4;              // penalty of a pinned row, x the curvature of the level's cost ALONG THE ROW'S NORMAL, per unit of the row's squared norm
+constexpr int kAsInnerSteps = 12;            // Newton steps on the augmented Lagrangian per working set, at most
+constexpr double kAsLamTol = 8.0;            // a multiplier counts once it exceeds this many roundings of the gradient it balances
+constexpr int kAsMaxWorkingSetChanges = 100; // nWSR of HoQp.cpp:141
+// Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  inline: one copy whatever the number of translation units; written between batches only.
+inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting value of the interior point = another path to the same vertex (tests: the result must not depend on it)
+inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
+inline int g_expTrace = 0;                               // per-iteration trace on stderr
+
+struct QpStats { int ipmIterations = 0, iterations = 0, adds = 0, drops = 0, zeroSteps = 0, innerSteps = 0, eliminated = 0, status = 0; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed
+
+// Cholesky that leaves out the directions without curvature (pivot <= floorv): row / column replaced by the identity, the right-hand side entry by zero, so their step is exactly zero.
+// A pivot is a difference, A_jj - sum_k L_jk^2, rounded relative to A_jj: it counts as curvature once it exceeds floorAbs + floorRel (j + 1) A_jj.
+inline bool choleskyExcluding(Mat& A, double floorAbs, double floorRel, std::vector<char>& excluded) {
   const int n = A.r;
+  excluded.assign(n, 0);
   for (int j = 0; j < n; ++j) {
     double d = A(j, j);
+    const double floorv = floorAbs + floorRel * double(j + 1) * A(j, j);
     for (int k = 0; k < j; ++k) d -= A(j, k) * A(j, k);
-    if (!(d > floorv)) d = floorv;
-    if (!(d > 0.0)) return false;
+    if (!(d == d)) return false;
+    if (!(d > floorv)) { excluded[j] = 1; for (int k = 0; k < j; ++k) A(j, k) = 0.0; A(j, j) = 1.0; for (int i = j + 1; i < n; ++i) A(i, j) = 0.0; for (int i = 0; i < j; ++i) A(i, j) = 0.0; continue; }
     d = std::sqrt(d);
     A(j, j) = d;
     for (int i = j + 1; i < n; ++i) { double t = A(i, j); for (int k = 0; k < j; ++k) t -= A(i, k) * A(j, k); A(i, j) = t / d; }
@@ -321,214 +349,355 @@ inline bool choleskyFloored(Mat& A, double floorv) {
   }
   return true;
 }
+inline void cholSolveExcluding(const Mat& L, const std::vector<char>& excluded, Vec& b) { for (size_t j = 0; j < b.size(); ++j) if (excluded[j]) b[j] = 0.0; cholSolve(L, b); }
 
-// ------------------------------------------------------------------------------------------------ dense convex QP: min 1/2 z'Hz + c'z  s.t.  D z <= f
-// Mehrotra predictor-corrector primal-dual interior point.  Returns iterations used, negative on failure.
-// sigma0: starting value of the slacks (floor) and multipliers.  1 for the top level; kLowerLevelStart below it, where the cost gradients are
-// ~1e4 and a unit start spends up to fifteen iterations on steps of a few per cent before the duality measure starts to fall (slowest of the
-// 256 bench instances: 45 -> 31 iterations per update; mean 32.8 -> 24.2).  A constant, so that both implementations start identically
-// whatever null-space basis they use; <= 0 selects sqrt(scale) (second / third attempts, see HoQp).
-constexpr double kLowerLevelStart = 300.0;
-constexpr double kStagnationMu = 1e-10;
-constexpr bool kPolishAdd = false;       // adding violated rows to the guess (ipm_dev.h: QM_IPM_POLISH_ADD)
-constexpr int kEarlyTriesOwn = 4; constexpr double kEarlyMuOwn = 1e-2, kEarlyNrpOwn = 1e-2, kEarlyNrdOwn = 1e-1, kEarlyDropOwn = 0.1;   // = QM_IPM_EARLY_*_OWN (ipm_dev.h)
-constexpr bool kZeroTryOwn = true;       // = QM_IPM_ZERO_TRY_OWN of the kernels (ipm_dev.h)
-constexpr int kPolishCorrections = 4;    // releases + additions per polish attempt (ipm_dev.h: QM_IPM_POLISH_CORRECTIONS)   // = QM_IPM_STAGNATION_MU of the kernels (ipm_dev.h)
-// diagnostics of the last solveQpIpm call of this thread: 1 = the returned point is a polished (exact) vertex, 0 = the interior-point iterate stands
-static thread_local int g_ipmPolished = 0;
-static thread_local int g_ipmExit = 0; static thread_local double g_ipmExitMu = 0, g_ipmExitNrd = 0;   // TEMP diagnostics
-// Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  lowerLevelStart: the interior point's starting slacks / multipliers below the
-// top level -- a second value gives the ALGORITHMIC sensitivity of an instance (how far the oracle's own torques move when only the path of the
-// interior point changes; tests/test_gpu_wbc.py).  orthonormalNullSpace: Gram-Schmidt on the kernel basis, the round-3 kernels' basis, which
-// reproduces their round-4 failures inside the oracle (profiles/r04_notes.md section 1).
-static double g_expLowerLevelStart = kLowerLevelStart;
-static int g_expOrthonormalNullSpace = 0;
-static int g_expNoZeroTry = 0;   // the first level without its zero try (tests: the shortcut must not change the result)
-inline int solveQpIpm(const Mat& H, const Vec& c, const Mat& Din, const Vec& fin, Vec& z, int maxIter = 40, double* kktRes = nullptr, double sigma0 = 1.0,
-                      bool activeSetCorrection = false) {
-  const int n = H.r;
-  // rows that are identically zero carry no information (the reference's friction task creates them, WbcBase.cpp:458)
-  std::vector<int> keep;
-  for (int i = 0; i < Din.r; ++i) { bool nz = false; for (int j = 0; j < n; ++j) if (Din(i, j) != 0.0) { nz = true; break; } if (nz) keep.push_back(i); }
-  const int m = int(keep.size());
-  Mat D(m, n); Vec f(m);
-  for (int i = 0; i < m; ++i) { for (int j = 0; j < n; ++j) D(i, j) = Din(keep[i], j); f[i] = fin[keep[i]]; }
-  z.assign(n, 0.0);
-  if (m == 0) {
-    Mat L = H; if (!cholesky(L)) return -1;
-    z = -1.0 * c; cholSolve(L, z); return 0;
+// The reduced problem of one level.  G0 = (A Z)'(A Z) WITHOUT HoQp's 1e-12 I (reg, HoQp.cpp:66): the regulariser is part of every factorised matrix, but not of the
+// gradients -- in a direction no task sees it is the ONLY curvature, 1e-12 z, and a row pinned across such a direction would show a multiplier of that size (positive:
+// an equality for the levels below) although the level's cost does not depend on the row at all.  The limit reg -> 0 is taken consistently: directions without
+// curvature stay where they are (choleskyExcluding), and what is left of them after the last level is the minimum-norm completion (wbcUpdate).
+struct LevelQp {
+  Mat G0; Vec g; Mat D; Vec f; int mOwn = 0; double reg = 0.0;     // rows [0, mOwn) of D are the level's own (soft), the rest inherited (hard)
+  Mat AZ; Vec rhat;      // the level's task in its variables, cost 1/2 |AZ z + rhat|^2 (G0 = AZ'AZ, g = AZ'rhat); empty for a generic QP
+  int n() const { return G0.r; } int m() const { return D.r; }
+  // gradient of the smooth part.  In residual form when the task is known: AZ'(AZ z + rhat) is rounded relative to the RESIDUAL, G0 z + g relative to |G0| |z| -- two
+  // orders of magnitude worse where a weakly seen direction carries a large z (the arm accelerations of HierarchicalMpcWbc, 1e4 rad/s^2 through singular values of 1e-5)
+  Vec costGradient(const Vec& z) const { if (AZ.r > 0) return tmul(AZ, AZ * z + rhat); return G0 * z + g; }
+  // what one rounding of that gradient amounts to, component by component: the residual AZ z + rhat carries eps (|AZ| |z| + |rhat|) -- whatever its own size, it is a
+  // difference -- and the product with AZ' passes that on: the largest component of eps |AZ|'(|AZ| |z| + |rhat|).  (The generic form: eps (|G0| |z| + |g|), passed in.)
+  double gradientRounding(const Vec& z, double generic) const {
+    if (AZ.r == 0) return generic;
+    Vec a(AZ.r, 0.0);
+    for (int r = 0; r < AZ.r; ++r) { double t = std::fabs(rhat[r]); for (int c = 0; c < AZ.c; ++c) t += std::fabs(AZ(r, c)) * std::fabs(z[c]); a[r] = t; }
+    double worst = 0.0;
+    for (int c = 0; c < AZ.c; ++c) { double t = 0.0; for (int r = 0; r < AZ.r; ++r) t += std::fabs(AZ(r, c)) * a[r]; worst = std::max(worst, t); }
+    return std::max(worst, 1e-300);
   }
-  double pivotFloor = 0.0;
-  for (int i = 0; i < n; ++i) pivotFloor = std::max(pivotFloor, 1e-13 * H(i, i));
-  double scale = 1.0; for (double v : c) scale = std::max(scale, std::fabs(v)); for (double v : f) scale = std::max(scale, std::fabs(v));
-  // starting point: slacks max(sigma, f - D z), multipliers sigma (sigma0, or sqrt(scale) for the second / third attempt, see HoQp)
-  const double sigma = sigma0 > 0.0 ? sigma0 : std::sqrt(scale);
-  Vec s(m), lam(m, sigma);
-  { const Vec Dz = D * z; for (int i = 0; i < m; ++i) s[i] = std::max(sigma, f[i] - Dz[i]); }
-  // ---- active-set polish.  The normal-equation interior point stalls at a dual residual of ~1e-7 * scale (barrier weights ~1e14);
-  // an active-set solver like qpOASES returns the vertex itself.  With the active set read off the final iterate (multiplier larger
-  // than slack) the equality-constrained QP is solved by a few augmented-Lagrangian Newton steps from the interior-point solution:
-  //   grad = H z + c + D_A' (lam_A + rho r_A),  r = D z - f ;   (H + rho D_A' D_A) dz = -grad ;   lam_A += rho r_A(z + dz).
-  // The result is kept only if it is primal feasible and its multipliers are non-negative (else the interior-point iterate stands).
-  // activeSetCorrection (levels without slack variables of their own, i.e. every level below the first): the multiplier estimates after
-  // the FIRST step already tell whether the guess was right (rho is large: they agree with the final ones to two digits).  If some are
-  // negative while the point is feasible, those rows are released and the polish starts again from the interior-point iterate (once);
-  // if the guess is still wrong after that the attempt is abandoned at once instead of after two more steps and the check.  On the
-  // bench set the slowest instance read one weakly active row too many at both early attempts and went on for five more interior-point
-  // iterations (12 + three polishes = 24 passes of its second level; now 14).
-  // zero = the try BEFORE the first interior-point iteration (a level with slack variables of its own, kZeroTryOwn below): the guess is "no limit binds" --
-  // the working set holds the rows with a zero right-hand side only (v >= 0 of every slack variable, and the friction rows of a swing leg, 0 <= 0), the
-  // multiplier estimates start from zero.
-  auto tryPolish = [&](bool early, bool zero = false) -> bool {
-    std::vector<int> act;
-    for (int i = 0; i < m; ++i) if (zero ? (f[i] <= 1e-9 * scale) : (lam[i] > s[i])) act.push_back(i);
-    double hmax = 0.0; for (int i = 0; i < n; ++i) hmax = std::max(hmax, H(i, i));
-    const double rho = 1e6 * std::max(1.0, hmax);
-    // Active-set correction loop (levels without slack variables of their own): the estimates after the FIRST step of an attempt decide.  Negative
-    // multipliers at a feasible point -> those rows are released; rows outside the guess that the step violates (weakly active rows whose slack and
-    // multiplier both vanish: the interior point cannot classify them) -> they are added; either way the polish starts again from the interior-point
-    // iterate, at most kPolishCorrections times per attempt (round 3: one release, no add -- with robots in motion 14-28 % of the level-1 polishes
-    // were then rejected and the interior-point iterate, accurate to its tolerances only, stood).
-    for (int corrections = 0;; ) {
-      Mat K = H;
-      for (int r : act) for (int i = 0; i < n; ++i) { const double wi = rho * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
-      if (!choleskyFloored(K, pivotFloor)) return false;
-      Vec zp = z, lp(m, 0.0);
-      for (int r : act) lp[r] = zero ? 0.0 : lam[r];
-      bool again = false;
-      // zero try with nothing pinned but simple bounds (v_i >= 0: rows with a single entry, decoupled from everything else as long as no constraint row is in the
-      // working set): the first Newton step on the quadratic is the minimiser, the further steps would only repeat it
-      bool boundsOnly = zero;
-      if (zero) for (int r : act) { int nnz = 0; for (int j = 0; j < n; ++j) nnz += D(r, j) != 0.0; if (nnz > 1) { boundsOnly = false; break; } }
-      const int nSteps = boundsOnly ? 1 : 3;
-      for (int step = 0; step < nSteps; ++step) {
-        const Vec Dz = D * zp;
-        Vec t(m, 0.0);
-        for (int r : act) t[r] = lp[r] + rho * (Dz[r] - f[r]);
-        Vec dz = -1.0 * (H * zp + c + tmul(D, t));
-        cholSolve(K, dz);
-        for (int i = 0; i < n; ++i) zp[i] += dz[i];
-        const Vec Dz2 = D * zp;
-        for (int r : act) lp[r] += rho * (Dz2[r] - f[r]);
-        if (activeSetCorrection && step == 0) {
-          double viol = -1e300, lmin = 0.0;
-          for (int i = 0; i < m; ++i) viol = std::max(viol, Dz2[i] - f[i]);
-          for (int r : act) lmin = std::min(lmin, lp[r]);
-          if (corrections < kPolishCorrections && lmin < -1e-9 * scale && viol <= 1e-6 * scale) {
-            std::vector<int> kept;
-            for (int r : act) if (!(lp[r] < 0.0)) kept.push_back(r);
-            act.swap(kept); ++corrections; again = true;
-            break;
-          }
-          if (kPolishAdd && !early && corrections < kPolishCorrections && viol > 1e-8 * scale && viol <= 0.1 * scale) {   // (only once the interior point has converged)
-            std::vector<char> in(m, 0); for (int r : act) in[r] = 1;
-            for (int i = 0; i < m; ++i) if (!in[i] && Dz2[i] - f[i] > 1e-9 * scale) in[i] = 1;
-            act.clear(); for (int i = 0; i < m; ++i) if (in[i]) act.push_back(i);
-            ++corrections; again = true;
-            break;
-          }
-          if (!(viol <= 1e-8 * scale) || !(lmin >= -1e-8 * scale)) return false;
-        }
-      }
-      if (again) continue;
-      const Vec Dz = D * zp;
-      bool ok = true;
-      for (int i = 0; i < m; ++i) if (!(Dz[i] - f[i] <= 1e-9 * scale)) ok = false;
-      for (int r : act) if (!(lp[r] >= -1e-9 * scale)) ok = false;
-      for (double v : zp) if (!(v == v)) ok = false;
-      if (ok) { z = zp; return true; }
-      return false;
-    }
-  };
-  // The first level (equations of motion, torque limits, friction cones; slack variables of its own): away from the limits NO inequality row is active and
-  // the level is an equality-constrained least-squares problem -- one factorisation instead of two interior-point iterations and a polish.  Tried first;
-  // accepted (all rows feasible, all multipliers of the working set >= -1e-9 scale: then it IS the solution of the strictly convex QP) in every instance of
-  // the bench, moving, closed-loop and 2 x 2048 stress sets (profiles/r04_notes.md section 7); a rejected try leaves z, s, lam untouched.
-  if (kZeroTryOwn && !g_expNoZeroTry && !activeSetCorrection && tryPolish(true, true)) { g_ipmPolished = 1; return 0; }
-  int it = 0;
-  int earlyTries = 0; double lastTryMu = 1e300;
+};
+struct LevelWork {       // what the two phases share
+  std::vector<char> on;  // rows that take part (not identically zero, not eliminated)
+  Vec dn, wP;            // largest entry of a row; penalty weight of a pinned row
+  double hmax = 0.0, scale = 1.0, pivotFloor = 0.0;
+};
+inline LevelWork prepareLevel(const LevelQp& q) {
+  LevelWork w;
+  const int n = q.n(), m = q.m();
+  w.on.assign(m, 0); w.dn.assign(m, 0.0); w.wP.assign(m, 0.0);
+  for (int i = 0; i < n; ++i) w.hmax = std::max(w.hmax, q.G0(i, i));
+  for (double v : q.g) w.scale = std::max(w.scale, std::fabs(v));
+  for (int i = 0; i < m; ++i) {
+    double d2 = 0.0;
+    for (int j = 0; j < n; ++j) { w.dn[i] = std::max(w.dn[i], std::fabs(q.D(i, j))); d2 += q.D(i, j) * q.D(i, j); }
+    w.on[i] = w.dn[i] > 0.0;     // rows that vanish identically carry no information (WbcBase.cpp:458 creates them)
+    if (w.on[i]) { w.scale = std::max(w.scale, std::fabs(q.f[i])); }
+  }
+  // Augmentation weight of a pinned row: the largest curvature of the level's cost per unit of the row's squared norm -- along the normal of every pinned row the
+  // factorised matrix is then at least as stiff as the cost is anywhere, so T = L^-1 D_P' and S = T'T stay O(1) however weakly the cost itself sees the directions the
+  // row acts in (a cone row across force directions next to swing-leg tasks weighted x100: with the cost's own curvature along the normal S_jj reaches 1e10 and the
+  // products T mu lose the digits that keep the row on its bound), and the rounding it adds, eps hmax, is the rounding G = AZ'AZ carries anyway.
+  for (int i = 0; i < m; ++i) if (w.on[i]) {
+    double d2 = 0.0;
+    for (int j = 0; j < n; ++j) d2 += q.D(i, j) * q.D(i, j);
+    w.wP[i] = std::max(1.0, w.hmax) / d2;
+  }
+  w.pivotFloor = 0.0;   // (set per factorisation: relative to the largest diagonal entry of the matrix being factorised, activeSetPhase)
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------ phase 1: interior point on the inherited rows (a starting point, nothing more)
+// Mehrotra predictor-corrector on   min 1/2 z'Gz + g'z  s.t.  D z + s = f, s >= 0   from z = 0, slacks max(sigma0, f), multipliers sigma0.  Runs until the working set can
+// plausibly be read off the iterate (duality measure <= 1e-6 scale with residuals to match), until it has converged or stagnates at the rounding floor of its normal
+// equations, or until a step loses all accuracy (the previous iterate is handed over).  Returns the iterations used.
+struct IpmPoint { Vec z, s, lam; bool usable = false; };
+inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma0, IpmPoint& pt) {
+  const int n = q.n(), m = q.m();
+  std::vector<int> rows; for (int i = q.mOwn; i < m; ++i) if (w.on[i]) rows.push_back(i);
+  const int mr = int(rows.size());
+  pt.z.assign(n, 0.0); pt.s.assign(m, 0.0); pt.lam.assign(m, 0.0); pt.usable = false;
+  if (mr == 0) return 0;
+  const Mat& G = q.G0;       // (without HoQp's regulariser, as in the active-set phase: directions it alone would carry are left out of the factorisation)
+  Mat D(mr, n); Vec f(mr);
+  for (int r = 0; r < mr; ++r) { for (int j = 0; j < n; ++j) D(r, j) = q.D(rows[r], j); f[r] = q.f[rows[r]]; }
+  const double scale = w.scale, sigma = sigma0;
+  Vec z(n, 0.0), s(mr), lam(mr, sigma);
+  for (int i = 0; i < mr; ++i) s[i] = std::max(sigma, f[i]);
   Vec zPrev = z, sPrev = s, lamPrev = lam;
   double nrdPrev = 0.0, muPrev = 0.0;
-  for (; it < maxIter; ++it) {
-    const Vec rd = H * z + c + tmul(D, lam);
+  auto handOver = [&](const Vec& zz, const Vec& ss, const Vec& ll) { pt.z = zz; for (int r = 0; r < mr; ++r) { pt.s[rows[r]] = ss[r]; pt.lam[rows[r]] = ll[r]; } pt.usable = true; };
+  int it = 0;
+  for (; it < 40; ++it) {
+    const Vec rd = G * z + q.g + tmul(D, lam);
     Vec rp = D * z + s - f;
-    double mu = dot(s, lam) / m;
+    const double mu = dot(s, lam) / mr;
     double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
-    // Late iterations of degenerate problems (rows active with a zero multiplier) push the barrier weights to ~1e18 and the
-    // Newton step can lose all accuracy.  A step that blows the dual residual up (or produces NaN) is rejected: the previous
-    // iterate is returned, as converged if its complementarity was already <= 1e-8 * scale, flagged otherwise.
-    if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) {
-      z = zPrev; s = sPrev; lam = lamPrev;
-      if (kktRes) *kktRes = std::max(nrdPrev, muPrev);
-      if (!(muPrev <= 1e-8 * scale)) return -3;
-      g_ipmExit = 3; g_ipmExitMu = muPrev / scale; g_ipmExitNrd = nrdPrev / scale;
-      break;   // accepted as converged: polished below like any other final iterate
-    }
-    if (kktRes) *kktRes = std::max(nrd, std::max(nrp, mu));
-    // primal feasibility and complementarity tight; the dual residual tolerance is looser (see above)
-    if (nrd <= 1e-7 * scale && nrp <= 1e-9 * scale && mu <= 1e-12 * scale) { g_ipmExit = 1; g_ipmExitMu = mu / scale; g_ipmExitNrd = nrd / scale; break; }
-    // the polish is first tried as soon as the active set can plausibly be read off (mu <= 1e-6 scale; at most twice, the second time
-    // only after the complementarity has dropped another 100x): an accepted vertex is exact whatever iterate it started from; a
-    // rejected one leaves z, s, lam untouched and the interior point goes on
-    // A level WITH slack variables of its own (the first one: torque limits and friction cones soften the equations of motion, and away from the limits
-    // no row is active) is tried much earlier: from mu <= 1e-2 scale, up to four times, after every 10x drop.  Measured on the four parity sets
-    // (profiles/r04_notes.md section 7): the first attempt, after two interior-point iterations instead of four, is accepted in every instance of
-    // the bench and closed-loop sets and in 86 % of the stress instances (2.5 iterations on average instead of 3.9).
-    const bool ownSlack = !activeSetCorrection;
-    if (earlyTries < (ownSlack ? kEarlyTriesOwn : 2) && nrd <= (ownSlack ? kEarlyNrdOwn : 1e-4) * scale && nrp <= (ownSlack ? kEarlyNrpOwn : 1e-6) * scale &&
-        mu <= (ownSlack ? kEarlyMuOwn : 1e-6) * scale && mu <= (ownSlack ? kEarlyDropOwn : 0.01) * lastTryMu) {
-      ++earlyTries; lastTryMu = mu;
-      if (tryPolish(true)) { g_ipmPolished = 1; return it; }
-    }
-    // stagnation: complementarity no longer halves although it is already small (round-off floor of the normal equations) -- stop
-    // here instead of iterating into the divergence that follows; the polish finishes the job
-    // (1e-10: round 3 stopped at mu <= 1e-6 * scale, i.e. after one slow iteration at an iterate whose active set cannot be read yet -- with robots in
-    //  motion 14-28 % of the level-1 solves left that way, unpolished, 1e-5 .. 1e-1 off in the weakly weighted task directions)
-    if (it > 0 && mu > 0.5 * muPrev && mu <= kStagnationMu * scale && nrp <= 1e-9 * scale && nrd <= 1e-7 * scale) { g_ipmExit = 2; g_ipmExitMu = mu / scale; g_ipmExitNrd = nrd / scale; break; }
+    // a late Newton step of a degenerate problem (barrier weights ~1e18) can lose all accuracy: the previous iterate is what the active-set method starts from
+    if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) { handOver(zPrev, sPrev, lamPrev); return it; }
+    if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= 1e-6 * scale) { handOver(z, s, lam); return it; }     // the working set can be read: over to the active-set method, for good
+    if (it > 0 && mu > 0.5 * muPrev && mu <= kStagnationMu * scale) { handOver(z, s, lam); return it; }          // stagnation at the rounding floor
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
-    Mat K = H;
-    for (int r = 0; r < m; ++r) { const double w = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = w * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
-    if (!choleskyFloored(K, pivotFloor)) return -2;
+    Mat K = G;
+    for (int r = 0; r < mr; ++r) { const double wr = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
+    std::vector<char> excluded;
+    if (!choleskyExcluding(K, 10.0 * q.reg, 16.0 * kEps, excluded)) { handOver(zPrev, sPrev, lamPrev); return it; }
     auto solve = [&](const Vec& rc, Vec& dz, Vec& ds, Vec& dl) {
-      Vec t(m); for (int i = 0; i < m; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
+      Vec t(mr); for (int i = 0; i < mr; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
       dz = -1.0 * (rd + tmul(D, t));
-      cholSolve(K, dz);
+      cholSolveExcluding(K, excluded, dz);
       const Vec Ddz = D * dz;
-      ds.resize(m); dl.resize(m);
-      for (int i = 0; i < m; ++i) { ds[i] = -rp[i] - Ddz[i]; dl[i] = (-rc[i] - lam[i] * ds[i]) / s[i]; }
+      ds.resize(mr); dl.resize(mr);
+      for (int i = 0; i < mr; ++i) { ds[i] = -rp[i] - Ddz[i]; dl[i] = (-rc[i] - lam[i] * ds[i]) / s[i]; }
     };
-    auto maxStep = [&](const Vec& ds, const Vec& dl) { double a = 1.0; for (int i = 0; i < m; ++i) { if (ds[i] < 0) a = std::min(a, -s[i] / ds[i]); if (dl[i] < 0) a = std::min(a, -lam[i] / dl[i]); } return a; };
-    Vec rc(m), dz, ds, dl;
-    for (int i = 0; i < m; ++i) rc[i] = s[i] * lam[i];
+    auto maxStep = [&](const Vec& ds, const Vec& dl) { double a = 1.0; for (int i = 0; i < mr; ++i) { if (ds[i] < 0) a = std::min(a, -s[i] / ds[i]); if (dl[i] < 0) a = std::min(a, -lam[i] / dl[i]); } return a; };
+    Vec rc(mr), dz, ds, dl;
+    for (int i = 0; i < mr; ++i) rc[i] = s[i] * lam[i];
     solve(rc, dz, ds, dl);
     const double aAff = maxStep(ds, dl);
-    double muAff = 0; for (int i = 0; i < m; ++i) muAff += (s[i] + aAff * ds[i]) * (lam[i] + aAff * dl[i]); muAff /= m;
-    const double sigma = std::pow(muAff / mu, 3.0);
+    double muAff = 0; for (int i = 0; i < mr; ++i) muAff += (s[i] + aAff * ds[i]) * (lam[i] + aAff * dl[i]); muAff /= mr;
+    const double sig = std::pow(muAff / mu, 3.0);
     const double cw = std::min(1.0, 4.0 * aAff);
-    for (int i = 0; i < m; ++i) rc[i] = s[i] * lam[i] + cw * ds[i] * dl[i] - sigma * mu;
+    for (int i = 0; i < mr; ++i) rc[i] = s[i] * lam[i] + cw * ds[i] * dl[i] - sig * mu;
     solve(rc, dz, ds, dl);
     const double tau = std::max(0.995, 1.0 - mu);
     const double a = std::min(1.0, tau * maxStep(ds, dl));
     for (int i = 0; i < n; ++i) z[i] += a * dz[i];
-    for (int i = 0; i < m; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
+    for (int i = 0; i < mr; ++i) { s[i] += a * ds[i]; lam[i] += a * dl[i]; }
   }
-  if (it >= maxIter) return -4;   // iteration cap: a failure like the others (HoQp retries from a different starting point)
-  g_ipmPolished = tryPolish(false) ? 1 : 0;
-  if (!g_ipmPolished && getenv("QMO_DEBUG_EXIT")) fprintf(stderr, "UNPOLISHED n %d exit %d mu/s %.1e nrd/s %.1e it %d\n", n, g_ipmExit, g_ipmExitMu, g_ipmExitNrd, it);
+  handOver(z, s, lam);
   return it;
 }
 
+// ------------------------------------------------------------------------------------------------ phase 2: primal active-set method
+// States of a row: I inactive (D z < f; own rows: v = 0) | P pinned (D z = f; an own row has v = 0 as well, which is the optimum only if its multiplier vanishes) |
+// V violated (own rows only: v = D z - f > 0, the row is an exact quadratic penalty).
+//   iteration:  the minimiser on the working set from the current point, EXACTLY, by the range-space method on an augmented Hessian of the SAME size as the cost's:
+//                 K = G + sum_P w_j d_j d_j' + sum_V d d',   w_j = (curvature of the cost along d_j) / |d_j|^2         (Cholesky K = L L'; directions without curvature left out)
+//                 -- on the working set the added terms are constant, the minimiser is unchanged, and a pinned row across directions the cost does not see gives them the
+//                 curvature its own normal has; nothing is multiplied by a large penalty, so a weakly curved direction (singular values of 1e-5 next to swing-leg tasks
+//                 weighted x100 are routine) keeps its digits --
+//                 T = L^-1 D_P',  S = T'T,   u = L^-1 (-grad - D_P' W r_P),   S mu = T'u + r_P,   p = L^-T (u - T mu):   D_P (z + p) = f_P, mu = the multipliers.
+//                 (rows of the working set that are combinations of others show up as vanishing pivots of S and are skipped: their multiplier is zero)
+//               step cut at the first row that changes sign (I: reaches its bound; V: its violation returns to zero): that row is pinned -- own rows too: whether it ends
+//                 violated, inactive or exactly on its bound (reached through a direction without curvature) is decided by its multiplier
+//               full step: one or two more passes of the same solve from the new point (iterative refinement: the gradient is evaluated in residual form, exact to the
+//                 rounding of the residual), then the pinned row with the most negative multiplier is released (own rows: largest |multiplier|, to I or V by its sign);
+//                 none: done
+// Ties (several rows at the same step length: zero-margin rows of a degenerate vertex) go to the smallest row index.  A multiplier counts once lam_j |d_j| stands clear of
+// the rounding of the gradient it balances, kAsLamTol eps (hmax |z| + scale).  A row released and pinned again by a zero-length step is not released again before the
+// point has moved.  start: the point and working set of the interior point (rows with multiplier > slack, and rows its iterate violates), or z = 0 with the own rows
+// whose bound is zero pinned (the friction rows: 0 <= 0 -- away from the limits that IS the solution of the first level, in one factorisation).
+inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut) {
+  enum { I = 0, P = 1, V = 2 };
+  QpStats st;
+  const int n = q.n(), m = q.m(), mOwn = q.mOwn;
+  const Mat& D = q.D; const Vec& f = q.f;
+  const double scale = w.scale, tol = 1e-9 * scale, hmax = w.hmax;
+  std::vector<char> state(m, I), stuck(m, 0), guess(m, 0);   // guess: pinned on the interior point's word, not yet brought to its bound
+  Vec lam(m, 0.0);
+  z.assign(n, 0.0);
+  for (int i = 0; i < mOwn; ++i) if (w.on[i]) state[i] = f[i] < -tol ? V : (f[i] <= tol ? P : I);
+  if (start && start->usable) {
+    z = start->z;
+    const Vec Dz = D * z;
+    for (int i = mOwn; i < m; ++i) if (w.on[i] && (start->lam[i] > start->s[i] || Dz[i] - f[i] > 0.0)) { state[i] = P; guess[i] = 1; }
+  }
+  int lastReleased = -1, fullSteps = 0;
+  for (;; ++st.iterations) {
+    if (st.iterations > kAsMaxWorkingSetChanges) { st.status = 1; break; }
+    Mat K = q.G0;       // (without HoQp's regulariser: a direction it alone would carry counts as having no curvature, below)
+    std::vector<int> pin;
+    for (int r = 0; r < m; ++r) {
+      if (!w.on[r] || state[r] == I) continue;
+      const double wr = state[r] == P ? w.wP[r] : 1.0; if (state[r] == P) pin.push_back(r);
+      for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
+    }
+    const int k = int(pin.size());
+    // a direction has no curvature when its pivot does not stand clear of the rounding of the matrix being factorised, or of HoQp's regulariser (x10: the reference's
+    // 1e-12 I decides the directions whose curvature is comparable with it by a blend of task and minimum norm; here they count as unseen by the task)
+    std::vector<char> excluded, dependent;
+    if (!choleskyExcluding(K, 10.0 * q.reg, 16.0 * kEps, excluded)) { st.status = 2; break; }
+    auto forward = [&](Vec b) { for (int i = 0; i < n; ++i) { if (excluded[i]) { b[i] = 0.0; continue; } double t = b[i]; for (int c = 0; c < i; ++c) t -= K(i, c) * b[c]; b[i] = t / K(i, i); } return b; };
+    auto backward = [&](Vec b) { for (int i = n - 1; i >= 0; --i) { if (excluded[i]) { b[i] = 0.0; continue; } double t = b[i]; for (int c = i + 1; c < n; ++c) t -= K(c, i) * b[c]; b[i] = t / K(i, i); } return b; };
+    Mat Tm(n, k), S(k, k);
+    for (int j = 0; j < k; ++j) { Vec d(n); for (int c = 0; c < n; ++c) d[c] = D(pin[j], c); const Vec t = forward(d); for (int c = 0; c < n; ++c) Tm(c, j) = t[c]; }
+    for (int a = 0; a < k; ++a) for (int b2 = 0; b2 < k; ++b2) { double t = 0.0; for (int c = 0; c < n; ++c) t += Tm(c, a) * Tm(c, b2); S(a, b2) = t; }
+    if (k > 0) {   // dependent rows: pivot lost against the row's own diagonal entry (relative test, row by row: S_jj spans twelve orders of magnitude between cone and torque rows)
+      Vec sdiag(k); for (int j = 0; j < k; ++j) sdiag[j] = S(j, j);
+      dependent.assign(k, 0);
+      for (int j = 0; j < k; ++j) {
+        double d = S(j, j);
+        for (int c = 0; c < j; ++c) d -= S(j, c) * S(j, c);
+        if (!(d > 1e-11 * sdiag[j])) { dependent[j] = 1; for (int c = 0; c < j; ++c) S(j, c) = 0.0; S(j, j) = 1.0; for (int i = j + 1; i < k; ++i) S(i, j) = 0.0; continue; }
+        d = std::sqrt(d); S(j, j) = d;
+        for (int i = j + 1; i < k; ++i) { double t = S(i, j); for (int c = 0; c < j; ++c) t -= S(i, c) * S(j, c); S(i, j) = t / d; }
+      }
+    }
+    // A pinned row that is a combination of other pinned rows is skipped by the solve (no pivot in S).  That is safe while the whole pinned set sits ON its bounds -- the
+    // step keeps the others there and the combination with them.  The interior point's guess is different: its rows are still off their bounds by their slacks, the
+    // first step is meant to bring them there, and that step is only taken if it can be taken in full (below).  A guess with a dependent row, or one whose step another
+    // row cuts short, is dropped: the off-bound rows go back to inactive and the method continues from the same (feasible) point with what is left.
+    double zmax0 = 1.0; for (double v : z) zmax0 = std::max(zmax0, std::fabs(v));
+    bool offBound = false, anyDep = false;
+    for (int j = 0; j < k; ++j) { offBound = offBound || guess[pin[j]]; anyDep = anyDep || dependent[j]; }
+    auto dropGuess = [&]() {
+      for (int j = 0; j < k; ++j) if (guess[pin[j]]) { state[pin[j]] = I; guess[pin[j]] = 0; }
+      fullSteps = 0; ++st.drops;
+      if (g_expTrace) fprintf(stderr, "  AS it %d: the guessed working set is dropped\n", st.iterations);
+    };
+    if (offBound && anyDep) { dropGuess(); continue; }
+    // one pass of the solve from zz: the step p and the multipliers mu of the pinned rows at zz + p
+    auto solvePass = [&](const Vec& zz, Vec& pOut, Vec& muOut) {
+      const Vec Dz = D * zz;
+      Vec t(m, 0.0);
+      for (int r = 0; r < m; ++r) if (w.on[r]) { if (state[r] == P) t[r] = w.wP[r] * (Dz[r] - f[r]); else if (state[r] == V) t[r] = Dz[r] - f[r]; }
+      const Vec u = forward(-1.0 * (q.costGradient(zz) + tmul(D, t)));
+      Vec mu(k, 0.0);
+      for (int j = 0; j < k; ++j) { double tj = Dz[pin[j]] - f[pin[j]]; for (int c = 0; c < n; ++c) tj += Tm(c, j) * u[c]; mu[j] = tj; }
+      for (int j = 0; j < k; ++j) { if (dependent[j]) { mu[j] = 0.0; continue; } double tj = mu[j]; for (int c = 0; c < j; ++c) tj -= S(j, c) * mu[c]; mu[j] = tj / S(j, j); }
+      for (int j = k - 1; j >= 0; --j) { if (dependent[j]) { mu[j] = 0.0; continue; } double tj = mu[j]; for (int c = j + 1; c < k; ++c) tj -= S(c, j) * mu[c]; mu[j] = tj / S(j, j); }
+      Vec v = u;
+      for (int c = 0; c < n; ++c) for (int j = 0; j < k; ++j) v[c] -= Tm(c, j) * mu[j];
+      pOut = backward(v); muOut = mu;
+      ++st.innerSteps;
+    };
+    Vec p, mu;
+    solvePass(z, p, mu);
+    bool finite = true; for (double v : p) finite = finite && v == v;
+    if (!finite) { st.status = 2; break; }
+    double pmax = 0.0; for (double v : p) pmax = std::max(pmax, std::fabs(v));
+    const Vec Dz = D * z, Dp = D * p;
+    // what the pinned rows let through (rounding; a dependent row that was skipped): a row that is a combination of pinned rows shows a step component of that size
+    // and must not be taken for a blocking row
+    double leak = 0.0;
+    for (int i = 0; i < m; ++i) if (w.on[i] && state[i] == P) leak = std::max(leak, std::fabs(Dp[i] + (Dz[i] - f[i])) / w.dn[i]);   // (a pinned row not yet on its bound -- the interior point's guess -- is meant to get there: D p = -(D z - f))
+    // first sign change along the step
+    double alpha = 1.0; int block = -1;
+    for (int i = 0; i < m; ++i) {
+      if (!w.on[i] || state[i] == P) continue;
+      const double epsP = std::max(1e-13 * std::max(1.0, pmax), 1e3 * leak) * w.dn[i];
+      double a;
+      if (state[i] == I) { if (!(Dp[i] > epsP)) continue; a = std::max(0.0, f[i] - Dz[i]) / Dp[i]; }
+      else { if (!(Dp[i] < -epsP)) continue; a = std::max(0.0, Dz[i] - f[i]) / -Dp[i]; }
+      if (a < alpha) { alpha = a; block = i; }      // strictly smaller: ties keep the smallest index
+    }
+    if (g_expTrace) { int nV = 0, nEx = 0, nDep = 0; for (int i = 0; i < m; ++i) nV += w.on[i] && state[i] == V; for (char e : excluded) nEx += e; for (char e : dependent) nDep += e;
+      fprintf(stderr, "  AS it %d n %d P %d (dependent %d) V %d excl %d pmax %.3e alpha %.3e block %d leak %.1e\n", st.iterations, n, k, nDep, nV, nEx, pmax, alpha, block, leak); }
+    if (block >= 0 && offBound) { dropGuess(); continue; }
+    if (block >= 0) {
+      const bool moved = alpha * pmax > 1e-13 * zmax0;       // a step that does not move the point beyond its rounding counts as zero-length
+      for (int i = 0; i < n; ++i) z[i] += alpha * p[i];
+      if (moved) std::fill(stuck.begin(), stuck.end(), 0); else if (block == lastReleased) stuck[block] = 1;
+      lastReleased = -1;
+      state[block] = P; fullSteps = 0;
+      ++st.adds; if (!moved) ++st.zeroSteps;
+      continue;
+    }
+    for (int i = 0; i < n; ++i) z[i] += p[i];
+    std::fill(guess.begin(), guess.end(), 0);     // a full step: every pinned row is on its bound now
+    // refinement: the same working set once more from the new point (the gradient is re-evaluated exactly, the ratio test applies again) until the correction is
+    // rounding -- at most three full steps in a row
+    {
+      double zmax = 1.0; for (double v : z) zmax = std::max(zmax, std::fabs(v));
+      if (pmax > 1e-13 * zmax && fullSteps < 3) { ++fullSteps; --st.iterations; if (g_expTrace) fprintf(stderr, "    full step %d on this working set: correction %.3e (zmax %.3e)\n", fullSteps, pmax, zmax); continue; }
+    }
+    std::fill(lam.begin(), lam.end(), 0.0);
+    for (int j = 0; j < k; ++j) lam[pin[j]] = mu[j];
+    double zmaxF = 1.0; for (double v : z) zmaxF = std::max(zmaxF, std::fabs(v));
+    const double gradNoise = kAsLamTol * kEps * q.gradientRounding(z, hmax * zmaxF + scale);
+    int rel = -1; double worst = 1.0;
+    for (int i = 0; i < m; ++i) {
+      if (!w.on[i] || state[i] != P || stuck[i]) continue;
+      const double bad = (i < mOwn ? std::fabs(lam[i]) : -lam[i]) * w.dn[i] / gradNoise;
+      if (bad > worst) { worst = bad; rel = i; }
+    }
+    if (g_expTrace) { fprintf(stderr, "    full step: release %d (noise %.1e; hmax %.2e zmax %.2e scale %.2e)  pinned:", rel, gradNoise, hmax, zmaxF, scale); for (int i = 0; i < m; ++i) if (w.on[i] && state[i] == P) fprintf(stderr, " %d:%.2e", i, lam[i]); fprintf(stderr, "\n"); }
+    if (rel < 0) {
+      // the point satisfies the KKT conditions on its working set; the bounds themselves once more (partial steps accumulate rounding)
+      const Vec Df = D * z;
+      for (int i = 0; i < m; ++i) if (w.on[i] && (i >= mOwn || state[i] != V) && !(Df[i] - f[i] <= tol)) { st.status = 3; if (g_expTrace) fprintf(stderr, "    VIOLATED row %d state %d by %.3e (tol %.1e)\n", i, int(state[i]), Df[i] - f[i], tol); }
+      // strongly active rows: pinned with a multiplier that counts, or violated
+      for (int i = 0; i < m; ++i) if (w.on[i] && state[i] == P && !(lam[i] * w.dn[i] > gradNoise)) lam[i] = 0.0;
+      break;
+    }
+    state[rel] = (rel < mOwn && lam[rel] > 0.0) ? V : I; lam[rel] = 0.0; lastReleased = rel; fullSteps = 0;
+    ++st.drops;
+  }
+  lamOut = lam; stateOut = state;
+  return st;
+}
+
+// ------------------------------------------------------------------------------------------------ implied equalities
+// A row that a higher level left active with a positive multiplier (pinned, or an own row that ended violated) is an EQUALITY for every level below: stationarity of
+// that level, G z + g + sum_j lam_j d_j = 0, projected on the null space N the next level moves in (N'(G z + g) = 0) gives sum_j lam_j (d_j N) = 0 with lam_j > 0 --
+// the restricted rows are positively dependent, and every feasible direction w (d_j N w <= 0 for all j) has d_j N w = 0 for each of them.  The k-th row of such a set
+// is a combination of the others: an inequality solver meets them as a cone without interior, discovers them row by row through zero-length steps and over-pins the
+// dependent one on a rounding-size step component; an interior point has nothing to work in.  They are removed EXACTLY instead: z = N_E w with N_E the kernel of the
+// stacked equality rows (full-pivot LU, rank revealing: dependent rows cost nothing), the level is solved in w.
+inline Mat eliminateImpliedEqualities(LevelQp& q, const std::vector<char>& eq) {
+  const int n = q.n(), m = q.m();
+  std::vector<int> E; for (int i = q.mOwn; i < m; ++i) if (eq[i]) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || q.D(i, j) != 0.0; if (nz) E.push_back(i); }
+  if (E.empty()) return Mat();
+  Mat DE(int(E.size()), n);
+  for (size_t r = 0; r < E.size(); ++r) for (int j = 0; j < n; ++j) DE(int(r), j) = q.D(E[r], j);
+  const Mat N = kernelFullPivLU(DE);
+  LevelQp r; r.mOwn = q.mOwn; r.reg = q.reg; r.f = q.f;
+  r.G0 = T(N) * (q.G0 * N); r.g = tmul(N, q.g); r.D = q.D * N;
+  if (q.AZ.r > 0) { r.AZ = q.AZ * N; r.rhat = q.rhat; r.G0 = T(r.AZ) * r.AZ; r.g = tmul(r.AZ, r.rhat); }
+  // rows that are combinations of the eliminated ones vanish up to rounding in the new variables: they stay tight, and carry no information
+  for (int i = 0; i < m; ++i) {
+    double dOld = 0.0, dNew = 0.0;
+    for (int j = 0; j < n; ++j) dOld = std::max(dOld, std::fabs(q.D(i, j)));
+    for (int j = 0; j < r.D.c; ++j) dNew = std::max(dNew, std::fabs(r.D(i, j)));
+    if (eq[i] || !(dNew > 1e-12 * dOld)) for (int j = 0; j < r.D.c; ++j) r.D(i, j) = 0.0;
+  }
+  q = r;
+  return N;
+}
+
+// One level: z (decision variables of the level as the reference counts them), and the rows that are strongly active at the solution (eq, in / out).
+inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
+  const int nFull = q.n(), m = q.m();
+  eq.resize(m, 0);
+  QpStats st;
+  z.assign(nFull, 0.0);
+  if (nFull == 0) return st;
+  const Mat N = eliminateImpliedEqualities(q, eq);
+  const bool reduced = N.r > 0;
+  if (reduced) st.eliminated = nFull - N.c;
+  if (reduced && N.c == 0) return st;          // the equalities leave nothing to decide: z = 0
+  const LevelWork w = prepareLevel(q);
+  IpmPoint pt;
+  bool hard = false; for (int i = q.mOwn; i < m; ++i) hard = hard || w.on[i];
+  int ipmIt = 0;
+  if (hard && q.mOwn == 0 && !g_expNoInteriorPoint) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt);
+  Vec zw, lam; std::vector<char> state;
+  st = activeSetPhase(q, w, &pt, zw, lam, state);
+  st.ipmIterations = ipmIt; st.eliminated = reduced ? nFull - N.c : 0;
+  if (st.status == 2) zw.assign(q.n(), 0.0);      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
+  z = reduced ? N * zw : zw;
+  for (int i = 0; i < m; ++i) if (w.on[i]) eq[i] = eq[i] || state[i] == 2 || (state[i] == 1 && lam[i] > 0.0);
+  return st;
+}
+
+// generic convex QP  min 1/2 z'Hz + c'z  s.t.  D z <= f  (tests: KKT residuals, enumeration): every row hard, feasible start required at z = 0 unless the interior point finds one
+inline QpStats solveQpGeneric(const Mat& H, const Vec& c, const Mat& D, const Vec& f, Vec& z) {
+  LevelQp q; q.G0 = H; q.g = c; q.D = D; q.f = f; q.mOwn = 0; q.reg = 0.0;
+  std::vector<char> eq;
+  return solveLevel(q, eq, z);
+}
+
 // ------------------------------------------------------------------------------------------------ HoQp (HoQp.cpp:12-158)
-constexpr double kInheritedMargin = 1e-5;   // second-attempt relaxation of inherited inequality rows (see HoQp)
 struct HoQp {
   Task task, stackedTasksPrev, stackedTasks;
   bool hasEq = false, hasIneq = false;
   int numSlack = 0, numDec = 0, numPrevSlack = 0;
-  Mat Zprev, Z, Hm, Dm;
+  Mat Zprev, Z, Hm, Dm, aZ;
   Vec slackPrev, xPrev, cv, fv, stackedSlack, slackSol, decSol;
-  int qpIters = 0, attempts = 0, polished = 0;   // attempts: 0 = the first solve converged, 1 / 2 = the relaxed re-solves, 3 = level skipped
+  QpStats stats, completionStats;
+  bool completed = false;
+  std::vector<char> stackedEq;   // per row of stackedTasks.d: strongly active at this level's solution or above -> an equality for the levels below
+  std::vector<int> sel, selNext; // the coordinates of x that ARE the level's decision variables: z = (x - xPrev)[sel] (the kernel bases carry an identity block, kernelFullPivLU); selNext: the next level's
+  int qpIters = 0, attempts = 0, polished = 0;   // (diagnostics kept for the tests: attempts is always 0 -- no relaxed re-solve exists any more; polished = the level ended at a verified vertex)
 
-  HoQp(const Task& t, const HoQp* higher) : task(t) {
+  HoQp(const Task& t, const HoQp* higher, bool canonical = false) : task(t) {
     // initVars
     numSlack = task.d.r; hasEq = task.a.r > 0; hasIneq = numSlack > 0;
     if (higher) { Zprev = higher->Z; stackedTasksPrev = higher->stackedTasks; slackPrev = higher->stackedSlack; xPrev = higher->solution(); numPrevSlack = higher->stackedTasks.d.r; numDec = Zprev.c; }
@@ -537,8 +706,8 @@ struct HoQp {
     const int nz = numDec + numSlack;
     // buildHMatrix
     Hm = Mat(nz, nz);
-    Mat aZ;
-    if (hasEq) { aZ = task.a * Zprev; Mat zz = T(aZ) * aZ; for (int i = 0; i < numDec; ++i) zz(i, i) += 1e-12; setBlock(Hm, 0, 0, zz); }
+    Mat zz0(numDec, numDec);
+    if (hasEq) { aZ = task.a * Zprev; zz0 = T(aZ) * aZ; Mat zz = zz0; for (int i = 0; i < numDec; ++i) zz(i, i) += 1e-12; setBlock(Hm, 0, 0, zz); }
     for (int i = 0; i < numSlack; ++i) Hm(numDec + i, numDec + i) = 1.0;
     // buildCVector
     cv = Vec(nz, 0.0);
@@ -551,9 +720,7 @@ struct HoQp {
       const Mat dz = stackedTasksPrev.d * Zprev;
       setBlock(Dm, numSlack, 0, dz);
       const Vec dx = stackedTasksPrev.d * xPrev;
-      // x_prev satisfies the inherited rows with its slack, so this margin is >= 0 in exact arithmetic; rounding (and the 1e-9 * scale
-      // feasibility tolerance of the polished vertex) can leave it at -1e-8, which a lower level whose null space no longer sees the
-      // row cannot repair.  Clamp at zero.
+      // x_prev satisfies the inherited rows with its slack, so this margin is >= 0 in exact arithmetic; rounding can leave it at -1e-13.  Clamp at zero.
       for (int i = 0; i < numPrevSlack; ++i) fv[numSlack + i] = std::max(0.0, stackedTasksPrev.f[i] - dx[i] + slackPrev[i]);
     }
     if (hasIneq) {
@@ -562,47 +729,56 @@ struct HoQp {
       const Vec dx = task.d * xPrev;
       for (int i = 0; i < numSlack; ++i) { Dm(numSlack + numPrevSlack + i, numDec + i) = -1.0; fv[numSlack + numPrevSlack + i] = task.f[i] - dx[i]; }
     }
-    // solveProblem
-    Vec sol;
-    // A degenerate low-priority level -- more inherited rows active at x_prev than the remaining null space has dimensions, so that
-    // {z : D_prev Z z <= margin} has no interior (three-leg stance: 5 free directions, 7 active rows) -- stalls the interior point.
-    // Further attempts: every inherited row gets a margin of at least kInheritedMargin (1e-5 N / Nm: 3e-7 of the limits it bounds), then
-    // 100x that, and the iteration starts from slacks / multipliers of O(sqrt(scale)).  If that fails too the level is skipped (z = 0: x stays the
-    // higher priorities' solution) and the failure is reported.  2 x 2048 random configurations: 6 second attempts, no skip.
-    if (nz > 0) {
-      g_ipmPolished = 0;
-      qpIters = solveQpIpm(Hm, cv, Dm, fv, sol, 40, nullptr, higher ? g_expLowerLevelStart : 1.0, numSlack == 0);
-      for (int attempt = 1; attempt <= 2 && qpIters < 0; ++attempt) {
-        Vec fr = fv;
-        const double margin = attempt == 1 ? kInheritedMargin : 100.0 * kInheritedMargin;   // 1e-5, then 1e-3
-        for (int i = 0; i < numPrevSlack; ++i) fr[numSlack + i] = std::max(margin, fr[numSlack + i]);
-        g_ipmPolished = 0;
-        qpIters = solveQpIpm(Hm, cv, Dm, fr, sol, 40, nullptr, -1.0, numSlack == 0);
-        attempts = attempt;
-      }
-      if (qpIters < 0) { sol.assign(nz, 0.0); attempts = 3; }
-      polished = g_ipmPolished;
-    } else sol.clear();
+    // solveProblem: the reduced problem (slack block eliminated), own rows first, then the inherited ones
+    Vec sol(nz, 0.0);
+    if (numDec > 0) {
+      const int mAll = numSlack + numPrevSlack;
+      LevelQp q; q.G0 = zz0; q.g = Vec(cv.begin(), cv.begin() + numDec); if (hasEq) { q.AZ = aZ; q.rhat = task.a * xPrev - task.b; } q.D = Mat(mAll, numDec); q.f = Vec(mAll, 0.0); q.mOwn = numSlack; q.reg = hasEq ? 1e-12 : 0.0;
+      for (int i = 0; i < numSlack; ++i) { for (int j = 0; j < numDec; ++j) q.D(i, j) = Dm(numSlack + numPrevSlack + i, j); q.f[i] = fv[numSlack + numPrevSlack + i]; }
+      for (int i = 0; i < numPrevSlack; ++i) { for (int j = 0; j < numDec; ++j) q.D(numSlack + i, j) = Dm(numSlack + i, j); q.f[numSlack + i] = fv[numSlack + i]; }
+      std::vector<char> eqr(mAll, 0);
+      if (higher) for (int i = 0; i < numPrevSlack; ++i) eqr[numSlack + i] = higher->stackedEq[i];
+      if (g_expTrace) fprintf(stderr, "level: numDec %d own %d inherited %d\n", numDec, numSlack, numPrevSlack);
+      Vec zr;
+      stats = solveLevel(q, eqr, zr);
+      stackedEq = eqr;      // rows ordered as stackedTasks.d = [own; inherited] (Task::operator+)
+      if (g_expTrace) fprintf(stderr, " -> status %d eliminated %d ipm %d iterations %d adds %d drops %d zero steps %d inner %d\n", stats.status, stats.eliminated, stats.ipmIterations, stats.iterations, stats.adds, stats.drops, stats.zeroSteps, stats.innerSteps);
+      qpIters = stats.status ? -1 : std::min(stats.ipmIterations + stats.iterations, 59);
+      polished = stats.status == 0;
+      for (int i = 0; i < numDec; ++i) sol[i] = zr[i];
+    } else stackedEq.assign(numSlack + numPrevSlack, 0);
     decSol = Vec(sol.begin(), sol.begin() + numDec); slackSol = Vec(sol.begin() + numDec, sol.end());
-    // An interior point method leaves the slacks of inactive rows at O(sqrt(mu)) (v = 0 and its multiplier = 0 is a degenerate
-    // complementarity pair).  The exact minimiser, which an active-set solver like qpOASES returns, has v = max(0, D z - f):
-    // restore it from the decision variables, which are not affected.
+    // the slack variables of the level: v = max(0, D z - f), exactly
     if (hasIneq) {
       const Vec dz = (task.d * Zprev) * decSol;
       const Vec dx = task.d * xPrev;
       for (int i = 0; i < numSlack; ++i) slackSol[i] = std::max(0.0, dz[i] + dx[i] - task.f[i]);
     }
     // buildZMatrix
-    if (hasEq) Z = Zprev * kernelFullPivLU(aZ); else Z = Zprev;
-    if (g_expOrthonormalNullSpace && Z.c > 0) {   // EXPERIMENT: orthonormal columns (modified Gram-Schmidt, twice)
-      for (int pass = 0; pass < 2; ++pass)
-        for (int j = 0; j < Z.c; ++j) {
-          for (int k = 0; k < j; ++k) { double d = 0; for (int i = 0; i < Z.r; ++i) d += Z(i, k) * Z(i, j); for (int i = 0; i < Z.r; ++i) Z(i, j) -= d * Z(i, k); }
-          double nn = 0; for (int i = 0; i < Z.r; ++i) nn += Z(i, j) * Z(i, j); nn = std::sqrt(nn); for (int i = 0; i < Z.r; ++i) Z(i, j) /= nn;
-        }
-    }
+    if (higher) sel = higher->selNext; else { sel.resize(numDec); for (int j = 0; j < numDec; ++j) sel[j] = j; }
+    if (hasEq) { std::vector<int> freeCols; const Mat ker = kernelFullPivLU(aZ, nullptr, &freeCols); Z = Zprev * ker; for (int j : freeCols) selNext.push_back(sel[j]); } else { Z = Zprev; selNext = sel; }
     // stackSlackSolutions
     stackedSlack = higher ? vcat(higher->stackedSlack, slackSol) : slackSol;
+    // Canonical representative (wbcUpdate): among the minimisers of this level -- z* + ker w inside the inherited rows and, for the level's own rows, inside the slack
+    // they ended with -- the one of smallest norm in the level's own variables: what HoQp's 1e-12 I (HoQp.cpp:66) selects, in the limit 1e-12 -> 0.  It only moves the
+    // point the next level starts from: the next level still decides every direction of ker, and the rows pinned here are nobody's equalities.
+    if (canonical && hasEq && Z.c > 0 && numDec > 0) {
+      const Mat ker = kernelFullPivLU(aZ);
+      const Vec xL = solution();
+      const int mAll = stackedTasks.d.r;
+      LevelQp q; q.AZ = ker; q.rhat = decSol; q.G0 = T(ker) * ker; q.g = tmul(ker, decSol); q.mOwn = 0; q.reg = 0.0;
+      q.D = stackedTasks.d * Z; q.f = Vec(mAll, 0.0);
+      const Vec dx = stackedTasks.d * xL;
+      for (int i = 0; i < mAll; ++i) { const double slack = i < numSlack ? slackSol[i] : slackPrev[i - numSlack]; q.f[i] = std::max(0.0, stackedTasks.f[i] - dx[i] + slack); }   // (rows ordered [own; inherited], Task::operator+)
+      // (the rows strongly active at this level's solution are equalities on its solution set as well -- same argument as for the levels below -- and are eliminated
+      //  the same way; what the completion itself pins is not passed on)
+      std::vector<char> eqc = stackedEq;
+      Vec wv;
+      if (g_expTrace) fprintf(stderr, "completion: %d free directions\n", ker.c);
+      completionStats = solveLevel(q, eqc, wv);
+      completed = true;
+      if (completionStats.status == 0 || completionStats.status == 1) { const Vec dzv = ker * wv; for (int i = 0; i < numDec; ++i) decSol[i] += dzv[i]; }
+    }
   }
   Vec solution() const { return numDec > 0 ? xPrev + Zprev * decSol : xPrev; }
 };
@@ -628,22 +804,34 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
     task2 = tk.contactForce(uDes);
   }
   phase.reset(); phase.reset(new PhaseTimer(PH_WBC_QP));
-  HoQp h0(task0, nullptr);
-  HoQp h1(task1, &h0);
-  Vec x;
-  int status = (h0.qpIters < 0 || h0.qpIters >= 60 ? 1 : 0) | (h1.qpIters < 0 || h1.qpIters >= 60 ? 2 : 0);
-  if (diag) { for (int i = 0; i < 8; ++i) diag[i] = 0; diag[0] = h0.attempts + 10 * h0.polished; diag[1] = h1.attempts + 10 * h1.polished; diag[4] = h0.qpIters; diag[5] = h1.qpIters; }
-  if (h1.Z.c > 0) {
-    HoQp h2(task2, &h1); x = h2.solution(); status |= (h2.qpIters < 0 || h2.qpIters >= 60 ? 4 : 0);
-    if (diag) { diag[2] = h2.attempts + 10 * h2.polished; diag[6] = h2.qpIters; }
-    if (h2.Z.c > 0) {
-      // Directions no task sees (the arm accelerations of HierarchicalMpcWbc) are fixed in the reference only by HoQp's 1e-12
-      // regulariser and qpOASES' internal regularisation, i.e. "small".  Defined here as the minimum-norm completion: one more
-      // level with the task x = 0.
-      HoQp h3(Task(Mat::identity(36), Vec(36, 0.0), Mat(), Vec()), &h2); x = h3.solution(); status |= (h3.qpIters < 0 || h3.qpIters >= 60 ? 8 : 0);
-      if (diag) { diag[3] = h3.attempts + 10 * h3.polished; diag[7] = h3.qpIters; }
-    }
-  } else x = h1.solution();  // FLY: level 2 has no decision variables left -> skip
+  // Directions no task sees are fixed in the reference by HoQp's 1e-12 I alone (HoQp.cpp:66): every level returns, among its minimisers, the one of smallest norm IN ITS
+  // OWN VARIABLES z -- the coordinates of the kernel basis the levels above left.  Where the LAST level decides everything that is left (every gait of gait.info once
+  // the start-up branch is over) that choice is invisible: the next level re-decides the same directions, and the cascade runs without it.  Where directions are left
+  // over at the end (swing legs during the start-up branch, flight), the result is the minimum-norm point of the last level RELATIVE TO the point the level above
+  // returned, which is itself only defined by the same rule: the cascade is then run again with the canonical representative taken at every level (HoQp, canonical).
+  // Taken in the limit 1e-12 -> 0 (with the regulariser itself those directions carry the rounding of the gradient divided by 1e-12).
+  std::unique_ptr<HoQp> h0, h1, h2;
+  const HoQp* last = nullptr;
+  bool canonical = false;
+  for (int pass = 0; pass < 2; ++pass) {
+    h2.reset();
+    h0.reset(new HoQp(task0, nullptr, canonical));
+    h1.reset(new HoQp(task1, h0.get(), canonical));
+    if (h1->Z.c > 0) h2.reset(new HoQp(task2, h1.get(), canonical));     // FLY: level 2 has no decision variables left -> skip
+    last = h2 ? h2.get() : h1.get();
+    if (canonical || !(last->Z.c > 0 && last->numDec > 0)) break;
+    canonical = true;
+  }
+  const HoQp* lv[3] = {h0.get(), h1.get(), h2.get()};
+  int status = 0;
+  if (diag) for (int i = 0; i < 8; ++i) diag[i] = 0;
+  for (int l = 0; l < 3; ++l) if (lv[l]) {
+    status |= lv[l]->stats.status ? (1 << l) : 0;
+    if (lv[l]->completed && lv[l]->completionStats.status) status |= 8;
+    if (diag) { diag[l] = 10 * lv[l]->polished; diag[4 + l] = lv[l]->qpIters; }
+  }
+  if (diag && last->completed) { diag[3] = 10 * (last->completionStats.status == 0); diag[7] = std::min(last->completionStats.ipmIterations + last->completionStats.iterations, 59); }
+  const Vec x = last->solution();
   // updateCmd (WbcBase.cpp:580-595)
   for (int i = 0; i < 36; ++i) out[i] = x[i];
   for (int i = 0; i < NJ; ++i) {
