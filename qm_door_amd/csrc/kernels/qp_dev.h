@@ -1,0 +1,588 @@
+// qp_dev.h -- one wavefront solves the QP of one HoQp level (qm_wbc/src/HoQp.cpp:60-150) with the slack block eliminated,
+//   min 1/2 |AZ z + rhat|^2 + 1/2 sum_{i own} max(0, DZ_i z - f_i)^2     s.t.   DZ_i z <= f_i  (i inherited; f_i >= 0: z = 0 is feasible).
+// Replaces the qpOASES call of HoQp.cpp:136-149 (an online active-set method, cold start, nWSR = 100) by a method of the same class:
+//   phase 2, ALWAYS: a primal active-set method -- a working set, one row changes per iteration, the iterate stays feasible, the point returned satisfies the KKT
+//     conditions on its working set: THE minimiser.  The minimiser on a working set is computed exactly by the range-space method on an augmented Hessian of the size
+//     of the cost's own (no penalty factor: a weakly curved direction keeps its digits):
+//        K = G + sum_P w_j d_j d_j' + sum_V d d'  = L L'      (matrix cores + in-register Cholesky; directions without curvature left out)
+//        T = L^-1 DZ'  (all rows, one forward substitution per lane),  S = T_P'T_P  (pinned rows; small Cholesky in LDS; dependent rows skipped)
+//        u = L^-1 (-grad - DZ_P' W r_P),   S mu = T_P'u + r_P,   p = L^-T (u - T_P mu)      =>  DZ_P (z + p) = f_P,  mu = the multipliers,  DZ p = T'(u - T_P mu)
+//   phase 1, levels with inherited rows only: Mehrotra's interior point from z = 0, until the working set can be read off its iterate -- a starting point and a guess
+//     for phase 2, nothing more (one active-set iteration then usually ends the level).
+// Same algorithm, constants and decisions as the CPU restatement (oracle/qmo_wbc.h: interiorPointPhase, activeSetPhase), which documents the reasoning.
+//
+// NP = n padded (8 / 20 / 36) sizes every register array and loop.  Lane roles: lane i < m0 owns inequality ROW i; lane c < NP owns COLUMN c (z_c, column c of K and
+// row c of L); lane q < r owns task row q of AZ (residual).
+#pragma once
+#include "gpu_rt.h"
+
+namespace qmk {
+
+constexpr double QP_EPS = 2.220446049250313e-16;
+constexpr double QP_REG = 1e-12;             // HoQp's regulariser (HoQp.cpp:66): a direction it alone would carry counts as having no curvature (x10)
+constexpr double QP_LAM_TOL = 8.0;           // = kAsLamTol of the CPU restatement
+constexpr int QP_MAX_CHANGES = 100;          // nWSR of HoQp.cpp:141
+constexpr int QP_KMAX = 28;                  // pinned rows the small system holds (S: QP_KMAX x (QP_KMAX + 1) doubles of LDS)
+constexpr int QP_SLD = QP_KMAX + 1;
+constexpr double QP_STAGNATION_MU = 1e-10;
+
+struct QpIo {
+  const double* G;      // [36][ldk] (A Z)'(A Z), zero outside n x n (no regulariser)
+  const double* AZ;     // [r][ldz] task rows in the level's variables
+  const double* rhat;   // [r]
+  const double* DZ;     // [56][ldz]; columns >= n zero; rows >= m0 finite
+  const double* fhat;   // [56]
+  double* Kt;           // [36][ldk] scratch: K tiles, then the rows of L, then the rows of T of the pinned set
+  double* wtL;          // [64] scratch: row weights
+  double* zs;           // [36] out: solution (lanes >= n write 0)
+  double* red;          // exchange scratch (>= 1024 doubles; the host emulation uses all of it)
+  double* fork;         // [1] command word of the fork-join with the three helper wavefronts (wbc_kernel): 0 = leave, NP = K tiles of that size
+  double* S;            // [QP_KMAX][QP_SLD] scratch: the small system of the pinned rows
+};
+
+// K = G + DZ' diag(w) DZ: the upper-triangle 16 x 16 tiles t with t % 4 == wave (wave < 0: all of them) on the matrix cores, written
+// (and mirrored) into the LDS square io.Kt.  Called by the solving wavefront and, between two workgroup barriers, by the three helper
+// wavefronts of wbc_kernel: a v_mfma_f64 holds one SIMD's matrix pipe for 64 cycles, the six tiles of NP = 36 are 84 of them.
+template <int NP, int LDZ_, int LDK_> __device__ __forceinline__ void ipmKTiles(const QpIo& io, int wave, int lane) {
+  constexpr int TP = (NP + 15) / 16, KS = 14;
+  const int l16 = lane & 15, h = lane >> 4;
+  int t = 0;
+#pragma unroll
+  for (int ti = 0; ti < TP; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < TP; ++tj, ++t) {
+      if (wave >= 0 && (t & 3) != wave) continue;
+      QmAcc acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+        const double gv = io.G[(i < 36 ? i : 0) * LDK_ + (j < 36 ? j : 0)];
+        acc[r] = (i < 36 && j < 36) ? gv : 0.0;
+      }
+#pragma unroll 1
+      for (int k0 = 0; k0 < KS; k0 += 7) {   // the operands of seven k steps are read from LDS before the first matrix-core instruction
+        double av[7], bv[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const int kk = 4 * (k0 + q) + h, ja = ti * 16 + l16, jb = tj * 16 + l16;
+          const double w = io.wtL[kk];
+          const double ra = io.DZ[kk * LDZ_ + (ja < 36 ? ja : 0)], rb = io.DZ[kk * LDZ_ + (jb < 36 ? jb : 0)];
+          av[q] = ja < NP ? w * ra : 0.0; bv[q] = jb < NP ? rb : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) qmMfma(acc, av[q], bv[q], io.red);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + h + 4 * r, j = tj * 16 + l16;
+        if (i < NP && j < NP) { io.Kt[i * LDK_ + j] = acc[r]; if (ti != tj) io.Kt[j * LDK_ + i] = acc[r]; }
+      }
+    }
+}
+
+// sum over 14 of the 56 rows of DZ[i][column of this lane] * bc[i] (bc: io.red[0..63], published by the solving wavefront): the share
+// of wavefront `wave` of a 56-row column sum; the partial sums meet in io.red[128 + 64 wave + lane]
+template <int LDZ_> __device__ __forceinline__ void ipmColSumShare(const QpIo& io, int wave, int lane) {
+  const int colL = lane < 36 ? lane : 0, i0 = 14 * wave;
+  const double* bc = io.red;
+  double t[14], g[14];
+#pragma unroll
+  for (int q = 0; q < 14; ++q) { t[q] = io.DZ[(i0 + q) * LDZ_ + colL]; g[q] = bc[i0 + q]; }
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 14; q += 2) { a0 += t[q] * g[q]; a1 += t[q + 1] * g[q + 1]; }
+  io.red[128 + 64 * wave + lane] = a0 + a1;
+}
+// the whole sum on four wavefronts (fork-join as for the K tiles), or on this one
+template <int LDZ_> __device__ __forceinline__ double ipmColSum(const QpIo& io, int lane) {
+  if (io.fork) {
+    io.fork[0] = 200.0;
+    QM_LDS_BARRIER();
+    ipmColSumShare<LDZ_>(io, 0, lane);
+    QM_LDS_BARRIER();
+    return (io.red[128 + lane] + io.red[192 + lane]) + (io.red[256 + lane] + io.red[320 + lane]);
+  }
+  double s = 0.0;
+  for (int w = 0; w < 4; ++w) { ipmColSumShare<LDZ_>(io, w, lane); QM_WAVE_SYNC(); s += io.red[128 + 64 * w + lane]; }
+  return s;
+}
+
+// One step of the factorisation K = L L^T by row operations (lane c holds column c of K in kc), as a template recursion so that the DPP
+// controls are immediates.  Multipliers L[r][J] = (scaled row J) at lane r: rows J + 1 (on the pivot chain) and J + 2 take them by
+// v_readlane; rows J + 3 .. NP - 1 by DPP row_newbcast -- ONE v_fmac_f64_dpp per row update -- from copies of the row's lanes
+// 16 g .. 16 g + 15 replicated into the four rows of 16 lanes, applied one step late so that the replication (LDS crossbar) is off the
+// pivot chain.  Row updates of one row commute.
+// A pivot that does not stand clear of its own rounding -- it is a difference, K_jj - sum_k L_jk^2, rounded relative to K_jj: floorAbs + floorRel (j + 1) K_jj -- marks
+// a direction without curvature: its column of L becomes the unit vector (its row is cleared after the recursion), its right-hand side entry zero (exMask).
+template <int J, int R, int NP> struct IpmDppRows {
+  static __device__ __forceinline__ void run(double* kc, const double* bcP, double ncP, double* red) {
+    if constexpr (R < NP) { qmFmacRowBcast<R % 16, R == J + 3 || R % 16 == 0>(kc[R], bcP[R / 16], ncP, red); IpmDppRows<J, R + 1, NP>::run(kc, bcP, ncP, red); }
+  }
+};
+template <int NP, int J> struct IpmFactorStep {
+  static constexpr int NG = (NP + 15) / 16;
+  static __device__ __forceinline__ void run(double* kc, double& myInv, double* bcP, double& ncP, double diag0, double floorAbs, double floorRel, unsigned long long& exMask, int lane, double* red) {
+    if constexpr (J < NP) {
+      const double piv = qmReadLane(kc[J], J, red);
+      const double d0 = qmReadLane(diag0, J, red);
+      const bool ex = !(piv > floorAbs + floorRel * double(J + 1) * d0);     // (wave uniform; NaN pivots count as excluded: the caller checks the result)
+      if (ex) exMask |= 1ull << J;
+      const double dfl = ex ? 1.0 : piv;
+      const double inv = qmRsqrtPos(dfl);
+      kc[J] = (lane == J) ? dfl * inv : (ex ? 0.0 : kc[J] * inv);
+      if (lane == J) myInv = inv;                              // 1 / L_jj
+      const QmGather gk = qmGather(kc[J], red);                // L[r][j] = gk.get(r)
+      if constexpr (J + 1 < NP) kc[J + 1] -= gk.get(J + 1) * kc[J];
+      if constexpr (J + 2 < NP) kc[J + 2] -= gk.get(J + 2) * kc[J];
+      if constexpr (J >= 1) IpmDppRows<J - 1, J + 2, NP>::run(kc, bcP, ncP, red);     // the previous step's rows J + 2 .. NP - 1
+      if constexpr (J + 3 < NP) {
+        if constexpr (NG > 0 && (J + 3) / 16 <= 0) bcP[0] = qmReplicateRow<0>(kc[J], red);
+        if constexpr (NG > 1 && (J + 3) / 16 <= 1) bcP[1] = qmReplicateRow<1>(kc[J], red);
+        if constexpr (NG > 2 && (J + 3) / 16 <= 2) bcP[2] = qmReplicateRow<2>(kc[J], red);
+        ncP = -kc[J];
+      }
+      IpmFactorStep<NP, J + 1>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, exMask, lane, red);
+    }
+  }
+};
+
+struct QpOff { int G, AZ, rhat, DZ, fhat, Kt, wtL, zs, red, fork, S; };
+struct QpResult { int status; int ipmIterations, iterations; bool strong; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed | 4 more pinned rows than the small system holds
+
+// A called function, not inlined: the kernel around it sits at 512 VGPRs with scratch, and three inlined instantiations of this body add
+// ~1400 scalar-register spills to it; as a function each instantiation gets its own allocation.  The arrays arrive as offsets into the
+// workgroup's dynamic LDS and are re-based on that symbol here, so that every access stays a ds_ instruction (pointers passed through a
+// call are generic: the same body ran 20 % slower on flat loads).
+// n: variables; r: task rows of AZ; m0: inequality rows; own: the rows are the level's own (soft) -- otherwise inherited (hard); rowOn: this lane's row takes part;
+// sigma0: starting value of the interior point (<= 0: no interior point -- the level's own rows, and the tests' cold runs).
+template <int NP, int LDZ_, int LDK_>
+__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOn, double sigma0, int lane) {
+  QM_DYNAMIC_LDS(ldsBase);
+  const QpIo io{ldsBase + off.G, ldsBase + off.AZ, ldsBase + off.rhat, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork, ldsBase + off.S};
+  enum { ST_I = 0, ST_P = 1, ST_V = 2 };
+  const double* G = io.G; const double* DZ = io.DZ; const double* AZ = io.AZ; double* red = io.red;
+  double* bc = io.red;              // [0..63] broadcast line (z, multipliers, u, v ...)
+  double* ms = io.red + 64;         // [64..127] the small system's right-hand side / solution, by slot
+  double* resL = io.red + 384;      // [384..447] task residual, by task row; [448..511] |.| version for the rounding bound
+  auto allSum = [&](double v) { return qmAllSum(v, red); };
+  auto allMax = [&](double v) { return qmAllMax(v, red); };
+  auto allMin = [&](double v) { return qmAllMin(v, red); };
+  const int colL = lane < NP ? lane : 0;       // idle lanes alias column 0 / row 0 (results unused)
+  const int rowL = lane < 56 ? lane : 0;
+  const int tskL = lane < r ? lane : 0;
+  const bool colOn = lane < n;
+  // ---- what the two phases share (prepareLevel of the CPU restatement)
+  const double hmax = allMax(colOn ? G[colL * LDK_ + colL] : 0.0);
+  const double fl = rowOn ? io.fhat[rowL] : 0.0;
+  double dn = 0.0, d2 = 0.0;
+  {
+#pragma unroll 1
+    for (int j = 0; j < NP; j += 4) {
+      const double t0 = DZ[rowL * LDZ_ + j], t1 = DZ[rowL * LDZ_ + j + 1], t2 = DZ[rowL * LDZ_ + j + 2], t3 = DZ[rowL * LDZ_ + j + 3];
+      dn = fmax(fmax(dn, fmax(fabs(t0), fabs(t1))), fmax(fabs(t2), fabs(t3)));
+      d2 += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+    }
+  }
+  const double wA = rowOn ? fmax(1.0, hmax) / d2 : 0.0;      // augmentation weight of the row when pinned
+  double gC;                                                   // g = AZ' rhat (for the scale)
+  {
+    double a0 = 0.0;
+    for (int q = 0; q < r; ++q) a0 += AZ[q * LDZ_ + colL] * io.rhat[q];
+    gC = colOn ? a0 : 0.0;
+  }
+  const double scale = fmax(1.0, allMax(fmax(rowOn ? fabs(fl) : 0.0, fabs(gC))));
+  const double tol = 1e-9 * scale;
+  const double floorAbs = 10.0 * QP_REG, floorRel = 16.0 * QP_EPS;
+  double zc = 0.0;
+  double kc[NP], uc[NP], tt[NP], myInv = 1.0;   // row c of L, row c of L^T, T row of this lane's inequality row
+  unsigned long long exMask = 0ull;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) { kc[q] = 0.0; uc[q] = 0.0; tt[q] = 0.0; }
+
+  // D z of this lane's row for the vector in bc
+  auto rowDot = [&]() {
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < NP; j += 4) {   // eight LDS reads in flight, then the multiply-adds (a lone wavefront has nothing else to hide them)
+      const double t0 = DZ[rowL * LDZ_ + j], t1 = DZ[rowL * LDZ_ + j + 1], t2 = DZ[rowL * LDZ_ + j + 2], t3 = DZ[rowL * LDZ_ + j + 3];
+      const double z0 = bc[j], z1 = bc[j + 1], z2 = bc[j + 2], z3 = bc[j + 3];
+      d0 += t0 * z0; d1 += t1 * z1; d0 += t2 * z2; d1 += t3 * z3;
+    }
+    return d0 + d1;
+  };
+  // gradient of the smooth cost at the vector in bc, in residual form AZ'(AZ z + rhat) (the CPU restatement's costGradient); absForm: the rounding bound
+  // |AZ|'(|AZ| |z| + |rhat|) instead
+  auto costGradient = [&](bool absForm) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < NP; j += 2) {
+      const double t0 = AZ[tskL * LDZ_ + j], t1 = AZ[tskL * LDZ_ + j + 1];
+      const double z0 = bc[j], z1 = bc[j + 1];
+      if (absForm) { a0 += fabs(t0) * fabs(z0); a1 += fabs(t1) * fabs(z1); } else { a0 += t0 * z0; a1 += t1 * z1; }
+    }
+    const double rh = io.rhat[tskL];
+    QM_WAVE_SYNC();
+    if (lane < 64) resL[lane] = lane < r ? (absForm ? (a0 + a1) + fabs(rh) : (a0 + a1) + rh) : 0.0;
+    QM_WAVE_SYNC();
+    double g0 = 0.0, g1 = 0.0;
+#pragma unroll 1
+    for (int q = 0; q + 1 < r; q += 2) {
+      const double t0 = AZ[q * LDZ_ + colL], t1 = AZ[(q + 1) * LDZ_ + colL];
+      if (absForm) { g0 += fabs(t0) * resL[q]; g1 += fabs(t1) * resL[q + 1]; } else { g0 += t0 * resL[q]; g1 += t1 * resL[q + 1]; }
+    }
+    if (r & 1) { const double t0 = AZ[(r - 1) * LDZ_ + colL]; g0 += (absForm ? fabs(t0) : t0) * resL[r - 1]; }
+    return colOn ? g0 + g1 : 0.0;
+  };
+  // K = G + DZ' diag(wt) DZ = L L^T: tiles on the matrix cores, factorisation in registers, rows of L (and 1 / L_cc) to LDS, rows of L^T back
+  auto factorise = [&](double wt) {
+    if (lane < 56) io.wtL[lane] = wt;
+    QM_WAVE_SYNC();
+    if (NP > 16 && io.fork) {   // several tiles: the helper wavefronts take theirs between two workgroup barriers
+      io.fork[0] = double(NP);
+      QM_LDS_BARRIER();
+      ipmKTiles<NP, LDZ_, LDK_>(io, 0, lane);
+      QM_LDS_BARRIER();
+    } else {
+      ipmKTiles<NP, LDZ_, LDK_>(io, -1, lane);
+    }
+    QM_WAVE_SYNC();
+    // lane c holds column c of K in kc; after step j, kc[j] of lane c is L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
+    myInv = 1.0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const double kv = io.Kt[q * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
+      kc[q] = (colOn && q < n) ? kv : ((q == lane) ? 1.0 : 0.0);   // identity padding beyond n
+    }
+    double diag0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) diag0 = (q == lane) ? kc[q] : diag0;
+    exMask = 0ull;
+    {
+      double bcP[3] = {0.0, 0.0, 0.0}, ncP = 0.0;
+      IpmFactorStep<NP, 0>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, exMask, lane, red);
+    }
+    const bool myEx = lane < NP && ((exMask >> lane) & 1ull);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) kc[q] = myEx ? ((q == lane) ? 1.0 : 0.0) : kc[q];     // an excluded direction: its row of L is the unit vector as well
+    // the back substitution L^T x = t walks the COLUMNS of L^T: U[r][c] (c > r) sits in lane c, register r.  One transpose through LDS per factorisation puts it into
+    // lane r, register c -- and leaves the rows of L in LDS for the forward substitutions of the inequality rows (T, below)
+    QM_WAVE_SYNC();
+    if (lane < NP) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) io.Kt[lane * LDK_ + q] = kc[q];
+    }
+    QM_WAVE_SYNC();
+#pragma unroll
+    for (int cc = 0; cc < NP; ++cc) uc[cc] = io.Kt[cc * LDK_ + colL];   // U[lane][cc] for cc > lane
+    QM_WAVE_SYNC();
+  };
+  // L t = rhs (forward substitution; lane c owns row c of L), then L^T x = t (back substitution; lane r owns row r of L^T in uc); excluded directions: zero
+  auto forward = [&](double acc) {
+    acc = (lane < NP && ((exMask >> lane) & 1ull)) ? 0.0 : acc;
+    double tC = 0.0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const double tr = qmReadLane(acc * myInv, q, red);
+      if (lane == q) tC = tr;
+      acc -= (lane > q) ? kc[q] * tr : 0.0;
+    }
+    return tC;
+  };
+  auto backward = [&](double tC) {
+    double bacc = (lane < NP && ((exMask >> lane) & 1ull)) ? 0.0 : tC, x = 0.0;
+#pragma unroll
+    for (int cc = NP - 1; cc >= 0; --cc) {
+      const double dc = qmReadLane(bacc * myInv, cc, red);
+      if (lane == cc) x = dc;
+      bacc -= (lane < cc) ? uc[cc] * dc : 0.0;
+    }
+    return colOn ? x : 0.0;
+  };
+
+  // ================================================================== phase 1: interior point (inherited rows only): a starting point and a guess
+  int ipmIt = 0;
+  bool usable = false;
+  double s1 = 1.0, l1 = 0.0;
+  const double nRows = allSum(rowOn ? 1.0 : 0.0);
+  if (sigma0 > 0.0 && !own && nRows > 0.0) {
+    s1 = rowOn ? fmax(sigma0, fl) : 1.0; l1 = rowOn ? sigma0 : 0.0;
+    double zcPrev = 0.0, s1p = s1, l1p = l1, nrdPrev = 0.0, muPrev = 0.0;
+#pragma unroll 1
+    for (; ipmIt < 40; ++ipmIt) {
+      QM_WAVE_SYNC();
+      bc[lane] = zc;
+      QM_WAVE_SYNC();
+      const double Dz = rowDot();
+      const double rp1 = rowOn ? (Dz + s1 - fl) : 0.0;
+      double rdz;
+      {
+        double a0 = gC, a1 = 0.0;
+#pragma unroll 1
+        for (int j = 0; j < NP; j += 4) {   // G symmetric
+          const double t0 = G[j * LDK_ + colL], t1 = G[(j + 1) * LDK_ + colL], t2 = G[(j + 2) * LDK_ + colL], t3 = G[(j + 3) * LDK_ + colL];
+          const double z0 = bc[j], z1 = bc[j + 1], z2 = bc[j + 2], z3 = bc[j + 3];
+          a0 += t0 * z0; a1 += t1 * z1; a0 += t2 * z2; a1 += t3 * z3;
+        }
+        QM_WAVE_SYNC();
+        bc[lane] = rowOn ? l1 : 0.0;
+        QM_WAVE_SYNC();
+        const double dtl = ipmColSum<LDZ_>(io, lane);     // D^T lambda: 56 rows, shared with the helper wavefronts
+        rdz = colOn ? (a0 + a1) + dtl : 0.0;
+      }
+      const double mu = allSum(rowOn ? s1 * l1 : 0.0) / nRows;
+      const double nrd = allMax(fabs(rdz));
+      const double nrp = allMax(fabs(rp1));
+      const double nanProbe = allSum(rdz + rp1);  // NaN anywhere -> NaN here (fmax drops NaNs)
+      // a late Newton step of a degenerate problem (barrier weights ~1e18) can lose all accuracy: the previous iterate is what the active-set method starts from
+      if (ipmIt > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) { zc = zcPrev; s1 = s1p; l1 = l1p; usable = true; break; }
+      if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= 1e-6 * scale) { usable = true; break; }               // the working set can be read: over to the active-set method, for good
+      if (ipmIt > 0 && mu > 0.5 * muPrev && mu <= QP_STAGNATION_MU * scale) { usable = true; break; }               // stagnation at the rounding floor
+      zcPrev = zc; s1p = s1; l1p = l1; nrdPrev = nrd; muPrev = mu;
+      const double w1 = l1 / s1;
+      factorise(rowOn ? w1 : 0.0);
+      double ds1 = 0.0, dl1 = 0.0, dzc = 0.0, alphaAff = 1.0, sigma = 0.0, cw = 1.0;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + cw * ds1 * dl1 - sigma * mu;
+        const double t1 = rowOn ? (l1 * rp1 - rc1) / s1 : 0.0;
+        QM_WAVE_SYNC();
+        bc[lane] = t1;
+        QM_WAVE_SYNC();
+        const double dtt = ipmColSum<LDZ_>(io, lane);   // D^T t
+        dzc = backward(forward(colOn ? -rdz - dtt : 0.0));
+        QM_WAVE_SYNC();
+        bc[lane] = dzc;
+        QM_WAVE_SYNC();
+        const double Ddz = rowDot();
+        if (rowOn) { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
+        double amax = 1.0;
+        if (rowOn) { if (ds1 < 0) amax = fmin(amax, -s1 / ds1); if (dl1 < 0) amax = fmin(amax, -l1 / dl1); }
+        amax = allMin(amax);
+        if (pass == 0) {
+          alphaAff = amax;
+          const double muAff = allSum(rowOn ? (s1 + alphaAff * ds1) * (l1 + alphaAff * dl1) : 0.0) / nRows;
+          const double ratio = muAff / mu;
+          sigma = ratio * ratio * ratio;
+          cw = fmin(1.0, 4.0 * alphaAff);
+        } else {
+          const double tau = fmax(0.995, 1.0 - mu);
+          const double al = fmin(1.0, tau * amax);
+          zc += al * dzc;
+          if (rowOn) { s1 += al * ds1; l1 += al * dl1; }
+        }
+      }
+    }
+    if (ipmIt >= 40) usable = true;      // iteration cap: the last iterate is handed over like any other
+    if (!(allSum(zc) == allSum(zc))) { usable = false; zc = 0.0; }
+  }
+
+  // ================================================================== phase 2: primal active set
+  int state = ST_I;
+  bool guess = false, stuck = false;
+  if (own && rowOn) state = fl < -tol ? ST_V : (fl <= tol ? ST_P : ST_I);
+  if (usable) {
+    QM_WAVE_SYNC();
+    bc[lane] = zc;
+    QM_WAVE_SYNC();
+    const double Dz = rowDot();
+    if (rowOn && (l1 > s1 || Dz - fl > 0.0)) { state = ST_P; guess = true; }
+  }
+  double lam = 0.0;                  // multiplier of this lane's row (pinned rows)
+  int status = 0, it = 0, lastReleased = -1, fullSteps = 0;
+  bool strong = false;
+#pragma unroll 1
+  for (;; ++it) {
+    if (it > QP_MAX_CHANGES) { status = 1; break; }
+    const bool pinned = rowOn && state == ST_P;
+    const unsigned long long pinMask = qmBallot(pinned);
+    const int k = qmPopCount(pinMask);
+    if (k > QP_KMAX) { status = 4; break; }
+    const int slot = qmPopCount(pinMask & ((1ull << lane) - 1ull));     // this lane's place among the pinned rows
+    factorise(rowOn ? (state == ST_P ? wA : (state == ST_V ? 1.0 : 0.0)) : 0.0);
+    if (!(allSum(myInv) == allSum(myInv))) { status = 2; break; }
+    // ---- T = L^-1 DZ': this lane's row, by forward substitution over the rows of L in LDS (wave-uniform reads); 1 / L_cc from the lanes
+    {
+      QM_WAVE_SYNC();
+      bc[lane] = myInv;
+      QM_WAVE_SYNC();
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        double acc = DZ[rowL * LDZ_ + c];
+#pragma unroll
+        for (int q = 0; q < c; ++q) acc -= io.Kt[c * LDK_ + q] * tt[q];
+        tt[c] = ((exMask >> c) & 1ull) ? 0.0 : acc * bc[c];
+      }
+      QM_WAVE_SYNC();
+    }
+    // ---- S = T_P'T_P: the pinned rows publish their T rows (over the rows of L, no longer needed), each computes its row of S; Cholesky in LDS with the
+    //      dependent rows (pivot lost against the row's own diagonal entry) left out
+    unsigned long long depMask = 0ull;
+    if (k > 0) {
+      if (pinned) {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) io.Kt[slot * LDK_ + c] = tt[c];
+      }
+      QM_WAVE_SYNC();
+      if (pinned) {
+#pragma unroll 1
+        for (int sb = 0; sb < k; ++sb) {
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+          for (int c = 0; c + 1 < NP; c += 2) { a0 += tt[c] * io.Kt[sb * LDK_ + c]; a1 += tt[c + 1] * io.Kt[sb * LDK_ + c + 1]; }
+          if (NP & 1) a0 += tt[NP - 1] * io.Kt[sb * LDK_ + NP - 1];
+          io.S[slot * QP_SLD + sb] = a0 + a1;
+        }
+      }
+      QM_WAVE_SYNC();
+      const int sl = lane < k ? lane : 0;
+      const double sdiag = io.S[sl * QP_SLD + sl];
+#pragma unroll 1
+      for (int j = 0; j < k; ++j) {
+        const double d = io.S[j * QP_SLD + j];
+        const double dj0 = io.S[j * QP_SLD + j];
+        (void)dj0;
+        const double sj = qmReadLane(sdiag, j, red);
+        const bool dep = !(d > 1e-11 * sj);
+        if (dep) depMask |= 1ull << j;
+        const double dj = dep ? 1.0 : sqrt(d);
+        QM_WAVE_SYNC();
+        if (lane == j) io.S[j * QP_SLD + j] = dj;
+        else if (lane > j && lane < k) io.S[lane * QP_SLD + j] = dep ? 0.0 : io.S[lane * QP_SLD + j] / dj;
+        if (dep && lane < j) io.S[j * QP_SLD + lane] = 0.0;
+        QM_WAVE_SYNC();
+        if (!dep && lane > j && lane < k) {
+          const double lij = io.S[lane * QP_SLD + j];
+          for (int q = j + 1; q <= lane; ++q) io.S[lane * QP_SLD + q] -= lij * io.S[q * QP_SLD + j];
+        }
+        QM_WAVE_SYNC();
+      }
+    }
+    // ---- the interior point's guess: its rows are still off their bounds; the first step is meant to bring them there and is only taken in full.  A guess with a
+    //      dependent row, or whose step another row cuts short, is dropped
+    const bool offBound = qmBallot(pinned && guess) != 0ull;
+    if (offBound && depMask != 0ull) { if (guess) { state = ST_I; guess = false; } fullSteps = 0; continue; }
+    // ---- passes on this working set
+    bool rebuild = false, done = false;
+#pragma unroll 1
+    for (;;) {
+      QM_WAVE_SYNC();
+      bc[lane] = zc;
+      QM_WAVE_SYNC();
+      const double Dz = rowDot();
+      const double rRow = Dz - fl;
+      const double gradC = costGradient(false);
+      QM_WAVE_SYNC();
+      bc[lane] = rowOn ? (state == ST_P ? wA * rRow : (state == ST_V ? rRow : 0.0)) : 0.0;
+      QM_WAVE_SYNC();
+      const double dtt = ipmColSum<LDZ_>(io, lane);
+      const double uC = forward(colOn ? -(gradC + dtt) : 0.0);
+      QM_WAVE_SYNC();
+      bc[lane] = lane < NP ? uC : 0.0;
+      QM_WAVE_SYNC();
+      double muMine = 0.0;
+      if (k > 0) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int c = 0; c + 1 < NP; c += 2) { a0 += tt[c] * bc[c]; a1 += tt[c + 1] * bc[c + 1]; }
+        if (NP & 1) a0 += tt[NP - 1] * bc[NP - 1];
+        if (pinned) ms[slot] = (a0 + a1) + rRow;
+        QM_WAVE_SYNC();
+        // S mu = rhs (lane = row of the small factor)
+#pragma unroll 1
+        for (int j = 0; j < k; ++j) {
+          const double xj = ((depMask >> j) & 1ull) ? 0.0 : ms[j] / io.S[j * QP_SLD + j];
+          QM_WAVE_SYNC();
+          if (lane == j) ms[j] = xj;
+          else if (lane > j && lane < k) ms[lane] -= io.S[lane * QP_SLD + j] * xj;
+          QM_WAVE_SYNC();
+        }
+#pragma unroll 1
+        for (int j = k - 1; j >= 0; --j) {
+          const double xj = ((depMask >> j) & 1ull) ? 0.0 : ms[j] / io.S[j * QP_SLD + j];
+          QM_WAVE_SYNC();
+          if (lane == j) ms[j] = xj;
+          else if (lane < j) ms[lane] -= io.S[j * QP_SLD + lane] * xj;
+          QM_WAVE_SYNC();
+        }
+        muMine = pinned ? ms[slot] : 0.0;
+      }
+      double vC = uC;
+      for (int sb = 0; sb < k; ++sb) vC -= io.Kt[sb * LDK_ + colL] * ms[sb];
+      vC = lane < NP ? vC : 0.0;
+      const double pC = backward(vC);
+      QM_WAVE_SYNC();
+      bc[lane] = vC;
+      QM_WAVE_SYNC();
+      double Dp;
+      {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int c = 0; c + 1 < NP; c += 2) { a0 += tt[c] * bc[c]; a1 += tt[c + 1] * bc[c + 1]; }
+        if (NP & 1) a0 += tt[NP - 1] * bc[NP - 1];
+        Dp = a0 + a1;
+      }
+      const double nanProbe = allSum(pC);
+      if (!(nanProbe == nanProbe)) { status = 2; done = true; break; }
+      const double pmax = allMax(fabs(pC));
+      const double zmax0 = fmax(1.0, allMax(fabs(zc)));
+      // what the pinned rows let through: a row that is a combination of pinned rows shows a step component of that size and must not be taken for a blocking row
+      const double leak = allMax(pinned ? fabs(Dp + rRow) / dn : 0.0);
+      // first sign change along the step
+      double a = 2.0;
+      if (rowOn && state != ST_P) {
+        const double epsP = fmax(1e-13 * fmax(1.0, pmax), 1e3 * leak) * dn;
+        if (state == ST_I) { if (Dp > epsP) a = fmax(0.0, -rRow) / Dp; }
+        else { if (Dp < -epsP) a = fmax(0.0, rRow) / -Dp; }
+      }
+      const double amin = allMin(a);
+      if (amin < 1.0) {
+        const int block = qmFirstBit(qmBallot(a == amin));          // ties keep the smallest row index
+        if (offBound) { if (guess) { state = ST_I; guess = false; } fullSteps = 0; rebuild = true; break; }      // the guess is dropped; nothing moves
+        const bool moved = amin * pmax > 1e-13 * zmax0;             // a step that does not move the point beyond its rounding counts as zero-length
+        zc += amin * pC;
+        if (moved) stuck = false; else if (lane == block && block == lastReleased) stuck = true;
+        lastReleased = -1;
+        if (lane == block) state = ST_P;
+        fullSteps = 0; rebuild = true;
+        break;
+      }
+      zc += pC;
+      guess = false;                      // a full step: every pinned row is on its bound now
+      lam = muMine;
+      // refinement: the same working set once more from the new point until the correction is rounding -- at most three full steps in a row
+      const double zmax1 = fmax(1.0, allMax(fabs(zc)));
+      if (pmax > 1e-13 * zmax1 && fullSteps < 3) { ++fullSteps; continue; }
+      // multipliers: one counts once lam |d| stands clear of the rounding of the gradient it balances
+      QM_WAVE_SYNC();
+      bc[lane] = zc;
+      QM_WAVE_SYNC();
+      const double bound = allMax(costGradient(true));
+      const double gradNoise = QP_LAM_TOL * QP_EPS * fmax(bound, 1e-300);
+      const double bad = (pinned && !stuck) ? (own ? fabs(lam) : -lam) * dn / gradNoise : 0.0;
+      const double worst = allMax(bad);
+      if (worst > 1.0) {
+        const int rel = qmFirstBit(qmBallot(bad == worst));
+        if (lane == rel) { state = (own && lam > 0.0) ? ST_V : ST_I; lam = 0.0; }
+        lastReleased = rel; fullSteps = 0; rebuild = true;
+        break;
+      }
+      // the point satisfies the KKT conditions on its working set; the bounds themselves once more (partial steps accumulate rounding)
+      QM_WAVE_SYNC();
+      bc[lane] = zc;
+      QM_WAVE_SYNC();
+      const double Df = rowDot() - fl;
+      const bool viol = rowOn && (!own || state != ST_V) && !(Df <= tol);
+      if (qmBallot(viol) != 0ull) status = 3;
+      strong = rowOn && (state == ST_V || (state == ST_P && lam * dn > gradNoise));
+      done = true;
+      break;
+    }
+    if (done) break;
+    (void)rebuild;
+  }
+  if (status == 2) zc = 0.0;      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
+  if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
+  return QpResult{status, ipmIt, it, strong};
+}
+
+}  // namespace qmk

@@ -11,8 +11,8 @@
 //   nle_k  = sum_b  J_k,b^T [ m (a_c + g) ; I alpha + w x I w ]          (lane k = generalized velocity k)
 //   M_ik   = sum_b  J_i,b^T diag(m, I_b) J_k,b                           (lane k owns column k)
 //   dJ v   = bias acceleration of the frame point                        (no dJ matrix is ever formed)
-// QP: Mehrotra predictor-corrector interior point on the reference's (H, c, D, f) of HoQp::formulateProblem with the slack
-// block eliminated analytically (it is diagonal), so the factorised system is n x n (n <= 36) instead of (n + 56)^2.
+// QP: the reference's (H, c, D, f) of HoQp::formulateProblem with the slack block eliminated analytically (it is diagonal), so the factorised system is n x n
+// (n <= 36) instead of (n + 56)^2; every level ends with a primal active-set method (qp_dev.h), an interior point only hands it its starting point.
 // Only the highest-priority task may carry inequality rows (true for both reference controllers).
 #pragma once
 #include <type_traits>
@@ -23,7 +23,7 @@
 #endif
 #include "linesearch_kernel.h"  // DblIn
 #include "sweep_dev.h"
-#include "ipm_dev.h"
+#include "qp_dev.h"
 #include "wave_gemm.h"
 
 namespace qmk {
@@ -238,6 +238,162 @@ __device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane)
   }
 }
 
+// N = kernel(rows) (rows: r x n in LDS, row stride LDZ, destroyed): the reference takes Eigen's FullPivLU::kernel() (HoQp.cpp:129), i.e. the basis [-U11^-1 U12; I] in the
+// column order full pivoting leaves -- NOT an orthonormal one -- with Eigen 3.3's pivot order: the largest entry of the remaining corner, ties to the smallest column
+// position, then the smallest row position (its scalar visitor walks the column-major corner column by column and keeps the first strict maximum).  The level tasks carry
+// unit rows: exact ties are the rule, and the basis -- the coordinates the minimum-norm representative of a level is taken in -- depends on the order.  The kernels and the
+// CPU restatement (qmo_core.h kernelFullPivLU) take the same decisions with the same roundings.  Result: N (n x nNew, row stride LDK) in K; returns nNew.
+// Also used for the implied equalities of a level (rows = the strongly active inequality rows, wbc_kernel).  A called function: three call sites, one copy; the arrays
+// arrive as offsets into the dynamic LDS (qp_dev.h: qpSolve).
+__device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n, int kOff, int vhOff, int redOff, int lane) {
+  QM_DYNAMIC_LDS(ldsBase);
+  double* rows = ldsBase + rowsOff; double* K = ldsBase + kOff; double* Vh = ldsBase + vhOff; double* red = ldsBase + redOff;
+  (void)red;
+  static_assert(MAXR <= 24 && ND <= 36 && 128 + 64 + 32 <= MAXR * 40, "index tables of the null-space step fit the region they are carved from");
+  {
+      int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
+      int* colPerm = ip; int* rowOf = ip + 40; int* pivOk = ip + 64; int* freePos = ip + 96;
+      const int size = r < n ? r : n;
+      // Lanes: row i of A Z is worked on by up to three lanes, i, r + i and 2 r + i ("chunks"), each eliminating a contiguous third of the column positions behind the pivot
+      // (r <= 21: three chunks, 22: two) -- with one lane per row only r of the 64 lanes worked and a step was 35 dependent LDS round trips long.  Same arithmetic per
+      // entry, same decisions: the chunks' column ranges are in increasing order, so "largest magnitude, first position on ties" of a row is the best of chunk 0, else 1,
+      // else 2; the per-row state (rowPos, best, bj) is kept identical in the lanes of a row, the pivot's row is chosen among the chunk-0 lanes (lane = row index) as before.
+      const int nChunk = 3 * r <= 64 ? 3 : (2 * r <= 64 ? 2 : 1);
+      const int chunk = (lane >= r ? 1 : 0) + (lane >= 2 * r ? 1 : 0);
+      const bool active = lane < nChunk * r;
+      const int rowIdx = active ? lane - chunk * r : 0;
+      double* xchgV = Vh + 128; int* xchgJ = reinterpret_cast<int*>(Vh + 192);   // exchange of the chunks' candidates (64 doubles, 64 ints; beyond the index tables)
+      int rowPos = rowIdx;
+      int colPermReg = lane;     // lane j: the original column at position j (swapped between lanes with v_readlane; LDS copy after the loop)
+      int rowOfReg = 0;          // lane k: the row that gave pivot k
+      double maxPivot = 0.0;
+      int nonzero = 0;
+      double* row = rows + rowIdx * LDZ;
+      // largest entry of this lane's row over the column positions >= k, first one on ties (Eigen's visitor keeps the first strict maximum of its column-major walk: within a row that is the smallest column position).  Loads in
+      // batches of eight before any store: a store to LDS between two loads of the same array serialises them (the compiler cannot tell the rows apart)
+      double best = -1.0; int bj = 0;
+      if (active) {
+#pragma unroll 1
+        for (int j0 = 0; j0 < n; j0 += 8) {
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = fabs(row[j0 + q < n ? j0 + q : 0]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (j0 + q < n && v[q] > best) { best = v[q]; bj = j0 + q; }
+        }
+      }
+      // One step = one dependent chain; what is on it besides the elimination itself is kept in registers: the pivot's lane from a ballot (the
+      // smallest-row-position rule needs a second reduction only when two rows tie), its column and value by v_readlane, the permutations in lanes.
+#pragma unroll 1
+      for (int k = 0; k < size; ++k) {
+        const bool mine = lane < r && rowPos >= k;
+        const double gmax = qmAllMax(mine ? best : -1.0, red);
+        if (!(gmax > 0.0)) break;
+        const bool cand = mine && best == gmax;
+        const unsigned long long tied = qmBallot(cand);
+        int Lp;
+        if ((tied & (tied - 1)) == 0) Lp = qmFirstBit(tied);
+        else Lp = int(qmAllMin(cand ? double((bj * 64 + rowPos) * 64 + lane) : 1e9, red)) & 63;   // ties between rows: the smallest COLUMN position, then the smallest row position (Eigen's column-major scan)
+        const int pr = qmReadLaneInt(rowPos, Lp), pc = qmReadLaneInt(bj, Lp);
+        maxPivot = fmax(maxPivot, gmax);
+        if (active) { if (rowIdx == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
+        { const int ck = qmReadLaneInt(colPermReg, k), cp = qmReadLaneInt(colPermReg, pc); if (lane == k) colPermReg = cp; else if (lane == pc) colPermReg = ck; }
+        if (lane == k) rowOfReg = Lp;
+        double vk = 0.0, vpc = 0.0;
+        if (active) { vk = row[k]; vpc = row[pc]; }
+        QM_WAVE_SYNC();
+        if (pc != k && lane < r) { row[k] = vpc; row[pc] = vk; }
+        const double pivot = qmReadLane(vpc, Lp);
+        QM_WAVE_SYNC();
+        // elimination of the rows still below the pivot, this lane's share of the column positions; the largest entry of the updated row (positions > k) is found on
+        // the way: the next step's candidate
+        const double* prow = rows + Lp * LDZ;
+        best = -1.0; bj = k + 1;
+        const int len = n - k - 1, per = (len + nChunk - 1) / nChunk;
+        const int jLo = k + 1 + chunk * per, jHi = (jLo + per < n) ? jLo + per : n;
+        if (active && rowPos > k) {
+          const double f = vpc / pivot;
+#pragma unroll 1
+          for (int j0 = jLo; j0 < jHi; j0 += 8) {
+            double a[8], pv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int j = j0 + q < jHi ? j0 + q : jLo; a[q] = row[j]; pv[q] = prow[j]; }
+            // product and difference rounded separately (no fused multiply-add): the pivot search compares these numbers for EQUALITY of magnitude with
+            // entries of other rows (the level tasks carry unit rows, so exact ties are the rule, not the exception) and must take the decisions the
+            // oracle's kernelFullPivLU takes on the host
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = qmSubNoFma(a[q], qmMulNoFma(f, pv[q]));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (j0 + q < jHi) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
+          }
+        }
+        if (nChunk > 1) {   // the row's candidate: the chunks' candidates in the order of their column ranges (strictly larger wins: first position on ties)
+          QM_WAVE_SYNC();
+          xchgV[lane] = best; xchgJ[lane] = bj;
+          QM_WAVE_SYNC();
+          if (active) {
+            double b0 = xchgV[rowIdx]; int j0 = xchgJ[rowIdx];
+            const double b1 = xchgV[rowIdx + r]; const int j1 = xchgJ[rowIdx + r];
+            const double b2 = nChunk > 2 ? xchgV[rowIdx + 2 * r] : -1.0; const int j2 = nChunk > 2 ? xchgJ[rowIdx + 2 * r] : 0;
+            if (b1 > b0) { b0 = b1; j0 = j1; }
+            if (b2 > b0) { b0 = b2; j0 = j2; }
+            best = b0; bj = j0;
+          }
+        }
+        ++nonzero;
+        QM_WAVE_SYNC();
+      }
+      if (lane < n) colPerm[lane] = colPermReg;
+      if (lane < nonzero) rowOf[lane] = rowOfReg;
+      QM_WAVE_SYNC();
+      // rank: pivots above Eigen's default threshold eps * size * max pivot; the others' columns count as free
+      const double thresh = maxPivot * 2.220446049250313e-16 * double(size);
+      // (rank and the list of free column positions from two ballots: as loops over the LDS table -- one of them on lane 0 alone -- they were 36 + 18 dependent LDS round trips)
+      const bool okReg = lane < nonzero && fabs(rows[rowOfReg * LDZ + lane]) > thresh;
+      if (lane < nonzero) pivOk[lane] = okReg ? 1 : 0;
+      const int rank = qmPopCount(qmBallot(okReg));
+      const int nNew = n - rank;
+      const bool freeReg = lane < n && !okReg;
+      const unsigned long long freeMask = qmBallot(freeReg);
+      if (freeReg) freePos[qmPopCount(freeMask & ((1ull << lane) - 1ull))] = lane;
+      for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;      // N (n x nNew), one kernel vector per lane / column
+      QM_WAVE_SYNC();
+      {
+        // U11 X = -U12 for this lane's free column: back substitution over the accepted pivots, X(:, lane) in registers (fully unrolled: compile-time
+        // indices), the U entries as wave-uniform LDS reads; the results leave for LDS after the loop (no store between the loads)
+        const int fp = lane < nNew ? freePos[lane] : 0;
+        // (which pivots count and where their rows are: read once, all loads in flight together, instead of one LDS round trip in front of every step)
+        bool okk[MAXR]; int rb[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) { const int ok = pivOk[k < nonzero ? k : 0], ro = rowOf[k < nonzero ? k : 0]; okk[k] = k < nonzero && ok != 0; rb[k] = ro * LDZ; }
+        double xk[MAXR];
+#pragma unroll
+        for (int k = MAXR - 1; k >= 0; --k) {
+          xk[k] = 0.0;
+          if (okk[k]) {   // wave-uniform
+            const double* urow = rows + rb[k];
+            double u[MAXR];
+#pragma unroll
+            for (int k2 = k + 1; k2 < MAXR; ++k2) u[k2] = urow[k2 < n ? k2 : 0];
+            double sacc = fp >= k ? -urow[fp] : 0.0;
+#pragma unroll
+            for (int k2 = k + 1; k2 < MAXR; ++k2) sacc -= (k2 < nonzero ? u[k2] : 0.0) * xk[k2];
+            xk[k] = sacc / urow[k];
+          }
+        }
+        if (lane < nNew) {
+#pragma unroll
+          for (int k = 0; k < MAXR; ++k) if (okk[k]) K[colPerm[k] * LDK + lane] = xk[k];
+          K[colPerm[fp] * LDK + lane] = 1.0;
+        }
+      }
+      QM_WAVE_SYNC();
+      QM_TICK(16);
+    QM_WAVE_SYNC();
+    return nNew;
+  }
+}
+
 __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(WbcArgs a) {
 #if defined(QM_WBC_OPAQUE_MASK) && !defined(QMGPU_HOST_EMULATION)
   // Experiment (tools/wbc_variants.py): array group g of the LDS carve is addressed through one opaque
@@ -352,7 +508,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 #elif QM_WBC_EXP == 5
     __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);   // experiment: pure timing -- every helper arrives ~16 k cycles later
 #endif
-    const IpmIo hio{G, gs, DZ, fhat, K, wt, zs, red, forkCmd};
+    const QpIo hio{G, nullptr, nullptr, DZ, fhat, K, wt, zs, red, forkCmd, nullptr};
 #if defined(QM_WBC_DUMP) && !defined(QMGPU_HOST_EMULATION)
     int dbgIt = 0;
 #endif
@@ -558,10 +714,114 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   }
   QM_WAVE_SYNC();
 
-  const int numLevels = 4;  // level 3 = minimum-norm completion (task x = 0) of whatever no task pinned
-  int n = ND;  // current null-space dimension
+  // scratch of the implied-equality step: the body / wrench tables of the model update are free by now (the desired pass has joined)
+  double* scrA = lds + W_BODY;       // 904 doubles: W_BODY | W_DOF | W_WR
+  double* scrB = lds + W_BODY2;      // 784 doubles: W_BODY2 | W_DOF2
+  static_assert(W_DOF == W_BODY + 640 && W_WR == W_DOF + 144 && W_M == W_WR + 120 && 24 * LDZ <= 904 && MAXR * LDZ <= 904 && 18 * LDZ <= 784, "scratch regions of the implied-equality step");
+  static_assert(QP_KMAX * QP_SLD <= MAXR * 40, "the small system of the pinned rows fits the table region");
+  // rows of `cnt` x n  <-  rows N_E (N_E: n x nE in K), in place, 24 rows at a time through scrA; columns >= nE cleared
+  auto rightMultiply = [&](double* rowsP, int cnt, int n, int nE) {
 #pragma unroll 1
-  for (int level = 0; level < numLevels; ++level) {
+    for (int r0 = 0; r0 < cnt; r0 += 24) {
+      const int c = cnt - r0 < 24 ? cnt - r0 : 24;
+      forkGemm(false, rowsP + r0 * LDZ, LDZ, K, LDK, c, nE, n, scrA, LDZ, 0.0);
+      QM_WAVE_SYNC();
+      for (int e = lane; e < c * LDZ; e += 64) { const int j = e % LDZ; rowsP[r0 * LDZ + e] = j < nE ? scrA[e] : 0.0; }
+      QM_WAVE_SYNC();
+    }
+  };
+  // The QP of one level (or of its canonical representative) in nVars variables: task rows AZp (rRows x nVars) with residual rhatp at z = 0, inequality rows DZ / fhat
+  // (own: the level's own, soft; else inherited, hard).  Rows a higher level left strongly active (eqIn) are equalities here: removed exactly by the change of variables
+  // z = N_E w (N_E = kernel of those rows; oracle/qmo_wbc.h eliminateImpliedEqualities has the argument), the QP is solved in w.  Result: z in zs[0 .. nVars);
+  // strongOut: this lane's row is strongly active at the solution; returns the solver's status.  AZp and DZ are overwritten when rows are eliminated.
+  auto levelQp = [&](double* AZp, int rRows, double* rhatp, int nVars, bool own, bool rowOnIn, bool eqIn, bool& strongOut, int& passes) -> int {
+    int nQ = nVars;
+    bool rowOn = rowOnIn, reduced = false;
+    strongOut = false;
+    if (!own) {
+      unsigned long long eqMask = qmBallot(rowOn && eqIn);
+      if (eqMask != 0ull) {
+        // (at most MAXR rows go into the elimination -- the rest, necessarily combinations of them in <= 18 variables, stay inequality rows)
+        int slotE = qmPopCount(eqMask & ((1ull << lane) - 1ull));
+        const bool mineE = rowOn && eqIn && slotE < MAXR;
+        const int kE = qmPopCount(eqMask) < MAXR ? qmPopCount(eqMask) : MAXR;
+        if (mineE) for (int j = 0; j < LDZ; ++j) scrA[slotE * LDZ + j] = j < nVars ? DZ[lane * LDZ + j] : 0.0;
+        QM_WAVE_SYNC();
+        nQ = wbcNullSpace(int(scrA - lds), kE, nVars, int(K - lds), int(Vh - lds), int(red - lds), lane);
+        if (nQ == 0) { if (lane < ND) zs[lane] = 0.0; QM_WAVE_SYNC(); return 0; }     // the equalities leave nothing to decide
+        for (int e = lane; e < nVars * LDZ; e += 64) { const int i = e / LDZ, j = e - i * LDZ; scrB[e] = j < nQ ? K[i * LDK + j] : 0.0; }     // N_E survives the solve in scrB
+        double dnOld = 0.0, dnNew = 0.0;
+        if (lane < m0) for (int j = 0; j < nVars; ++j) dnOld = fmax(dnOld, fabs(DZ[lane * LDZ + j]));
+        QM_WAVE_SYNC();
+        rightMultiply(AZp, rRows, nVars, nQ);
+        rightMultiply(DZ, m0, nVars, nQ);
+        if (lane < m0) for (int j = 0; j < nQ; ++j) dnNew = fmax(dnNew, fabs(DZ[lane * LDZ + j]));
+        // rows that are combinations of the eliminated ones vanish up to rounding in the new variables: they stay tight, and carry no information
+        rowOn = rowOn && !mineE && dnNew > 1e-12 * dnOld;
+        if (lane < m0 && !rowOn) for (int j = 0; j < LDZ; ++j) DZ[lane * LDZ + j] = 0.0;
+        QM_WAVE_SYNC();
+        reduced = true;
+      }
+    }
+    // G = (A Z)'(A Z) (HoQp.cpp:60-76, without its 1e-12 I: qp_dev.h)
+    for (int e = lane; e < ND * LDK; e += 64) G[e] = 0.0;
+    QM_WAVE_SYNC();
+    forkGemm(true, AZp, LDZ, AZp, LDZ, nQ, nQ, rRows, G, LDK, 0.0);
+    QM_WAVE_SYNC();
+    const QpOff io{int(G - lds), int(AZp - lds), int(rhatp - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds), int(Vh - lds)};
+    const double sigma0 = own ? -1.0 : 300.0;
+    QpResult res;
+    if (nQ <= 8) res = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, lane);
+    else if (nQ <= 20) res = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, lane);
+    else res = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, lane);
+    QM_WAVE_SYNC();
+    passes = res.ipmIterations + res.iterations;
+    strongOut = rowOn && res.strong;
+    if (reduced) {   // z = N_E w
+      double zf = 0.0;
+      if (lane < nVars) for (int j = 0; j < nQ; ++j) zf += scrB[lane * LDZ + j] * zs[j];
+      QM_WAVE_SYNC();
+      if (lane < ND) zs[lane] = lane < nVars ? zf : 0.0;
+      QM_WAVE_SYNC();
+    }
+    return res.status;
+  };
+  // margins of the inequality rows at the current x, with the slack the first level left them (>= 0 up to rounding: clamped, as in the oracle's HoQp)
+  auto marginsAtX = [&]() {
+    if (lane < m0) { double s = f0[lane]; for (int q = 0; q < ND; ++q) s -= D0[lane * ND + q] * xs[q]; s += v0[lane]; fhat[lane] = fmax(s, 0.0); }
+  };
+  auto rowNonZero = [&](int n) { bool nz = false; if (lane < m0) for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; return nz; };
+  // row-major copy (stride ND -> stride LDZ) of `rows` rows: what the products with Z = I of the first level are, entry for entry (x * 1 + 0 + ... is exact)
+  auto copyRows = [&](const double* src, double* dst, int rows) {
+#pragma unroll 1
+    for (int e0 = 0; e0 < rows * ND; e0 += 8 * 64) {
+      double t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int e = e0 + 64 * q + lane; t[q] = src[e < rows * ND ? e : 0]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) QM_KEEP(t[q]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int e = e0 + 64 * q + lane; if (e < rows * ND) dst[(e / ND) * LDZ + (e % ND)] = t[q]; }
+    }
+  };
+
+  // Directions no task sees are fixed in the reference by HoQp's 1e-12 I alone (HoQp.cpp:66): every level returns, among its minimisers, the one of smallest norm in its
+  // own variables z.  Where the last level decides everything that is left (every gait of gait.info once the start-up branch is over) that choice is invisible -- the next
+  // level re-decides the same directions -- and the cascade runs without it (pass 0).  Where directions are left over at the end, the cascade runs again with the
+  // canonical representative taken at every level (pass 1; oracle/qmo_wbc.h wbcUpdate has the argument).
+  int n = ND;
+  bool canonical = false;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+  status = 0; n = ND;
+  // x = 0, Z = I
+  for (int e = lane; e < ND * LDZ; e += 64) Z[e] = ((e / LDZ) == (e % LDZ)) ? 1.0 : 0.0;
+  if (lane < ND) xs[lane] = 0.0;
+  if (lane < MAXM) v0[lane] = 0.0;
+  bool eqRow = false;     // this lane's inequality row is strongly active at some level so far: an equality for the levels below
+  QM_WAVE_SYNC();
+#pragma unroll 1
+  for (int level = 0; level < 3; ++level) {
     if (n == 0) break;  // FLY: nothing left to decide
     QM_TICK(4);
     // ---- assemble this level's equality task A x = b  (rows r)
@@ -680,8 +940,6 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
           }
         }
       }
-    } else if (level == 3) {
-      r = ND;  // A = I, b = 0: handled without materialising A (see below)
     } else {
       r = a.variant == 0 ? 14 : 12;
       if (lane < 12) { A[lane * ND + 24 + lane] = 1.0; bvec[lane] = uDes[lane]; }  // contact forces (WbcBase.cpp:566-578)
@@ -699,283 +957,97 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     if (level == 0) QM_WBC_CHECKPOINT(1);   // task 0: A, b, D0, f0
     QM_TICK(5);
     // ---- reduced data: AZ = A Z (r x n), rhat = A x - b, DZ = D0 Z, fhat
-    const int mOwn = (level == 0) ? m0 : 0, mPrev = (level == 0) ? 0 : m0;
-    const int mRows = mOwn + mPrev;  // <= 56, one row per lane
-    const double* AZp = AZ;
-    // row-major copy (stride ND -> stride LDZ) of `rows` rows: what the products with Z = I of the first level are, entry for entry (x * 1 + 0 + ... is exact)
-    auto copyRows = [&](const double* src, double* dst, int rows) {
-#pragma unroll 1
-      for (int e0 = 0; e0 < rows * ND; e0 += 8 * 64) {
-        double t[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const int e = e0 + 64 * q + lane; t[q] = src[e < rows * ND ? e : 0]; }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) QM_KEEP(t[q]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const int e = e0 + 64 * q + lane; if (e < rows * ND) dst[(e / ND) * LDZ + (e % ND)] = t[q]; }
-      }
-    };
-    if (level == 3) AZp = Z;  // A = I  =>  A Z = Z
-    else if (level == 0) copyRows(A, AZ, r);   // Z = I (n = ND)
-    else forkGemm(false, A, ND, Z, LDZ, r, n, ND, AZ, LDZ, 0.0);
-    QM_TICK(11);
-    // D Z on the matrix cores; columns >= n stay zero padding (the interior point always spans whole tiles)
-    for (int e = lane; e < m0 * LDZ; e += 64) DZ[e] = 0.0;
+    for (int e = lane; e < MAXR * LDZ; e += 64) AZ[e] = 0.0;
+    for (int e = lane; e < MAXM * LDZ; e += 64) DZ[e] = 0.0;     // columns >= n stay zero padding (the solver always spans whole tiles); rows >= m0 finite
     QM_WAVE_SYNC();
-    if (level == 0) copyRows(D0, DZ, m0);
-    else forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0);
+    if (level == 0) { copyRows(A, AZ, r); copyRows(D0, DZ, m0); }   // Z = I (n = ND)
+    else { forkGemm(false, A, ND, Z, LDZ, r, n, ND, AZ, LDZ, 0.0); forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0); }
     QM_WAVE_SYNC();
     QM_TICK(12);
-    if (lane < r) {  // A x_prev - b (temporarily in tzv)
-      double s;
-      if (level == 3) s = xs[lane];
-      else { s = -bvec[lane]; for (int q = 0; q < ND; ++q) s += A[lane * ND + q] * xs[q]; }
-      tzv[lane] = s;
-    }
-    bool rowActive = lane < mRows;
-    if (lane < m0) {
-      double s = f0[lane];
-      if (level > 0) { for (int q = 0; q < ND; ++q) s -= D0[lane * ND + q] * xs[q]; s += v0[lane]; s = fmax(s, 0.0); }   // margin of x_prev: >= 0 up to rounding (see the oracle's HoQp)
-      fhat[lane] = s;
-    }
+    if (lane < r) { double s = -bvec[lane]; for (int q = 0; q < ND; ++q) s += A[lane * ND + q] * xs[q]; tzv[lane] = s; }   // A x_prev - b
+    if (level == 0) { if (lane < m0) fhat[lane] = f0[lane]; } else marginsAtX();
     QM_WAVE_SYNC();
     QM_TICK(13);
-    // G = AZ^T AZ + 1e-12 I (HoQp.cpp:60-76), g = AZ^T (A x_prev - b) (HoQp.cpp:78-90)
-    for (int e = lane; e < ND * LDK; e += 64) G[e] = 0.0;
-    QM_WAVE_SYNC();
-    forkGemm(true, AZp, LDZ, AZp, LDZ, n, n, r, G, LDK, 1e-12);
-    QM_TICK(14);
-    if (lane < ND) { double s = 0.0; if (lane < n) for (int q = 0; q < r; ++q) s += AZp[q * LDZ + lane] * tzv[q]; gs[lane] = s; zs[lane] = 0.0; }
-    // rows that vanish identically carry no information (dropped, as in the oracle's IPM)
-    if (rowActive && mPrev > 0) { bool nz = false; for (int j = 0; j < n; ++j) nz = nz || DZ[lane * LDZ + j] != 0.0; rowActive = nz; }
-    QM_WAVE_SYNC();
-
-    if (level == 0) QM_WBC_CHECKPOINT(2);   // reduced data of level 0: AZ, DZ, fhat, G, g
+    if (level == 0) QM_WBC_CHECKPOINT(2);   // reduced data of level 0: AZ, DZ, fhat
     QM_TICK(6);
-    // ---- interior point iterations (ipm_dev.h): K on the matrix cores, factorisation and solves in registers
-    const double pivotFloor = 1e-13 * qmAllMax(lane < n ? G[lane * LDK + lane] : 0.0, red);
-    const bool own = mOwn > 0;
-    const double nRowsTot = qmAllSum(rowActive ? (own ? 2.0 : 1.0) : 0.0, red);
-    int it = 0;
-    if (nRowsTot > 0.0) {
-      const IpmOff io{int(G - lds), int(gs - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds)};
-      IpmResult res;
-      if (n <= 8) res = ipmSolve<8, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane);
-      else if (n <= 20) res = ipmSolve<20, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane);
-      else res = ipmSolve<36, LDZ, LDK>(io, n, m0, own, rowActive, level > 0 ? 300.0 : 1.0, lane);
-      it = res.iterations;
-      QM_WAVE_SYNC();
-    } else {
-      // no inequality rows at all: z = -G^-1 g  (LDS Cholesky; never on the hot path of the reference's task sets)
-      for (int e = lane; e < n * n; e += 64) K[(e / n) * LDK + (e % n)] = G[(e / n) * LDK + (e % n)];
-      if (lane < n) dzs[lane] = -gs[lane];
-      QM_WAVE_SYNC();
-      ldsCholesky(K, n, lane, pivotFloor);
-      ldsCholSolve(K, n, dzs, lane);
-      if (lane < n) zs[lane] = dzs[lane];
-      QM_WAVE_SYNC();
-    }
-    if (it >= 60) status |= (1 << level);
+    // ---- the level's QP (qp_dev.h)
+    bool strong = false; int passes = 0;
+    const bool hadEq = level > 0 && qmBallot(eqRow && rowNonZero(n)) != 0ull;
+    const int st = levelQp(AZ, r, tzv, n, level == 0, rowNonZero(n), eqRow, strong, passes);
+    eqRow = eqRow || strong;
+    if (st != 0) status |= (1 << level);
 #ifdef QM_RICCATI_TIMING
-    if (lane == 0 && inst < 256) qmk::qmRiccatiTicks[512 + inst * 4 + 1 + level] = (unsigned long long)it;
+    if (lane == 0 && inst < 256) qmk::qmRiccatiTicks[512 + inst * 4 + 1 + level] = (unsigned long long)passes;
 #endif
     if (level == 0) QM_WBC_CHECKPOINT(3);   // z of level 0
     QM_TICK(7);
-    // ---- x = x_prev + Z z (HoQp.h:31-34); keep the slack solution of task 0 (HoQp.cpp:152-158)
+    // ---- x = x_prev + Z z (HoQp.h:31-34); the level's own variables stay in rds (the canonical representative is taken relative to them)
     double xn = 0.0;
-    if (lane < ND) { xn = xs[lane]; for (int j = 0; j < n; ++j) xn += Z[lane * LDZ + j] * zs[j]; }
-    // slack solution of task 0 = max(0, D x - f): the interior point leaves inactive slacks at O(sqrt(mu)) (degenerate
-    // complementarity); the exact minimiser -- what qpOASES hands to the next level -- is restored from z.
-    if (level == 0 && lane < m0) { double dzv = 0.0; for (int j = 0; j < n; ++j) dzv += DZ[lane * LDZ + j] * zs[j]; v0[lane] = fmax(0.0, dzv - fhat[lane]); }
+    if (lane < ND) { xn = xs[lane]; for (int j = 0; j < n; ++j) xn += Z[lane * LDZ + j] * zs[j]; rds[lane] = zs[lane]; }
     QM_WAVE_SYNC();
     if (lane < ND) xs[lane] = xn;
-#ifdef QMGPU_EMU_DEBUG
     QM_WAVE_SYNC();
-    if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d it %d x:", level, it); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
+    // slack solution of task 0 (HoQp.cpp:152-158): v = max(0, D x - f), exactly
+    if (level == 0 && lane < m0) { double s = -f0[lane]; for (int q = 0; q < ND; ++q) s += D0[lane * ND + q] * xs[q]; v0[lane] = fmax(0.0, s); }
+    QM_WAVE_SYNC();
+#ifdef QMGPU_EMU_DEBUG
+    if (lane == 0 && inst == QMGPU_DEBUG_INST) { printf("EMU level %d passes %d status %d x:", level, passes, st); for (int i = 0; i < 36; ++i) printf(" %.10g", xs[i]); printf("\n"); }
 #endif
     if (level == 0) QM_WBC_CHECKPOINT(4);   // x, v0 after level 0
-    if (level == numLevels - 1) break;
-
     QM_TICK(8);
-    // ---- Z <- Z kernel(A Z) (HoQp.cpp:126-133): the reference takes Eigen's FullPivLU::kernel() of A Z, i.e. the basis [-U11^-1 U12; I] in the column
-    //      order full pivoting leaves -- NOT an orthonormal one.  Round 4: the kernels do the same (as the oracle does on the host).  Until
-    //      round 3 a Householder QR gave an orthonormal basis here; the projected optimum is the same, the conditioning of the NEXT level's interior
-    //      point is not: in the LU basis every null vector carries a 1 on one original coordinate, the inherited cone / limit rows stay nearly
-    //      axis-aligned and the normal equations G + (DZ)' W (DZ) keep their accuracy when W reaches 1e14; in the rotated basis the same rows spread
-    //      over all coordinates and the Newton steps lose 5-7 digits (dual residual 1e-8 instead of 1e-15 at mu = 1e-8: start-up branch + trot
-    //      failed all three attempts on the GPU AND in the oracle once it was given an orthonormal basis; profiles/r04_notes.md section 1).
-    //      With the same construction both implementations also solve numerically the SAME level problems (same z coordinates up to rounding).
-    //      Lane i < r owns row i of A Z in LDS (destroyed here); columns are swapped physically, rows stay where they are (rowPos = their
-    //      permuted position).  U row k = the pivot row of step k, entries at column positions >= k.
-    {
-      int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
-      int* colPerm = ip; int* rowOf = ip + 40; int* pivOk = ip + 64; int* freePos = ip + 96;
-      const int size = r < n ? r : n;
-      // Lanes: row i of A Z is worked on by up to three lanes, i, r + i and 2 r + i ("chunks"), each eliminating a contiguous third of the column positions behind the pivot
-      // (r <= 21: three chunks, 22: two) -- with one lane per row only r of the 64 lanes worked and a step was 35 dependent LDS round trips long.  Same arithmetic per
-      // entry, same decisions: the chunks' column ranges are in increasing order, so "largest magnitude, first position on ties" of a row is the best of chunk 0, else 1,
-      // else 2; the per-row state (rowPos, best, bj) is kept identical in the lanes of a row, the pivot's row is chosen among the chunk-0 lanes (lane = row index) as before.
-      const int nChunk = 3 * r <= 64 ? 3 : (2 * r <= 64 ? 2 : 1);
-      const int chunk = (lane >= r ? 1 : 0) + (lane >= 2 * r ? 1 : 0);
-      const bool active = lane < nChunk * r;
-      const int rowIdx = active ? lane - chunk * r : 0;
-      double* xchgV = Vh + 128; int* xchgJ = reinterpret_cast<int*>(Vh + 192);   // exchange of the chunks' candidates (64 doubles, 64 ints; beyond the index tables)
-      int rowPos = rowIdx;
-      int colPermReg = lane;     // lane j: the original column at position j (swapped between lanes with v_readlane; LDS copy after the loop)
-      int rowOfReg = 0;          // lane k: the row that gave pivot k
-      double maxPivot = 0.0;
-      int nonzero = 0;
-      double* row = AZ + rowIdx * LDZ;
-      // largest entry of this lane's row over the column positions >= k, first one on ties (the oracle scans positions in increasing order).  Loads in
-      // batches of eight before any store: a store to LDS between two loads of the same array serialises them (the compiler cannot tell the rows apart)
-      double best = -1.0; int bj = 0;
-      if (active) {
-#pragma unroll 1
-        for (int j0 = 0; j0 < n; j0 += 8) {
-          double v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = fabs(row[j0 + q < n ? j0 + q : 0]);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) if (j0 + q < n && v[q] > best) { best = v[q]; bj = j0 + q; }
-        }
-      }
-      // One step = one dependent chain; what is on it besides the elimination itself is kept in registers: the pivot's lane from a ballot (the
-      // smallest-row-position rule needs a second reduction only when two rows tie), its column and value by v_readlane, the permutations in lanes.
-#pragma unroll 1
-      for (int k = 0; k < size; ++k) {
-        QM_TICK(15);
-        const bool mine = lane < r && rowPos >= k;
-        const double gmax = qmAllMax(mine ? best : -1.0, red);
-        if (!(gmax > 0.0)) break;
-        QM_TICK(18);
-        const bool cand = mine && best == gmax;
-        const unsigned long long tied = qmBallot(cand);
-        int Lp;
-        if ((tied & (tied - 1)) == 0) Lp = qmFirstBit(tied);
-        else Lp = int(qmAllMin(cand ? double(rowPos * 64 + lane) : 1e9, red)) & 63;   // ties between rows: the smallest row position (the oracle's outer scan index)
-        const int pr = qmReadLaneInt(rowPos, Lp), pc = qmReadLaneInt(bj, Lp);
-        maxPivot = fmax(maxPivot, gmax);
-        if (active) { if (rowIdx == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
-        { const int ck = qmReadLaneInt(colPermReg, k), cp = qmReadLaneInt(colPermReg, pc); if (lane == k) colPermReg = cp; else if (lane == pc) colPermReg = ck; }
-        if (lane == k) rowOfReg = Lp;
-        QM_TICK(19);
-        double vk = 0.0, vpc = 0.0;
-        if (active) { vk = row[k]; vpc = row[pc]; }
-        QM_WAVE_SYNC();
-        if (pc != k && lane < r) { row[k] = vpc; row[pc] = vk; }
-        const double pivot = qmReadLane(vpc, Lp);
-        QM_WAVE_SYNC();
-        QM_TICK(20);
-        // elimination of the rows still below the pivot, this lane's share of the column positions; the largest entry of the updated row (positions > k) is found on
-        // the way: the next step's candidate
-        const double* prow = AZ + Lp * LDZ;
-        best = -1.0; bj = k + 1;
-        const int len = n - k - 1, per = (len + nChunk - 1) / nChunk;
-        const int jLo = k + 1 + chunk * per, jHi = (jLo + per < n) ? jLo + per : n;
-        if (active && rowPos > k) {
-          const double f = vpc / pivot;
-#pragma unroll 1
-          for (int j0 = jLo; j0 < jHi; j0 += 8) {
-            double a[8], pv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int j = j0 + q < jHi ? j0 + q : jLo; a[q] = row[j]; pv[q] = prow[j]; }
-            // product and difference rounded separately (no fused multiply-add): the pivot search compares these numbers for EQUALITY of magnitude with
-            // entries of other rows (the level tasks carry unit rows, so exact ties are the rule, not the exception) and must take the decisions the
-            // oracle's kernelFullPivLU takes on the host
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = qmSubNoFma(a[q], qmMulNoFma(f, pv[q]));
-#pragma unroll
-            for (int q = 0; q < 8; ++q) if (j0 + q < jHi) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
-          }
-        }
-        if (nChunk > 1) {   // the row's candidate: the chunks' candidates in the order of their column ranges (strictly larger wins: first position on ties)
-          QM_WAVE_SYNC();
-          xchgV[lane] = best; xchgJ[lane] = bj;
-          QM_WAVE_SYNC();
-          if (active) {
-            double b0 = xchgV[rowIdx]; int j0 = xchgJ[rowIdx];
-            const double b1 = xchgV[rowIdx + r]; const int j1 = xchgJ[rowIdx + r];
-            const double b2 = nChunk > 2 ? xchgV[rowIdx + 2 * r] : -1.0; const int j2 = nChunk > 2 ? xchgJ[rowIdx + 2 * r] : 0;
-            if (b1 > b0) { b0 = b1; j0 = j1; }
-            if (b2 > b0) { b0 = b2; j0 = j2; }
-            best = b0; bj = j0;
-          }
-        }
-        ++nonzero;
-        QM_WAVE_SYNC();
-        QM_TICK(21);
-      }
-      if (lane < n) colPerm[lane] = colPermReg;
-      if (lane < nonzero) rowOf[lane] = rowOfReg;
+    // ---- Z <- Z kernel(A Z) (HoQp.cpp:126-133); A Z again where the implied equalities overwrote it
+    if (hadEq) { for (int e = lane; e < MAXR * LDZ; e += 64) AZ[e] = 0.0; QM_WAVE_SYNC(); forkGemm(false, A, ND, Z, LDZ, r, n, ND, AZ, LDZ, 0.0); QM_WAVE_SYNC(); }
+    const int nOld = n;
+    const int nNew = wbcNullSpace(int(AZ - lds), r, n, int(K - lds), int(Vh - lds), int(red - lds), lane);
+    QM_TICK(16);
+    // Z N on the matrix cores (columns >= n of Z are zero, rows >= n of N too)
+    forkGemm(false, Z, LDZ, K, LDK, ND, nNew, n, Zn, LDZ, 0.0);
+    QM_WAVE_SYNC();
+    if (canonical && nNew > 0 && level > 0) {   // N itself is the task matrix of the canonical representative (level 0: Z = I, so Z N = N stays in Zn)
+      for (int e = lane; e < MAXR * LDZ; e += 64) { const int i = e / LDZ, j = e - i * LDZ; AZ[e] = (i < nOld && j < nNew) ? K[i * LDK + j] : 0.0; }
       QM_WAVE_SYNC();
-      // rank: pivots above Eigen's default threshold eps * size * max pivot; the others' columns count as free
-      const double thresh = maxPivot * 2.220446049250313e-16 * double(size);
-      // (rank and the list of free column positions from two ballots: as loops over the LDS table -- one of them on lane 0 alone -- they were 36 + 18 dependent LDS round trips)
-      const bool okReg = lane < nonzero && fabs(AZ[rowOfReg * LDZ + lane]) > thresh;
-      if (lane < nonzero) pivOk[lane] = okReg ? 1 : 0;
-      const int rank = qmPopCount(qmBallot(okReg));
-      const int nNew = n - rank;
-      const bool freeReg = lane < n && !okReg;
-      const unsigned long long freeMask = qmBallot(freeReg);
-      if (freeReg) freePos[qmPopCount(freeMask & ((1ull << lane) - 1ull))] = lane;
-      for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;      // N (n x nNew), one kernel vector per lane / column
-      QM_WAVE_SYNC();
-      QM_TICK(15);
-      {
-        // U11 X = -U12 for this lane's free column: back substitution over the accepted pivots, X(:, lane) in registers (fully unrolled: compile-time
-        // indices), the U entries as wave-uniform LDS reads; the results leave for LDS after the loop (no store between the loads)
-        const int fp = lane < nNew ? freePos[lane] : 0;
-        // (which pivots count and where their rows are: read once, all loads in flight together, instead of one LDS round trip in front of every step)
-        bool okk[MAXR]; int rb[MAXR];
-#pragma unroll
-        for (int k = 0; k < MAXR; ++k) { const int ok = pivOk[k < nonzero ? k : 0], ro = rowOf[k < nonzero ? k : 0]; okk[k] = k < nonzero && ok != 0; rb[k] = ro * LDZ; }
-        double xk[MAXR];
-#pragma unroll
-        for (int k = MAXR - 1; k >= 0; --k) {
-          xk[k] = 0.0;
-          if (okk[k]) {   // wave-uniform
-            const double* urow = AZ + rb[k];
-            double u[MAXR];
-#pragma unroll
-            for (int k2 = k + 1; k2 < MAXR; ++k2) u[k2] = urow[k2 < n ? k2 : 0];
-            double sacc = fp >= k ? -urow[fp] : 0.0;
-#pragma unroll
-            for (int k2 = k + 1; k2 < MAXR; ++k2) sacc -= (k2 < nonzero ? u[k2] : 0.0) * xk[k2];
-            xk[k] = sacc / urow[k];
-          }
-        }
-        if (lane < nNew) {
-#pragma unroll
-          for (int k = 0; k < MAXR; ++k) if (okk[k]) K[colPerm[k] * LDK + lane] = xk[k];
-          K[colPerm[fp] * LDK + lane] = 1.0;
-        }
-      }
-      QM_WAVE_SYNC();
-      QM_TICK(16);
-      // Z N on the matrix cores (columns >= n of Z are zero, rows >= n of N too)
-      forkGemm(false, Z, LDZ, K, LDK, ND, nNew, n, Zn, LDZ, 0.0);
-      QM_WAVE_SYNC();
-      {   // Z <- Z N with the columns >= nNew cleared: all loads first (a store between two loads of LDS serialises them), the column index carried along instead of e % LDZ
-        constexpr int NIT = (ND * LDZ + 63) / 64;
-        double t[NIT];
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) { const int e = lane + 64 * i; t[i] = Zn[e < ND * LDZ ? e : 0]; }
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) QM_KEEP(t[i]);
-        int col = lane >= LDZ ? lane - LDZ : lane;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-          const int e = lane + 64 * i;
-          if (e < ND * LDZ) Z[e] = col < nNew ? t[i] : 0.0;
-          col += 64 - LDZ; if (col >= LDZ) col -= LDZ;
-        }
-      }
-      n = nNew;
-      QM_WAVE_SYNC();
-      QM_TICK(17);
     }
+    {   // Z <- Z N with the columns >= nNew cleared: all loads first (a store between two loads of LDS serialises them), the column index carried along instead of e % LDZ
+      constexpr int NIT = (ND * LDZ + 63) / 64;
+      double t[NIT];
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) { const int e = lane + 64 * i; t[i] = Zn[e < ND * LDZ ? e : 0]; }
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) QM_KEEP(t[i]);
+      int col = lane >= LDZ ? lane - LDZ : lane;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int e = lane + 64 * i;
+        if (e < ND * LDZ) Z[e] = col < nNew ? t[i] : 0.0;
+        col += 64 - LDZ; if (col >= LDZ) col -= LDZ;
+      }
+    }
+    n = nNew;
+    QM_WAVE_SYNC();
+    QM_TICK(17);
     if (level == 0) QM_WBC_CHECKPOINT(5);   // Z after the first null space
     if (level == 1) QM_WBC_CHECKPOINT(6);
+    // ---- canonical representative of the level (pass 1): min |z* + N w|^2 inside the inequality rows, i.e. task rows N (nOld x n), residual z* (rds); x += Z w
+    if (canonical && n > 0) {
+      double* AZc = level == 0 ? Zn : AZ;
+      if (level == 0) { for (int e = lane; e < ND * LDZ; e += 64) { const int j = e % LDZ; if (j >= n) Zn[e] = 0.0; } }
+      for (int e = lane; e < MAXM * LDZ; e += 64) DZ[e] = 0.0;
+      QM_WAVE_SYNC();
+      forkGemm(false, D0, ND, Z, LDZ, m0, n, ND, DZ, LDZ, 0.0);
+      marginsAtX();
+      QM_WAVE_SYNC();
+      bool strongC = false; int passesC = 0;
+      const int stc = levelQp(AZc, nOld, rds, n, false, rowNonZero(n), eqRow, strongC, passesC);
+      if (stc != 0) status |= 8;
+      double xc = 0.0;
+      if (lane < ND) { xc = xs[lane]; for (int j = 0; j < n; ++j) xc += Z[lane * LDZ + j] * zs[j]; }
+      QM_WAVE_SYNC();
+      if (lane < ND) xs[lane] = xc;
+      QM_WAVE_SYNC();
+    }
+  }
+  if (canonical || n == 0) break;
+  canonical = true;
   }
   QM_WAVE_SYNC();
   QM_WBC_CHECKPOINT(7);
@@ -999,3 +1071,4 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 }
 
 }  // namespace qmk
+

@@ -412,12 +412,13 @@ def test_full_size_hoqp_levels_against_a_primal_active_set_method(interface, ora
     assert checked >= 25 and undecided <= 3
 
 
-def test_zero_try_of_the_first_level_does_not_change_the_result(interface, oracle):
-    """The first HoQP level tries "no limit binds" before any interior-point iteration (oracle/qmo_wbc.h kZeroTryOwn = QM_IPM_ZERO_TRY_OWN of the kernels).
-    An accepted try must be THE solution of the level: 512 random instances over every contact mode, robots in motion, with the try and without it
-    (qmo_set_experiment 2).  Bound on the torques: 1e-6 (the tolerance the path is held to) unless the instance is path sensitive with EITHER algorithm -- it moves
-    as much when nothing but the starting value of the lower levels changes: a level-1 problem that ends unpolished on one of the two paths keeps the interior
-    point's own accuracy, ~4e-6 in the weakly weighted directions --, and no more such instances with the try than without."""
+def test_every_level_ends_at_the_same_vertex_whatever_the_path(interface, oracle):
+    """Every HoQP level ends with a primal active-set method (oracle/qmo_wbc.h activeSetPhase): the point it returns satisfies the KKT conditions on its working set and is
+    THE minimiser -- so it cannot depend on how the method got there.  512 random instances over every contact mode, robots in motion, both controllers, three paths: the
+    product's (interior point from 300 -> active set), another interior-point start (100), and no interior point at all (the active-set method cold from z = 0, one
+    working-set change at a time).  Stated bound: torques equal to 1e-9 rel-inf on all but 1 % of the instances (measured on 2 x 2048: 99.7 % within 1e-13, the rest nearly
+    degenerate level problems -- a direction whose curvature sits at the rounding of the normal equations, or a multiplier at the rounding of its gradient -- where a
+    path-dependent decision is unavoidable in any arithmetic), median <= 1e-13, and no level is ever flagged."""
     import test_gpu_wbc as TW
     for variant in (0, 1):
         B = 512
@@ -430,46 +431,46 @@ def test_zero_try_of_the_first_level_does_not_change_the_result(interface, oracl
                 return oracle.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], per, c["t"], c["il"].copy(), variant=variant)
             finally:
                 oracle.set_experiment()
-        ref, ref_alt = run(no_zero_try=True), run(no_zero_try=True, lower_level_start=100.0)
-        got, got_alt = run(), run(lower_level_start=100.0)
-        assert (ref["iterations"][:, 0] >= 1).all() and (got["iterations"][:, 0] == 0).mean() >= 0.95     # the try is accepted (0 iterations) almost always
-        assert (got["status"] != 0).sum() <= (ref["status"] != 0).sum()
+        ref, alt, cold = run(), run(lower_level_start=100.0), run(no_interior_point=True)
+        assert (ref["status"] == 0).all() and (alt["status"] == 0).all() and (cold["status"] == 0).all()
+        assert (ref["polished"][ref["iterations"] > 0] == 1).all()             # every level that ran ended at a verified vertex
         tau = lambda r: r["out"][:, 36:]  # noqa: E731
-        dev = S.rel_inf(tau(got), tau(ref))
-        sens_old, sens_new = S.rel_inf(tau(ref_alt), tau(ref)), S.rel_inf(tau(got_alt), tau(got))
-        bad = dev > np.maximum(1e-6, 10.0 * np.maximum(sens_old, sens_new))
-        print("zero try vs interior point, variant", variant, "max", dev.max(), "p99", np.percentile(dev, 99), "above 1e-7:", int((dev > 1e-7).sum()),
-              "path sensitive (> 1e-7) without / with the try:", int((sens_old > 1e-7).sum()), int((sens_new > 1e-7).sum()))
-        assert bad.sum() == 0, (variant, np.nonzero(bad)[0][:8], dev[bad][:8], sens_old[bad][:8], sens_new[bad][:8])
-        assert np.median(dev) <= 1e-8 and (dev > 1e-7).sum() <= max(2, (sens_old > 1e-7).sum())
-        assert (sens_new > 1e-7).sum() <= (sens_old > 1e-7).sum() + 3
+        for name, other in (("start 100", alt), ("cold active set", cold)):
+            dev = S.rel_inf(tau(ref), tau(other))
+            print("variant", variant, name, "max", dev.max(), "p99", np.percentile(dev, 99), "median", np.median(dev), "above 1e-9:", int((dev > 1e-9).sum()))
+            assert np.median(dev) <= 1e-13 and (dev > 1e-9).sum() <= B // 100, (variant, name, dev.max(), int((dev > 1e-9).sum()))
+        # the cold method needs more working-set changes, the product's path fewer passes in the tail
+        assert cold["iterations"][:, 1].max() >= ref["iterations"][:, 1].max() - 5
 
 
-def test_degenerate_lowest_level_is_bistable_in_the_oracle_itself(interface, oracle):
+def test_degenerate_lowest_level_is_solved_on_its_face(interface, oracle):
     """tests/golden/wbc_degenerate_stance_tick.npz: the WBC inputs of ONE tick of the static-walk closed loop (tests/test_closed_loop.py, instance 72, t = 10.501 s, full
-    stance) on which the GPU loop and the oracle loop -- each fed by its own plan, inputs 1e-11 apart -- returned torques 12 % apart.  This pins what that is: not a kernel
-    defect (the emulated kernel reproduces the oracle on these inputs, test_emu_parity / 2e-14 on the GPU) but the degenerate class of DESIGN.md section 5.  The contact-force
-    level inherits rows with zero margin that leave it no interior: its exact solution is z = 0; the relaxed re-solve (every inherited margin >= 1e-5, HoQp's fallback when the
-    first attempt does not converge) moves the level by O(10) for a violation of 1e-5.  Which of the two the SAME implementation returns depends on the path of its interior
-    point: here the oracle with lower-level starting values 300 (product) and 100."""
+    stance) on which the round-4 implementations -- an interior point with a relaxed re-solve behind it -- returned torques 12 % apart for inputs 1e-11 apart.  The
+    contact-force level inherits rows the level above left strongly active: positively dependent in the variables that are left, a cone without interior.  They are
+    equalities for this level (oracle/qmo_wbc.h eliminateImpliedEqualities) and are removed exactly before anything is solved.  Pinned here: the level's answer is the
+    exact one (nothing moves: z = 0 up to rounding, no inherited row violated), it does not depend on the path (interior-point start, no interior point), and it is
+    STABLE: input perturbations of 1e-9 relative move the torques by a small multiple of that."""
     c = np.load(os.path.join(S.ROOT, "tests", "golden", "wbc_degenerate_stance_tick.npz"))
     args = (c["xd"], c["ud"], c["rbd"], int(c["mode"]), 0.001, float(c["t"]))
+    outs = []
     try:
-        sa, out_a, _ = oracle.wbc_update(*args, c["il"].copy())
-        lv_a = oracle.wbc_level(2, *args, c["il"].copy())
-        oracle.set_experiment(lower_level_start=100.0)
-        sb, out_b, _ = oracle.wbc_update(*args, c["il"].copy())
-        lv_b = oracle.wbc_level(2, *args, c["il"].copy())
+        for kw in (dict(), dict(lower_level_start=100.0), dict(no_interior_point=True)):
+            oracle.set_experiment(**kw)
+            st, out, _ = oracle.wbc_update(*args, c["il"].copy())
+            assert st == 0
+            outs.append(out)
     finally:
         oracle.set_experiment()
-    assert sa == 0 and sb == 0
-    assert np.abs(lv_a["H"] - lv_b["H"]).max() <= 1e-9 and np.abs(lv_a["D"] - lv_b["D"]).max() <= 1e-9      # the same level-2 problem on both paths (levels 0 and 1 agree to 1e-12)
-    H, cc, D, f = lv_a["H"], lv_a["c"], lv_a["D"], lv_a["f"]
-    za, zb = lv_a["sol"], lv_b["sol"]
-    obj = lambda v: 0.5 * v @ H @ v + cc @ v  # noqa: E731
-    small, large = (za, zb) if np.abs(za).max() < np.abs(zb).max() else (zb, za)
-    assert np.abs(small).max() <= 1e-9 and (D @ small - f).max() <= 1e-9                 # the exact problem: nothing to gain inside the inherited rows
-    assert np.abs(large).max() >= 1.0 and 1e-7 <= (D @ large - f).max() <= 1.01e-5      # the relaxed problem: a large step for a violation of the 1e-5 margin
-    assert obj(large) < obj(small) - 1.0
-    dev = np.abs(out_a[36:] - out_b[36:]).max() / max(1.0, np.abs(out_a[36:]).max())
-    assert 1e-2 <= dev <= 1.0, dev                                                        # what the torques make of it
+    tau_scale = max(1.0, np.abs(outs[0][36:]).max())
+    for o in outs[1:]:
+        assert np.abs(o[36:] - outs[0][36:]).max() <= 1e-10 * tau_scale
+    lv = oracle.wbc_level(2, *args, c["il"].copy())
+    assert np.abs(lv["sol"]).max() <= 1e-9 and (lv["D"] @ lv["sol"] - lv["f"]).max() <= 1e-9        # the exact level: nothing to gain inside the inherited rows
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(8):
+        xd = c["xd"] * (1 + 1e-9 * rng.uniform(-1, 1, 30)); rbd = c["rbd"].copy(); rbd[:48] *= 1 + 1e-9 * rng.uniform(-1, 1, 48)
+        st, out, _ = oracle.wbc_update(xd, c["ud"], rbd, int(c["mode"]), 0.001, float(c["t"]), c["il"].copy())
+        assert st == 0
+        worst = max(worst, np.abs(out[36:] - outs[0][36:]).max() / tau_scale)
+    assert worst <= 1e-6, worst          # (an amplification of <= 1e3 of the input perturbation; the round-4 oracle moved by 1.2e-1 here)
