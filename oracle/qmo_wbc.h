@@ -320,20 +320,22 @@ struct WbcTasks {
 constexpr double kLowerLevelStart = 300.0;   // starting slacks / multipliers of the interior point (a unit start spends up to fifteen iterations on steps of a few per cent)
 constexpr double kStagnationMu = 1e-10;
 constexpr double kEps = 2.220446049250313e-16;
+constexpr double kMinNormCheap = 1e4;
 constexpr double kAsRho = 1e4;              // penalty of a pinned row, x the curvature of the level's cost ALONG THE ROW'S NORMAL, per unit of the row's squared norm
 constexpr int kAsInnerSteps = 12;            // Newton steps on the augmented Lagrangian per working set, at most
 constexpr double kAsLamTol = 8.0;            // a multiplier counts once it exceeds this many roundings of the gradient it balances
 constexpr int kAsMaxWorkingSetChanges = 100; // nWSR of HoQp.cpp:141
 // Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  inline: one copy whatever the number of translation units; written between batches only.
 inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting value of the interior point = another path to the same vertex (tests: the result must not depend on it)
+inline int g_expNoMinNormStart = 0;                      // 1: the first level without its minimum-norm start (tests: same torques)
 inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
-struct QpStats { int ipmIterations = 0, iterations = 0, adds = 0, drops = 0, zeroSteps = 0, innerSteps = 0, eliminated = 0, status = 0; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed
+struct QpStats { int ipmIterations = 0, iterations = 0, adds = 0, drops = 0, zeroSteps = 0, innerSteps = 0, eliminated = 0, status = 0; bool minNorm = false; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed
 
 // Cholesky that leaves out the directions without curvature (pivot <= floorv): row / column replaced by the identity, the right-hand side entry by zero, so their step is exactly zero.
 // A pivot is a difference, A_jj - sum_k L_jk^2, rounded relative to A_jj: it counts as curvature once it exceeds floorAbs + floorRel (j + 1) A_jj.
-inline bool choleskyExcluding(Mat& A, double floorAbs, double floorRel, std::vector<char>& excluded) {
+inline bool choleskyExcluding(Mat& A, double floorAbs, double floorRel, std::vector<char>& excluded, const std::vector<char>* forced = nullptr) {
   const int n = A.r;
   excluded.assign(n, 0);
   for (int j = 0; j < n; ++j) {
@@ -341,7 +343,7 @@ inline bool choleskyExcluding(Mat& A, double floorAbs, double floorRel, std::vec
     const double floorv = floorAbs + floorRel * double(j + 1) * A(j, j);
     for (int k = 0; k < j; ++k) d -= A(j, k) * A(j, k);
     if (!(d == d)) return false;
-    if (!(d > floorv)) { excluded[j] = 1; for (int k = 0; k < j; ++k) A(j, k) = 0.0; A(j, j) = 1.0; for (int i = j + 1; i < n; ++i) A(i, j) = 0.0; for (int i = 0; i < j; ++i) A(i, j) = 0.0; continue; }
+    if (!(d > floorv) || (forced && (*forced)[j])) { excluded[j] = 1; for (int k = 0; k < j; ++k) A(j, k) = 0.0; A(j, j) = 1.0; for (int i = j + 1; i < n; ++i) A(i, j) = 0.0; for (int i = 0; i < j; ++i) A(i, j) = 0.0; continue; }
     d = std::sqrt(d);
     A(j, j) = d;
     for (int i = j + 1; i < n; ++i) { double t = A(i, j); for (int k = 0; k < j; ++k) t -= A(i, k) * A(j, k); A(i, j) = t / d; }
@@ -408,10 +410,12 @@ inline LevelWork prepareLevel(const LevelQp& q) {
 // plausibly be read off the iterate (duality measure <= 1e-6 scale with residuals to match), until it has converged or stagnates at the rounding floor of its normal
 // equations, or until a step loses all accuracy (the previous iterate is handed over).  Returns the iterations used.
 struct IpmPoint { Vec z, s, lam; bool usable = false; };
-inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma0, IpmPoint& pt) {
+constexpr double kIpmHandOverMu = 1e-8;     // duality measure (x scale) at which the working set is read off the iterate; x 1e-2 for each of the (at most two) resumptions
+inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma0, IpmPoint& pt, double muTarget = kIpmHandOverMu, bool resume = false, int itStart = 0) {
   const int n = q.n(), m = q.m();
   std::vector<int> rows; for (int i = q.mOwn; i < m; ++i) if (w.on[i]) rows.push_back(i);
   const int mr = int(rows.size());
+  const IpmPoint from = pt;
   pt.z.assign(n, 0.0); pt.s.assign(m, 0.0); pt.lam.assign(m, 0.0); pt.usable = false;
   if (mr == 0) return 0;
   const Mat& G = q.G0;       // (without HoQp's regulariser, as in the active-set phase: directions it alone would carry are left out of the factorisation)
@@ -420,19 +424,20 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
   const double scale = w.scale, sigma = sigma0;
   Vec z(n, 0.0), s(mr), lam(mr, sigma);
   for (int i = 0; i < mr; ++i) s[i] = std::max(sigma, f[i]);
+  if (resume) { z = from.z; for (int r = 0; r < mr; ++r) { s[r] = from.s[rows[r]]; lam[r] = from.lam[rows[r]]; } }     // (the guess its last iterate gave was refuted: on from there)
   Vec zPrev = z, sPrev = s, lamPrev = lam;
   double nrdPrev = 0.0, muPrev = 0.0;
   auto handOver = [&](const Vec& zz, const Vec& ss, const Vec& ll) { pt.z = zz; for (int r = 0; r < mr; ++r) { pt.s[rows[r]] = ss[r]; pt.lam[rows[r]] = ll[r]; } pt.usable = true; };
-  int it = 0;
+  int it = itStart;
   for (; it < 40; ++it) {
     const Vec rd = G * z + q.g + tmul(D, lam);
     Vec rp = D * z + s - f;
     const double mu = dot(s, lam) / mr;
     double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
     // a late Newton step of a degenerate problem (barrier weights ~1e18) can lose all accuracy: the previous iterate is what the active-set method starts from
-    if (it > 0 && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) { handOver(zPrev, sPrev, lamPrev); return it; }
-    if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= 1e-6 * scale) { handOver(z, s, lam); return it; }     // the working set can be read: over to the active-set method, for good
-    if (it > 0 && mu > 0.5 * muPrev && mu <= kStagnationMu * scale) { handOver(z, s, lam); return it; }          // stagnation at the rounding floor
+    if (it > itStart && (!(nrd == nrd) || !(mu == mu) || nrd > 100.0 * std::max(nrdPrev, 1e-9 * scale))) { handOver(zPrev, sPrev, lamPrev); return it; }
+    if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= muTarget * scale) { handOver(z, s, lam); return it; }     // the working set can be read: over to the active-set method, for good
+    if (it > itStart && mu > 0.5 * muPrev && mu <= kStagnationMu * scale) { handOver(z, s, lam); return it; }          // stagnation at the rounding floor
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = G;
     for (int r = 0; r < mr; ++r) { const double wr = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
@@ -484,7 +489,7 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
 // the rounding of the gradient it balances, kAsLamTol eps (hmax |z| + scale).  A row released and pinned again by a zero-length step is not released again before the
 // point has moved.  start: the point and working set of the interior point (rows with multiplier > slack, and rows its iterate violates), or z = 0 with the own rows
 // whose bound is zero pinned (the friction rows: 0 <= 0 -- away from the limits that IS the solution of the first level, in one factorisation).
-inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut) {
+inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut, const std::vector<char>* fixedVars = nullptr, bool* guessRefuted = nullptr) {
   enum { I = 0, P = 1, V = 2 };
   QpStats st;
   const int n = q.n(), m = q.m(), mOwn = q.mOwn;
@@ -494,26 +499,31 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
   Vec lam(m, 0.0);
   z.assign(n, 0.0);
   for (int i = 0; i < mOwn; ++i) if (w.on[i]) state[i] = f[i] < -tol ? V : (f[i] <= tol ? P : I);
+  // (fixedVars: the variables the zero-bound own rows act on are held at zero instead of the rows being pinned -- solveLevel, the first attempt on a level with own rows)
+  std::vector<char> rowOn = w.on;
+  if (fixedVars) for (int i = 0; i < mOwn; ++i) if (rowOn[i] && state[i] == P) { bool inside = true; for (int j = 0; j < n; ++j) if (D(i, j) != 0.0 && !(*fixedVars)[j]) inside = false; if (inside) { rowOn[i] = 0; state[i] = I; } }
   if (start && start->usable) {
     z = start->z;
     const Vec Dz = D * z;
-    for (int i = mOwn; i < m; ++i) if (w.on[i] && (start->lam[i] > start->s[i] || Dz[i] - f[i] > 0.0)) { state[i] = P; guess[i] = 1; }
+    for (int i = mOwn; i < m; ++i) if (rowOn[i] && (start->lam[i] > 1.0 * start->s[i] || Dz[i] - f[i] > 0.0)) { state[i] = P; guess[i] = 1; }
   }
   int lastReleased = -1, fullSteps = 0;
   for (;; ++st.iterations) {
     if (st.iterations > kAsMaxWorkingSetChanges) { st.status = 1; break; }
     Mat K = q.G0;       // (without HoQp's regulariser: a direction it alone would carry counts as having no curvature, below)
-    std::vector<int> pin;
+    std::vector<int> pin;      // the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
+    for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && !guess[r]) pin.push_back(r);
+    for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && guess[r]) pin.push_back(r);
     for (int r = 0; r < m; ++r) {
-      if (!w.on[r] || state[r] == I) continue;
-      const double wr = state[r] == P ? w.wP[r] : 1.0; if (state[r] == P) pin.push_back(r);
+      if (!rowOn[r] || state[r] == I) continue;
+      const double wr = state[r] == P ? w.wP[r] : 1.0;
       for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); }
     }
     const int k = int(pin.size());
     // a direction has no curvature when its pivot does not stand clear of the rounding of the matrix being factorised, or of HoQp's regulariser (x10: the reference's
     // 1e-12 I decides the directions whose curvature is comparable with it by a blend of task and minimum norm; here they count as unseen by the task)
     std::vector<char> excluded, dependent;
-    if (!choleskyExcluding(K, 10.0 * q.reg, 16.0 * kEps, excluded)) { st.status = 2; break; }
+    if (!choleskyExcluding(K, 10.0 * q.reg, 16.0 * kEps, excluded, fixedVars)) { st.status = 2; break; }
     auto forward = [&](Vec b) { for (int i = 0; i < n; ++i) { if (excluded[i]) { b[i] = 0.0; continue; } double t = b[i]; for (int c = 0; c < i; ++c) t -= K(i, c) * b[c]; b[i] = t / K(i, i); } return b; };
     auto backward = [&](Vec b) { for (int i = n - 1; i >= 0; --i) { if (excluded[i]) { b[i] = 0.0; continue; } double t = b[i]; for (int c = i + 1; c < n; ++c) t -= K(c, i) * b[c]; b[i] = t / K(i, i); } return b; };
     Mat Tm(n, k), S(k, k);
@@ -537,17 +547,13 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     double zmax0 = 1.0; for (double v : z) zmax0 = std::max(zmax0, std::fabs(v));
     bool offBound = false, anyDep = false;
     for (int j = 0; j < k; ++j) { offBound = offBound || guess[pin[j]]; anyDep = anyDep || dependent[j]; }
-    auto dropGuess = [&]() {
-      for (int j = 0; j < k; ++j) if (guess[pin[j]]) { state[pin[j]] = I; guess[pin[j]] = 0; }
-      fullSteps = 0; ++st.drops;
-      if (g_expTrace) fprintf(stderr, "  AS it %d: the guessed working set is dropped\n", st.iterations);
-    };
-    if (offBound && anyDep) { dropGuess(); continue; }
+    // (a guess with dependent rows: those leave first -- the ratio test meets them again if the step crosses them)
+    if (offBound && anyDep) { for (int j = 0; j < k; ++j) if (dependent[j] && guess[pin[j]]) { state[pin[j]] = I; guess[pin[j]] = 0; } fullSteps = 0; if (g_expTrace) fprintf(stderr, "  AS it %d: dependent rows of the guess leave the working set\n", st.iterations); --st.iterations; continue; }
     // one pass of the solve from zz: the step p and the multipliers mu of the pinned rows at zz + p
     auto solvePass = [&](const Vec& zz, Vec& pOut, Vec& muOut) {
       const Vec Dz = D * zz;
       Vec t(m, 0.0);
-      for (int r = 0; r < m; ++r) if (w.on[r]) { if (state[r] == P) t[r] = w.wP[r] * (Dz[r] - f[r]); else if (state[r] == V) t[r] = Dz[r] - f[r]; }
+      for (int r = 0; r < m; ++r) if (rowOn[r]) { if (state[r] == P) t[r] = w.wP[r] * (Dz[r] - f[r]); else if (state[r] == V) t[r] = Dz[r] - f[r]; }
       const Vec u = forward(-1.0 * (q.costGradient(zz) + tmul(D, t)));
       Vec mu(k, 0.0);
       for (int j = 0; j < k; ++j) { double tj = Dz[pin[j]] - f[pin[j]]; for (int c = 0; c < n; ++c) tj += Tm(c, j) * u[c]; mu[j] = tj; }
@@ -567,20 +573,23 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     // what the pinned rows let through (rounding; a dependent row that was skipped): a row that is a combination of pinned rows shows a step component of that size
     // and must not be taken for a blocking row
     double leak = 0.0;
-    for (int i = 0; i < m; ++i) if (w.on[i] && state[i] == P) leak = std::max(leak, std::fabs(Dp[i] + (Dz[i] - f[i])) / w.dn[i]);   // (a pinned row not yet on its bound -- the interior point's guess -- is meant to get there: D p = -(D z - f))
+    for (int i = 0; i < m; ++i) if (rowOn[i] && state[i] == P) leak = std::max(leak, std::fabs(Dp[i] + (Dz[i] - f[i])) / w.dn[i]);   // (a pinned row not yet on its bound -- the interior point's guess -- is meant to get there: D p = -(D z - f))
     // first sign change along the step
     double alpha = 1.0; int block = -1;
     for (int i = 0; i < m; ++i) {
-      if (!w.on[i] || state[i] == P) continue;
+      if (!rowOn[i] || state[i] == P) continue;
       const double epsP = std::max(1e-13 * std::max(1.0, pmax), 1e3 * leak) * w.dn[i];
       double a;
       if (state[i] == I) { if (!(Dp[i] > epsP)) continue; a = std::max(0.0, f[i] - Dz[i]) / Dp[i]; }
       else { if (!(Dp[i] < -epsP)) continue; a = std::max(0.0, Dz[i] - f[i]) / -Dp[i]; }
       if (a < alpha) { alpha = a; block = i; }      // strictly smaller: ties keep the smallest index
     }
-    if (g_expTrace) { int nV = 0, nEx = 0, nDep = 0; for (int i = 0; i < m; ++i) nV += w.on[i] && state[i] == V; for (char e : excluded) nEx += e; for (char e : dependent) nDep += e;
+    if (g_expTrace) { int nV = 0, nEx = 0, nDep = 0; for (int i = 0; i < m; ++i) nV += rowOn[i] && state[i] == V; for (char e : excluded) nEx += e; for (char e : dependent) nDep += e;
       fprintf(stderr, "  AS it %d n %d P %d (dependent %d) V %d excl %d pmax %.3e alpha %.3e block %d leak %.1e\n", st.iterations, n, k, nDep, nV, nEx, pmax, alpha, block, leak); }
-    if (block >= 0 && offBound) { dropGuess(); continue; }
+    if (block >= 0 && offBound && alpha >= 1.0 - 1e-9) block = -1;      // (a row the guessed step reaches at its very end is not in its way)
+    // the step that was to bring the guessed rows onto their bounds is cut short by another row: the guess is wrong.  Nothing has moved yet: the caller may let the
+    // interior point go on from its iterate and read the working set again (solveLevel; at most twice -- after that the step is taken as far as it goes)
+    if (block >= 0 && offBound && guessRefuted && st.adds == 0 && st.drops == 0) { *guessRefuted = true; st.status = 6; break; }
     if (block >= 0) {
       const bool moved = alpha * pmax > 1e-13 * zmax0;       // a step that does not move the point beyond its rounding counts as zero-length
       for (int i = 0; i < n; ++i) z[i] += alpha * p[i];
@@ -596,7 +605,9 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     // rounding -- at most three full steps in a row
     {
       double zmax = 1.0; for (double v : z) zmax = std::max(zmax, std::fabs(v));
-      if (pmax > 1e-13 * zmax && fullSteps < 3) { ++fullSteps; --st.iterations; if (g_expTrace) fprintf(stderr, "    full step %d on this working set: correction %.3e (zmax %.3e)\n", fullSteps, pmax, zmax); continue; }
+      // (a correction that is itself small -- the step from the interior point's iterate -- is a Newton step on a quadratic: exact up to the rounding of the solve, which
+      //  scales with the correction; only a step that moved the point by more than 1e-4 of its size is refined)
+      if (pmax > 1e-13 * zmax && (pmax > 1e-4 * zmax || fullSteps > 0) && fullSteps < 3) { ++fullSteps; --st.iterations; if (g_expTrace) fprintf(stderr, "    full step %d on this working set: correction %.3e (zmax %.3e)\n", fullSteps, pmax, zmax); continue; }
     }
     std::fill(lam.begin(), lam.end(), 0.0);
     for (int j = 0; j < k; ++j) lam[pin[j]] = mu[j];
@@ -604,17 +615,25 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     const double gradNoise = kAsLamTol * kEps * q.gradientRounding(z, hmax * zmaxF + scale);
     int rel = -1; double worst = 1.0;
     for (int i = 0; i < m; ++i) {
-      if (!w.on[i] || state[i] != P || stuck[i]) continue;
+      if (!rowOn[i] || state[i] != P || stuck[i]) continue;
       const double bad = (i < mOwn ? std::fabs(lam[i]) : -lam[i]) * w.dn[i] / gradNoise;
       if (bad > worst) { worst = bad; rel = i; }
     }
-    if (g_expTrace) { fprintf(stderr, "    full step: release %d (noise %.1e; hmax %.2e zmax %.2e scale %.2e)  pinned:", rel, gradNoise, hmax, zmaxF, scale); for (int i = 0; i < m; ++i) if (w.on[i] && state[i] == P) fprintf(stderr, " %d:%.2e", i, lam[i]); fprintf(stderr, "\n"); }
+    if (g_expTrace) { fprintf(stderr, "    full step: release %d (noise %.1e; hmax %.2e zmax %.2e scale %.2e)  pinned:", rel, gradNoise, hmax, zmaxF, scale); for (int i = 0; i < m; ++i) if (rowOn[i] && state[i] == P) fprintf(stderr, " %d:%.2e", i, lam[i]); fprintf(stderr, "\n"); }
     if (rel < 0) {
       // the point satisfies the KKT conditions on its working set; the bounds themselves once more (partial steps accumulate rounding)
       const Vec Df = D * z;
-      for (int i = 0; i < m; ++i) if (w.on[i] && (i >= mOwn || state[i] != V) && !(Df[i] - f[i] <= tol)) { st.status = 3; if (g_expTrace) fprintf(stderr, "    VIOLATED row %d state %d by %.3e (tol %.1e)\n", i, int(state[i]), Df[i] - f[i], tol); }
+      for (int i = 0; i < m; ++i) if (rowOn[i] && (i >= mOwn || state[i] != V) && !(Df[i] - f[i] <= tol)) { st.status = 3; if (g_expTrace) fprintf(stderr, "    VIOLATED row %d state %d by %.3e (tol %.1e)\n", i, int(state[i]), Df[i] - f[i], tol); }
+      // held variables: the cost must not want them moved (else the zero-bound rows have to be treated as rows: status 5, solveLevel starts over)
+      if (fixedVars) {
+        const Vec Dzf = D * z;
+        Vec t(m, 0.0);
+        for (int r = 0; r < m; ++r) if (rowOn[r]) { if (state[r] == P) t[r] = lam[r]; else if (state[r] == V) t[r] = Dzf[r] - f[r]; }
+        const Vec gfull = q.costGradient(z) + tmul(D, t);
+        for (int j = 0; j < n; ++j) if ((*fixedVars)[j] && std::fabs(gfull[j]) > gradNoise) st.status = 5;
+      }
       // strongly active rows: pinned with a multiplier that counts, or violated
-      for (int i = 0; i < m; ++i) if (w.on[i] && state[i] == P && !(lam[i] * w.dn[i] > gradNoise)) lam[i] = 0.0;
+      for (int i = 0; i < m; ++i) if (rowOn[i] && state[i] == P && !(lam[i] * w.dn[i] > gradNoise)) lam[i] = 0.0;
       break;
     }
     state[rel] = (rel < mOwn && lam[rel] > 0.0) ? V : I; lam[rel] = 0.0; lastReleased = rel; fullSteps = 0;
@@ -666,10 +685,75 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
   const LevelWork w = prepareLevel(q);
   IpmPoint pt;
   bool hard = false; for (int i = q.mOwn; i < m; ++i) hard = hard || w.on[i];
+  const bool useIpm = hard && q.mOwn == 0 && !g_expNoInteriorPoint;
   int ipmIt = 0;
-  if (hard && q.mOwn == 0 && !g_expNoInteriorPoint) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt);
+  if (useIpm) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt);
   Vec zw, lam; std::vector<char> state;
-  st = activeSetPhase(q, w, &pt, zw, lam, state);
+  // A level with own rows whose bound is zero (the friction rows of the first level: every one of them acts on the contact forces only, 0 <= 0 at z = 0): pinning
+  // them all holds those forces at zero.  Tried in that form first -- the variables held, the rows left out: no working set to carry, one factorisation and one solve away
+  // from the limits -- and kept if, at the end, the cost does not want the held variables moved (the first level's cost vanishes at its minimiser: it never does, unless
+  // torque limits are violated).  Otherwise the level is solved again with those rows as rows.
+  bool solved = false;
+  // A level with own rows only and a task the variables can meet exactly (the first level: equations of motion and contact rows, 18 independent rows in 36 variables):
+  // away from the limits its minimisers are the solutions of A Z z = -rhat, and the one the reference's 1e-12 I selects is the one of smallest norm,
+  //   z = (A Z)' y,   (A Z)(A Z)' y = -rhat        (a Cholesky of the size of the TASK: 18 instead of 36)
+  // -- contact forces that carry the robot and small accelerations, inside the friction cones and the torque limits in every regular tick.  Taken if it is: every own
+  // row strictly satisfied (then no row is active, the point is the level's minimiser AND its canonical representative: wbcUpdate needs no completion here).
+  bool minNorm = false;
+  if (q.mOwn > 0 && q.mOwn == m && q.AZ.r > 0 && q.AZ.r <= q.n() && !g_expNoMinNormStart) {
+    const int r = q.AZ.r, n = q.n();
+    Mat Gd(r, r);
+    // (weighted norm: the variables the zero-bound rows act on -- the contact forces under their cones -- are cheap, kMinNormCheap x, so that forces carry the robot and
+    //  the accelerations stay small: the unweighted point, with 1 N costing as much as 1 rad/s^2, leaves the cones)
+    Vec winv(n, 1.0);
+    for (int i = 0; i < q.mOwn; ++i) if (w.on[i] && q.f[i] == 0.0) for (int c = 0; c < n; ++c) if (q.D(i, c) != 0.0) winv[c] = kMinNormCheap;
+    for (int a = 0; a < r; ++a) for (int b = 0; b < r; ++b) { double t = 0.0; for (int c = 0; c < n; ++c) t += q.AZ(a, c) * winv[c] * q.AZ(b, c); Gd(a, b) = t; }
+    double dmax = 0.0; for (int a = 0; a < r; ++a) dmax = std::max(dmax, Gd(a, a));
+    bool ok = true;
+    for (int j = 0; j < r && ok; ++j) {     // plain Cholesky; a pivot lost against the diagonal (dependent task rows) ends the attempt
+      double d = Gd(j, j);
+      for (int k = 0; k < j; ++k) d -= Gd(j, k) * Gd(j, k);
+      if (!(d > 1e-10 * dmax)) { ok = false; break; }
+      d = std::sqrt(d); Gd(j, j) = d;
+      for (int i = j + 1; i < r; ++i) { double t = Gd(i, j); for (int k = 0; k < j; ++k) t -= Gd(i, k) * Gd(j, k); Gd(i, j) = t / d; }
+      for (int i = 0; i < j; ++i) Gd(i, j) = 0.0;
+    }
+    if (ok) {
+      Vec y = -1.0 * q.rhat;
+      cholSolve(Gd, y);
+      zw = tmul(q.AZ, y);
+      for (int c = 0; c < n; ++c) zw[c] *= winv[c];
+      const Vec res = q.AZ * zw + q.rhat, Dz = q.D * zw;
+      double resmax = 0.0, rscale = 1.0; for (int a = 0; a < r; ++a) { resmax = std::max(resmax, std::fabs(res[a])); rscale = std::max(rscale, std::fabs(q.rhat[a])); }
+      ok = resmax <= 1e-9 * rscale;
+      if (g_expTrace) { fprintf(stderr, "    min-norm: residual %.2e (scale %.2e) zmax %.2e; violated rows:", resmax, rscale, [&]{ double zm = 0; for (double v : zw) zm = std::max(zm, std::fabs(v)); return zm; }()); for (int i = 0; i < m; ++i) if (w.on[i] && !(Dz[i] - q.f[i] <= 0.0)) fprintf(stderr, " %d:%.2e", i, Dz[i] - q.f[i]); fprintf(stderr, "\n"); }
+      for (int i = 0; i < m && ok; ++i) if (w.on[i] && !(Dz[i] - q.f[i] <= 0.0)) ok = false;
+      for (double v : zw) ok = ok && v == v;
+    }
+    if (ok) { minNorm = solved = true; st = QpStats(); st.minNorm = true; lam.assign(m, 0.0); state.assign(m, 0); }
+    if (g_expTrace) fprintf(stderr, "  minimum-norm start of the level: %s\n", ok ? "taken" : "rejected");
+  }
+  if (!solved && q.mOwn > 0) {
+    std::vector<char> fixedVars(q.n(), 0); bool any = false;
+    for (int i = 0; i < q.mOwn; ++i) if (w.on[i] && std::fabs(q.f[i]) <= 1e-9 * w.scale) for (int j = 0; j < q.n(); ++j) if (q.D(i, j) != 0.0) { fixedVars[j] = 1; any = true; }
+    if (any) {
+      st = activeSetPhase(q, w, nullptr, zw, lam, state, &fixedVars);
+      solved = st.status == 0;
+      if (!solved && g_expTrace) fprintf(stderr, "  held-variable form rejected (status %d): the zero-bound rows as rows\n", st.status);
+      if (solved) for (int i = 0; i < q.mOwn; ++i) if (w.on[i] && std::fabs(q.f[i]) <= 1e-9 * w.scale && state[i] == 0) { state[i] = 1; lam[i] = 0.0; }   // (reported as pinned with a vanishing multiplier: what they are)
+    }
+  }
+  if (!solved) {
+    double muTarget = kIpmHandOverMu;
+    for (int resumed = 0;; ++resumed) {
+      bool refuted = false;
+      st = activeSetPhase(q, w, &pt, zw, lam, state, nullptr, (useIpm && pt.usable && resumed < 2) ? &refuted : nullptr);
+      if (!refuted) break;
+      muTarget *= 1e-2;
+      if (g_expTrace) fprintf(stderr, "  guess refuted: interior point resumed (target %.0e)\n", muTarget);
+      ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt, muTarget, true, ipmIt);
+    }
+  }
   st.ipmIterations = ipmIt; st.eliminated = reduced ? nFull - N.c : 0;
   if (st.status == 2) zw.assign(q.n(), 0.0);      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
   z = reduced ? N * zw : zw;
@@ -828,9 +912,9 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
   for (int l = 0; l < 3; ++l) if (lv[l]) {
     status |= lv[l]->stats.status ? (1 << l) : 0;
     if (lv[l]->completed && lv[l]->completionStats.status) status |= 8;
-    if (diag) { diag[l] = 10 * lv[l]->polished; diag[4 + l] = lv[l]->qpIters; }
+    if (diag) { diag[l] = lv[l]->polished + 10 * std::min(lv[l]->stats.iterations, 99) + 1000 * std::min(lv[l]->stats.drops, 99); diag[4 + l] = lv[l]->qpIters; }
   }
-  if (diag && last->completed) { diag[3] = 10 * (last->completionStats.status == 0); diag[7] = std::min(last->completionStats.ipmIterations + last->completionStats.iterations, 59); }
+  if (diag && last->completed) { diag[3] = (last->completionStats.status == 0) + 10 * std::min(last->completionStats.iterations, 99); diag[7] = std::min(last->completionStats.ipmIterations + last->completionStats.iterations, 59); }
   const Vec x = last->solution();
   // updateCmd (WbcBase.cpp:580-595)
   for (int i = 0; i < 36; ++i) out[i] = x[i];

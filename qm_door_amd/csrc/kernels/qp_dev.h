@@ -9,7 +9,7 @@
 //        u = L^-1 (-grad - DZ_P' W r_P),   S mu = T_P'u + r_P,   p = L^-T (u - T_P mu)      =>  DZ_P (z + p) = f_P,  mu = the multipliers,  DZ p = T'(u - T_P mu)
 //   phase 1, levels with inherited rows only: Mehrotra's interior point from z = 0, until the working set can be read off its iterate -- a starting point and a guess
 //     for phase 2, nothing more (one active-set iteration then usually ends the level).
-// Same algorithm, constants and decisions as the CPU restatement (oracle/qmo_wbc.h: interiorPointPhase, activeSetPhase), which documents the reasoning.
+// Same algorithm, constants and decisions as the CPU restatement (the tests' checker; DESIGN.md section 4.7 has the reasoning).
 //
 // NP = n padded (8 / 20 / 36) sizes every register array and loop.  Lane roles: lane i < m0 owns inequality ROW i; lane c < NP owns COLUMN c (z_c, column c of K and
 // row c of L); lane q < r owns task row q of AZ (residual).
@@ -18,6 +18,11 @@
 
 namespace qmk {
 
+#if defined(QM_QP_TRACE) && !defined(QMGPU_HOST_EMULATION)
+#define QP_TRACE_ON (blockIdx.x == (QM_QP_TRACE) && lane == 0)      // experiments only: device printf of one instance's active-set iterations
+#else
+#define QP_TRACE_ON (lane == 0)
+#endif
 constexpr double QP_EPS = 2.220446049250313e-16;
 constexpr double QP_REG = 1e-12;             // HoQp's regulariser (HoQp.cpp:66): a direction it alone would carry counts as having no curvature (x10)
 constexpr double QP_LAM_TOL = 8.0;           // = kAsLamTol of the CPU restatement
@@ -121,11 +126,11 @@ template <int J, int R, int NP> struct IpmDppRows {
 };
 template <int NP, int J> struct IpmFactorStep {
   static constexpr int NG = (NP + 15) / 16;
-  static __device__ __forceinline__ void run(double* kc, double& myInv, double* bcP, double& ncP, double diag0, double floorAbs, double floorRel, unsigned long long& exMask, int lane, double* red) {
+  static __device__ __forceinline__ void run(double* kc, double& myInv, double* bcP, double& ncP, double diag0, double floorAbs, double floorRel, unsigned long long forced, unsigned long long& exMask, int lane, double* red) {
     if constexpr (J < NP) {
       const double piv = qmReadLane(kc[J], J, red);
       const double d0 = qmReadLane(diag0, J, red);
-      const bool ex = !(piv > floorAbs + floorRel * double(J + 1) * d0);     // (wave uniform; NaN pivots count as excluded: the caller checks the result)
+      const bool ex = ((forced >> J) & 1ull) || !(piv > floorAbs + floorRel * double(J + 1) * d0);     // (wave uniform; NaN pivots count as excluded: the caller checks the result)
       if (ex) exMask |= 1ull << J;
       const double dfl = ex ? 1.0 : piv;
       const double inv = qmRsqrtPos(dfl);
@@ -141,7 +146,7 @@ template <int NP, int J> struct IpmFactorStep {
         if constexpr (NG > 2 && (J + 3) / 16 <= 2) bcP[2] = qmReplicateRow<2>(kc[J], red);
         ncP = -kc[J];
       }
-      IpmFactorStep<NP, J + 1>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, exMask, lane, red);
+      IpmFactorStep<NP, J + 1>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, forced, exMask, lane, red);
     }
   }
 };
@@ -154,9 +159,11 @@ struct QpResult { int status; int ipmIterations, iterations; bool strong; };   /
 // workgroup's dynamic LDS and are re-based on that symbol here, so that every access stays a ds_ instruction (pointers passed through a
 // call are generic: the same body ran 20 % slower on flat loads).
 // n: variables; r: task rows of AZ; m0: inequality rows; own: the rows are the level's own (soft) -- otherwise inherited (hard); rowOn: this lane's row takes part;
-// sigma0: starting value of the interior point (<= 0: no interior point -- the level's own rows, and the tests' cold runs).
+// sigma0: starting value of the interior point (<= 0: no interior point -- the level's own rows, and the tests' cold runs); tryHeld (a level with own rows whose bound is
+// zero -- the friction rows of the first level, each acting on the contact forces only): the variables those rows act on are HELD at zero and the rows left out, instead
+// of the rows being pinned: no working set to carry.  status 5 = the cost wants a held variable moved -- the caller solves again with the rows as rows.
 template <int NP, int LDZ_, int LDK_>
-__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOn, double sigma0, int lane) {
+__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, int lane) {
   QM_DYNAMIC_LDS(ldsBase);
   const QpIo io{ldsBase + off.G, ldsBase + off.AZ, ldsBase + off.rhat, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork, ldsBase + off.S};
   enum { ST_I = 0, ST_P = 1, ST_V = 2 };
@@ -167,12 +174,14 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   auto allSum = [&](double v) { return qmAllSum(v, red); };
   auto allMax = [&](double v) { return qmAllMax(v, red); };
   auto allMin = [&](double v) { return qmAllMin(v, red); };
+  QM_TICK_DECL;
   const int colL = lane < NP ? lane : 0;       // idle lanes alias column 0 / row 0 (results unused)
   const int rowL = lane < 56 ? lane : 0;
   const int tskL = lane < r ? lane : 0;
   const bool colOn = lane < n;
   // ---- what the two phases share (prepareLevel of the CPU restatement)
   const double hmax = allMax(colOn ? G[colL * LDK_ + colL] : 0.0);
+  bool rowOn = rowOnIn;
   const double fl = rowOn ? io.fhat[rowL] : 0.0;
   double dn = 0.0, d2 = 0.0;
   {
@@ -192,12 +201,20 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   }
   const double scale = fmax(1.0, allMax(fmax(rowOn ? fabs(fl) : 0.0, fabs(gC))));
   const double tol = 1e-9 * scale;
+  unsigned long long heldMask = 0ull;
+  if (tryHeld && own) {
+    const bool cand = rowOn && fabs(fl) <= tol;
+    for (int j = 0; j < n; ++j) if (qmBallot(cand && DZ[rowL * LDZ_ + j] != 0.0) != 0ull) heldMask |= 1ull << j;
+    bool inside = cand;       // a zero-bound row that acts on held variables only is satisfied with them: left out
+    for (int j = 0; j < n; ++j) inside = inside && (DZ[rowL * LDZ_ + j] == 0.0 || ((heldMask >> j) & 1ull));
+    rowOn = rowOn && !inside;
+  }
   const double floorAbs = 10.0 * QP_REG, floorRel = 16.0 * QP_EPS;
   double zc = 0.0;
-  double kc[NP], uc[NP], tt[NP], myInv = 1.0;   // row c of L, row c of L^T, T row of this lane's inequality row
+  double kc[NP], uc[NP], myInv = 1.0;   // row c of L, row c of L^T
   unsigned long long exMask = 0ull;
 #pragma unroll
-  for (int q = 0; q < NP; ++q) { kc[q] = 0.0; uc[q] = 0.0; tt[q] = 0.0; }
+  for (int q = 0; q < NP; ++q) { kc[q] = 0.0; uc[q] = 0.0; }
 
   // D z of this lane's row for the vector in bc
   auto rowDot = [&]() {
@@ -235,6 +252,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   };
   // K = G + DZ' diag(wt) DZ = L L^T: tiles on the matrix cores, factorisation in registers, rows of L (and 1 / L_cc) to LDS, rows of L^T back
   auto factorise = [&](double wt) {
+    QM_TICK(7);
     if (lane < 56) io.wtL[lane] = wt;
     QM_WAVE_SYNC();
     if (NP > 16 && io.fork) {   // several tiles: the helper wavefronts take theirs between two workgroup barriers
@@ -259,7 +277,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     exMask = 0ull;
     {
       double bcP[3] = {0.0, 0.0, 0.0}, ncP = 0.0;
-      IpmFactorStep<NP, 0>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, exMask, lane, red);
+      IpmFactorStep<NP, 0>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, heldMask, exMask, lane, red);
     }
     const bool myEx = lane < NP && ((exMask >> lane) & 1ull);
 #pragma unroll
@@ -275,6 +293,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
 #pragma unroll
     for (int cc = 0; cc < NP; ++cc) uc[cc] = io.Kt[cc * LDK_ + colL];   // U[lane][cc] for cc > lane
     QM_WAVE_SYNC();
+    QM_TICK(2);
   };
   // L t = rhs (forward substitution; lane c owns row c of L), then L^T x = t (back substitution; lane r owns row r of L^T in uc); excluded directions: zero
   auto forward = [&](double acc) {
@@ -299,14 +318,25 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     return colOn ? x : 0.0;
   };
 
+  QM_TICK(0);
   // ================================================================== phase 1: interior point (inherited rows only): a starting point and a guess
   int ipmIt = 0;
   bool usable = false;
   double s1 = 1.0, l1 = 0.0;
   const double nRows = allSum(rowOn ? 1.0 : 0.0);
-  if (sigma0 > 0.0 && !own && nRows > 0.0) {
-    s1 = rowOn ? fmax(sigma0, fl) : 1.0; l1 = rowOn ? sigma0 : 0.0;
-    double zcPrev = 0.0, s1p = s1, l1p = l1, nrdPrev = 0.0, muPrev = 0.0;
+  const bool ipmOn = sigma0 > 0.0 && !own && nRows > 0.0;
+  if (ipmOn) { s1 = rowOn ? fmax(sigma0, fl) : 1.0; l1 = rowOn ? sigma0 : 0.0; }
+  double muTarget = 1e-8;            // duality measure (x scale) at which the working set is read off the iterate (= kIpmHandOverMu of the CPU restatement)
+  int resumed = 0, status = 0, it = 0;
+  bool strong = false;
+  // The interior point hands over; if the step that is to bring its guessed rows onto their bounds is cut short by another row, the guess is wrong -- nothing has moved
+  // yet, the interior point goes on from its iterate (target x 1e-2) and the working set is read again, at most twice; after that the step is taken as far as it goes.
+#pragma unroll 1
+  for (;;) {
+  if (ipmOn) {
+    const int itStart = ipmIt;
+    double zcPrev = zc, s1p = s1, l1p = l1, nrdPrev = 0.0, muPrev = 0.0;
+    usable = false;
 #pragma unroll 1
     for (; ipmIt < 40; ++ipmIt) {
       QM_WAVE_SYNC();
@@ -334,9 +364,12 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       const double nrp = allMax(fabs(rp1));
       const double nanProbe = allSum(rdz + rp1);  // NaN anywhere -> NaN here (fmax drops NaNs)
       // a late Newton step of a degenerate problem (barrier weights ~1e18) can lose all accuracy: the previous iterate is what the active-set method starts from
-      if (ipmIt > 0 && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) { zc = zcPrev; s1 = s1p; l1 = l1p; usable = true; break; }
-      if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= 1e-6 * scale) { usable = true; break; }               // the working set can be read: over to the active-set method, for good
-      if (ipmIt > 0 && mu > 0.5 * muPrev && mu <= QP_STAGNATION_MU * scale) { usable = true; break; }               // stagnation at the rounding floor
+      if (ipmIt > itStart && (!(nanProbe == nanProbe) || !(mu == mu) || nrd > 100.0 * fmax(nrdPrev, 1e-9 * scale))) { zc = zcPrev; s1 = s1p; l1 = l1p; usable = true; break; }
+#if defined(QMGPU_EMU_DEBUG) || defined(QM_QP_TRACE)
+      if (QP_TRACE_ON) printf("EMU   ipm it %d n %d mu/s %.3e nrd/s %.3e nrp/s %.3e\n", ipmIt, n, mu / scale, nrd / scale, nrp / scale);
+#endif
+      if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= muTarget * scale) { usable = true; break; }               // the working set can be read: over to the active-set method, for good
+      if (ipmIt > itStart && mu > 0.5 * muPrev && mu <= QP_STAGNATION_MU * scale) { usable = true; break; }               // stagnation at the rounding floor
       zcPrev = zc; s1p = s1; l1p = l1; nrdPrev = nrd; muPrev = mu;
       const double w1 = l1 / s1;
       factorise(rowOn ? w1 : 0.0);
@@ -376,6 +409,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     if (!(allSum(zc) == allSum(zc))) { usable = false; zc = 0.0; }
   }
 
+  QM_TICK(1);
   // ================================================================== phase 2: primal active set
   int state = ST_I;
   bool guess = false, stuck = false;
@@ -388,8 +422,9 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     if (rowOn && (l1 > s1 || Dz - fl > 0.0)) { state = ST_P; guess = true; }
   }
   double lam = 0.0;                  // multiplier of this lane's row (pinned rows)
-  int status = 0, it = 0, lastReleased = -1, fullSteps = 0;
-  bool strong = false;
+  int lastReleased = -1, fullSteps = 0, changes = 0;
+  bool refuted = false;
+  status = 0; it = 0; strong = false;
 #pragma unroll 1
   for (;; ++it) {
     if (it > QP_MAX_CHANGES) { status = 1; break; }
@@ -397,40 +432,41 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     const unsigned long long pinMask = qmBallot(pinned);
     const int k = qmPopCount(pinMask);
     if (k > QP_KMAX) { status = 4; break; }
-    const int slot = qmPopCount(pinMask & ((1ull << lane) - 1ull));     // this lane's place among the pinned rows
+    // this lane's place among the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
+    const unsigned long long tightMask = qmBallot(pinned && !guess), below = (1ull << lane) - 1ull;
+    const int slot = (pinned && guess) ? qmPopCount(tightMask) + qmPopCount(pinMask & ~tightMask & below) : qmPopCount(tightMask & below);
     factorise(rowOn ? (state == ST_P ? wA : (state == ST_V ? 1.0 : 0.0)) : 0.0);
     if (!(allSum(myInv) == allSum(myInv))) { status = 2; break; }
-    // ---- T = L^-1 DZ': this lane's row, by forward substitution over the rows of L in LDS (wave-uniform reads); 1 / L_cc from the lanes
-    {
-      QM_WAVE_SYNC();
-      bc[lane] = myInv;
-      QM_WAVE_SYNC();
-#pragma unroll
-      for (int c = 0; c < NP; ++c) {
-        double acc = DZ[rowL * LDZ_ + c];
-#pragma unroll
-        for (int q = 0; q < c; ++q) acc -= io.Kt[c * LDK_ + q] * tt[q];
-        tt[c] = ((exMask >> c) & 1ull) ? 0.0 : acc * bc[c];
-      }
-      QM_WAVE_SYNC();
-    }
-    // ---- S = T_P'T_P: the pinned rows publish their T rows (over the rows of L, no longer needed), each computes its row of S; Cholesky in LDS with the
-    //      dependent rows (pivot lost against the row's own diagonal entry) left out
+    QM_TICK(7);
+    // ---- T_P = L^-1 DZ_P' by slot into LDS, S = T_P'T_P
     unsigned long long depMask = 0ull;
     if (k > 0) {
-      if (pinned) {
-#pragma unroll
-        for (int c = 0; c < NP; ++c) io.Kt[slot * LDK_ + c] = tt[c];
+      // one forward substitution per pinned row, in slot order (rows on their bounds first), through the register-resident factor: t_c lands in lane c and goes to
+      // row `slot` of the LDS square (the K tiles are no longer needed).  (A lane-per-row substitution over L in LDS, fully unrolled, was 630 terms of straight-line
+      // code per instantiation: 74 cycles per term at NP = 36, the function no longer fits the instruction cache.)
+      {
+        unsigned long long tm = tightMask, gm = pinMask & ~tightMask;
+#pragma unroll 1
+        for (int sidx = 0; sidx < k; ++sidx) {
+          int rowI;
+          if (tm != 0ull) { rowI = qmFirstBit(tm); tm &= tm - 1ull; } else { rowI = qmFirstBit(gm); gm &= gm - 1ull; }
+          const double d = DZ[rowI * LDZ_ + colL];
+          const double t = forward(colOn ? d : 0.0);
+          QM_WAVE_SYNC();
+          if (lane < NP) io.Kt[sidx * LDK_ + lane] = t;
+        }
       }
       QM_WAVE_SYNC();
-      if (pinned) {
+      QM_TICK(3);
+      {   // S = T_P'T_P: lane a < k its row
+        const int sa = lane < k ? lane : 0;
 #pragma unroll 1
         for (int sb = 0; sb < k; ++sb) {
           double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-          for (int c = 0; c + 1 < NP; c += 2) { a0 += tt[c] * io.Kt[sb * LDK_ + c]; a1 += tt[c + 1] * io.Kt[sb * LDK_ + c + 1]; }
-          if (NP & 1) a0 += tt[NP - 1] * io.Kt[sb * LDK_ + NP - 1];
-          io.S[slot * QP_SLD + sb] = a0 + a1;
+#pragma unroll 1
+          for (int c = 0; c + 1 < NP; c += 2) { a0 += io.Kt[sa * LDK_ + c] * io.Kt[sb * LDK_ + c]; a1 += io.Kt[sa * LDK_ + c + 1] * io.Kt[sb * LDK_ + c + 1]; }
+          if (NP & 1) a0 += io.Kt[sa * LDK_ + NP - 1] * io.Kt[sb * LDK_ + NP - 1];
+          if (lane < k) io.S[lane * QP_SLD + sb] = a0 + a1;
         }
       }
       QM_WAVE_SYNC();
@@ -457,10 +493,17 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         QM_WAVE_SYNC();
       }
     }
+    QM_TICK(4);
     // ---- the interior point's guess: its rows are still off their bounds; the first step is meant to bring them there and is only taken in full.  A guess with a
     //      dependent row, or whose step another row cuts short, is dropped
     const bool offBound = qmBallot(pinned && guess) != 0ull;
-    if (offBound && depMask != 0ull) { if (guess) { state = ST_I; guess = false; } fullSteps = 0; continue; }
+    if (offBound && depMask != 0ull) {     // a guess with dependent rows: those leave first -- the ratio test meets them again if the step crosses them
+#if defined(QMGPU_EMU_DEBUG) || defined(QM_QP_TRACE)
+      if (QP_TRACE_ON) printf("EMU   AS it %d: dependent rows of the guess leave (k %d dep %llx)\n", it, k, depMask);
+#endif
+      if (pinned && guess && ((depMask >> slot) & 1ull)) { state = ST_I; guess = false; }
+      fullSteps = 0; --it; continue;
+    }
     // ---- passes on this working set
     bool rebuild = false, done = false;
 #pragma unroll 1
@@ -475,18 +518,26 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       bc[lane] = rowOn ? (state == ST_P ? wA * rRow : (state == ST_V ? rRow : 0.0)) : 0.0;
       QM_WAVE_SYNC();
       const double dtt = ipmColSum<LDZ_>(io, lane);
+      QM_TICK(5);
       const double uC = forward(colOn ? -(gradC + dtt) : 0.0);
       QM_WAVE_SYNC();
       bc[lane] = lane < NP ? uC : 0.0;
       QM_WAVE_SYNC();
       double muMine = 0.0;
       if (k > 0) {
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int c = 0; c + 1 < NP; c += 2) { a0 += tt[c] * bc[c]; a1 += tt[c + 1] * bc[c + 1]; }
-        if (NP & 1) a0 += tt[NP - 1] * bc[NP - 1];
-        if (pinned) ms[slot] = (a0 + a1) + rRow;
-        QM_WAVE_SYNC();
+        // right-hand side of the small system: T_P'u + r_P -- lane s < k takes row s of T_P from LDS, the pinned lanes add their residuals
+        {
+          const int sl2 = lane < k ? lane : 0;
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+          for (int c = 0; c + 1 < NP; c += 2) { a0 += io.Kt[sl2 * LDK_ + c] * bc[c]; a1 += io.Kt[sl2 * LDK_ + c + 1] * bc[c + 1]; }
+          if (NP & 1) a0 += io.Kt[sl2 * LDK_ + NP - 1] * bc[NP - 1];
+          QM_WAVE_SYNC();
+          if (lane < k) ms[lane] = a0 + a1;
+          QM_WAVE_SYNC();
+          if (pinned) ms[slot] += rRow;
+          QM_WAVE_SYNC();
+        }
         // S mu = rhs (lane = row of the small factor)
 #pragma unroll 1
         for (int j = 0; j < k; ++j) {
@@ -511,16 +562,13 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       vC = lane < NP ? vC : 0.0;
       const double pC = backward(vC);
       QM_WAVE_SYNC();
-      bc[lane] = vC;
+      bc[lane] = pC;
       QM_WAVE_SYNC();
-      double Dp;
-      {
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int c = 0; c + 1 < NP; c += 2) { a0 += tt[c] * bc[c]; a1 += tt[c + 1] * bc[c + 1]; }
-        if (NP & 1) a0 += tt[NP - 1] * bc[NP - 1];
-        Dp = a0 + a1;
-      }
+      const double Dp = rowDot();
+      QM_TICK(6);
+#if defined(QMGPU_EMU_DEBUG) || defined(QM_QP_TRACE)
+      { const double pm_ = allMax(fabs(pC)); if (QP_TRACE_ON) printf("EMU   AS it %d n %d k %d dep %llx ex %llx offBound %d fullSteps %d pmax %.3e\n", it, n, k, depMask, exMask, int(offBound), fullSteps, pm_); }
+#endif
       const double nanProbe = allSum(pC);
       if (!(nanProbe == nanProbe)) { status = 2; done = true; break; }
       const double pmax = allMax(fabs(pC));
@@ -534,15 +582,20 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         if (state == ST_I) { if (Dp > epsP) a = fmax(0.0, -rRow) / Dp; }
         else { if (Dp < -epsP) a = fmax(0.0, rRow) / -Dp; }
       }
-      const double amin = allMin(a);
+      double amin = allMin(a);
+      if (offBound && amin >= 1.0 - 1e-9) amin = 2.0;       // (a row the guessed step reaches at its very end is not in its way)
+      if (amin < 1.0 && offBound && ipmOn && resumed < 2 && changes == 0) { refuted = true; done = true; break; }     // the guess is refuted before anything moved: back to the interior point
       if (amin < 1.0) {
         const int block = qmFirstBit(qmBallot(a == amin));          // ties keep the smallest row index
-        if (offBound) { if (guess) { state = ST_I; guess = false; } fullSteps = 0; rebuild = true; break; }      // the guess is dropped; nothing moves
+#if defined(QMGPU_EMU_DEBUG) || defined(QM_QP_TRACE)
+        if (QP_TRACE_ON) printf("EMU     blocked by row %d at alpha %.3e\n", block, amin);
+#endif
         const bool moved = amin * pmax > 1e-13 * zmax0;             // a step that does not move the point beyond its rounding counts as zero-length
         zc += amin * pC;
         if (moved) stuck = false; else if (lane == block && block == lastReleased) stuck = true;
         lastReleased = -1;
         if (lane == block) state = ST_P;
+        ++changes;
         fullSteps = 0; rebuild = true;
         break;
       }
@@ -551,7 +604,9 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       lam = muMine;
       // refinement: the same working set once more from the new point until the correction is rounding -- at most three full steps in a row
       const double zmax1 = fmax(1.0, allMax(fabs(zc)));
-      if (pmax > 1e-13 * zmax1 && fullSteps < 3) { ++fullSteps; continue; }
+      // (only a step that moved the point by more than 1e-4 of its size: a smaller one -- from the interior point's iterate -- is exact up to a rounding that scales with it)
+      if (pmax > 1e-13 * zmax1 && (pmax > 1e-4 * zmax1 || fullSteps > 0) && fullSteps < 3) { ++fullSteps; continue; }
+      QM_TICK(7);
       // multipliers: one counts once lam |d| stands clear of the rounding of the gradient it balances
       QM_WAVE_SYNC();
       bc[lane] = zc;
@@ -562,8 +617,11 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       const double worst = allMax(bad);
       if (worst > 1.0) {
         const int rel = qmFirstBit(qmBallot(bad == worst));
+#if defined(QMGPU_EMU_DEBUG) || defined(QM_QP_TRACE)
+        if (QP_TRACE_ON) printf("EMU     release row %d (worst %.3e)\n", rel, worst);
+#endif
         if (lane == rel) { state = (own && lam > 0.0) ? ST_V : ST_I; lam = 0.0; }
-        lastReleased = rel; fullSteps = 0; rebuild = true;
+        lastReleased = rel; fullSteps = 0; rebuild = true; ++changes;
         break;
       }
       // the point satisfies the KKT conditions on its working set; the bounds themselves once more (partial steps accumulate rounding)
@@ -573,13 +631,31 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       const double Df = rowDot() - fl;
       const bool viol = rowOn && (!own || state != ST_V) && !(Df <= tol);
       if (qmBallot(viol) != 0ull) status = 3;
+      if (heldMask != 0ull) {      // held variables: the cost must not want them moved
+        QM_WAVE_SYNC();
+        bc[lane] = zc;
+        QM_WAVE_SYNC();
+        const double gz = costGradient(false);
+        QM_WAVE_SYNC();
+        bc[lane] = rowOn ? (state == ST_P ? lam : (state == ST_V ? Df : 0.0)) : 0.0;
+        QM_WAVE_SYNC();
+        const double gd = ipmColSum<LDZ_>(io, lane);
+        const bool wants = lane < n && ((heldMask >> lane) & 1ull) && fabs(gz + gd) > gradNoise;
+        if (qmBallot(wants) != 0ull) status = 5;
+      }
       strong = rowOn && (state == ST_V || (state == ST_P && lam * dn > gradNoise));
+      QM_TICK(8);
       done = true;
       break;
     }
     if (done) break;
     (void)rebuild;
   }
+  if (!refuted) break;
+  ++resumed; muTarget *= 1e-2;
+  }
+  QM_TICK(7);
+  QM_TICK_FLUSH(NP == 36 ? 160 : (NP == 20 ? 256 : 288), blockIdx.x == 0 && lane == 0);
   if (status == 2) zc = 0.0;      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
   return QpResult{status, ipmIt, it, strong};

@@ -242,7 +242,7 @@ __device__ inline void ldsCholSolve(const double* L, int n, double* y, int lane)
 // column order full pivoting leaves -- NOT an orthonormal one -- with Eigen 3.3's pivot order: the largest entry of the remaining corner, ties to the smallest column
 // position, then the smallest row position (its scalar visitor walks the column-major corner column by column and keeps the first strict maximum).  The level tasks carry
 // unit rows: exact ties are the rule, and the basis -- the coordinates the minimum-norm representative of a level is taken in -- depends on the order.  The kernels and the
-// CPU restatement (qmo_core.h kernelFullPivLU) take the same decisions with the same roundings.  Result: N (n x nNew, row stride LDK) in K; returns nNew.
+// CPU restatement of the tests take the same decisions with the same roundings.  Result: N (n x nNew, row stride LDK) in K; returns nNew.
 // Also used for the implied equalities of a level (rows = the strongly active inequality rows, wbc_kernel).  A called function: three call sites, one copy; the arrays
 // arrive as offsets into the dynamic LDS (qp_dev.h: qpSolve).
 __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n, int kOff, int vhOff, int redOff, int lane) {
@@ -388,8 +388,6 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
         }
       }
       QM_WAVE_SYNC();
-      QM_TICK(16);
-    QM_WAVE_SYNC();
     return nNew;
   }
 }
@@ -732,7 +730,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   };
   // The QP of one level (or of its canonical representative) in nVars variables: task rows AZp (rRows x nVars) with residual rhatp at z = 0, inequality rows DZ / fhat
   // (own: the level's own, soft; else inherited, hard).  Rows a higher level left strongly active (eqIn) are equalities here: removed exactly by the change of variables
-  // z = N_E w (N_E = kernel of those rows; oracle/qmo_wbc.h eliminateImpliedEqualities has the argument), the QP is solved in w.  Result: z in zs[0 .. nVars);
+  // z = N_E w (N_E = kernel of those rows; DESIGN.md section 4.7 has the argument), the QP is solved in w.  Result: z in zs[0 .. nVars);
   // strongOut: this lane's row is strongly active at the solution; returns the solver's status.  AZp and DZ are overwritten when rows are eliminated.
   auto levelQp = [&](double* AZp, int rRows, double* rhatp, int nVars, bool own, bool rowOnIn, bool eqIn, bool& strongOut, int& passes) -> int {
     int nQ = nVars;
@@ -763,6 +761,60 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
         reduced = true;
       }
     }
+    // ---- minimum-norm start of a level with own rows only (the first level; DESIGN.md section 4.7 has the argument): its task can be met exactly, away from the
+    //      limits its minimisers are the solutions of A Z z = -rhat, and the one taken is the one of smallest weighted norm -- the variables the zero-bound rows act on
+    //      (the contact forces under their cones) 1e4 times cheaper than the rest, so that forces carry the robot and accelerations stay small --
+    //        z = W^-1 (A Z)' y,   (A Z) W^-1 (A Z)' y = -rhat        (a Cholesky of the size of the TASK, 18, in LDS: no 36 x 36 factorisation, no working set)
+    //      kept if every own row is satisfied at it.
+    if (own && rRows <= nQ && rRows <= MAXR) {
+      double winv = 1.0;
+      if (lane < nQ) for (int i = 0; i < m0; ++i) if (fhat[i] == 0.0 && DZ[i * LDZ + lane] != 0.0) winv = 1e4;
+      // B = W^-1 (A Z)' (n x r) in Zn (free until the level's null space), then (A Z) B on the matrix cores into K
+      for (int e = lane; e < nQ * rRows; e += 64) { const int c = e / rRows, j = e - c * rRows; Zn[c * LDZ + j] = AZp[j * LDZ + c]; }
+      QM_WAVE_SYNC();
+      if (lane < nQ) for (int j = 0; j < rRows; ++j) Zn[lane * LDZ + j] *= winv;
+      for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;
+      QM_WAVE_SYNC();
+      forkGemm(false, AZp, LDZ, Zn, LDZ, rRows, rRows, nQ, K, LDK, 0.0);
+      QM_WAVE_SYNC();
+      const double dmax = qmAllMax(lane < rRows ? K[lane * LDK + lane] : 0.0, red);
+      // plain Cholesky in LDS (lane = row); a pivot lost against the diagonal (dependent task rows) ends the attempt
+      bool ok = true;
+#pragma unroll 1
+      for (int j = 0; j < rRows; ++j) {
+        const double d = K[j * LDK + j];
+        if (!(d > 1e-10 * dmax)) { ok = false; break; }
+        const double dj = sqrt(d);
+        QM_WAVE_SYNC();
+        if (lane == j) K[j * LDK + j] = dj;
+        else if (lane > j && lane < rRows) K[lane * LDK + j] = K[lane * LDK + j] / dj;
+        QM_WAVE_SYNC();
+        if (lane > j && lane < rRows) {
+          const double lij = K[lane * LDK + j];
+          for (int q = j + 1; q <= lane; ++q) K[lane * LDK + q] -= lij * K[q * LDK + j];
+        }
+        QM_WAVE_SYNC();
+      }
+      if (ok) {
+        if (lane < rRows) dzs[lane] = -rhatp[lane];
+        QM_WAVE_SYNC();
+        ldsCholSolve(K, rRows, dzs, lane);
+        QM_WAVE_SYNC();
+        double zc = 0.0;
+        if (lane < nQ) { for (int q = 0; q < rRows; ++q) zc += AZp[q * LDZ + lane] * dzs[q]; zc *= winv; }
+        QM_WAVE_SYNC();
+        if (lane < ND) zs[lane] = lane < nQ ? zc : 0.0;
+        QM_WAVE_SYNC();
+        double res = 0.0, rsc = 1.0, dzr = 0.0;
+        if (lane < rRows) { res = rhatp[lane]; for (int c = 0; c < nQ; ++c) res += AZp[lane * LDZ + c] * zs[c]; rsc = fabs(rhatp[lane]); }
+        if (lane < m0) { for (int c = 0; c < nQ; ++c) dzr += DZ[lane * LDZ + c] * zs[c]; dzr -= fhat[lane]; }
+        const double resmax = qmAllMax(fabs(res), red), rscale = fmax(1.0, qmAllMax(rsc, red));
+        const bool viol = rowOn && !(dzr <= 0.0);
+        const double nanProbe = qmAllSum(zc, red);
+        ok = resmax <= 1e-9 * rscale && qmBallot(viol) == 0ull && nanProbe == nanProbe;
+      }
+      if (ok) { passes = 0; strongOut = false; return 0; }
+    }
     // G = (A Z)'(A Z) (HoQp.cpp:60-76, without its 1e-12 I: qp_dev.h)
     for (int e = lane; e < ND * LDK; e += 64) G[e] = 0.0;
     QM_WAVE_SYNC();
@@ -770,11 +822,16 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     QM_WAVE_SYNC();
     const QpOff io{int(G - lds), int(AZp - lds), int(rhatp - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds), int(Vh - lds)};
     const double sigma0 = own ? -1.0 : 300.0;
-    QpResult res;
-    if (nQ <= 8) res = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, lane);
-    else if (nQ <= 20) res = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, lane);
-    else res = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, lane);
-    QM_WAVE_SYNC();
+    auto solve = [&](bool tryHeld) {
+      QpResult rr;
+      if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);
+      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);
+      else rr = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);
+      QM_WAVE_SYNC();
+      return rr;
+    };
+    QpResult res = solve(own);                       // own rows: first with the variables of the zero-bound rows held (qp_dev.h) ...
+    if (own && res.status != 0) res = solve(false);  // ... and, if the cost wants them moved, with those rows as rows
     passes = res.ipmIterations + res.iterations;
     strongOut = rowOn && res.strong;
     if (reduced) {   // z = N_E w
@@ -808,7 +865,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   // Directions no task sees are fixed in the reference by HoQp's 1e-12 I alone (HoQp.cpp:66): every level returns, among its minimisers, the one of smallest norm in its
   // own variables z.  Where the last level decides everything that is left (every gait of gait.info once the start-up branch is over) that choice is invisible -- the next
   // level re-decides the same directions -- and the cascade runs without it (pass 0).  Where directions are left over at the end, the cascade runs again with the
-  // canonical representative taken at every level (pass 1; oracle/qmo_wbc.h wbcUpdate has the argument).
+  // canonical representative taken at every level (pass 1; DESIGN.md section 4.7 has the argument).
   int n = ND;
   bool canonical = false;
 #pragma unroll 1

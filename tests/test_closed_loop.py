@@ -21,27 +21,23 @@ def _summary(rows):
                 nodes=sorted({r["N"] for r in rows}))
 
 
-def _check(rows, tol=1e-6, offenders=None, ticks=None, loose_per=20000, loose_max=1e-3, status_mismatch=0, gross_per=None):
-    """Discrete outcomes exact on every instance of every cycle (modes, line-search step lengths and step types, WBC status words tick by tick); X, U, x0
-    within 1e-6 rel-inf over the whole run; torques within 1e-6 on every tick -- or, when `offenders` is given (the 256 x 100 x 10 run), on all but a stated
-    handful: at most 1 tick in 20,000 may exceed 1e-6, none 1e-3, each listed with the oracle's per-level diagnostics in gpurun_out/closed_loop_v*.json
-    (measured, round 4: 5 of 256,000, all <= 1e-4: level-1 problems that end unpolished on one side)."""
+def _check(rows, tol=1e-6, offenders=None, ticks=None, loose_per=None, loose_max=1e-4):
+    """Discrete outcomes exact on every instance of every cycle (modes, line-search step lengths and step types, WBC status words tick by tick: none set on either
+    side); X, U, x0 within 1e-6 rel-inf over the whole run; torques within 1e-6 on EVERY tick -- every WBC level ends at the vertex of its QP on both sides
+    (oracle/qmo_wbc.h activeSetPhase), there is no unpolished or relaxed class left to carve out.  `loose_per` (HierarchicalMpcWbc only, whose contact-force level
+    decides the arm accelerations through singular values of 1e-5: the level itself is conditioned 1e10): at most 1 tick in `loose_per` above 1e-6, none above
+    `loose_max`; each is listed with the oracle's per-level diagnostics in gpurun_out/closed_loop_v*.json."""
     s = _summary(rows)
     assert s["modes_equal"] and s["policy_mode_differs"] == 0, s
     assert s["alpha_differs"] == 0 and s["step_type_differs"] == 0, s
     assert s["riccati_status"] == [0, 0], s
     assert max(s["X_max"], s["U_max"], s["x0_max"]) <= tol, s
-    if offenders is None:
-        assert s["wbc_status"] == [0, 0] and s["tau_max"] <= tol, s
+    assert s["wbc_status"] == [0, 0], (s, [o for o in (offenders or []) if o["status"] != [0, 0]][:5])
+    if loose_per is None:
+        assert s["tau_max"] <= tol, (s, (offenders or [])[:5])
     else:
-        mismatch = [o for o in offenders if o["status"][0] != o["status"][1]]
-        assert len(mismatch) <= status_mismatch, mismatch
-        failed = [o for o in offenders if o["status"][0] != 0 or o["status"][1] != 0]
-        # a level that needed the relaxed re-solve in the oracle is the stated degenerate class (its minimiser moves by O(1) with the 1e-5 margin): listed, not bounded
-        loose = [o for o in offenders if o["status"] == [0, 0] and o["tau_dev"] > tol and not any(a > 0 for a in o.get("attempts", []))]
-        assert len(failed) <= ticks // 100000 + 1, failed          # ticks on which an implementation reports a level that did not converge
-        gross = [o for o in loose if o["tau_dev"] > loose_max]
-        assert len(loose) <= ticks // loose_per and len(gross) <= (ticks // gross_per if gross_per else 0), (len(loose), gross)
+        loose = [o for o in offenders if o["tau_dev"] > tol]
+        assert len(loose) <= ticks // loose_per and all(o["tau_dev"] <= loose_max for o in loose), loose
     return s
 
 
@@ -78,10 +74,9 @@ def test_closed_loop_256_instances_100_cycles(interface, variant):
     if variant == 0:
         _check(rows, offenders=offenders, ticks=B * cycles * 10)
     else:
-        # HierarchicalMpcWbc gives the arm no task of its own: its accelerations follow from the contact-force level through the base rows of the equations of
-        # motion (they reach 1e3 .. 1e4 rad/s^2) and every level is conditioned accordingly -- stated bound: at most 1 tick in 2,000 above 1e-6, at most 1 in 50,000 above 1e-2
-        # outside the relaxed-re-solve class (measured, round 4: 49-56 of 256,000; 0-2 of them above 1e-2 from build to build, the largest 1.1: levels 1 and 2 unpolished)
-        _check(rows, offenders=offenders, ticks=B * cycles * 10, loose_per=2000, loose_max=1e-2, status_mismatch=2, gross_per=50000)
+        # HierarchicalMpcWbc gives the arm no task of its own: its accelerations follow from the contact-force level through the base rows of the equations of motion
+        # (they reach 1e3 .. 1e4 rad/s^2) and that level is conditioned accordingly
+        _check(rows, offenders=offenders, ticks=B * cycles * 10, loose_per=50000)
 
 
 @pytest.mark.gpu
@@ -98,12 +93,9 @@ def test_closed_loop_static_walk_three_leg_stances(interface):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     json.dump(dict(instances=B, ticks_per_cycle=10, t_start=sc.t_start, gait="static_walk", summary=s, offenders=offenders, per_cycle=rows), open(path, "w"), indent=1)
     assert set(int(m) for m in sc.md[1:sc.nev]) == {13, 7, 14, 11}      # three-leg stances only, all four of them
-    # Stated bound: at most 1 tick in 10,000 above 1e-6 and 1 in 25,000 above 1e-3 (measured: 3 of 76,800 ticks, 1.2e-6, 2.7e-5 and ONE of 0.12).  The large one is the
-    # degenerate class of DESIGN.md section 5, pinned as tests/golden/wbc_degenerate_stance_tick.npz (test_oracle_invariants.py): full stance, the lowest level inherits
-    # rows with zero margin that leave it no interior -- its exact answer is z = 0, with every margin relaxed by 1e-5 (the re-solve an implementation falls back to when
-    # its first attempt does not converge) the level moves by 16 and the torques by 12 %; which of the two an implementation returns flips under input perturbations of
-    # 1e-13 in the ORACLE ITSELF, and the two loops here feed their own plans back (inputs 1e-11 apart).  With the oracle's inputs the kernels return the oracle's torques to 2e-14.
-    _check(rows, offenders=offenders, ticks=B * cycles * 10, loose_per=10000, gross_per=25000, loose_max=1e-3)
+    # Three-leg stances: the lowest level routinely inherits strongly active rows -- a cone without interior for an inequality solver; removed as equalities here.  The
+    # tick round 4 pinned as bistable (tests/golden/wbc_degenerate_stance_tick.npz, 12 % apart for inputs 1e-11 apart) is one of these: test_oracle_invariants.py.
+    _check(rows, offenders=offenders, ticks=B * cycles * 10)
 
 
 @pytest.mark.gpu
@@ -119,4 +111,4 @@ def test_closed_loop_flying_trot_flight_phases(interface):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     json.dump(dict(instances=B, ticks_per_cycle=10, t_start=sc.t_start, gait="flying_trot", summary=s, offenders=offenders, per_cycle=rows), open(path, "w"), indent=1)
     assert 0 in set(int(m) for m in sc.md[1:sc.nev])          # flight phases inside the run
-    _check(rows, offenders=offenders, ticks=B * cycles * 10, loose_per=10000, gross_per=25000, loose_max=1e-3)
+    _check(rows, offenders=offenders, ticks=B * cycles * 10)

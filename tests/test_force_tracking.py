@@ -144,7 +144,7 @@ def test_config4_force_tracking_n100_batch1024():
     r.update(w)
     ref = S.Oracle(itf.problem, fast=True).cycle_batch(N, x0, tt, ts, nev, ev, md, contact=contact, rbd=rbd, ee_force=fe, t_eval=mv["t_eval"], time=mv["time"],
                                                        input_last=mv["input_last"])   # all 1024 instances
-    S.assert_parity(S.parity_report("configs3_force_tracking_1024xN100_moving", r, ref), tau_outliers=2, tau_outlier_tol=1e-5)     # measured over the round's builds: 0, 1 or 2 of 1024 between 2e-6 and 7e-6
+    S.assert_parity(S.parity_report("configs3_force_tracking_1024xN100_moving", r, ref))
     # the force soft constraint does its job: at the end of the horizon the planned contact force is closer to the reference than without it
     from numpy.linalg import norm
     k_end = N

@@ -53,11 +53,11 @@ lq = raw[128:128 + len(LQ)]
 print("lq_node_kernel, node 7 of instance 0 (two wavefronts share the SIMD): ticks per section, total", int(lq.sum()), " kernel ms", round(ms[1], 4))
 for n, v in zip(LQ, lq): print("  %-34s %8.0f  %4.1f %%" % (n, v, 100 * v / lq.sum()))
 
-IPM = ["(pass bookkeeping / loop back-edge)", "residuals D z, G z, D^T lambda", "reductions / decisions", "weights + K tiles (MFMA)", "factorisation + transposition", "(tail)", "pass: right-hand side (56-row product)", "pass: forward substitution", "pass: back substitution", "pass: D dz", "pass: steps, step lengths, reductions"]
+IPM = ["setup (row norms, scale)", "interior point (all of it but its factorisations)", "weights + K tiles (MFMA) + factorisation + transposition", "T = L^-1 DZ' (forward substitutions, one per lane)", "S = T_P'T_P + small Cholesky", "pass: residuals D z, AZ'(AZ z + rhat), D^T t", "pass: forward, small solve, backward, D p", "decisions / reductions / bookkeeping", "final checks (rounding bound, bounds)", "-", "-"]
 for base, name in ((160, "NP = 36"), (256, "NP = 20"), (288, "NP = 8")):
     v = raw[base:base + 11]
     if v.sum() > 0:
-        print("wbc interior point, %s, instance 0: total %d ticks of %.0f (kernel %.4f ms)" % (name, v.sum(), ms[4] * tot / ms[2] if ms[2] else 0, ms[4]))
+        print("wbc level QP (all calls of the size), %s, instance 0: total %d ticks of %.0f (kernel %.4f ms)" % (name, v.sum(), ms[4] * tot / ms[2] if ms[2] else 0, ms[4]))
         for n_, x in zip(IPM, v): print("  %-40s %9.0f  %4.1f %%" % (n_, x, 100 * x / v.sum()))
 
 WBC = ["S1-S2 inputs, coordinates", "S3 measured pass", "S4 nle, M, Jacobians", "S5 desired pass", "task 0 inequality rows + level-loop re-entry (null space of the previous level ends here)", "assemble level task", "reduced data", "interior point", "x update", "(after the last null space)", "torques", "  reduced data: A Z", "  reduced data: zero + D Z", "  reduced data: A x - b, margins", "  reduced data: zero + (A Z)^T A Z", "  null space: full-pivot LU of A Z", "  null space: kernel vectors (back substitution)", "  null space: Z N, copy", "    LU: max reduction", "    LU: pivot lane, permutations", "    LU: swap, pivot broadcast", "    LU: elimination"]   # (g and the vanishing-row test are what is left in "reduced data" above)
