@@ -27,7 +27,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _test_support():
+    """tests/support.py (the oracle wrapper and the emulation build): reached from the cpu_baseline leg and from --emulate only -- never from a timed region"""
+    t = os.path.join(ROOT, "tests")
+    if t not in sys.path:
+        sys.path.insert(0, t)
+    import support
+    return support
 
 BATCH_PER_GPU = 256
 HORIZON_N = 100
@@ -89,14 +97,13 @@ def steady_state(itf, sc, steps, warmup, emulate=False):
     """config.steady_state: what the controller does between the first tick and shutdown -- the SAME 256 instances in a receding
     horizon: every step shifts the horizon by one MPC period (10 ms, mpcDesiredFrequency task.info:147), resamples the previous solution on the shifted grid
     ON THE DEVICE as the initial guess (qmgpu_warm_start_batch; coldStart false, task.info:143), solves, evaluates the policy between two nodes and runs the
-    WBC on a robot IN MOTION: the measured state follows the instance's own plan plus a seeded disturbance (tests/closed_loop.py: measurement), inputLast_
+    WBC on a robot IN MOTION: the measured state follows the instance's own plan plus a seeded disturbance (qm_door_amd/harness.py: measurement), inputLast_
     is carried from step to step, the centroidal observation comes from qmgpu_frontend_batch.
     The measurements depend on the plans, so the sequence is produced once, untimed (record pass: plan -> host -> measurement -> device), and then REPLAYED
     from device-resident inputs with nothing but qmgpu_warm_start_batch + qmgpu_cycle_batch per step inside the timed region; the replay must reproduce the
     recorded trajectories bit for bit (checked)."""
     import torch
-    import closed_loop as CL
-    import gpu_harness as G
+    from qm_door_amd import harness as CL, harness as G
     from qm_door_amd import abi, api
     f64 = torch.float64
     B, N = len(sc["x0"]), HORIZON_N
@@ -203,7 +210,7 @@ def self_launch(args, argv):
         port = so.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     if args.emulate:   # build the emulation library once, before the ranks race for it
-        import support as S
+        S = _test_support()
         S.build_emu()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + argv
@@ -236,7 +243,7 @@ def cpu_baseline(itf, sc, budget_s=15.0):
     workload, in SURVEY.md 8(d)'s three modes: one thread; three worker threads over the shooting nodes of one instance (the
     reference's own nThreads = 3, task.info:78); all hardware threads over instances (the reported value).  Plus the split of a
     one-thread cycle into LQ approximation + projection / Riccati / line search / WBC model / WBC QPs."""
-    import support as S
+    S = _test_support()
     orc = S.Oracle(itf.problem, fast=True)
     assert orc.lib.qmo_is_fast_build() == 1
 
@@ -281,6 +288,7 @@ def main():
                     help="CPU test of the multi-rank path only (tests/test_bench_contract.py): host-emulated kernels (tests/emu), gloo, tiny sizes; NOT a measurement")
     ap.add_argument("--batch-per-gpu", type=int, default=BATCH_PER_GPU, help="only with --emulate / --sweep")
     ap.add_argument("--nodes", type=int, default=HORIZON_N, help="only with --emulate")
+    ap.add_argument("--global-batch", type=int, default=CONFIG3_GLOBAL_BATCH, help="only with --emulate: size of the ONE global batch of configs[2] (2048), so that a toy run reaches the 'all of it' branch")
     ap.add_argument("--sweep", action="store_true", help="N = 1 only: also time 512 / 1024 / 2048 instances on the one GPU (config.batch_sweep)")
     args = ap.parse_args()
     if not args.emulate and (args.batch_per_gpu != BATCH_PER_GPU or args.nodes != HORIZON_N):
@@ -296,10 +304,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and not (args.gpus == 1 and world == 1):
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
-    import gpu_harness as G
-    from qm_door_amd import abi, api
+    from qm_door_amd import abi, api, harness as G
     if args.emulate:
-        import support as S
+        S = _test_support()
         G.DEVICE = "cpu"
         lib = abi.load_library(S.build_emu())
     else:
@@ -327,10 +334,13 @@ def main():
     if world > 1:
         # configs[2]: the first 256 * world instances of the ONE global batch (all 2048 at world = 8), contiguous shards
         total = B * world
-        glob = build_config3(itf, total=max(total, CONFIG3_GLOBAL_BATCH))
+        whole = args.global_batch
+        if whole != CONFIG3_GLOBAL_BATCH and not args.emulate:
+            raise SystemExit("--global-batch changes the workload BASELINE.json names: allowed with --emulate only")
+        glob = build_config3(itf, total=max(total, whole))
         lo, hi = sharding.shard_bounds(total, world, rank)
         sc = shard_of(glob, lo, hi)
-        workload = (f"configs[2]: ONE global batch of {total} MPC instances ({'all' if total == CONFIG3_GLOBAL_BATCH else 'the first ' + str(total)} of the {CONFIG3_GLOBAL_BATCH} of seed 1), randomised base pose + EE "
+        workload = (f"configs[2]: ONE global batch of {total} MPC instances ({'all' if total == whole else 'the first ' + str(total)} of the {whole} of seed 1), randomised base pose + EE "
                     f"target, horizon N={N}, dt=0.015, trot; contiguous shards of {B} per GPU; 1 SQP iteration + filter line search + 3-level WBC; all-gather of trajectories + torques")
     else:
         sc = build_scenario(itf, B, seed=0)
@@ -460,6 +470,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not args.emulate else "synthetic; HOST-EMULATED kernels (tests/emu) -- a functional test of the multi-rank path, not a measurement",
             "config": {"workload": workload,
+                       "wbc_inputs": "headline: robots at rest, t = 20 s, FIRST tick (inputLast_ = 0: the reference's spurious first-tick joint accelerations, torque limits active); the moving-robot, carried-inputLast_ regime is config.steady_state",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon_nodes": N, "gait": "trot", "seed": 0 if world == 1 else 1, "results_finite_and_converged": ok,
                        "collective": ("all_gather(X,U,tau,mode) over " + ("gloo (emulation)" if args.emulate else "RCCL")) if collective else "none",
                        "per_rank_value": rank_values, "per_rank_value_min": min(rank_values), "per_rank_value_max": max(rank_values),
@@ -503,8 +514,12 @@ if __name__ == "__main__":
         main()
     except SystemExit:
         raise
-    except BaseException as e:      # noqa: BLE001 -- say WHICH rank failed, then exit non-zero at once: the launcher tears the other ranks down
+    except KeyboardInterrupt:
+        raise
+    except Exception as e:      # noqa: BLE001 -- say WHICH rank failed, then exit non-zero at once: the launcher tears the other ranks down
         import traceback
         traceback.print_exc()
         print(f"[bench] rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        # (no destroy_process_group here: with its peers parked in a barrier the hand-shake would never return; the launcher tears them down on this exit code)
         os._exit(1)

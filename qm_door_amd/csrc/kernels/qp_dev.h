@@ -422,12 +422,12 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     if (rowOn && (l1 > s1 || Dz - fl > 0.0)) { state = ST_P; guess = true; }
   }
   double lam = 0.0;                  // multiplier of this lane's row (pinned rows)
-  int lastReleased = -1, fullSteps = 0, changes = 0;
+  int lastReleased = -1, fullSteps = 0, changes = 0, guard = 0;
   bool refuted = false;
   status = 0; it = 0; strong = false;
 #pragma unroll 1
   for (;; ++it) {
-    if (it > QP_MAX_CHANGES) { status = 1; break; }
+    if (it > QP_MAX_CHANGES || ++guard > 4 * QP_MAX_CHANGES) { status = 1; break; }      // (guard: every trip of the loop counts, also those that do not change the working set)
     const bool pinned = rowOn && state == ST_P;
     const unsigned long long pinMask = qmBallot(pinned);
     const int k = qmPopCount(pinMask);
@@ -497,7 +497,8 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     // ---- the interior point's guess: its rows are still off their bounds; the first step is meant to bring them there and is only taken in full.  A guess with a
     //      dependent row, or whose step another row cuts short, is dropped
     const bool offBound = qmBallot(pinned && guess) != 0ull;
-    if (offBound && depMask != 0ull) {     // a guess with dependent rows: those leave first -- the ratio test meets them again if the step crosses them
+    const bool depGuess = qmBallot(pinned && guess && ((depMask >> slot) & 1ull)) != 0ull;     // (a dependency among rows already on their bounds is harmless: skipped by the solve)
+    if (offBound && depGuess) {     // a guess with dependent rows: those leave first -- the ratio test meets them again if the step crosses them
 #if defined(QMGPU_EMU_DEBUG) || defined(QM_QP_TRACE)
       if (QP_TRACE_ON) printf("EMU   AS it %d: dependent rows of the guess leave (k %d dep %llx)\n", it, k, depMask);
 #endif

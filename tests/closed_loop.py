@@ -1,198 +1,9 @@
-"""Receding-horizon closed loop of a batch of robots -- the controller's steady state (QMController::update / advanceMpc,
-qm_controllers/src/QMController.cpp:116-157,316-327) -- behind one interface with two backends: the C ABI on the GPU and the CPU oracle.
-
-Per MPC cycle (100 Hz, mpcDesiredFrequency task.info:147):  measurement -> centroidal observation (front end) -> event-aligned shooting grid
-(timeHorizon 1.0 s, dt 0.015: ~67 nodes + one per mode switch, task.info:79,141) -> previous solution resampled as the initial guess (coldStart false,
-task.info:143) -> one SQP iteration.  Per WBC tick (1 kHz, ten per MPC cycle): policy evaluation at the tick's time -> WBC update with the measured
-state of that tick and inputLast_ carried from the previous tick.
-
-The "robot" is a plan follower: the measured configuration is the backend's OWN plan at the tick's time plus a seeded, smooth disturbance, the measured
-velocities are the plan's finite-difference base rates / planned joint rates plus a disturbance (measurement() below, plain numpy, shared by both backends).
-A deviation between the backends therefore feeds back into their next inputs: the loops are independent and are compared cycle by cycle.
-
-No oracle import here: bench.py's steady-state leg uses GpuBackend + measurement() only; OracleBackend takes the tests' Oracle object as an argument.
-"""
+"""Closed loop, test side: the oracle backend and the lock-step comparison of two backends.  The scenario, the plan-following measurement and the GPU backend are
+in qm_door_amd/harness.py (bench.py's steady-state leg drives them without touching tests/)."""
 import numpy as np
 
-MPC_PERIOD = 0.01        # mpcDesiredFrequency 100 (task.info:147)
-WBC_PERIOD = 0.001       # ros_control update rate of the controller (1 kHz)
-HORIZON = 1.0            # timeHorizon (task.info:141)
-
-
-class Disturbance:
-    """a sin(w t + phi) per instance and coordinate on the measured configuration / velocities (smooth, so that the measurement of a plan follower stays
-    differentiable); amplitudes 2-4 mm / mrad and 2-4 cm/s / crad/s"""
-
-    def __init__(self, batch, rng):
-        self.amp_q = np.c_[np.full((batch, 3), 0.002), np.full((batch, 3), 0.003), np.full((batch, 18), 0.004)] * rng.uniform(0.3, 1.0, (batch, 24))
-        self.amp_v = np.c_[np.full((batch, 3), 0.02), np.full((batch, 3), 0.02), np.full((batch, 18), 0.04)] * rng.uniform(0.3, 1.0, (batch, 24))
-        self.om = rng.uniform(2.0, 9.0, (batch, 24)); self.ph_q = rng.uniform(0, 2 * np.pi, (batch, 24)); self.ph_v = rng.uniform(0, 2 * np.pi, (batch, 24))
-
-    def dq(self, t):
-        return self.amp_q * np.sin(self.om * t + self.ph_q)
-
-    def dv(self, t):
-        return self.amp_v * np.sin(self.om * t + self.ph_v)
-
-
-class Scenario(Disturbance):
-    """Seeded batch: initial poses (xy, yaw, joints perturbed), two target knots spanning the run (base + end-effector displaced), stance then trot,
-    a start time just before the WBC's start-up branch ends (t = 10 s, HierarchicalWbc.cpp:23), smooth per-coordinate disturbances."""
-
-    def __init__(self, itf, batch, seed=31, t_start=9.5, cycles=100, gait_start=0.12, max_nodes=96, horizon=HORIZON, gait="trot"):
-        from qm_door_amd import abi, api
-        rng = np.random.default_rng(seed)
-        self.B, self.t_start, self.cycles, self.max_nodes, self.horizon = batch, t_start, cycles, max_nodes, horizon
-        self.dt = itf.problem.settings.dt
-        x_nom = itf.initial_state
-        q0 = np.tile(x_nom[6:30], (batch, 1))
-        q0[:, 0:2] = rng.uniform(-0.5, 0.5, (batch, 2)); q0[:, 3] = rng.uniform(-0.5, 0.5, batch)
-        q0[:, 6:] += rng.uniform(-1, 1, (batch, 18)) * 0.05
-        self.q0 = q0
-        self.v0 = np.c_[rng.uniform(-0.1, 0.1, (batch, 6)), rng.uniform(-0.2, 0.2, (batch, 18))]     # [w_world, v_lin, dq_j] at the first tick
-        t_end = t_start + cycles * MPC_PERIOD + horizon + 0.5
-        # targets: knot 0 = the initial pose at t_start, knot 1 = displaced base (and the end-effector with it) 2.5 s later
-        yaw = q0[:, 3]
-        ts = np.zeros((batch, 2, 37)); tt = np.tile(np.array([t_start, t_start + 2.5]), (batch, 1))
-        move = np.c_[rng.uniform(-0.3, 0.3, (batch, 2)), np.zeros(batch), rng.uniform(-0.3, 0.3, batch)]     # dx, dy, dz = 0, dyaw
-        for i in range(batch):
-            for k in range(2):
-                base = np.r_[q0[i, 0:2] + k * move[i, 0:2], x_nom[8], yaw[i] + k * move[i, 3], 0.0, 0.0]
-                c, s = np.cos(base[3]), np.sin(base[3])
-                ee = np.r_[base[0] + c * 0.6, base[1] + s * 0.6, x_nom[8] + 0.036 + 0.05 * k]
-                ts[i, k] = np.r_[np.zeros(6), base, x_nom[12:30], ee, 0.0, 0.0, np.sin(base[3] / 2), np.cos(base[3] / 2)]
-        self.tt, self.ts = tt, ts
-        # stance until t_start + gait_start, then trot (gait.info) tiled past the last horizon
-        g = api.GaitSchedule(lib=itf.lib)
-        nev, ev, md = g.mode_schedule(gait, t_start + gait_start, t_start + gait_start, t_end)
-        ev = np.array(ev); md = np.array(md, dtype=np.int32)
-        assert md[0] == 15 and nev <= abi.MAX_EVENTS          # the tiler puts the default STANCE mode in front of the template's first phase
-        self.nev, self.ev, self.md = int(nev), ev, md
-        Disturbance.__init__(self, batch, rng)
-        self.lib = itf.lib
-
-    def grid(self, t0):
-        """event-aligned shooting grid of one MPC cycle (the same for every instance: they share the gait): (N, grid[N + 1])"""
-        from qm_door_amd import api
-        return api.time_grid_with_events(t0, t0 + self.horizon, self.dt, self.ev[:self.nev], max_nodes=self.max_nodes, lib=self.lib)
-
-    def first_measurement(self):
-        return pack_rbd(self.q0 + self.dq(self.t_start), self.v0 + self.dv(self.t_start))
-
-
-def pack_rbd(q, v):
-    """q = [p(3), zyx(3), q_j(18)], v = [w_world(3), v_lin(3), dq_j(18)] -> rbdState[55] (the end-effector pose slots are only read by the target front end: unit quaternion)"""
-    B = q.shape[0]
-    r = np.zeros((B, 55))
-    r[:, 0:3] = q[:, 3:6]; r[:, 3:6] = q[:, 0:3]; r[:, 6:24] = q[:, 6:24]; r[:, 24:48] = v; r[:, 54] = 1.0
-    return r
-
-
-def interp_plan(T, X, U, t):
-    """(x, u) of every instance at time t: LinearInterpolation as MPC_MRT_Interface::evaluatePolicy applies it (end values held, U holds its last entry).
-    T [B][N+1], X [B][N+1][30], U [B][N][30]."""
-    B, N = U.shape[0], U.shape[1]
-    lb = (T < t).sum(axis=1)                      # first index with T >= t
-    interval = lb - 1
-    idx = np.clip(interval, 0, N - 1)
-    rows = np.arange(B)
-    t0, t1 = T[rows, idx], T[rows, idx + 1]
-    length = t1 - t0
-    alpha = np.where(length > 2 * np.finfo(float).eps, (t1 - t) / np.where(length == 0, 1.0, length), 1.0)
-    alpha = np.where(interval < 0, 1.0, np.where(interval >= N, 0.0, alpha))[:, None]
-    x = alpha * X[rows, idx] + (1 - alpha) * X[rows, idx + 1]
-    u = alpha * U[rows, np.minimum(idx, N - 1)] + (1 - alpha) * U[rows, np.minimum(idx + 1, N - 1)]
-    return x, u
-
-
-def measurement(sc, plan, t, h=1e-3):
-    """rbdState [B][55] at time t of robots that follow `plan` (dict T, X, U): configuration = plan + disturbance, base twist = finite difference of the
-    planned base pose over h (ZYX Euler rates mapped to the world angular velocity), joint rates = planned joint velocities, + disturbance."""
-    x, u = interp_plan(plan["T"], plan["X"], plan["U"], t)
-    xh, _ = interp_plan(plan["T"], plan["X"], plan["U"], t + h)
-    q = x[:, 6:30] + sc.dq(t)
-    rate = (xh[:, 6:12] - x[:, 6:12]) / h
-    z, y = x[:, 9], x[:, 10]
-    sz, cz, sy, cy = np.sin(z), np.cos(z), np.sin(y), np.cos(y)
-    zd, yd, xd = rate[:, 3], rate[:, 4], rate[:, 5]
-    w = np.c_[-sz * yd + cz * cy * xd, cz * yd + sz * cy * xd, zd - sy * xd]
-    v = np.c_[w, rate[:, 0:3], u[:, 12:30]] + sc.dv(t)
-    return pack_rbd(q, v)
-
-
-class GpuBackend:
-    """The loop through the C ABI: front end, warm start, MPC, policy evaluation and WBC are the library's kernels; buffers stay on the device, the plan is
-    downloaded once per cycle for the plan-following measurement."""
-
-    def __init__(self, itf, sc, variant=0):
-        import torch
-        import gpu_harness as G
-        from qm_door_amd import abi
-        self.torch, self.G, self.abi, self.itf, self.sc, self.variant = torch, G, abi, itf, sc, variant
-        B, Nmax, f64 = sc.B, sc.max_nodes, torch.float64
-        self.sol = G.make_solver(itf, B, Nmax)
-        z = lambda *shape, dtype=f64: torch.zeros(shape, dtype=dtype, device=G.DEVICE)  # noqa: E731
-        self.sets = [dict(S=z(B, abi.NSTATS)) for _ in range(2)]      # two output sets: the previous solution stays resident for the warm start
-        self.cur, self.prevN = 0, 0
-        self.x0, self.ftt, self.fts = z(B, 30), z(B, 2), z(B, 2, 37)
-        self.wx, self.wu = z(B, Nmax + 1, 30), z(B, Nmax, 30)
-        self.tt, self.ts = G.dev(sc.tt, f64), G.dev(sc.ts, f64)
-        self.sn, self.se, self.sm = G.dev(np.full(B, sc.nev, dtype=np.int32), torch.int32), G.dev(np.tile(sc.ev, (B, 1)), f64), G.dev(np.tile(sc.md, (B, 1)), torch.int32)
-        self.kind, self.cmd, self.lastee = z(B, dtype=torch.int32), z(B, 7), z(B, 7)
-        self.il = z(B, 30)
-        self.xd, self.ud, self.pm = z(B, 30), z(B, 30), z(B, dtype=torch.int32)
-        self.out, self.status = z(B, 54), z(B, dtype=torch.int32)
-        self.period = G.dev(np.full(B, WBC_PERIOD), f64)
-        self.N = 0
-
-    def _views(self, s, N):
-        """exact-size output tensors of buffer set s for N nodes (the event-aligned grid changes N from cycle to cycle), cached"""
-        cache = s.setdefault("_v", {})
-        if N not in cache:
-            t, B = self.torch, self.sc.B
-            z = lambda *shape, dtype=t.float64: t.zeros(shape, dtype=dtype, device=self.G.DEVICE)  # noqa: E731
-            cache[N] = dict(T=z(B, N + 1), X=z(B, N + 1, 30), U=z(B, N, 30), M=z(B, N + 1, dtype=t.int32))
-        return cache[N]
-
-    def observe(self, rbd, t):
-        """rbdState -> centroidal state on the device (qmgpu_frontend_batch; the target outputs of the front end are not used: the scenario's targets are)"""
-        G, t64 = self.G, self.torch.float64
-        self.rbd = G.dev(rbd, t64)
-        a = self.sol.frontend_args(self.sc.B, self.rbd, G.dev(np.full(self.sc.B, t), t64), self.kind, self.cmd, self.lastee, self.x0, self.ftt, self.fts)
-        self.sol.frontend(a)
-        return self.x0
-
-    def mpc(self, t0, N, grid):
-        from qm_door_amd import api
-        G, t64, B = self.G, self.torch.float64, self.sc.B
-        nxt = self.cur ^ 1
-        o = self._views(self.sets[nxt], N)
-        gd = G.dev(np.tile(grid, (B, 1)), t64)
-        warm = self.prevN > 0
-        if warm:
-            p = self._views(self.sets[self.cur], self.prevN)
-            wx = self.wx.view(-1)[:B * (N + 1) * 30].view(B, N + 1, 30); wu = self.wu.view(-1)[:B * N * 30].view(B, N, 30)
-            self.sol.warm_start(B, self.prevN, p["T"], p["X"], p["U"], N, gd, self.x0, wx, wu)
-        args = api.GpuSolver.mpc_args(B, N, self.x0, self.tt, self.ts, self.sn, self.se, self.sm, o["T"], o["X"], o["U"], o["M"], self.sets[nxt]["S"],
-                                      t0=G.dev(np.full(B, t0), t64), time_grid=gd, warm_x=wx if warm else None, warm_u=wu if warm else None)
-        self.sol.mpc(args)
-        self.cur, self.prevN, self.N = nxt, N, N
-        self.torch.cuda.synchronize() if G.DEVICE == "cuda" else None
-        self.plan = dict(T=o["T"].cpu().numpy(), X=o["X"].cpu().numpy(), U=o["U"].cpu().numpy(), mode=o["M"].cpu().numpy(), stats=self.sets[nxt]["S"].cpu().numpy(),
-                         x0=self.x0.cpu().numpy())
-        return self.plan
-
-    def tick(self, t, rbd, time):
-        """policy evaluation at t + WBC update with the measurement of this tick; inputLast_ stays on the device between ticks"""
-        from qm_door_amd import api
-        G, t64, B = self.G, self.torch.float64, self.sc.B
-        o = self._views(self.sets[self.cur], self.N)
-        self.sol.policy_eval(B, self.N, o["T"], o["X"], o["U"], o["M"], G.dev(np.full(B, t), t64), self.xd, self.ud, self.pm)
-        rb = G.dev(rbd, t64)
-        a = api.GpuSolver.wbc_args(B, rb, self.period, G.dev(np.full(B, time), t64), self.il, self.out, self.status, self.xd, self.ud, self.pm, self.variant)
-        self.sol.wbc(a)
-        self.torch.cuda.synchronize() if G.DEVICE == "cuda" else None
-        return dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), mode=self.pm.cpu().numpy(), input_last=self.il.cpu().numpy())
+from qm_door_amd.harness import *  # noqa: F401,F403
+from qm_door_amd.harness import MPC_PERIOD, WBC_PERIOD, HORIZON, measurement  # noqa: F401
 
 
 class OracleBackend:

@@ -75,6 +75,22 @@ def test_bench_two_ranks_on_the_emulation_path():
     assert "EMULATED" in d["data"] and "cpu_baseline" not in d
 
 
+def test_bench_eight_ranks_take_the_whole_global_batch_on_the_emulation_path():
+    """CPU: the launch the driver makes on an 8-GPU node -- eight ranks, configs[2]'s ONE global batch taken WHOLE (the branch no 1- or 2-rank run reaches), contiguous
+    shards, all-gather, the line -- at toy size on the host-emulated kernels over gloo (--global-batch 8: one instance per rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--emulate", "--batch-per-gpu", "1", "--global-batch", "8", "--nodes", "4", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 8 and cfg["global_batch"] == 8 and cfg["batch_per_gpu"] == 1 and len(cfg["per_rank_value"]) == 8
+    assert cfg["workload"].startswith("configs[2]: ONE global batch of 8 MPC instances (all of the 8 of seed 1)")
+    assert cfg["gather_matches_local_results"] is True and cfg["results_finite_and_converged"] is True
+
+
 def test_bench_refuses_a_changed_workload_outside_the_emulation():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch-per-gpu", "8"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert p.returncode != 0 and "BASELINE" in (p.stderr + p.stdout)
