@@ -194,6 +194,9 @@ inline void householderQR(const Mat& A, Mat& Q, Mat& Rout) {
 // tasks carry unit rows, exact ties are the rule; the basis, and with it the coordinates the minimum-norm completion is taken in, depends on this order.
 // (no fused multiply-add in the elimination, in EITHER build of the oracle: the pivot search compares the updated entries for equality of magnitude --
 // the level tasks carry unit rows, exact ties are the rule -- and the kernels' wbc_kernel.h takes the same decisions with the same roundings)
+#if defined(__clang__)
+#error "qmo_core.h: kernelFullPivLU relies on GCC's optimize(\"fp-contract=off\") attribute; build the oracle with g++ (oracle/Makefile) or add -ffp-contract=off for this compiler"
+#endif
 __attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr, std::vector<int>* freeOut = nullptr) {
   Mat A = Ain;
   const int rows = A.r, cols = A.c, size = std::min(rows, cols);

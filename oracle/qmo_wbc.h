@@ -322,8 +322,6 @@ constexpr double kStagnationMu = 1e-10;
 constexpr double kEps = 2.220446049250313e-16;
 constexpr double kMinNormCheap = 1e4;
 constexpr int kIpmMinVariables = 8;
-constexpr double kAsRho = 1e4;              // penalty of a pinned row, x the curvature of the level's cost ALONG THE ROW'S NORMAL, per unit of the row's squared norm
-constexpr int kAsInnerSteps = 12;            // Newton steps on the augmented Lagrangian per working set, at most
 constexpr double kAsLamTol = 8.0;            // a multiplier counts once it exceeds this many roundings of the gradient it balances
 constexpr int kAsMaxWorkingSetChanges = 100; // nWSR of HoQp.cpp:141
 // Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  inline: one copy whatever the number of translation units; written between batches only.
@@ -354,10 +352,11 @@ inline bool choleskyExcluding(Mat& A, double floorAbs, double floorRel, std::vec
 }
 inline void cholSolveExcluding(const Mat& L, const std::vector<char>& excluded, Vec& b) { for (size_t j = 0; j < b.size(); ++j) if (excluded[j]) b[j] = 0.0; cholSolve(L, b); }
 
-// The reduced problem of one level.  G0 = (A Z)'(A Z) WITHOUT HoQp's 1e-12 I (reg, HoQp.cpp:66): the regulariser is part of every factorised matrix, but not of the
-// gradients -- in a direction no task sees it is the ONLY curvature, 1e-12 z, and a row pinned across such a direction would show a multiplier of that size (positive:
-// an equality for the levels below) although the level's cost does not depend on the row at all.  The limit reg -> 0 is taken consistently: directions without
-// curvature stay where they are (choleskyExcluding), and what is left of them after the last level is the minimum-norm completion (wbcUpdate).
+// The reduced problem of one level.  G0 = (A Z)'(A Z) WITHOUT HoQp's 1e-12 I (reg, HoQp.cpp:66).  The regulariser is neither part of the factorised matrices nor of
+// the gradients: in a direction no task sees it would be the ONLY curvature, 1e-12 z -- the step there would be the rounding of the gradient divided by 1e-12, and a row
+// pinned across such a direction would show a multiplier of that size (positive: an equality for the levels below) although the level's cost does not depend on the row
+// at all.  The limit reg -> 0 is taken instead: a direction whose pivot does not exceed 10 reg plus its own rounding counts as having no curvature and stays where it is
+// (choleskyExcluding), and where directions are left over after the last level the canonical representative is taken (wbcUpdate).
 struct LevelQp {
   Mat G0; Vec g; Mat D; Vec f; int mOwn = 0; double reg = 0.0;     // rows [0, mOwn) of D are the level's own (soft), the rest inherited (hard)
   Mat AZ; Vec rhat;      // the level's task in its variables, cost 1/2 |AZ z + rhat|^2 (G0 = AZ'AZ, g = AZ'rhat); empty for a generic QP
@@ -378,8 +377,8 @@ struct LevelQp {
 };
 struct LevelWork {       // what the two phases share
   std::vector<char> on;  // rows that take part (not identically zero, not eliminated)
-  Vec dn, wP;            // largest entry of a row; penalty weight of a pinned row
-  double hmax = 0.0, scale = 1.0, pivotFloor = 0.0;
+  Vec dn, wP;            // largest entry of a row; augmentation weight of a pinned row
+  double hmax = 0.0, scale = 1.0;
 };
 inline LevelWork prepareLevel(const LevelQp& q) {
   LevelWork w;
@@ -402,7 +401,6 @@ inline LevelWork prepareLevel(const LevelQp& q) {
     for (int j = 0; j < n; ++j) d2 += q.D(i, j) * q.D(i, j);
     w.wP[i] = std::max(1.0, w.hmax) / d2;
   }
-  w.pivotFloor = 0.0;   // (set per factorisation: relative to the largest diagonal entry of the matrix being factorised, activeSetPhase)
   return w;
 }
 
@@ -488,8 +486,13 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
 //                 none: done
 // Ties (several rows at the same step length: zero-margin rows of a degenerate vertex) go to the smallest row index.  A multiplier counts once lam_j |d_j| stands clear of
 // the rounding of the gradient it balances, kAsLamTol eps (hmax |z| + scale).  A row released and pinned again by a zero-length step is not released again before the
-// point has moved.  start: the point and working set of the interior point (rows with multiplier > slack, and rows its iterate violates), or z = 0 with the own rows
-// whose bound is zero pinned (the friction rows: 0 <= 0 -- away from the limits that IS the solution of the first level, in one factorisation).
+// point has moved.
+// start: z = 0 with the own rows whose bound is zero pinned (or, in the held-variable form of solveLevel, their variables held), or the interior point's iterate with
+// its GUESS of the working set: the rows with multiplier > slack and the rows the iterate violates.  The guessed rows are still off their bounds by their slacks; the
+// first step is meant to bring them there.  Rows of the guess that are combinations of other pinned rows leave first (the small system orders the rows already on
+// their bounds in front, so that a dependency shows on a guessed row); a row the guessed step reaches only at its very end is not in its way; and if another row cuts
+// the step short before anything has moved, the guess is refuted and solveLevel lets the interior point go on (at most twice; after that the step is taken as far as
+// it goes and the row that cut it is pinned).  The first full step puts every pinned row on its bound; from there on the method is the textbook one.
 inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut, const std::vector<char>* fixedVars = nullptr, bool* guessRefuted = nullptr) {
   enum { I = 0, P = 1, V = 2 };
   QpStats st;
@@ -589,6 +592,7 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     if (g_expTrace) { int nV = 0, nEx = 0, nDep = 0; for (int i = 0; i < m; ++i) nV += rowOn[i] && state[i] == V; for (char e : excluded) nEx += e; for (char e : dependent) nDep += e;
       fprintf(stderr, "  AS it %d n %d P %d (dependent %d) V %d excl %d pmax %.3e alpha %.3e block %d leak %.1e\n", st.iterations, n, k, nDep, nV, nEx, pmax, alpha, block, leak); }
     if (block >= 0 && offBound && alpha >= 1.0 - 1e-9) block = -1;      // (a row the guessed step reaches at its very end is not in its way)
+    if (block >= 0 && fullSteps > 0 && pmax <= 1e-9 * zmax0) block = -1;  // (a refinement correction at rounding size changes no row's side: a row that ends exactly ON its bound -- a violated own row whose violation the level removes -- would otherwise be pinned or not by the last bit)
     // the step that was to bring the guessed rows onto their bounds is cut short by another row: the guess is wrong.  Nothing has moved yet: the caller may let the
     // interior point go on from its iterate and read the working set again (solveLevel; at most twice -- after that the step is taken as far as it goes)
     if (block >= 0 && offBound && guessRefuted && st.adds == 0 && st.drops == 0) { *guessRefuted = true; st.status = 6; break; }
@@ -635,7 +639,9 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
         for (int j = 0; j < n; ++j) if ((*fixedVars)[j] && std::fabs(gfull[j]) > gradNoise) st.status = 5;
       }
       // strongly active rows: pinned with a multiplier that counts, or violated
-      for (int i = 0; i < m; ++i) if (rowOn[i] && state[i] == P && !(lam[i] * w.dn[i] > gradNoise)) lam[i] = 0.0;
+      // (a violated own row's multiplier is its violation; one that ends on its bound is not strongly active)
+      { const Vec Dv = D * z; for (int i = 0; i < m; ++i) if (rowOn[i] && state[i] == V) lam[i] = Dv[i] - f[i]; }
+      for (int i = 0; i < m; ++i) if (rowOn[i] && state[i] != I && !(lam[i] * w.dn[i] > gradNoise)) lam[i] = 0.0;
       break;
     }
     state[rel] = (rel < mOwn && lam[rel] > 0.0) ? V : I; lam[rel] = 0.0; lastReleased = rel; fullSteps = 0;
@@ -761,7 +767,7 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
   st.ipmIterations = ipmIt; st.eliminated = reduced ? nFull - N.c : 0;
   if (st.status == 2) zw.assign(q.n(), 0.0);      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
   z = reduced ? N * zw : zw;
-  for (int i = 0; i < m; ++i) if (w.on[i]) eq[i] = eq[i] || state[i] == 2 || (state[i] == 1 && lam[i] > 0.0);
+  for (int i = 0; i < m; ++i) if (w.on[i]) eq[i] = eq[i] || (state[i] != 0 && lam[i] > 0.0);
   return st;
 }
 

@@ -585,6 +585,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       }
       double amin = allMin(a);
       if (offBound && amin >= 1.0 - 1e-9) amin = 2.0;       // (a row the guessed step reaches at its very end is not in its way)
+      if (fullSteps > 0 && pmax <= 1e-9 * zmax0) amin = 2.0;  // (a refinement correction at rounding size changes no row's side)
       if (amin < 1.0 && offBound && ipmOn && resumed < 2 && changes == 0) { refuted = true; done = true; break; }     // the guess is refuted before anything moved: back to the interior point
       if (amin < 1.0) {
         const int block = qmFirstBit(qmBallot(a == amin));          // ties keep the smallest row index
@@ -644,7 +645,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         const bool wants = lane < n && ((heldMask >> lane) & 1ull) && fabs(gz + gd) > gradNoise;
         if (qmBallot(wants) != 0ull) status = 5;
       }
-      strong = rowOn && (state == ST_V || (state == ST_P && lam * dn > gradNoise));
+      strong = rowOn && ((state == ST_V && Df * dn > gradNoise) || (state == ST_P && lam * dn > gradNoise));       // (a violated own row's multiplier is its violation)
       QM_TICK(8);
       done = true;
       break;
