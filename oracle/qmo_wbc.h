@@ -409,7 +409,8 @@ inline LevelWork prepareLevel(const LevelQp& q) {
 // plausibly be read off the iterate (duality measure <= 1e-6 scale with residuals to match), until it has converged or stagnates at the rounding floor of its normal
 // equations, or until a step loses all accuracy (the previous iterate is handed over).  Returns the iterations used.
 struct IpmPoint { Vec z, s, lam; bool usable = false; };
-constexpr double kIpmHandOverMu = 1e-8;     // duality measure (x scale) at which the working set is read off the iterate; x 1e-2 for each of the (at most two) resumptions
+constexpr double kIpmHandOverMu = 1e-8;     // duality measure (x scale) at which the working set is read off the iterate; x 1e-2 for each of the (at most two) resumptions.  (1e-6 saves 7 % of the passes and is NOT
+                                            //  taken: a direction at the exclusion floor of the factorisation stays where the interior point left it, and at 1e-6 that is up to 0.7 of the torques away from the minimiser, at 1e-8 5e-4.)
 inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma0, IpmPoint& pt, double muTarget = kIpmHandOverMu, bool resume = false, int itStart = 0) {
   const int n = q.n(), m = q.m();
   std::vector<int> rows; for (int i = q.mOwn; i < m; ++i) if (w.on[i]) rows.push_back(i);
@@ -612,7 +613,8 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     {
       double zmax = 1.0; for (double v : z) zmax = std::max(zmax, std::fabs(v));
       // (a correction that is itself small -- the step from the interior point's iterate -- is a Newton step on a quadratic: exact up to the rounding of the solve, which
-      //  scales with the correction; only a step that moved the point by more than 1e-4 of its size is refined)
+      //  scales with the correction; only a step that moved the point by more than 1e-4 of its size is refined.  Refining every full step was measured in round 5 on
+      //  HierarchicalMpcWbc's closed loop: the same 27 of 256,000 ticks deviate by the same amounts, so it is not paid for)
       if (pmax > 1e-13 * zmax && (pmax > 1e-4 * zmax || fullSteps > 0) && fullSteps < 3) { ++fullSteps; --st.iterations; if (g_expTrace) fprintf(stderr, "    full step %d on this working set: correction %.3e (zmax %.3e)\n", fullSteps, pmax, zmax); continue; }
     }
     std::fill(lam.begin(), lam.end(), 0.0);
@@ -697,13 +699,16 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
   //  2 iterations on average there and 14 at most, against 9.6 / 20 passes with the interior point in front: measured on 40k closed-loop ticks)
   const bool useIpm = hard && q.mOwn == 0 && q.n() > kIpmMinVariables && !g_expNoInteriorPoint;
   int ipmIt = 0;
-  if (useIpm) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt);
   Vec zw, lam; std::vector<char> state;
+  bool solved = false;
+  // (Tried and NOT kept: the level's unconstrained minimiser first -- one factorisation from z = 0, done if no row is in its way: 22 % of a trot's ticks.  A direction whose
+  //  curvature sits at the exclusion floor of the factorisation is then either solved for or left at ZERO, the full size of its component apart; behind the interior point it is
+  //  left at the interior point's iterate, which is next to the minimiser either way.  HierarchicalMpcWbc's closed loop went from 5e-4 to 0.8 in its worst tick.)
+  if (!solved && useIpm) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt);
   // A level with own rows whose bound is zero (the friction rows of the first level: every one of them acts on the contact forces only, 0 <= 0 at z = 0): pinning
   // them all holds those forces at zero.  Tried in that form first -- the variables held, the rows left out: no working set to carry, one factorisation and one solve away
   // from the limits -- and kept if, at the end, the cost does not want the held variables moved (the first level's cost vanishes at its minimiser: it never does, unless
   // torque limits are violated).  Otherwise the level is solved again with those rows as rows.
-  bool solved = false;
   // A level with own rows only and a task the variables can meet exactly (the first level: equations of motion and contact rows, 18 independent rows in 36 variables):
   // away from the limits its minimisers are the solutions of A Z z = -rhat, and the one the reference's 1e-12 I selects is the one of smallest norm,
   //   z = (A Z)' y,   (A Z)(A Z)' y = -rhat        (a Cholesky of the size of the TASK: 18 instead of 36)

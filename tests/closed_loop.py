@@ -32,9 +32,28 @@ class OracleBackend:
 
     def tick(self, t, rbd, time):
         xd, ud, md = self.o.policy_eval_batch(self.plan["T"], self.plan["X"], self.plan["U"], self.plan["mode"], t)
+        self.last = (xd, ud, np.array(rbd, dtype=np.float64), md, time, self.il.copy())
         w = self.o.wbc_batch(xd, ud, rbd, md, WBC_PERIOD, time, self.il, self.variant)
+        self.last_out = w["out"]
         self.il = w["input_last"]
         return dict(out=w["out"], status=w["status"], mode=md, input_last=self.il, attempts=w["attempts"], polished=w["polished"], iterations=w["iterations"])
+
+    def sensitivity(self, idx, eps=1e-9, draws=3, seed=5):
+        """How far the ORACLE's own torques of the last tick move (rel-inf, per instance of idx) when its inputs -- desired state and input, measurement, inputLast_ --
+        are perturbed by eps relative (a few seeded directions): the conditioning of the tick's cascade, measured on the checker alone.  Two backends whose MPC plans
+        agree to 1e-13 cannot agree on the torques by better than this scaled to 1e-13 -- or, where a level sits on a discrete decision (a direction at the
+        exclusion floor of the factorisation: solved for, or left where the interior point put it), by better than the jump itself."""
+        from support import rel_inf
+        xd, ud, rbd, md, time, il = self.last
+        idx = np.asarray(idx, dtype=np.int64)
+        rng = np.random.default_rng(seed)
+        base = self.last_out[idx, 36:]
+        worst = np.zeros(len(idx))
+        for _ in range(draws):
+            p = lambda a: a[idx] * (1 + eps * rng.uniform(-1, 1, a[idx].shape))  # noqa: E731
+            w = self.o.wbc_batch(p(xd), p(ud), p(rbd), md[idx], WBC_PERIOD, time, p(il), self.variant)
+            worst = np.maximum(worst, rel_inf(w["out"][:, 36:], base))
+        return worst
 
 
 def run_lockstep(sc, a, b, ticks=10, on_cycle=None, offenders=None, tol=1e-6):
@@ -71,11 +90,15 @@ def run_lockstep(sc, a, b, ticks=10, on_cycle=None, offenders=None, tol=1e-6):
             row["policy_mode_differs"] += int((wa["mode"] != wb["mode"]).sum())
             if offenders is not None:
                 e = rel_inf(wa["out"][:, 36:], wb["out"][:, 36:])
-                for i in np.nonzero((e > tol) | (wa["status"] != 0) | (wb["status"] != 0))[0]:
+                bad = np.nonzero((e > tol) | (wa["status"] != 0) | (wb["status"] != 0))[0]
+                sens = b.sensitivity(bad) if len(bad) and hasattr(b, "sensitivity") else None
+                for n_, i in enumerate(bad):
                     rec = dict(cycle=k, tick=j, instance=int(i), time=float(t), tau_dev=float(e[i]), status=[int(wa["status"][i]), int(wb["status"][i])], mode=int(wb["mode"][i]))
                     for key in ("attempts", "polished", "iterations"):
                         if key in wb:
                             rec[key] = wb[key][i].tolist()
+                    if sens is not None:
+                        rec["oracle_tau_move_under_1e-9_input_perturbation"] = float(sens[n_])
                     offenders.append(rec)
         # the measurement the next cycle starts from: each loop's own plan at the next MPC time
         for s in range(2):
