@@ -264,6 +264,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       ipmKTiles<NP, LDZ_, LDK_>(io, -1, lane);
     }
     QM_WAVE_SYNC();
+    QM_TICK(9);
     // lane c holds column c of K in kc; after step j, kc[j] of lane c is L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
     myInv = 1.0;
 #pragma unroll
@@ -275,10 +276,12 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
 #pragma unroll
     for (int q = 0; q < NP; ++q) diag0 = (q == lane) ? kc[q] : diag0;
     exMask = 0ull;
+    QM_TICK(10);
     {
       double bcP[3] = {0.0, 0.0, 0.0}, ncP = 0.0;
       IpmFactorStep<NP, 0>::run(kc, myInv, bcP, ncP, diag0, floorAbs, floorRel, heldMask, exMask, lane, red);
     }
+    QM_TICK(11);
     const bool myEx = lane < NP && ((exMask >> lane) & 1ull);
 #pragma unroll
     for (int q = 0; q < NP; ++q) kc[q] = myEx ? ((q == lane) ? 1.0 : 0.0) : kc[q];     // an excluded direction: its row of L is the unit vector as well
@@ -372,6 +375,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       if (ipmIt > itStart && mu > 0.5 * muPrev && mu <= QP_STAGNATION_MU * scale) { usable = true; break; }               // stagnation at the rounding floor
       zcPrev = zc; s1p = s1; l1p = l1; nrdPrev = nrd; muPrev = mu;
       const double w1 = l1 / s1;
+      QM_TICK(12);
       factorise(rowOn ? w1 : 0.0);
       double ds1 = 0.0, dl1 = 0.0, dzc = 0.0, alphaAff = 1.0, sigma = 0.0, cw = 1.0;
 #pragma unroll 1
@@ -382,11 +386,14 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         bc[lane] = t1;
         QM_WAVE_SYNC();
         const double dtt = ipmColSum<LDZ_>(io, lane);   // D^T t
+        QM_TICK(13);
         dzc = backward(forward(colOn ? -rdz - dtt : 0.0));
+        QM_TICK(14);
         QM_WAVE_SYNC();
         bc[lane] = dzc;
         QM_WAVE_SYNC();
         const double Ddz = rowDot();
+        QM_TICK(15);
         if (rowOn) { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
         double amax = 1.0;
         if (rowOn) { if (ds1 < 0) amax = fmin(amax, -s1 / ds1); if (dl1 < 0) amax = fmin(amax, -l1 / dl1); }
@@ -405,6 +412,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         }
       }
     }
+    QM_TICK(16);
     if (ipmIt >= 40) usable = true;      // iteration cap: the last iterate is handed over like any other
     if (!(allSum(zc) == allSum(zc))) { usable = false; zc = 0.0; }
   }

@@ -53,9 +53,9 @@ lq = raw[128:128 + len(LQ)]
 print("lq_node_kernel, node 7 of instance 0 (two wavefronts share the SIMD): ticks per section, total", int(lq.sum()), " kernel ms", round(ms[1], 4))
 for n, v in zip(LQ, lq): print("  %-34s %8.0f  %4.1f %%" % (n, v, 100 * v / lq.sum()))
 
-IPM = ["setup (row norms, scale)", "interior point (all of it but its factorisations)", "weights + K tiles (MFMA) + factorisation + transposition", "T = L^-1 DZ' (forward substitutions, one per lane)", "S = T_P'T_P + small Cholesky", "pass: residuals D z, AZ'(AZ z + rhat), D^T t", "pass: forward, small solve, backward, D p", "decisions / reductions / bookkeeping", "final checks (rounding bound, bounds)", "-", "-"]
+IPM = ["setup (row norms, scale)", "interior point (all of it but its factorisations)", "factorise: transposition through LDS (rows of L out, rows of L^T back)", "T = L^-1 DZ' (forward substitutions, one per lane)", "S = T_P'T_P + small Cholesky", "pass: residuals D z, AZ'(AZ z + rhat), D^T t", "pass: forward, small solve, backward, D p", "decisions / reductions / bookkeeping (what no other slot holds)", "final checks (rounding bound, bounds)", "  factorise: weights + K tiles (fork-join)", "  factorise: columns of K into registers", "  factorise: elimination (in registers)", "  ipm: residuals, reductions, hand-over tests", "  ipm pass: t, D^T t", "  ipm pass: forward + backward", "  ipm pass: D dz", "  ipm pass: step lengths, update (+ loop exit)"]
 for base, name in ((160, "NP = 36"), (256, "NP = 20"), (288, "NP = 8")):
-    v = raw[base:base + 11]
+    v = raw[base:base + 17]
     if v.sum() > 0:
         print("wbc level QP (all calls of the size), %s, instance 0: total %d ticks of %.0f (kernel %.4f ms)" % (name, v.sum(), ms[4] * tot / ms[2] if ms[2] else 0, ms[4]))
         for n_, x in zip(IPM, v): print("  %-40s %9.0f  %4.1f %%" % (n_, x, 100 * x / v.sum()))
