@@ -319,6 +319,19 @@ int qmo_qp_solve(int n, int m, const double* H, const double* c, const double* D
   return it;
 }
 
+// kernelFullPivLU on its own (tests: the pivot order is Eigen's).  A row major [rows][cols]; ker row major [cols][cols] (the first dimker columns are the basis);
+// freeCols[dimker]: the original column each basis vector carries its 1 on; pivSeq[2 k], pivSeq[2 k + 1]: row / column POSITION of pivot k when it was chosen.  Returns dimker.
+int qmo_kernel_full_piv_lu(int rows, int cols, const double* A, double* ker, int32_t* freeCols, int32_t* pivSeq, int32_t* nPiv) {
+  std::vector<int> fr, seq;
+  int rank = 0;
+  const Mat N = kernelFullPivLU(Mat::from(A, rows, cols), &rank, &fr, &seq);
+  for (int i = 0; i < cols; ++i) for (int j = 0; j < cols; ++j) ker[i * cols + j] = j < N.c ? N(i, j) : 0.0;
+  for (size_t j = 0; j < fr.size(); ++j) freeCols[j] = fr[j];
+  for (size_t k = 0; k < seq.size(); ++k) pivSeq[k] = seq[k];
+  *nPiv = int(seq.size() / 2);
+  return N.c;
+}
+
 // The three QPs of one WBC update (H c D f per level), for checking the GPU's structured solve against the dense data.
 int qmo_wbc_levels(const qmgpu_problem* P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
                    const double* inputLastIn, int level, int32_t* dims /*nz, rows, numDec*/, double* H, double* c, double* D, double* f, double* sol, double* xLevel) {

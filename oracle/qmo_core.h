@@ -197,7 +197,7 @@ inline void householderQR(const Mat& A, Mat& Q, Mat& Rout) {
 #if defined(__clang__)
 #error "qmo_core.h: kernelFullPivLU relies on GCC's optimize(\"fp-contract=off\") attribute; build the oracle with g++ (oracle/Makefile) or add -ffp-contract=off for this compiler"
 #endif
-__attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr, std::vector<int>* freeOut = nullptr) {
+__attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivLU(const Mat& Ain, int* rankOut = nullptr, std::vector<int>* freeOut = nullptr, std::vector<int>* pivSeqOut = nullptr /* (row, column) POSITIONS of every pivot at the time it was chosen */) {
   Mat A = Ain;
   const int rows = A.r, cols = A.c, size = std::min(rows, cols);
   std::vector<int> colPerm(cols);
@@ -209,6 +209,7 @@ __attribute__((optimize("fp-contract=off"), noinline)) inline Mat kernelFullPivL
     int pr = k, pc = k; double best = 0.0;
     for (int j = k; j < cols; ++j) for (int i = k; i < rows; ++i) if (std::fabs(A(i, j)) > best) { best = std::fabs(A(i, j)); pr = i; pc = j; }
     if (best == 0.0) break;
+    if (pivSeqOut) { pivSeqOut->push_back(pr); pivSeqOut->push_back(pc); }
     maxPivot = std::max(maxPivot, best);
     if (pr != k) for (int j = 0; j < cols; ++j) std::swap(A(k, j), A(pr, j));
     if (pc != k) { for (int i = 0; i < rows; ++i) std::swap(A(i, k), A(i, pc)); std::swap(colPerm[k], colPerm[pc]); }

@@ -195,6 +195,15 @@ class Oracle:
         it = self.lib.qmo_qp_solve(n, m, p(np.ascontiguousarray(H)), p(np.ascontiguousarray(c)), p(np.ascontiguousarray(D)), p(np.ascontiguousarray(f)), p(z), C.byref(res))
         return it, z, res.value
 
+    def kernel_full_piv_lu(self, A):
+        """oracle/qmo_core.h kernelFullPivLU: (basis [cols][dimker], free columns, pivot positions [(row, column), ...])"""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        r, c = A.shape
+        ker, free, seq, npiv = np.zeros((c, c)), np.zeros(c, dtype=np.int32), np.zeros(2 * min(r, c), dtype=np.int32), C.c_int32(0)
+        self.lib.qmo_kernel_full_piv_lu.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
+        dim = self.lib.qmo_kernel_full_piv_lu(r, c, p(A), p(ker), p(free), p(seq), C.byref(npiv))
+        return ker[:, :dim].copy(), free[:dim].tolist(), [(int(seq[2 * k]), int(seq[2 * k + 1])) for k in range(npiv.value)]
+
     def wbc_level(self, level, x_des, u_des, rbd, mode, period, time, input_last, variant=0):
         dims = np.zeros(3, dtype=np.int32)
         H, c, D, f, sol, xl = np.zeros(128 * 128), np.zeros(128), np.zeros(160 * 128), np.zeros(160), np.zeros(128), np.zeros(36)

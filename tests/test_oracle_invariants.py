@@ -412,6 +412,81 @@ def test_full_size_hoqp_levels_against_a_primal_active_set_method(interface, ora
     assert checked >= 25 and undecided <= 3
 
 
+def _eigen_full_piv_lu(A, column_major=True):
+    """Independent numpy restatement of Eigen 3.3's FullPivLU::computeInPlace + kernel() (upstream: bottomRightCorner(..).cwiseAbs().maxCoeff(&row, &col) is a scalar
+    visitor over a column-major expression: column by column, first strict maximum).  column_major=False: the row-by-row scan of round 4, kept to show that the test
+    tells the two orders apart.  Returns (pivot positions, kernel basis with a 1 on each free column, free columns)."""
+    A = np.array(A, dtype=np.float64); r, c = A.shape; perm = list(range(c)); seq = []
+    for k in range(min(r, c)):
+        best, pr, pc = 0.0, k, k
+        scan = ((i, j) for j in range(k, c) for i in range(k, r)) if column_major else ((i, j) for i in range(k, r) for j in range(k, c))
+        for i, j in scan:
+            if abs(A[i, j]) > best:
+                best, pr, pc = abs(A[i, j]), i, j
+        if best == 0.0:
+            break
+        seq.append((pr, pc))
+        A[[k, pr]] = A[[pr, k]]; A[:, [k, pc]] = A[:, [pc, k]]; perm[k], perm[pc] = perm[pc], perm[k]
+        for i in range(k + 1, r):
+            f = A[i, k] / A[k, k]
+            A[i, k + 1:] = A[i, k + 1:] - f * A[k, k + 1:]
+    piv = np.abs(np.array([A[k, k] for k in range(len(seq))]))
+    ok = [k for k in range(len(seq)) if piv[k] > piv.max() * 2.220446049250313e-16 * min(r, c)]
+    freep = [j for j in range(c) if j not in ok]
+    N = np.zeros((c, len(freep)))
+    for col, fp in enumerate(freep):
+        x = {}
+        for k in reversed(ok):
+            s_ = -A[k, fp] if fp >= k else 0.0
+            for k2 in ok:
+                if k2 > k:
+                    s_ -= A[k, k2] * x[k2]
+            x[k] = s_ / A[k, k]
+        for k in ok:
+            N[perm[k], col] = x[k]
+        N[perm[fp], col] = 1.0
+    return seq, N, [perm[fp] for fp in freep]
+
+
+def test_kernel_basis_follows_eigens_pivot_order(interface, oracle):
+    """HoQp.cpp:129 takes Eigen's fullPivLu().kernel(): the basis depends on the pivot order wherever magnitudes tie, and the level tasks carry unit rows -- ties are the
+    rule.  Three matrices with HAND-DERIVED pivot sequences (Eigen's column-major visitor: first strict maximum column by column):
+      M1 = [0 0 0 1; 1 0 1 0]: column 0 holds the first 1 at row 1 -> pivot (1, 0) [a row-by-row scan takes (0, 3)]; after the row swap the corner row is [0 0 1] ->
+           pivot position (1, 3); pivot columns {0, 3}, free {2, 1} in position order; basis [-1 0 1 0], [0 1 0 0]  (row-by-row: free {0, 1}, basis [1 0 -1 0], [0 1 0 0])
+      M2 = [1 1 0; 1 0 1]: pivot (0, 0); row 1 becomes [0 -1 1]: |-1| = |1| ties -> the smaller column, position (1, 1); free {2}; basis [-1 1 1]
+      M3 = [0 1 1; 0 1 -1; 2 0 0] / tied unit rows around a larger entry: pivot (2, 0) (the 2), then the corner [1 1; 1 -1] -> (1, 1)... derived below
+    and one A Z of a real stance tick (18 x 36, level 0) against the independent numpy restatement above -- same pivots, same basis to 1e-12."""
+    M1 = np.array([[0, 0, 0, 1], [1, 0, 1, 0]], dtype=float)
+    ker, free, seq = oracle.kernel_full_piv_lu(M1)
+    assert seq == [(1, 0), (1, 3)] and free == [2, 1]
+    assert np.array_equal(ker, np.array([[-1, 0], [0, 1], [1, 0], [0, 0]], dtype=float))
+    M2 = np.array([[1, 1, 0], [1, 0, 1]], dtype=float)
+    ker, free, seq = oracle.kernel_full_piv_lu(M2)
+    assert seq == [(0, 0), (1, 1)] and free == [2] and np.array_equal(ker[:, 0], np.array([-1.0, 1.0, 1.0]))
+    # M3: step 0: the 2 at (2, 0).  Rows 0 and 2 swap: [2 0 0 0; 0 1 -1 0; 0 1 1 1].  Step 1: corner columns 1..3, rows 1..2, column by column: |1| at (1, 1) first
+    # -> pivot (1, 1), no swap; row 2 becomes [0 0 2 1].  Step 2: corner [2 1] -> (2, 2).  Pivot columns {0, 1, 2}, free {3}: 2 x2 = -1 -> x2 = -1/2, x1 = x2 = -1/2, x0 = 0
+    M3 = np.array([[0, 1, 1, 1], [0, 1, -1, 0], [2, 0, 0, 0]], dtype=float)
+    ker, free, seq = oracle.kernel_full_piv_lu(M3)
+    assert seq == [(2, 0), (1, 1), (2, 2)] and free == [3] and np.array_equal(ker[:, 0], np.array([0.0, -0.5, -0.5, 1.0]))
+    for M in (M1, M2, M3):      # the numpy restatement agrees with the hand derivation as well
+        s_, N_, f_ = _eigen_full_piv_lu(M)
+        k_, fr_, sq_ = oracle.kernel_full_piv_lu(M)
+        assert s_ == sq_ and f_ == fr_ and np.array_equal(N_, k_)
+    # a real level-0 task of a trot stance tick (LF_RH): equations of motion, contact rows, zero-force rows of the swing legs
+    xd = S.perturbed_states(interface.initial_state, 1, seed=8)[0]
+    ud = np.zeros(30); ud[[2, 11]] = interface.robot_mass * 9.81 / 2
+    rbd = S.rbd_from_state(oracle, xd)
+    tk = oracle.wbc_task(0, xd, ud, rbd, 9, 0.002, 20.0, np.zeros(30))
+    A = tk["A"]
+    assert A.shape == (18, 36)
+    ker, free, seq = oracle.kernel_full_piv_lu(A)
+    s_, N_, f_ = _eigen_full_piv_lu(A)
+    assert seq == s_ and free == f_ and ker.shape == (36, 18)
+    assert np.abs(ker - N_).max() <= 1e-12 * max(1.0, np.abs(N_).max()) and np.abs(A @ ker).max() <= 1e-9
+    # (on THIS matrix the two scan orders agree -- its unit rows are ordered like their columns; M1 above is the case that tells them apart)
+    assert _eigen_full_piv_lu(M1, column_major=False)[0] == [(0, 3), (1, 2)]
+
+
 def test_every_level_ends_at_the_same_vertex_whatever_the_path(interface, oracle):
     """Every HoQP level ends with a primal active-set method (oracle/qmo_wbc.h activeSetPhase): the point it returns satisfies the KKT conditions on its working set and is
     THE minimiser -- so it cannot depend on how the method got there.  512 random instances over every contact mode, robots in motion, both controllers, three paths: the
