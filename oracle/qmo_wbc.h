@@ -328,6 +328,7 @@ constexpr int kAsMaxWorkingSetChanges = 100; // nWSR of HoQp.cpp:141
 inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting value of the interior point = another path to the same vertex (tests: the result must not depend on it)
 inline int g_expNoMinNormStart = 0;                      // 1: the first level without its minimum-norm start (tests: same torques)
 inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
+inline int g_expGuessOrder = 1;
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
 struct QpStats { int ipmIterations = 0, iterations = 0, adds = 0, drops = 0, zeroSteps = 0, innerSteps = 0, eliminated = 0, status = 0; bool minNorm = false; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed
@@ -518,7 +519,14 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     Mat K = q.G0;       // (without HoQp's regulariser: a direction it alone would carry counts as having no curvature, below)
     std::vector<int> pin;      // the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
     for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && !guess[r]) pin.push_back(r);
-    for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && guess[r]) pin.push_back(r);
+    { // (the guessed rows by decreasing multiplier estimate of the interior point, lam |d|: of two guessed rows that depend on each other -- the two sides of a friction
+      //  pyramid at its apex -- the one with the smaller estimate then shows the vanishing pivot and leaves; in index order it was the later one, the wrong one half of
+      //  the time: released with a negative multiplier one iteration later, the other pinned by a zero-length step after that -- two factorisations for nothing)
+      std::vector<int> gs;
+      for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && guess[r]) gs.push_back(r);
+      if (start && start->usable && g_expGuessOrder) std::stable_sort(gs.begin(), gs.end(), [&](int a, int b) { return start->lam[a] * w.dn[a] > start->lam[b] * w.dn[b]; });
+      for (int r : gs) pin.push_back(r);
+    }
     for (int r = 0; r < m; ++r) {
       if (!rowOn[r] || state[r] == I) continue;
       const double wr = state[r] == P ? w.wP[r] : 1.0;

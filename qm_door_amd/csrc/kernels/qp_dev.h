@@ -442,7 +442,21 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     if (k > QP_KMAX) { status = 4; break; }
     // this lane's place among the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
     const unsigned long long tightMask = qmBallot(pinned && !guess), below = (1ull << lane) - 1ull;
-    const int slot = (pinned && guess) ? qmPopCount(tightMask) + qmPopCount(pinMask & ~tightMask & below) : qmPopCount(tightMask & below);
+    int slot = qmPopCount(tightMask & below);
+    if (pinMask != tightMask) {
+      // the guessed rows by decreasing multiplier estimate of the interior point, lam |d| (ties: smaller index): of two guessed rows that depend on each other -- the two
+      // sides of a friction pyramid at its apex -- the one with the smaller estimate then shows the vanishing pivot and leaves (the CPU restatement has the numbers)
+      const double key = l1 * dn;
+      int rank = 0;
+      unsigned long long gm = pinMask & ~tightMask;
+#pragma unroll 1
+      while (gm != 0ull) {
+        const int b = qmFirstBit(gm); gm &= gm - 1ull;
+        const double kb = qmReadLane(key, b, red);
+        rank += (kb > key || (kb == key && b < lane)) ? 1 : 0;
+      }
+      if (pinned && guess) slot = qmPopCount(tightMask) + rank;
+    }
     factorise(rowOn ? (state == ST_P ? wA : (state == ST_V ? 1.0 : 0.0)) : 0.0);
     if (!(allSum(myInv) == allSum(myInv))) { status = 2; break; }
     QM_TICK(7);
@@ -453,11 +467,9 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       // row `slot` of the LDS square (the K tiles are no longer needed).  (A lane-per-row substitution over L in LDS, fully unrolled, was 630 terms of straight-line
       // code per instantiation: 74 cycles per term at NP = 36, the function no longer fits the instruction cache.)
       {
-        unsigned long long tm = tightMask, gm = pinMask & ~tightMask;
 #pragma unroll 1
         for (int sidx = 0; sidx < k; ++sidx) {
-          int rowI;
-          if (tm != 0ull) { rowI = qmFirstBit(tm); tm &= tm - 1ull; } else { rowI = qmFirstBit(gm); gm &= gm - 1ull; }
+          const int rowI = qmFirstBit(qmBallot(pinned && slot == sidx));
           const double d = DZ[rowI * LDZ_ + colL];
           const double t = forward(colOn ? d : 0.0);
           QM_WAVE_SYNC();
