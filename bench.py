@@ -39,6 +39,7 @@ def _test_support():
 
 BATCH_PER_GPU = 256
 HORIZON_N = 100
+OVERLAP = True     # --no-overlap: the WBC of a cycle on the compute stream itself (qmgpu_set_overlap off); see config.overlap in the line
 CONFIG3_GLOBAL_BATCH = 2048           # BASELINE.json configs[2]
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X public spec, v_mfma_f64_16x16x4_f64 (not listed in MI355X_MICROARCH.md)
 
@@ -111,6 +112,7 @@ def steady_state(itf, sc, steps, warmup, emulate=False):
     total = warmup + steps
     dist_ = CL.Disturbance(B, np.random.default_rng(5))
     sol = G.make_solver(itf, B, N)
+    sol.set_overlap(OVERLAP)
     z = lambda *shape, dtype=f64: torch.zeros(shape, dtype=dtype, device=G.DEVICE)  # noqa: E731
     sets = [dict(T=z(B, N + 1), X=z(B, N + 1, 30), U=z(B, N, 30), M=z(B, N + 1, dtype=torch.int32), S=z(B, abi.NSTATS)) for _ in range(2)]
     wx, wu = z(B, N + 1, 30), z(B, N, 30)
@@ -282,6 +284,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-steady-state", action="store_true", help="skip config.steady_state (the receding-horizon leg, N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="qmgpu_set_overlap off: every kernel of a step on one stream, one after the other (the kernel times then add up to the step)")
     ap.add_argument("--force-collective", action="store_true",
                     help="single process: run the N > 1 code path (pack -> RCCL all_gather_into_tensor -> unpack) on a 1-rank nccl group and verify it")
     ap.add_argument("--emulate", action="store_true",
@@ -291,6 +294,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=CONFIG3_GLOBAL_BATCH, help="only with --emulate: size of the ONE global batch of configs[2] (2048), so that a toy run reaches the 'all of it' branch")
     ap.add_argument("--sweep", action="store_true", help="N = 1 only: also time 512 / 1024 / 2048 instances on the one GPU (config.batch_sweep)")
     args = ap.parse_args()
+    global OVERLAP
+    OVERLAP = not args.no_overlap
     if not args.emulate and (args.batch_per_gpu != BATCH_PER_GPU or args.nodes != HORIZON_N):
         raise SystemExit("--batch-per-gpu / --nodes change the workload BASELINE.json names: allowed with --emulate only")
 
@@ -347,8 +352,14 @@ def main():
         workload = f"configs[1]: batch={B} MPC instances per GPU, horizon N={N}, dt=0.015, trot, 1 SQP iteration + filter line search + 3-level WBC"
     assert hi - lo == B if world > 1 else True
 
+    def make_buffers(sc_, b):
+        mb_ = G.MpcBatch(sc_["x0"], sc_["tt"], sc_["ts"], np.full(b, sc_["nev"], dtype=np.int32), np.tile(sc_["ev"], (b, 1)), np.tile(sc_["md"], (b, 1)), N)
+        wb_ = G.WbcBatch(sc_["rbd"], np.full(b, 0.002), np.full(b, 20.0), np.zeros((b, 30)))
+        return mb_, wb_
+
     def make(sc_, b):
         sol_ = G.make_solver(itf, b, N)
+        sol_.set_overlap(OVERLAP)
         mb_ = G.MpcBatch(sc_["x0"], sc_["tt"], sc_["ts"], np.full(b, sc_["nev"], dtype=np.int32), np.tile(sc_["ev"], (b, 1)), np.tile(sc_["md"], (b, 1)), N)
         wb_ = G.WbcBatch(sc_["rbd"], np.full(b, 0.002), np.full(b, 20.0), np.zeros((b, 30)))
         return sol_, mb_, wb_, G.dev(np.zeros(b), torch.float64)
@@ -366,16 +377,45 @@ def main():
         if not args.emulate:
             torch.cuda.synchronize()
 
+    # With the overlap on, the WBC of step k is still running when qmgpu_cycle_batch returns.  The gather of step k is therefore enqueued one step LATE, behind
+    # qmgpu_cycle_batch(k + 1) -- which has made the compute stream wait for WBC k before its own policy evaluation -- from a second set of output buffers (the solver
+    # alternates between two), so nothing of step k is overwritten before it is packed; the last step's gather follows a qmgpu_join_wbc in drain().  Every gather is inside the
+    # timed region, as before.
+    from qm_door_amd import api as _api
+    two_sets = collective and OVERLAP
+    mbs, wbs = [mb], [wb]
+    if two_sets:
+        mb1, wb1 = make_buffers(sc, B)
+        wb1.il = wb.il      # inputLast_ is carried from step to step: one buffer
+        wb1.args = _api.GpuSolver.wbc_args(B, wb1.rbd, wb1.period, wb1.time, wb1.il, wb1.out, wb1.status)
+        mbs.append(mb1); wbs.append(wb1)
+    state = {"k": 0, "pending": None}
+
+    def gather_of(i):
+        packed = sharding.pack(mbs[i].oX, mbs[i].oU, wbs[i].out, mbs[i].oM)
+        if inflight["work"] is not None:
+            inflight["work"].wait()
+        inflight["work"] = dist.all_gather_into_tensor(gathered, packed, async_op=True)
+        inflight["buf"] = packed
+
     def step():
-        sol.cycle(mb.args, t_eval, wb.args)
+        cur = state["k"] % len(mbs)
+        sol.cycle(mbs[cur].args, t_eval, wbs[cur].args)
+        state["k"] += 1
+        state["last"] = cur
         if collective:
-            packed = sharding.pack(mb.oX, mb.oU, wb.out, mb.oM)
-            if inflight["work"] is not None:
-                inflight["work"].wait()
-            inflight["work"] = dist.all_gather_into_tensor(gathered, packed, async_op=True)
-            inflight["buf"] = packed
+            if two_sets:
+                if state["pending"] is not None:
+                    gather_of(state["pending"])
+                state["pending"] = cur
+            else:
+                gather_of(cur)
 
     def drain():
+        if two_sets and state["pending"] is not None:
+            sol.join_wbc()
+            gather_of(state["pending"])
+            state["pending"] = None
         if inflight["work"] is not None:
             inflight["work"].wait()
             inflight["work"] = None
@@ -405,7 +445,7 @@ def main():
     kernel_ms = sol.kernel_ms_mean(args.steps)  # [ad, lq, riccati, linesearch, wbc, whole]
     sol.enable_timing(False)
 
-    res = mb.results(); wres = wb.results()
+    res = mbs[state.get("last", 0)].results(); wres = wbs[state.get("last", 0)].results()
     ok = bool(np.isfinite(res["X"]).all() and np.isfinite(wres["out"]).all() and (res["stats"][:, 7] == 0).all() and (wres["status"] == 0).all())
     gather_ok = None
     if collective:   # this rank's block of the gathered tensor is what it solved, bit for bit; every other block is finite and carries that rank's initial states
@@ -470,6 +510,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not args.emulate else "synthetic; HOST-EMULATED kernels (tests/emu) -- a functional test of the multi-rank path, not a measurement",
             "config": {"workload": workload,
+                       "overlap": ("the WBC launch of step k runs on a second stream of the handle (qmgpu_set_overlap) next to the node kernels of step k + 1: a WBC launch lasts as long as its slowest instance, "
+                                   "the CUs its fast instances leave are filled by ad_node / lq_node of the next step (the reference runs MPC and WBC in different threads); every step's outputs are produced, "
+                                   "the timed region ends with a device-wide synchronisation; kernel_ms are per-launch HIP-event durations and now overlap (their sum exceeds ms_per_step); --no-overlap: one stream"
+                                   + ("; the all-gather of step k is enqueued behind the launch of step k + 1, from alternating output buffers" if collective else "")) if OVERLAP else "off (--no-overlap): one stream, kernels back to back",
                        "wbc_inputs": "headline: robots at rest, t = 20 s, FIRST tick (inputLast_ = 0: the reference's spurious first-tick joint accelerations, torque limits active); the moving-robot, carried-inputLast_ regime is config.steady_state",
                        "batch_per_gpu": B, "global_batch": world * B, "horizon_nodes": N, "gait": "trot", "seed": 0 if world == 1 else 1, "results_finite_and_converged": ok,
                        "collective": ("all_gather(X,U,tau,mode) over " + ("gloo (emulation)" if args.emulate else "RCCL")) if collective else "none",

@@ -183,6 +183,12 @@ int qmgpu_destroy(qmgpu_handle h);
 /* Use an externally owned HIP stream (hipStream_t passed as void*); NULL restores the handle's own stream. */
 int qmgpu_set_stream(qmgpu_handle h, void* hip_stream);
 int qmgpu_synchronize(qmgpu_handle h);
+/* Optional (default off): the WBC launch of qmgpu_cycle_batch goes to a second stream owned by the handle, ordered behind the cycle's policy evaluation.  A WBC launch lasts as
+ * long as its slowest instance while most CUs have finished theirs; the node kernels of the NEXT qmgpu_cycle_batch (which do not depend on it -- the reference runs its MPC and
+ * its WBC in different threads, QMController.cpp:116-157 / 316-327) then fill those CUs.  With the option on, the WBC outputs of a cycle are complete after qmgpu_synchronize,
+ * or on the handle's stream after qmgpu_join_wbc (a device-side wait, no host wait) -- NOT after the caller synchronises its own stream; every other entry point joins first. */
+int qmgpu_set_overlap(qmgpu_handle h, int enable);
+int qmgpu_join_wbc(qmgpu_handle h);
 /* Replace the settings behind a live handle (gains, weights, limits, barrier parameters; the model is fixed at create time):
  * what the reference's dynamic_reconfigure callbacks do at run time (WbcBase::dynamicCallback, qm_wbc/src/WbcBase.cpp:74-121;
  * QMController::dynamicCallback, qm_controllers/src/QMController.cpp:358-363).  Ordered on the handle's stream: calls enqueued

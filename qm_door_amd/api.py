@@ -108,6 +108,13 @@ class GpuSolver:
     def synchronize(self):
         abi.check(self.lib, self.lib.qmgpu_synchronize(self.handle))
 
+    def set_overlap(self, on=True):
+        """qmgpu_set_overlap: the WBC of cycle() on a stream of its own, next to the following cycle's node kernels; its outputs are complete after synchronize() / join_wbc()"""
+        abi.check(self.lib, self.lib.qmgpu_set_overlap(self.handle, int(on)))
+
+    def join_wbc(self):
+        abi.check(self.lib, self.lib.qmgpu_join_wbc(self.handle))
+
     def enable_timing(self, on=True):
         abi.check(self.lib, self.lib.qmgpu_enable_timing(self.handle, int(on)))
 

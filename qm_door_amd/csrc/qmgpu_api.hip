@@ -45,6 +45,10 @@ struct DeviceGuard {
 struct qmgpu_context {
   int device = 0, maxBatch = 0, maxNodes = 0;
   hipStream_t ownStream = nullptr, stream = nullptr;
+  // qmgpu_set_overlap: the WBC of qmgpu_cycle_batch runs on a stream of its own; the next cycle's node kernels fill the CUs its fast instances have left
+  hipStream_t wbcStream = nullptr;
+  hipEvent_t evPolicy = nullptr, evWbc = nullptr;
+  bool overlap = false, wbcPending = false;
   qmgpu_problem hostProblem;
   int dtype = QMGPU_F64;
   // device buffers of the fp64 kernels (MPC scratch, model / settings, R'); the WBC and the front end always run in fp64
@@ -154,6 +158,9 @@ int qmgpu_destroy(qmgpu_handle h) {
   int prev = -1;
   const bool sw = hipGetDevice(&prev) == hipSuccess && prev != h->device && hipSetDevice(h->device) == hipSuccess;
   hipStreamSynchronize(h->stream);
+  if (h->wbcStream) { hipStreamSynchronize(h->wbcStream); hipStreamDestroy(h->wbcStream); }
+  if (h->evPolicy) hipEventDestroy(h->evPolicy);
+  if (h->evWbc) hipEventDestroy(h->evWbc);
   for (void* p : h->allocations) hipFree(p);
   for (auto& set : h->ring) for (auto& e : set) if (e) hipEventDestroy(e);
   if (h->ownStream) hipStreamDestroy(h->ownStream);
@@ -163,15 +170,41 @@ int qmgpu_destroy(qmgpu_handle h) {
   return QMGPU_OK;
 }
 
+// the handle's stream waits for a WBC still running on the overlap stream (no host wait); after it everything is ordered on h->stream again
+static void joinWbc(qmgpu_handle h) {
+  if (h->wbcPending) { HIP_CHECK(hipStreamWaitEvent(h->stream, h->evWbc, 0)); h->wbcPending = false; }
+}
+
 int qmgpu_set_stream(qmgpu_handle h, void* hip_stream) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->ownStream;
-  return QMGPU_OK;
+  return guarded([&]() { DeviceGuard onDevice(h->device); joinWbc(h); h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->ownStream; });
 }
 
 int qmgpu_synchronize(qmgpu_handle h) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); HIP_CHECK(hipStreamSynchronize(h->stream)); });
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device); joinWbc(h); HIP_CHECK(hipStreamSynchronize(h->stream)); });
+}
+
+int qmgpu_set_overlap(qmgpu_handle h, int enable) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() { DeviceGuard onDevice(h->device);
+    joinWbc(h);
+    if (enable && !h->evWbc) {
+      // a HIGH-PRIORITY stream: the runtime spreads streams of one priority over a few hardware queues round robin, and two streams that land on the same queue run
+      // their kernels one after the other (measured: the second handle of a process got no overlap at all); priority levels have hardware queues of their own
+      int least = 0, greatest = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_CHECK(hipStreamCreateWithPriority(&h->wbcStream, hipStreamNonBlocking, greatest));
+      HIP_CHECK(hipEventCreateWithFlags(&h->evPolicy, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&h->evWbc, hipEventDisableTiming));
+    }
+    h->overlap = enable != 0;
+  });
+}
+
+int qmgpu_join_wbc(qmgpu_handle h) {
+  if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
+  return guarded([&]() { DeviceGuard onDevice(h->device); joinWbc(h); });
 }
 
 int qmgpu_update_settings(qmgpu_handle h, const qmgpu_settings* settings) {
@@ -286,12 +319,12 @@ static void enqueueMpc(qmgpu_handle h, const qmgpu_mpc_args* a) {
   h->lastBatch = a->batch; h->lastN = a->num_nodes;
 }
 
-static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w) {
+static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w, hipStream_t stream) {
   if (!w || w->batch < 1) throw std::invalid_argument("bad WBC arguments");
   if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
   if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
   WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, w->ee_force};
-  QM_LAUNCH_DYN(wbc_kernel, w->batch, WBC_THREADS, WBC_LDS_BYTES, h->stream, wa);
+  QM_LAUNCH_DYN(wbc_kernel, w->batch, WBC_THREADS, WBC_LDS_BYTES, stream, wa);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -363,9 +396,10 @@ int qmgpu_gait_schedule_batch(qmgpu_handle h, int batch, const qmgpu_gait* templ
 int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
+    joinWbc(h);
     beginTiming(h);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
-    enqueueWbc(h, args);
+    enqueueWbc(h, args, h->stream);
     if (h->timing) HIP_CHECK(hipEventRecord(h->ev[5], h->stream));
     finishTiming(h, false, true);
   });
@@ -389,13 +423,21 @@ int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t
     if (wbc->batch != mpc->batch) throw std::invalid_argument("MPC and WBC batch sizes differ");
     beginTiming(h);
     enqueueMpc(h, mpc);
+    joinWbc(h);      // (overlap: the previous cycle's WBC still reads the policy buffers -- it ran next to the node kernels just enqueued)
     QM_LAUNCH(policy_eval_kernel, mpc->batch, 64, h->stream, mpc->batch, mpc->num_nodes, mpc->out_t, mpc->out_x, mpc->out_u, mpc->out_mode, t_eval, h->dPolX, h->dPolU,
               h->dPolMode);
-    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
     qmgpu_wbc_args w = *wbc;
     w.state_desired = h->dPolX; w.input_desired = h->dPolU; w.mode = h->dPolMode;
-    enqueueWbc(h, &w);
-    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[5], h->stream));
+    hipStream_t ws = h->stream;
+    if (h->overlap) {
+      HIP_CHECK(hipEventRecord(h->evPolicy, h->stream));
+      HIP_CHECK(hipStreamWaitEvent(h->wbcStream, h->evPolicy, 0));
+      ws = h->wbcStream;
+    }
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[4], ws));
+    enqueueWbc(h, &w, ws);
+    if (h->timing) HIP_CHECK(hipEventRecord(h->ev[5], ws));
+    if (h->overlap) { HIP_CHECK(hipEventRecord(h->evWbc, ws)); h->wbcPending = true; }
     finishTiming(h, true, true);
   });
 }

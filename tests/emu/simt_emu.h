@@ -240,11 +240,17 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { s
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return 0; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* l, int* g) { *l = 0; *g = 0; return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }   // (launches are synchronous on the host: every event has happened)
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0); return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new double(0); return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }

@@ -324,3 +324,30 @@ def test_emu_dense_tracking_weights_take_the_general_path():
         assert np.abs(oX[i] - ref["X"]).max() <= 1e-8 * max(1.0, np.abs(ref["X"]).max())
         assert np.abs(oU[i] - ref["U"]).max() <= 1e-8 * max(1.0, np.abs(ref["U"]).max())
         assert np.allclose(oS[i][:7], ref["stats"][:7], rtol=1e-8, atol=1e-10)      # merit before / after the step includes the off-diagonal terms
+
+
+def test_emu_cycle_with_the_overlap_option(emu):
+    """qmgpu_set_overlap / qmgpu_join_wbc through the host-emulated library: the code path of the second stream (events, joins, the carried inputLast_) executes and two
+    cycles give the torques of two cycles without it, bit for bit (on the host every launch is synchronous: this checks the plumbing, the GPU test checks the schedule)."""
+    itf, orc = emu
+    B, N = 1, 4
+    x0 = S.perturbed_states(itf.initial_state, B, seed=5)
+    tgt = S.nominal_target(orc, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = api.GaitSchedule(lib=itf.lib).mode_schedule("trot", 0.0, 0.0, 1.0)
+    rbd = np.zeros((B, 55)); rbd[:, 0:3] = x0[:, 9:12]; rbd[:, 3:6] = x0[:, 6:9]; rbd[:, 6:24] = x0[:, 12:30]
+    outs = []
+    for overlap in (False, True):
+        sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+        sol.set_overlap(overlap)
+        oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+        a = sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), ev[None, :].copy(), md[None, :].copy(), oT, oX, oU, oM, oS, t0=np.zeros(B))
+        il, out, st = np.zeros((B, 30)), np.zeros((B, 54)), np.zeros(B, dtype=np.int32)
+        w = sol.wbc_args(B, rbd, np.full(B, 0.002), np.full(B, 20.0), il, out, st)
+        for _ in range(2):
+            sol.cycle(a, np.zeros(B), w)
+        sol.join_wbc(); sol.synchronize()
+        outs.append((out.copy(), il.copy(), int(st[0])))
+        sol.close()
+    assert outs[0][2] == 0 and np.isfinite(outs[0][0]).all() and np.abs(outs[0][1]).max() > 0
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

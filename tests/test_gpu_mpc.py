@@ -199,3 +199,56 @@ def test_receding_horizon_cycles_with_device_warm_start(interface, oracle):
             assert r["stats"][1] < ref[i]["stats"][1] or cycle > 1            # the warm start begins closer to feasibility than the cold start did
             ref[i] = r
         mb, prev = nb, cur
+
+
+def test_wbc_overlap_stream_changes_nothing_but_the_schedule(interface, oracle):
+    """qmgpu_set_overlap (include/qmgpu.h): the WBC launch of qmgpu_cycle_batch on a second stream of the handle, next to the NEXT cycle's node kernels.  Six cycles back to
+    back on two alternating sets of inputs (so that a policy buffer or an inputLast_ read too early, or overwritten too late, would show), inputLast_ carried, no host
+    synchronisation in between: outputs of every cycle bit-identical to the same sequence on one stream; qmgpu_join_wbc orders the handle's stream behind the pending WBC
+    (a copy enqueued on that stream afterwards sees the finished torques); every other entry point joins by itself (qmgpu_wbc_solve_batch on the carried inputLast_)."""
+    import torch
+    import gpu_harness as G
+    B, N, cycles = 96, 30, 6
+    rng = np.random.default_rng(3)
+    x0, tt, ts, nev, ev, md = _scenario(interface, oracle, B, N, seed=21)
+    sn, se, sm = np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)), np.tile(md, (B, 1))
+    x0b = x0 + 0.02 * rng.standard_normal(x0.shape)
+
+    def rbd_of(x):
+        r = np.zeros((B, 55)); r[:, 0:3] = x[:, 9:12]; r[:, 3:6] = x[:, 6:9]; r[:, 6:24] = x[:, 12:30]; r[:, 24:48] = 0.05 * rng.standard_normal((B, 24))
+        return r
+    rbds = [rbd_of(x0), rbd_of(x0b)]
+
+    def run(overlap):
+        sol = G.make_solver(interface, B, N)
+        sol.set_overlap(overlap)
+        mbs = [G.MpcBatch(x, tt, ts, sn, se, sm, N) for x in (x0, x0b)]
+        il = G.dev(np.zeros((B, 30)), torch.float64)
+        outs = [torch.zeros((B, 54), dtype=torch.float64, device="cuda") for _ in range(cycles)]
+        stats = [torch.zeros(B, dtype=torch.int32, device="cuda") for _ in range(cycles)]
+        rb = [G.dev(r, torch.float64) for r in rbds]
+        per, tim, te = G.dev(np.full(B, 0.002), torch.float64), G.dev(np.full(B, 20.0), torch.float64), G.dev(np.full(B, 0.004), torch.float64)
+        from qm_door_amd import api
+        keep = []
+        for k in range(cycles):
+            w = api.GpuSolver.wbc_args(B, rb[k & 1], per, tim, il, outs[k], stats[k])
+            keep.append(w)
+            sol.cycle(mbs[k & 1].args, te, w)
+        sol.join_wbc()
+        copy_on_stream = outs[-1].clone()          # enqueued on the handle's (= torch's current) stream behind the join
+        # one more WBC through the stand-alone entry point: it must see the inputLast_ the last cycle's WBC wrote
+        extra = torch.zeros((B, 54), dtype=torch.float64, device="cuda")
+        xd, ud, mode = G.dev(x0, torch.float64), G.dev(np.zeros((B, 30)), torch.float64), G.dev(np.full(B, 15), torch.int32)
+        w2 = api.GpuSolver.wbc_args(B, rb[0], per, tim, il, extra, stats[0], xd, ud, mode)
+        sol.wbc(w2)
+        sol.synchronize()
+        res = dict(outs=[o.cpu().numpy() for o in outs], copy=copy_on_stream.cpu().numpy(), extra=extra.cpu().numpy(), il=il.cpu().numpy(), X=[m.oX.cpu().numpy() for m in mbs],
+                   status=[s_.cpu().numpy() for s_ in stats])
+        sol.close()
+        return res
+    a, b = run(False), run(True)
+    for k in range(cycles):
+        assert np.isfinite(a["outs"][k]).all() and np.array_equal(a["outs"][k], b["outs"][k]), k
+    assert np.array_equal(b["copy"], b["outs"][-1])
+    assert np.array_equal(a["extra"], b["extra"]) and np.array_equal(a["il"], b["il"]) and all(np.array_equal(p_, q_) for p_, q_ in zip(a["X"], b["X"]))
+    assert not np.array_equal(a["outs"][2], a["outs"][3])      # the two input sets (and the carried inputLast_) really give different cycles
