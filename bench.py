@@ -169,7 +169,8 @@ def steady_state(itf, sc, steps, warmup, emulate=False):
     speed = np.abs(np.concatenate([r["rbd"].cpu().numpy()[:, 24:48] for r in rec[warmup:]])).mean(axis=0)
     res = {"value": B * steps / elapsed, "unit": "cycles/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "what": "receding horizon: shifted grid (10 ms per step), device-resampled warm start of every solve (qmgpu_warm_start_batch inside the timed region), policy evaluated between "
-                   "nodes, WBC on robots in motion (plan-following measurement + seeded disturbance, inputLast_ carried); replay of a recorded input sequence, inputs resident",
+                   "nodes, WBC on robots in motion (plan-following measurement + seeded disturbance, inputLast_ carried); replay of a recorded input sequence, inputs resident"
+                   + ("; the WBC of step k next to the node kernels of step k + 1 (config.overlap): kernel_ms are overlapping intervals" if OVERLAP else ""),
            "kernel_ms": dict(zip(["ad", "lq", "riccati", "linesearch", "wbc", "whole"], kms)),
            "replay_reproduces_the_recorded_run_bit_for_bit": same,
            "results_finite_and_converged": bool(np.isfinite(rec_last["X"]).all() and np.isfinite(rec_last["out"]).all() and (rec_last["stats"][:, 7] == 0).all() and (rec_last["status"] == 0).all()),
@@ -446,6 +447,18 @@ def main():
     sol.enable_timing(False)
 
     res = mbs[state.get("last", 0)].results(); wres = wbs[state.get("last", 0)].results()
+    # Per-kernel launch durations with the device to themselves (roofline): with the overlap on, ad_node of step k + 1 is LAUNCHED while the WBC of step k still holds the CUs
+    # and its HIP-event interval includes that wait (0.71 instead of 0.37 ms) -- not a property of the kernel.  A short calibration pass of the same cycle on one stream, after
+    # the timed region and outside `value`, gives the unobstructed durations; the kernels the overlap does not touch (lq_node, riccati, line search) measure the same in both.
+    kernel_ms_serial = kernel_ms
+    if OVERLAP and not args.emulate:
+        cal = max(5, min(args.steps, 20))
+        sol.set_overlap(False); sol.enable_timing(True)
+        for _ in range(cal):
+            sol.cycle(mbs[0].args, t_eval, wbs[0].args)
+        sync()
+        kernel_ms_serial = sol.kernel_ms_mean(cal)
+        sol.enable_timing(False); sol.set_overlap(True)
     ok = bool(np.isfinite(res["X"]).all() and np.isfinite(wres["out"]).all() and (res["stats"][:, 7] == 0).all() and (wres["status"] == 0).all())
     gather_ok = None
     if collective:   # this rank's block of the gathered tensor is what it solved, bit for bit; every other block is finite and carries that rank's initial states
@@ -483,7 +496,7 @@ def main():
             cnt = int((nc == v).sum())
             for k, f in node_flops(int(v)).items():
                 flops[k] += cnt * f
-        dom_name = max(flops, key=lambda k: kernel_ms[names.index(k)])   # longest launch among the kernels that carry algorithmic FLOPs
+        dom_name = max(flops, key=lambda k: kernel_ms_serial[names.index(k)])   # longest launch (device to itself) among the kernels that carry algorithmic FLOPs
         path_flops = flops["ad_node_kernel"] + flops["lq_node_kernel"] + flops["riccati_kernel"]
         roof_kernel = dom_name
         kms = kernel_ms[names.index(roof_kernel)]
@@ -491,10 +504,10 @@ def main():
         achieved = tf(flops[roof_kernel], kms)
         tag, ctr = profile_counters()
         traffic = ctr.get(roof_kernel, {}).get("bytes")
-        src = (f"profiles/{tag}_counters.json (separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --steps 5`, summarised by tools/make_profile_summaries.py; "
+        src = (f"profiles/{tag}_counters.json (separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-overlap --steps 5`, summarised by tools/make_profile_summaries.py; "
                "NOT measured in this run)") if tag else "no committed counter set"
         # HBM GB/s and matrix-core busy per kernel: counter values per launch (committed profile) over THIS run's HIP-event launch times
-        hbm = {k: (ctr[k]["bytes"] / (kernel_ms[names.index(k)] * 1e-3) / 1e9) for k in names if k in ctr and kernel_ms[names.index(k)] > 0}
+        hbm = {k: (ctr[k]["bytes"] / (kernel_ms_serial[names.index(k)] * 1e-3) / 1e9) for k in names if k in ctr and kernel_ms_serial[names.index(k)] > 0}
         busy = {k: ctr[k]["mfma_busy"] for k in names if k in ctr and "mfma_busy" in ctr[k]}
         out = {
             "metric": "MPC+WBC cycles/sec (AlienGo+Z1, N=100)",
@@ -532,11 +545,17 @@ def main():
                          "note": "algorithmic dense-contraction FLOPs of SURVEY.md 8(d) per launch / HIP-event kernel time; fp64 matrix peak is the public spec; "
                                  "the path is latency bound, not MFMA bound (DESIGN.md)",
                          "kernel_ms": dict(zip(names + ["whole_call"], kernel_ms)),
+                         "kernel_ms_one_stream": dict(zip(names + ["whole_call"], kernel_ms_serial)),
+                         "kernel_ms_note": "kernel_ms: HIP events over the TIMED region (with the overlap on, ad_node's interval includes its wait for the CUs the previous step's WBC still holds, and whole_call spans two "
+                                           "streams); kernel_ms_one_stream: the same cycle on one stream in a calibration pass after the timed region (outside `value`): what `kernel`, kernel_frac and hbm_gbps are computed "
+                                           "from; `achieved` / `frac` use the timed region's duration of `kernel` (the overlap does not touch riccati / lq_node)",
                          # launches within 5 % of the longest one: since round 3 the three FLOP-carrying kernels take 0.45-0.47 ms each, so which of them is
                          # "the dominant kernel" (the longest; `kernel`, `frac` above) changes from run to run -- their fractions are all in kernel_frac
-                         "dominant_within_5pct": [k for k in flops if kernel_ms[names.index(k)] >= 0.95 * kernel_ms[names.index(roof_kernel)]],
-                         "kernel_frac": {k: (tf(flops[k], kernel_ms[names.index(k)]) or 0.0) / FP64_MFMA_PEAK_TFLOPS for k in flops},
-                         "path_achieved": tf(path_flops, kernel_ms[5]), "path_frac": (tf(path_flops, kernel_ms[5]) or 0.0) / FP64_MFMA_PEAK_TFLOPS},
+                         "dominant_within_5pct": [k for k in flops if kernel_ms_serial[names.index(k)] >= 0.95 * kernel_ms_serial[names.index(roof_kernel)]],
+                         "kernel_frac": {k: (tf(flops[k], kernel_ms_serial[names.index(k)]) or 0.0) / FP64_MFMA_PEAK_TFLOPS for k in flops},
+                         # the path: FLOPs of one step over the step's share of the timed region (with the overlap on, the launches of one cycle span more than that)
+                         "path_achieved": tf(path_flops, 1e3 * elapsed / args.steps) if not args.emulate else None,
+                         "path_frac": (tf(path_flops, 1e3 * elapsed / args.steps) or 0.0) / FP64_MFMA_PEAK_TFLOPS if not args.emulate else 0.0},
         }
         if batch_sweep is not None:
             out["config"]["batch_sweep"] = batch_sweep

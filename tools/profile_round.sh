@@ -8,10 +8,13 @@ set -u
 tag=$1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench -- python $R/bench.py --no-cpu-baseline --no-steady-state > $R/gpurun_out/prof_$tag.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/pmc_${tag}_sq -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench -- python $R/bench.py --no-cpu-baseline --no-steady-state --no-overlap > $R/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES -d $R/gpurun_out/pmc_${tag}_sq -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --no-overlap --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_fetch -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --no-overlap --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_write -o pmc -- python $R/bench.py --no-cpu-baseline --no-steady-state --no-overlap --steps 5 > /dev/null 2>&1
+# the default command (WBC of step k next to the node kernels of step k + 1): one more kernel trace, for the timeline (tools/kernel_timeline.py)
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_overlap -o bench -- python $R/bench.py --no-cpu-baseline --no-steady-state --steps 20 > /dev/null 2>&1
 cd $R
+python tools/kernel_timeline.py gpurun_out/prof_${tag}_overlap/bench_results.db 24 170 > gpurun_out/timeline_$tag.txt 2>&1
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 tail -1 gpurun_out/bench_$tag.json
