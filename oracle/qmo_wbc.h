@@ -317,10 +317,10 @@ struct WbcTasks {
 //   zero-margin row the first direction happens to cross -- up to 55 on three-leg stances).  Nothing the interior point returns is final.
 // Rows a higher level left STRONGLY active are equalities for every level below (see eliminateImpliedEqualities): they are removed from the problem exactly,
 // by a change of variables, before anything else -- the "cone without interior" a low level inherits is solved on its face.
-constexpr double kLowerLevelStart = 300.0;   // starting slacks / multipliers of the interior point (a unit start spends up to fifteen iterations on steps of a few per cent)
-                                             // (round 5, measured and NOT kept: 0.5 sqrt(scale) -- the duality measure then starts at 0.25 scale whatever the level's size; a moving trot's levels, scale
-                                             //  1e2 .. 1e4, need 5.9 instead of 9.3 passes on average.  But the tail is unchanged (8-14), a 256-instance launch lasts as long as its slowest instance
-                                             //  (wbc_kernel 0.507 -> 0.525 ms), and the other path leaves the directions at the exclusion floor elsewhere: stress p99 3.5e-14 -> 1.1e-11.)
+constexpr double kLowerLevelStart = 0.5;     // starting slacks / multipliers of the interior point in units of sqrt(scale): the duality measure starts at 0.25 scale whatever the size of the level's
+                                             // gradients and margins.  (Until round 5 the constant 300, tuned on the bench batch whose scale is 7e5; a moving trot's levels have scales of 1e2 .. 1e4 and spent
+                                             // four of nine iterations bringing the measure down to where it should have started: 9.3 -> 5.9 passes per tick there, 8.0 on the bench batch either way.  The
+                                             // slowest instances are as slow as before: it pays since the WBC launch shares the device with the next cycle's node kernels)
 constexpr double kStagnationMu = 1e-10;
 constexpr double kEps = 2.220446049250313e-16;
 constexpr double kMinNormCheap = 1e4;
@@ -409,7 +409,7 @@ inline LevelWork prepareLevel(const LevelQp& q) {
 }
 
 // ------------------------------------------------------------------------------------------------ phase 1: interior point on the inherited rows (a starting point, nothing more)
-// Mehrotra predictor-corrector on   min 1/2 z'Gz + g'z  s.t.  D z + s = f, s >= 0   from z = 0, slacks max(sigma0, f), multipliers sigma0.  Runs until the working set can
+// Mehrotra predictor-corrector on   min 1/2 z'Gz + g'z  s.t.  D z + s = f, s >= 0   from z = 0, slacks max(sigma, f), multipliers sigma = sigma0 sqrt(scale).  Runs until the working set can
 // plausibly be read off the iterate (duality measure <= 1e-6 scale with residuals to match), until it has converged or stagnates at the rounding floor of its normal
 // equations, or until a step loses all accuracy (the previous iterate is handed over).  Returns the iterations used.
 struct IpmPoint { Vec z, s, lam; bool usable = false; };
@@ -425,7 +425,7 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
   const Mat& G = q.G0;       // (without HoQp's regulariser, as in the active-set phase: directions it alone would carry are left out of the factorisation)
   Mat D(mr, n); Vec f(mr);
   for (int r = 0; r < mr; ++r) { for (int j = 0; j < n; ++j) D(r, j) = q.D(rows[r], j); f[r] = q.f[rows[r]]; }
-  const double scale = w.scale, sigma = sigma0;
+  const double scale = w.scale, sigma = sigma0 * std::sqrt(w.scale);
   Vec z(n, 0.0), s(mr), lam(mr, sigma);
   for (int i = 0; i < mr; ++i) s[i] = std::max(sigma, f[i]);
   if (resume) { z = from.z; for (int r = 0; r < mr; ++r) { s[r] = from.s[rows[r]]; lam[r] = from.lam[rows[r]]; } }     // (the guess its last iterate gave was refuted: on from there)

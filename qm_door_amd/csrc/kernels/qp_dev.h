@@ -159,7 +159,7 @@ struct QpResult { int status; int ipmIterations, iterations; bool strong; };   /
 // workgroup's dynamic LDS and are re-based on that symbol here, so that every access stays a ds_ instruction (pointers passed through a
 // call are generic: the same body ran 20 % slower on flat loads).
 // n: variables; r: task rows of AZ; m0: inequality rows; own: the rows are the level's own (soft) -- otherwise inherited (hard); rowOn: this lane's row takes part;
-// sigma0: starting value of the interior point (<= 0: no interior point -- the level's own rows, and the tests' cold runs); tryHeld (a level with own rows whose bound is
+// sigma0: starting slacks / multipliers of the interior point in units of sqrt(scale) (<= 0: no interior point -- the level's own rows, and the tests' cold runs); tryHeld (a level with own rows whose bound is
 // zero -- the friction rows of the first level, each acting on the contact forces only): the variables those rows act on are HELD at zero and the rows left out, instead
 // of the rows being pinned: no working set to carry.  status 5 = the cost wants a held variable moved -- the caller solves again with the rows as rows.
 template <int NP, int LDZ_, int LDK_>
@@ -328,7 +328,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   double s1 = 1.0, l1 = 0.0;
   const double nRows = allSum(rowOn ? 1.0 : 0.0);
   const bool ipmOn = sigma0 > 0.0 && !own && nRows > 0.0;
-  if (ipmOn) { s1 = rowOn ? fmax(sigma0, fl) : 1.0; l1 = rowOn ? sigma0 : 0.0; }
+  if (ipmOn) { const double sigma = sigma0 * sqrt(scale); s1 = rowOn ? fmax(sigma, fl) : 1.0; l1 = rowOn ? sigma : 0.0; }      // (start in units of sqrt(scale): the CPU restatement has the numbers)
   double muTarget = 1e-8;            // duality measure (x scale) at which the working set is read off the iterate (= kIpmHandOverMu of the CPU restatement)
   int resumed = 0, status = 0, it = 0;
   bool strong = false;

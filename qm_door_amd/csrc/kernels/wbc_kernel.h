@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     forkGemm(true, AZp, LDZ, AZp, LDZ, nQ, nQ, rRows, G, LDK, 0.0);
     QM_WAVE_SYNC();
     const QpOff io{int(G - lds), int(AZp - lds), int(rhatp - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds), int(Vh - lds)};
-    const double sigma0 = (own || nQ <= 8) ? -1.0 : 300.0;       // (small levels go without the interior point: cold, the active-set method is shorter there in mean and in the tail)
+    const double sigma0 = (own || nQ <= 8) ? -1.0 : 0.5;         // (small levels go without the interior point: cold, the active-set method is shorter there in mean and in the tail)
     auto solve = [&](bool tryHeld) {
       QpResult rr;
       if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);

@@ -269,7 +269,7 @@ class Oracle:
             out.update(x_des=pol[:, :30], u_des=pol[:, 30:], policy_mode=pm, out=wout, status=wst, input_last=il)
         return out
 
-    def set_experiment(self, lower_level_start=300.0, no_interior_point=False, trace=False):
+    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False):
         """experiment knobs of the WBC restatement (process-wide for this library; the defaults are the product's algorithm).  Both change only the PATH to the vertex
         every level ends at: another starting value of the interior point that runs in front of the active-set method, or no interior point at all (the active-set
         method cold from z = 0)."""

@@ -30,7 +30,7 @@ def _check(rows, tol=1e-6, offenders=None, ticks=None, loose_per=None, loose_max
     there is ill conditioned in the reference itself.  Stated bound: at most 1 tick in `loose_per` above 1e-6, none above `loose_max`, and EVERY such tick is shown to be
     ill conditioned on the checker alone: the oracle's own torques move by at least a tenth of the deviation under a 1e-9 relative perturbation of its inputs, three
     seeded draws (closed_loop.OracleBackend.sensitivity; measured: between 0.3 x and 1400 x the deviation, 21 of the 27 above it).  Measured (gpurun_out/closed_loop_v1.json, profiles/): 27 of 256,000 ticks, max 5.1e-4; the oracle against itself under
-    1e-13 input noise on the same run: 28 ticks above 1e-6, max 8.7e-3 (tools/oracle_sensitivity_closed_loop.py)."""
+    1e-13 input noise on the same run: 30 ticks above 1e-6, max 1.1e-2 (tools/oracle_sensitivity_closed_loop.py)."""
     s = _summary(rows)
     assert s["modes_equal"] and s["policy_mode_differs"] == 0, s
     assert s["alpha_differs"] == 0 and s["step_type_differs"] == 0, s

@@ -100,10 +100,10 @@ def stress_batch(interface, variant, B=2048):
     return dict(xd=xd, u=u, rbd=rbd, mode=mode, t=t, il=il)
 
 
-def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=3, seed=5):
+def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=8, seed=5):
     """How far the ORACLE's own torques move (||.||_inf relative, per instance of idx) under two kinds of change that leave the mathematical problem (almost) alone:
     (input) the desired state / measurement perturbed by eps relative, a few seeded directions; (path) another path to the same vertex -- the interior point that
-    runs in front of the active-set method started from 100 instead of 300, and no interior point at all (the active-set method cold from z = 0).  A well-posed
+    runs in front of the active-set method started from 0.15 sqrt(scale) instead of 0.5 sqrt(scale), and no interior point at all (the active-set method cold from z = 0).  A well-posed
     instance moves by ~1e2 * eps and not at all; an instance one of whose level problems is nearly degenerate -- a direction whose curvature sits at the rounding of
     the normal equations, a multiplier at the rounding of its gradient: a path-dependent decision no arithmetic can avoid -- moves by orders of magnitude more, and
     GPU / oracle agreement there cannot be better than that."""
@@ -116,7 +116,7 @@ def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=3, seed=5):
         rbd[:, :48] *= 1 + eps * rng.uniform(-1, 1, (len(idx), 48))
         worst = np.maximum(worst, S.rel_inf(orc.wbc_batch(*args(xd, rbd))["out"][:, 36:], base))
     path = np.zeros(len(idx))
-    for kw in (dict(lower_level_start=100.0), dict(no_interior_point=True)):
+    for kw in (dict(lower_level_start=0.15), dict(no_interior_point=True)):
         orc.set_experiment(**kw)
         try:
             path = np.maximum(path, S.rel_inf(orc.wbc_batch(*args(c["xd"][idx], c["rbd"][idx]))["out"][:, 36:], base))

@@ -490,7 +490,7 @@ def test_kernel_basis_follows_eigens_pivot_order(interface, oracle):
 def test_every_level_ends_at_the_same_vertex_whatever_the_path(interface, oracle):
     """Every HoQP level ends with a primal active-set method (oracle/qmo_wbc.h activeSetPhase): the point it returns satisfies the KKT conditions on its working set and is
     THE minimiser -- so it cannot depend on how the method got there.  512 random instances over every contact mode, robots in motion, both controllers, three paths: the
-    product's (interior point from 300 -> active set), another interior-point start (100), and no interior point at all (the active-set method cold from z = 0, one
+    product's (interior point from 0.5 sqrt(scale) -> active set), another interior-point start (0.15 sqrt(scale)), and no interior point at all (the active-set method cold from z = 0, one
     working-set change at a time).  Stated bound: torques equal to 1e-9 rel-inf on all but 1 % of the instances (measured on 2 x 2048: 99.7 % within 1e-13, the rest nearly
     degenerate level problems -- a direction whose curvature sits at the rounding of the normal equations, or a multiplier at the rounding of its gradient -- where a
     path-dependent decision is unavoidable in any arithmetic), median <= 1e-13, and no level is ever flagged."""
@@ -506,11 +506,11 @@ def test_every_level_ends_at_the_same_vertex_whatever_the_path(interface, oracle
                 return oracle.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], per, c["t"], c["il"].copy(), variant=variant)
             finally:
                 oracle.set_experiment()
-        ref, alt, cold = run(), run(lower_level_start=100.0), run(no_interior_point=True)
+        ref, alt, cold = run(), run(lower_level_start=0.15), run(no_interior_point=True)
         assert (ref["status"] == 0).all() and (alt["status"] == 0).all() and (cold["status"] == 0).all()
         assert (ref["polished"][ref["iterations"] > 0] == 1).all()             # every level that ran ended at a verified vertex
         tau = lambda r: r["out"][:, 36:]  # noqa: E731
-        for name, other in (("start 100", alt), ("cold active set", cold)):
+        for name, other in (("start 0.15 sqrt(scale)", alt), ("cold active set", cold)):
             dev = S.rel_inf(tau(ref), tau(other))
             print("variant", variant, name, "max", dev.max(), "p99", np.percentile(dev, 99), "median", np.median(dev), "above 1e-9:", int((dev > 1e-9).sum()))
             assert np.median(dev) <= 1e-13 and (dev > 1e-9).sum() <= B // 100, (variant, name, dev.max(), int((dev > 1e-9).sum()))
@@ -529,7 +529,7 @@ def test_degenerate_lowest_level_is_solved_on_its_face(interface, oracle):
     args = (c["xd"], c["ud"], c["rbd"], int(c["mode"]), 0.001, float(c["t"]))
     outs = []
     try:
-        for kw in (dict(), dict(lower_level_start=100.0), dict(no_interior_point=True)):
+        for kw in (dict(), dict(lower_level_start=0.15), dict(no_interior_point=True)):
             oracle.set_experiment(**kw)
             st, out, _ = oracle.wbc_update(*args, c["il"].copy())
             assert st == 0
