@@ -211,7 +211,8 @@ int qmgpu_update_settings(qmgpu_handle h, const qmgpu_settings* settings) {
   if (!h || !settings) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null argument");
   return guarded([&]() {
     DeviceGuard onDevice(h->device);
-    HIP_CHECK(hipStreamSynchronize(h->stream));   // kernels in flight still read the old values through dP
+    joinWbc(h);
+    HIP_CHECK(hipStreamSynchronize(h->stream));   // kernels in flight (a WBC on the overlap stream included) still read the old values through dP
     h->hostProblem.settings = *settings;
     HIP_CHECK(hipMemcpy(&h->m.dP->settings, &h->hostProblem.settings, sizeof(qmgpu_settings), hipMemcpyHostToDevice));
     QM_LAUNCH(input_weight_kernel, 1, 64, h->stream, h->m.dP, h->m.dZeros, h->m.dRw);
@@ -270,6 +271,7 @@ extern "C" int qmgpu_debug_wbc_dump(double* out, int doubles) {
 int qmgpu_debug_poison(qmgpu_handle h) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
+    joinWbc(h);      // (a pending WBC still reads the policy buffers, which are scratch)
     for (auto& sc : h->scratch) HIP_CHECK(hipMemsetAsync(sc.first, 0xFF, sc.second, h->stream));
     constexpr int kDoubles = 160 * 1024 / 8;
     HIP_CHECK(QM_ALLOW_DYNAMIC_LDS(lds_poison_kernel, kDoubles * 8));
