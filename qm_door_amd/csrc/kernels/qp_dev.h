@@ -267,11 +267,13 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     QM_TICK(9);
     // lane c holds column c of K in kc; after step j, kc[j] of lane c is L^T[j][c] = L[c][j], i.e. lane c ends up with ROW c of L (entries r <= c)
     myInv = 1.0;
+    // (all NP loads first, held in registers, then the selects: a load sunk into its select is a predicated LDS read with a wait of its own -- NP round trips in a row)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const double kv = io.Kt[q * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
-      kc[q] = (colOn && q < n) ? kv : ((q == lane) ? 1.0 : 0.0);   // identity padding beyond n
-    }
+    for (int q = 0; q < NP; ++q) kc[q] = io.Kt[q * LDK_ + colL];   // K symmetric: column c = row c, read conflict free
+#pragma unroll
+    for (int q = 0; q < NP; ++q) QM_KEEP(kc[q]);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) kc[q] = (colOn && q < n) ? kc[q] : ((q == lane) ? 1.0 : 0.0);   // identity padding beyond n
     double diag0 = 0.0;
 #pragma unroll
     for (int q = 0; q < NP; ++q) diag0 = (q == lane) ? kc[q] : diag0;
