@@ -315,10 +315,10 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
       QM_TICK(4);
       {
         const real sh = dd >= 3 ? dt : 0.0_r;
-        auto addRow = [&](int row, real dval, real vval, real cval) {
-          real* r = L1 + row * 64;
-          if (owner) { r[cD] += dval; r[cV] += fma(sh, dval, vval); r[cC] += cval; }
-        };
+        // (36 read-modify-writes of distinct LDS words: all reads first, held, then the sums, then the stores -- as `r[c] += v` every one waited for its own read, the compiler
+        //  cannot move a load across a store to the same array)
+        real dv[12], vv[12], cv[12];
+        auto addRow = [&](int row, real dval, real vval, real cval) { dv[row] = dval; vv[row] = vval; cv[row] = cval; };
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           addRow(i, f.lin[i].d, 0.0_r, isF ? f.lin[i].e : (isVal ? f.lin[i].v : 0.0_r));
@@ -326,6 +326,15 @@ __global__ void __launch_bounds__(64) QM_ONE_WAVE_PER_SIMD ad_node_kernel(LqArgs
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) addRow(6 + i, f.kin[i].d, f.kin[i].e, isVal ? f.kin[i].v : ((i < 3 && dd == i) ? 1.0_r : 0.0_r));
+        if (owner) {
+          real a0[12], a1[12], a2[12];
+#pragma unroll
+          for (int row = 0; row < 12; ++row) { const real* r = L1 + row * 64; a0[row] = r[cD]; a1[row] = r[cV]; a2[row] = r[cC]; }
+#pragma unroll
+          for (int row = 0; row < 12; ++row) { QM_KEEP(a0[row]); QM_KEEP(a1[row]); QM_KEEP(a2[row]); }
+#pragma unroll
+          for (int row = 0; row < 12; ++row) { real* r = L1 + row * 64; r[cD] = a0[row] + dv[row]; r[cV] = a1[row] + fma(sh, dv[row], vv[row]); r[cC] = a2[row] + cv[row]; }
+        }
       }
       QM_WAVE_SYNC();
       QM_TICK(5);
