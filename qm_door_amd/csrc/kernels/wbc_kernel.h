@@ -249,6 +249,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
   QM_DYNAMIC_LDS(ldsBase);
   double* rows = ldsBase + rowsOff; double* K = ldsBase + kOff; double* Vh = ldsBase + vhOff; double* red = ldsBase + redOff;
   (void)red;
+  QM_TICK_DECL;
   static_assert(MAXR <= 24 && ND <= 36 && 128 + 64 + 32 <= MAXR * 40, "index tables of the null-space step fit the region they are carved from");
   {
       int* ip = reinterpret_cast<int*>(Vh);        // colPerm[36] | rowOf[MAXR] | pivOk[MAXR] | freePos[36]  (the reflector table of round 3: free here)
@@ -284,6 +285,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
       }
       // One step = one dependent chain; what is on it besides the elimination itself is kept in registers: the pivot's lane from a ballot (the
       // smallest-row-position rule needs a second reduction only when two rows tie), its column and value by v_readlane, the permutations in lanes.
+      QM_TICK(0);
 #pragma unroll 1
       for (int k = 0; k < size; ++k) {
         const bool mine = lane < r && rowPos >= k;
@@ -295,6 +297,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
         if ((tied & (tied - 1)) == 0) Lp = qmFirstBit(tied);
         else Lp = int(qmAllMin(cand ? double((bj * 64 + rowPos) * 64 + lane) : 1e9, red)) & 63;   // ties between rows: the smallest COLUMN position, then the smallest row position (Eigen's column-major scan)
         const int pr = qmReadLaneInt(rowPos, Lp), pc = qmReadLaneInt(bj, Lp);
+        QM_TICK(1);
         maxPivot = fmax(maxPivot, gmax);
         if (active) { if (rowIdx == Lp) rowPos = k; else if (rowPos == k) rowPos = pr; }
         { const int ck = qmReadLaneInt(colPermReg, k), cp = qmReadLaneInt(colPermReg, pc); if (lane == k) colPermReg = cp; else if (lane == pc) colPermReg = ck; }
@@ -305,6 +308,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
         if (pc != k && lane < r) { row[k] = vpc; row[pc] = vk; }
         const double pivot = qmReadLane(vpc, Lp);
         QM_WAVE_SYNC();
+        QM_TICK(2);
         // elimination of the rows still below the pivot, this lane's share of the column positions; the largest entry of the updated row (positions > k) is found on
         // the way: the next step's candidate
         const double* prow = rows + Lp * LDZ;
@@ -327,6 +331,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
             for (int q = 0; q < 8; ++q) if (j0 + q < jHi) { row[j0 + q] = a[q]; const double v = fabs(a[q]); if (v > best) { best = v; bj = j0 + q; } }
           }
         }
+        QM_TICK(3);
         if (nChunk > 1) {   // the row's candidate: the chunks' candidates in the order of their column ranges (strictly larger wins: first position on ties)
           QM_WAVE_SYNC();
           xchgV[lane] = best; xchgJ[lane] = bj;
@@ -342,6 +347,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
         }
         ++nonzero;
         QM_WAVE_SYNC();
+        QM_TICK(4);
       }
       if (lane < n) colPerm[lane] = colPermReg;
       if (lane < nonzero) rowOf[lane] = rowOfReg;
@@ -358,6 +364,7 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
       if (freeReg) freePos[qmPopCount(freeMask & ((1ull << lane) - 1ull))] = lane;
       for (int e = lane; e < ND * LDK; e += 64) K[e] = 0.0;      // N (n x nNew), one kernel vector per lane / column
       QM_WAVE_SYNC();
+      QM_TICK(5);
       {
         // U11 X = -U12 for this lane's free column: back substitution over the accepted pivots, X(:, lane) in registers (fully unrolled: compile-time
         // indices), the U entries as wave-uniform LDS reads; the results leave for LDS after the loop (no store between the loads)
@@ -388,6 +395,8 @@ __device__ __attribute__((noinline)) int wbcNullSpace(int rowsOff, int r, int n,
         }
       }
       QM_WAVE_SYNC();
+      QM_TICK(6);
+      QM_TICK_FLUSH(352, blockIdx.x == 0 && lane == 0);
     return nNew;
   }
 }

@@ -65,6 +65,11 @@ v = raw[192:192 + len(WBC)]
 print("wbc_kernel, instance 0: total %d ticks (kernel %.4f ms)" % (v.sum(), ms[4]))
 for n_, x in zip(WBC, v): print("  %-60s %9.0f  %4.1f %%" % (n_[:60], x, 100 * x / v.sum()))
 
+NS = ["entry: row maxima", "step: max reduction, pivot lane", "step: swap, pivot broadcast", "step: elimination", "step: candidates of the chunks", "rank, free columns, zeroing", "kernel vectors (back substitution)"]
+v = raw[352:352 + len(NS)]
+print("wbcNullSpace (all calls of instance 0): total %d ticks" % v.sum())
+for n_, x in zip(NS, v): print("  %-50s %8.0f  %4.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
+
 LS = ["two model sweeps + constraints + EE cost", "defect", "tracking cost (two 30 x 30 forms)", "barriers"]
 v = raw[224:224 + len(LS)]
 print("linesearch nodePerformance, node 5 of instance 0 (all calls of a launch): total %d ticks (kernel %.4f ms)" % (v.sum(), ms[3]))
