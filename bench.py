@@ -562,9 +562,11 @@ def main():
         if world == 1 and not args.no_steady_state and not args.emulate:
             from qm_door_amd import api as _api
             sc_ss = dict(sc)
-            t_end = (args.steps + args.warmup) * 0.01 + N * itf.problem.settings.dt + 0.5
+            # one trot schedule covers the whole leg (QMGPU_MAX_EVENTS = 40 mode switches: ~14 s of trot); a longer --steps is cut to 1000 receding-horizon steps here
+            ss_steps, ss_warm = min(args.steps, 1000), min(args.warmup, 50)
+            t_end = (ss_steps + ss_warm) * 0.01 + N * itf.problem.settings.dt + 0.5
             sc_ss["nev"], sc_ss["ev"], sc_ss["md"] = _api.GaitSchedule(lib=itf.lib).mode_schedule("trot", 0.0, 0.0, t_end)
-            out["config"]["steady_state"] = steady_state(itf, sc_ss, args.steps, args.warmup)
+            out["config"]["steady_state"] = steady_state(itf, sc_ss, ss_steps, ss_warm)
         if world == 1 and not args.no_cpu_baseline and not args.emulate:
             out["cpu_baseline"] = cpu_baseline(itf, sc)
         print(json.dumps(out), flush=True)
