@@ -234,21 +234,32 @@ def test_wbc_overlap_stream_changes_nothing_but_the_schedule(interface, oracle):
             w = api.GpuSolver.wbc_args(B, rb[k & 1], per, tim, il, outs[k], stats[k])
             keep.append(w)
             sol.cycle(mbs[k & 1].args, te, w)
+        # a settings update right behind the last cycle: it must wait for the WBC still running on the other stream (which reads the gains) and apply to the next one
+        import ctypes as C
+        from qm_door_amd import abi
+        P2 = type(interface.problem).from_buffer_copy(interface.problem)
+        P2.settings.kp_base_height *= 3.0; P2.settings.kd_swing *= 0.5
+        abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(P2.settings)))
+        after_update = torch.zeros((B, 54), dtype=torch.float64, device="cuda")
+        wu = api.GpuSolver.wbc_args(B, rb[0], per, tim, il, after_update, stats[0])
+        keep.append(wu)
+        sol.cycle(mbs[0].args, te, wu)
         sol.join_wbc()
-        copy_on_stream = outs[-1].clone()          # enqueued on the handle's (= torch's current) stream behind the join
+        copy_on_stream = after_update.clone()          # enqueued on the handle's (= torch's current) stream behind the join
         # one more WBC through the stand-alone entry point: it must see the inputLast_ the last cycle's WBC wrote
         extra = torch.zeros((B, 54), dtype=torch.float64, device="cuda")
         xd, ud, mode = G.dev(x0, torch.float64), G.dev(np.zeros((B, 30)), torch.float64), G.dev(np.full(B, 15), torch.int32)
         w2 = api.GpuSolver.wbc_args(B, rb[0], per, tim, il, extra, stats[0], xd, ud, mode)
         sol.wbc(w2)
         sol.synchronize()
-        res = dict(outs=[o.cpu().numpy() for o in outs], copy=copy_on_stream.cpu().numpy(), extra=extra.cpu().numpy(), il=il.cpu().numpy(), X=[m.oX.cpu().numpy() for m in mbs],
+        res = dict(outs=[o.cpu().numpy() for o in outs], after_update=after_update.cpu().numpy(), copy=copy_on_stream.cpu().numpy(), extra=extra.cpu().numpy(), il=il.cpu().numpy(), X=[m.oX.cpu().numpy() for m in mbs],
                    status=[s_.cpu().numpy() for s_ in stats])
         sol.close()
         return res
     a, b = run(False), run(True)
     for k in range(cycles):
         assert np.isfinite(a["outs"][k]).all() and np.array_equal(a["outs"][k], b["outs"][k]), k
-    assert np.array_equal(b["copy"], b["outs"][-1])
+    assert np.array_equal(b["copy"], b["after_update"]) and np.array_equal(a["after_update"], b["after_update"])
+    assert not np.array_equal(a["after_update"], a["outs"][-2])      # (the new gains are in effect: same inputs as cycle 4, other torques -- and the last cycle before the update still used the old ones)
     assert np.array_equal(a["extra"], b["extra"]) and np.array_equal(a["il"], b["il"]) and all(np.array_equal(p_, q_) for p_, q_ in zip(a["X"], b["X"]))
     assert not np.array_equal(a["outs"][2], a["outs"][3])      # the two input sets (and the carried inputLast_) really give different cycles
