@@ -94,15 +94,24 @@ def build_config3(itf, total=CONFIG3_GLOBAL_BATCH, seed=1):
     return dict(x0=x0, tt=tt, ts=ts, nev=nev, ev=ev, md=md, rbd=rbd)
 
 
-def steady_state(itf, sc, steps, warmup, emulate=False):
+def _digest(*tensors):
+    """one number per tensor from the device (sum of the raw 64-bit words, exact in int64 arithmetic modulo 2^64): a running fingerprint of a step's outputs that costs a
+    reduction launch per tensor and no host synchronisation; two runs that agree bit for bit agree in it"""
+    import torch
+    return torch.stack([t.contiguous().view(torch.int64).sum() for t in tensors])
+
+
+def steady_state(itf, sc, steps, warmup, emulate=False, wbc_state="carry"):
     """config.steady_state: what the controller does between the first tick and shutdown -- the SAME 256 instances in a receding
     horizon: every step shifts the horizon by one MPC period (10 ms, mpcDesiredFrequency task.info:147), resamples the previous solution on the shifted grid
     ON THE DEVICE as the initial guess (qmgpu_warm_start_batch; coldStart false, task.info:143), solves, evaluates the policy between two nodes and runs the
     WBC on a robot IN MOTION: the measured state follows the instance's own plan plus a seeded disturbance (qm_door_amd/harness.py: measurement), inputLast_
     is carried from step to step, the centroidal observation comes from qmgpu_frontend_batch.
+    wbc_state: "carry" -- the WBC's solver state (qmgpu_wbc_args::working_set) travels from step to step like inputLast_; "cold" -- every tick starts cold (the record is
+    zeroed before every step: it still collects the pass counts).
     The measurements depend on the plans, so the sequence is produced once, untimed (record pass: plan -> host -> measurement -> device), and then REPLAYED
     from device-resident inputs with nothing but qmgpu_warm_start_batch + qmgpu_cycle_batch per step inside the timed region; the replay must reproduce the
-    recorded trajectories bit for bit (checked)."""
+    recorded run bit for bit on EVERY step (a fingerprint of X, U, the WBC output and its status words per step, compared after the timed region)."""
     import torch
     from qm_door_amd import harness as CL, harness as G
     from qm_door_amd import abi, api
@@ -120,19 +129,39 @@ def steady_state(itf, sc, steps, warmup, emulate=False):
     sn, se, sm = G.dev(np.full(B, sc["nev"], dtype=np.int32), torch.int32), G.dev(np.tile(sc["ev"], (B, 1)), f64), G.dev(np.tile(sc["md"], (B, 1)), torch.int32)
     kind, cmd, lastee, ftt, fts = z(B, dtype=torch.int32), z(B, 7), z(B, 7), z(B, 2), z(B, 2, 37)
     il0 = np.zeros((B, 30)); il0[:, 12:] = 0.0
-    out, status, period = z(B, 54), z(B, dtype=torch.int32), G.dev(np.full(B, 0.001), f64)
+    # the WBC writes alternating output sets: with the overlap on, the fingerprint of step k is taken behind cycle(k + 1) (which has made the stream wait for WBC k)
+    outs = [dict(out=z(B, 54), status=z(B, dtype=torch.int32)) for _ in range(2)]
+    # WbcBase::update's `period` is the time since the previous update (ros_control hands the elapsed period on; the desired joint accelerations are
+    # (v_des - inputLast_) / period, WbcBase.cpp:224-225).  This leg runs ONE tick per MPC cycle, 10 ms after the previous one: period = 10 ms.  (Until round 5 it passed the
+    # controller's nominal 1 ms with ticks 10 ms apart: accelerations ten times too large, torque limits violated by thousands of N m on a few robots whose first level
+    # then takes 40-46 working-set changes -- 4.4 ms launches in three of twenty steps, the whole of the "steady-state regression" of BENCH_r05; profiles/r06_notes.md.)
+    period = G.dev(np.full(B, CL.MPC_PERIOD), f64)
+    # (cold: two records used in turn and zeroed before their step -- the WBC of step k - 2 has been joined by then, the overlap stays as it is)
+    wss = [z(B, abi.WBC_STATE_WORDS, dtype=torch.int64) for _ in range(2 if wbc_state == "cold" else 1)]
     rec = []          # per step: device-resident inputs of the replay
     sync = (lambda: None) if emulate else torch.cuda.synchronize
 
-    def run_step(k, r, il, timed_outputs=None):
+    def run_step(k, r, il):
         cur, prev = sets[k & 1], sets[(k & 1) ^ 1]
         if k > 0:
             sol.warm_start(B, N, prev["T"], prev["X"], prev["U"], N, r["grid"], r["x0"], wx, wu)
         a = api.GpuSolver.mpc_args(B, N, r["x0"], tt, ts, sn, se, sm, cur["T"], cur["X"], cur["U"], cur["M"], cur["S"], t0=r["t0"], time_grid=r["grid"],
                                    warm_x=wx if k > 0 else None, warm_u=wu if k > 0 else None)
-        w = api.GpuSolver.wbc_args(B, r["rbd"], period, r["time"], il, out, status)
+        ws = wss[k % len(wss)]
+        if wbc_state == "cold":
+            ws.zero_()
+        o = outs[k & 1]
+        w = api.GpuSolver.wbc_args(B, r["rbd"], period, r["time"], il, o["out"], o["status"], working_set=ws)
         sol.cycle(a, r["t_eval"], w)
-        return cur
+        return cur, o
+
+    def fingerprints(k, prints, last=False):
+        """the fingerprint of step k - 1 once cycle(k) has been issued (the stream has joined WBC k - 1 by then); of step k itself after the last one"""
+        if k > 0:
+            prints.append(_digest(sets[(k - 1) & 1]["X"], sets[(k - 1) & 1]["U"], outs[(k - 1) & 1]["out"], outs[(k - 1) & 1]["status"]))
+        if last:
+            sol.join_wbc()
+            prints.append(_digest(sets[k & 1]["X"], sets[k & 1]["U"], outs[k & 1]["out"], outs[k & 1]["status"]))
 
     # ---- record pass (untimed)
     v0 = np.c_[np.random.default_rng(6).uniform(-0.1, 0.1, (B, 6)), np.random.default_rng(7).uniform(-0.2, 0.2, (B, 18))]
@@ -140,6 +169,8 @@ def steady_state(itf, sc, steps, warmup, emulate=False):
     rbd = CL.pack_rbd(q0 + dist_.dq(0.0), v0 + dist_.dv(0.0))
     il = G.dev(il0, f64)
     plan = None
+    rec_prints, passes, refuted = [], [], []
+    bad_steps = 0
     for k in range(total):
         t0 = k * CL.MPC_PERIOD
         if k > 0:
@@ -147,33 +178,70 @@ def steady_state(itf, sc, steps, warmup, emulate=False):
         r = dict(rbd=G.dev(rbd, f64), x0=z(B, 30), grid=G.dev(np.tile(t0 + dt * np.arange(N + 1), (B, 1)), f64), t0=G.dev(np.full(B, t0), f64),
                  t_eval=G.dev(np.full(B, t0 + 0.3 * CL.WBC_PERIOD), f64), time=G.dev(np.full(B, 20.0 + t0), f64))
         sol.frontend(sol.frontend_args(B, r["rbd"], r["t0"], kind, cmd, lastee, r["x0"], ftt, fts))
-        cur = run_step(k, r, il)
+        cur, o = run_step(k, r, il)
+        fingerprints(k, rec_prints, last=(k == total - 1))
         sync()
         plan = dict(T=cur["T"].cpu().numpy(), X=cur["X"].cpu().numpy(), U=cur["U"].cpu().numpy())
+        # interior-point + active-set passes of every instance in this step's WBC (words 13 / 14 of the record: a byte per solve, bit 7 = carried guess refuted)
+        cb = np.ascontiguousarray(wss[k % len(wss)].cpu().numpy()[:, 13:15]).view(np.uint8).reshape(B, 16)
+        passes.append((cb & 127).astype(np.int64).sum(axis=1)); refuted.append((cb >> 7).astype(np.int64).sum(axis=1))
+        stats_k, status_k, out_k = cur["S"].cpu().numpy(), o["status"].cpu().numpy(), o["out"].cpu().numpy()
+        bad_steps += int(not (np.isfinite(plan["X"]).all() and np.isfinite(out_k).all() and (stats_k[:, 7] == 0).all() and (status_k == 0).all()))
         rec.append(r)
-    rec_last = dict(X=plan["X"], out=out.cpu().numpy(), status=status.cpu().numpy(), stats=cur["S"].cpu().numpy())
+    rec_last = dict(stats=stats_k)
     # ---- replay: the first `warmup` steps untimed (step 0 is the cold start), then `steps` steps timed
     il = G.dev(il0, f64)
+    for w_ in wss:
+        w_.zero_()
+    prints = []
     for k in range(warmup):
         run_step(k, rec[k], il)
+        fingerprints(k, prints)
     sol.enable_timing(True)
     sync()
     t_begin = time.perf_counter()
     for k in range(warmup, total):
-        cur = run_step(k, rec[k], il)
+        run_step(k, rec[k], il)
+        fingerprints(k, prints, last=(k == total - 1))
     sync()
     elapsed = time.perf_counter() - t_begin
     kms = sol.kernel_ms_mean(steps)
+    hist = sol.kernel_ms_history(min(steps, 256))
     sol.enable_timing(False)
-    same = bool(np.array_equal(cur["X"].cpu().numpy(), rec_last["X"]) and np.array_equal(out.cpu().numpy(), rec_last["out"]))
+    same_steps = [bool(torch.equal(a_, b_)) for a_, b_ in zip(prints, rec_prints)]
     speed = np.abs(np.concatenate([r["rbd"].cpu().numpy()[:, 24:48] for r in rec[warmup:]])).mean(axis=0)
+    # a second, short replay of the same timed steps with a host synchronisation after every step: the wall-clock spread of single steps
+    il = G.dev(il0, f64)
+    for w_ in wss:
+        w_.zero_()
+    for k in range(warmup):
+        run_step(k, rec[k], il)
+    sync()
+    per_step = []
+    for k in range(warmup, total):
+        t1 = time.perf_counter()
+        run_step(k, rec[k], il)
+        sol.synchronize()
+        per_step.append(1e3 * (time.perf_counter() - t1))
+    pt, rt = np.array(passes[warmup:]), np.array(refuted[warmup:])
+    wbc_ms = hist[:, 4]
     res = {"value": B * steps / elapsed, "unit": "cycles/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "what": "receding horizon: shifted grid (10 ms per step), device-resampled warm start of every solve (qmgpu_warm_start_batch inside the timed region), policy evaluated between "
-                   "nodes, WBC on robots in motion (plan-following measurement + seeded disturbance, inputLast_ carried); replay of a recorded input sequence, inputs resident"
+                   "nodes, one WBC tick per step on robots in motion (plan-following measurement + seeded disturbance, inputLast_ carried, period = the 10 ms between two ticks); replay of a recorded input sequence, inputs resident"
                    + ("; the WBC of step k next to the node kernels of step k + 1 (config.overlap): kernel_ms are overlapping intervals" if OVERLAP else ""),
+           "wbc_state": {"carry": "qmgpu_wbc_args::working_set travels from step to step like inputLast_ (each level of the hierarchical QP starts from the rows and the point the previous tick ended with; "
+                                  "refuted guesses fall back to the cold path)", "cold": "every tick cold (record zeroed before every step), as the reference's qpOASES call"}[wbc_state],
            "kernel_ms": dict(zip(["ad", "lq", "riccati", "linesearch", "wbc", "whole"], kms)),
-           "replay_reproduces_the_recorded_run_bit_for_bit": same,
-           "results_finite_and_converged": bool(np.isfinite(rec_last["X"]).all() and np.isfinite(rec_last["out"]).all() and (rec_last["stats"][:, 7] == 0).all() and (rec_last["status"] == 0).all()),
+           "ms_per_step_synchronised": {"min": float(np.min(per_step)), "median": float(np.median(per_step)), "max": float(np.max(per_step)),
+                                        "note": "the same timed steps once more with a host synchronisation after each (no overlap across steps): the spread a caller that waits for every tick sees"},
+           "wbc_ms_per_step": {"min": float(wbc_ms.min()), "mean": float(wbc_ms.mean()), "max": float(wbc_ms.max()), "max_over_mean": float(wbc_ms.max() / wbc_ms.mean()),
+                               "all": [round(float(v), 4) for v in wbc_ms]},
+           "wbc_passes_per_instance": {"what": "interior-point + active-set iterations of all level QPs of one WBC tick (0 = every level ended at its first factorisation); a launch lasts as long as its slowest instance",
+                                       "mean": float(pt.mean()), "p99": float(np.percentile(pt, 99)), "max": int(pt.max()), "max_per_step": [int(v) for v in pt.max(axis=1)],
+                                       "mean_per_step": [round(float(v), 2) for v in pt.mean(axis=1)], "guesses_refuted_per_step": [int(v) for v in rt.sum(axis=1)]},
+           "replay_reproduces_the_recorded_run_bit_for_bit": bool(all(same_steps) and len(same_steps) == total),
+           "replay_steps_compared": len(same_steps), "replay_steps_differing": int(len(same_steps) - sum(same_steps)),
+           "results_finite_and_converged": bool(bad_steps == 0), "steps_with_a_non_finite_or_unconverged_instance": bad_steps,
            "line_search_full_steps_last_solve": int((rec_last["stats"][:, 4] == 1.0).sum()),
            "mean_abs_measured_velocity": {"base_angular": float(speed[0:3].mean()), "base_linear": float(speed[3:6].mean()), "joints": float(speed[6:].mean())}}
     sol.close()
@@ -286,6 +354,7 @@ def main():
     ap.add_argument("--no-steady-state", action="store_true", help="skip config.steady_state (the receding-horizon leg, N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="qmgpu_set_overlap off: every kernel of a step on one stream, one after the other (the kernel times then add up to the step)")
+    ap.add_argument("--wbc-state", choices=["carry", "cold"], default="carry", help="steady-state leg: the WBC's solver state travels from step to step (qmgpu_wbc_args::working_set), or every tick cold")
     ap.add_argument("--force-collective", action="store_true",
                     help="single process: run the N > 1 code path (pack -> RCCL all_gather_into_tensor -> unpack) on a 1-rank nccl group and verify it")
     ap.add_argument("--emulate", action="store_true",
@@ -566,7 +635,7 @@ def main():
             ss_steps, ss_warm = min(args.steps, 1000), min(args.warmup, 50)
             t_end = (ss_steps + ss_warm) * 0.01 + N * itf.problem.settings.dt + 0.5
             sc_ss["nev"], sc_ss["ev"], sc_ss["md"] = _api.GaitSchedule(lib=itf.lib).mode_schedule("trot", 0.0, 0.0, t_end)
-            out["config"]["steady_state"] = steady_state(itf, sc_ss, ss_steps, ss_warm)
+            out["config"]["steady_state"] = steady_state(itf, sc_ss, ss_steps, ss_warm, wbc_state=args.wbc_state)
         if world == 1 and not args.no_cpu_baseline and not args.emulate:
             out["cpu_baseline"] = cpu_baseline(itf, sc)
         print(json.dumps(out), flush=True)

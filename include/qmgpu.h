@@ -58,6 +58,7 @@ extern "C" {
 #define QMGPU_NWBC_OUT 54
 #define QMGPU_MAX_EVENTS 40 /* per-instance mode-schedule capacity */
 #define QMGPU_NSTATS 10
+#define QMGPU_WBC_STATE_WORDS 48 /* uint64 words per instance of qmgpu_wbc_args::working_set */
 #define QMGPU_F32_MAX_TARGET_KNOTS 64 /* target knots per instance an fp32 handle (qmgpu_create_ex, QMGPU_F32) can stage; more -> QMGPU_ERR_CAPACITY */
 
 typedef enum qmgpu_status {
@@ -185,8 +186,14 @@ int qmgpu_set_stream(qmgpu_handle h, void* hip_stream);
 int qmgpu_synchronize(qmgpu_handle h);
 /* Optional (default off): the WBC launch of qmgpu_cycle_batch goes to a second stream owned by the handle, ordered behind the cycle's policy evaluation.  A WBC launch lasts as
  * long as its slowest instance while most CUs have finished theirs; the node kernels of the NEXT qmgpu_cycle_batch (which do not depend on it -- the reference runs its MPC and
- * its WBC in different threads, QMController.cpp:116-157 / 316-327) then fill those CUs.  With the option on, the WBC outputs of a cycle are complete after qmgpu_synchronize,
- * or on the handle's stream after qmgpu_join_wbc (a device-side wait, no host wait) -- NOT after the caller synchronises its own stream; every other entry point joins first. */
+ * its WBC in different threads, QMController.cpp:116-157 / 316-327) then fill those CUs.  With the option on, the WBC outputs of a cycle (out, out_status, input_last, working_set)
+ * are complete after qmgpu_synchronize, or on the handle's stream after qmgpu_join_wbc (a device-side wait, no host wait) -- NOT after the caller synchronises its own stream.
+ * Which calls join by themselves: qmgpu_cycle_batch (before its policy evaluation), qmgpu_wbc_solve_batch, qmgpu_set_stream (the NEW stream waits), qmgpu_set_overlap,
+ * qmgpu_update_settings, qmgpu_debug_poison, qmgpu_synchronize, qmgpu_destroy.  Which do NOT: qmgpu_mpc_solve_batch, qmgpu_policy_eval_batch, qmgpu_frontend_batch,
+ * qmgpu_warm_start_batch, qmgpu_gait_schedule_batch, qmgpu_get_input_weight -- they touch nothing the library owns that a pending WBC reads or writes, and run next to it.
+ * The pending WBC still READS the caller's rbd_measured / period / time (and ee_force) of that cycle and reads and writes input_last / working_set: those buffers must not
+ * be modified -- by the caller's own kernels or copies on any stream, or through a non-joining call above -- until qmgpu_join_wbc, qmgpu_synchronize, or the next
+ * qmgpu_cycle_batch / qmgpu_wbc_solve_batch has been issued on the handle. */
 int qmgpu_set_overlap(qmgpu_handle h, int enable);
 int qmgpu_join_wbc(qmgpu_handle h);
 /* Replace the settings behind a live handle (gains, weights, limits, barrier parameters; the model is fixed at create time):
@@ -268,6 +275,15 @@ typedef struct qmgpu_wbc_args {
   const double* ee_force;              /* [batch][3] or NULL: external force on the arm end-effector (world axes, measured or from the contact
                                           model); enters the equations of motion, the torque limits and the torque recovery as J_ee^T f_e
                                           (force tracking, own formulation) */
+  uint64_t* working_set;               /* [batch][QMGPU_WBC_STATE_WORDS] in/out or NULL: solver state carried from tick to tick, next to input_last.
+                                          The reference cold-starts qpOASES on every level of every tick (HoQp.cpp:136-149); consecutive ticks of one
+                                          robot end almost always with the same rows on their bounds, so each level's active-set method starts from the
+                                          rows the previous tick pinned (same vertex whatever the path; a guess the first step refutes falls back to the
+                                          cold path).  Zero-initialise it; zero it again to force a cold tick.
+                                          word 0: bit 63 valid | contact mode | variant << 8 | start-up task set << 9  (a tick with another key starts cold)
+                                          words 1..12: bit 63 valid | bits 0..55 rows pinned, one word per solve [1 + 6 pass + 2 level + completion]
+                                          words 13, 14: passes of every solve of the last tick, pass 0 / canonical pass (one byte per [2 level + completion]:
+                                          bits 0..6 interior-point + active-set iterations, bit 7 the carried guess was refuted); word 15 reserved */
 } qmgpu_wbc_args;
 
 int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args);
@@ -328,6 +344,9 @@ int qmgpu_debug_get_lq(qmgpu_handle h, int instance, int node, double* A, double
 int qmgpu_last_kernel_ms(qmgpu_handle h, double* ms6);
 /* Same, averaged over the last `last_calls` timed calls (event ring of 256 calls; no per-call host sync is needed). */
 int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6);
+/* The same six durations of EACH of the last `last_calls` timed calls, oldest first: ms6_per_call [last_calls][6] (a launch of the sequential kernels lasts as long as
+ * its slowest instance: the spread from call to call is what a real-time caller has to budget for). */
+int qmgpu_kernel_ms_history(qmgpu_handle h, int last_calls, double* ms6_per_call);
 int qmgpu_enable_timing(qmgpu_handle h, int enable);
 /* Test aid: fills every scratch buffer behind the handle and the LDS of every CU with NaN, so that a kernel reading memory that
  * nothing wrote in this call shows up as NaN in the results instead of passing on left-over values. */

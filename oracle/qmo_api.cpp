@@ -16,11 +16,15 @@ using namespace qmo;
 // built by the entry points below until cleared (null).  Set from the tests' thread before a call; not part of the timed baselines.
 static const double* g_contactRef = nullptr;
 static const double* g_wbcEeForce = nullptr;
+// solver state carried from WBC tick to WBC tick (the counterpart of qmgpu_wbc_args::working_set): [B][QMGPU_WBC_STATE_WORDS] words, instance i of the batch entry points
+// (and the one instance of qmo_wbc_update) uses its own block; null: every tick cold.  Set from the tests' thread before a call.
+static uint64_t* g_wbcWorkingSet = nullptr;
 
 extern "C" {
 
 void qmo_set_ee_contact_ref(const double* ref /* [K][6] or null */) { g_contactRef = ref; }
 void qmo_set_wbc_ee_force(const double* f3 /* [3] or null */) { g_wbcEeForce = f3; }
+void qmo_set_wbc_working_set(uint64_t* ws /* [B][QMGPU_WBC_STATE_WORDS] or null */) { g_wbcWorkingSet = ws; }
 
 void qmo_flow_map(const qmgpu_problem* P, const double* x, const double* u, double* f) { flowMap<double>(P->model, P->settings.gravity, x, u, f); }
 
@@ -187,7 +191,7 @@ int qmo_cycle_batch_warm_mt(const qmgpu_problem* P, int batch, int N, int K, int
           if (outPolicy) for (int j = 0; j < 30; ++j) { outPolicy[size_t(i) * 60 + j] = xd[j]; outPolicy[size_t(i) * 60 + 30 + j] = ud[j]; }
           if (outPolicyMode) outPolicyMode[i] = md;
           const int ws = wbcUpdate(*P, variant, xd, ud, rbd + size_t(i) * 55, md, period[i], time[i], inputLast + size_t(i) * 30, outWbc + size_t(i) * 54, nullptr,
-                                   eeForce ? eeForce + size_t(i) * 3 : nullptr);
+                                   eeForce ? eeForce + size_t(i) * 3 : nullptr, nullptr, g_wbcWorkingSet ? g_wbcWorkingSet + size_t(i) * QMGPU_WBC_STATE_WORDS : nullptr);
           outWbcStatus[i] = ws;
           bad = bad || ws != 0;
         }
@@ -209,10 +213,10 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
 }
 
 // experiment knobs of the WBC restatement (qmo_wbc.h; defaults = the product's algorithm): key 0 = starting value of the interior point that runs in front of the active-set method
-// (default 300), key 3 = no interior point at all (the active-set method cold from z = 0 on every level), key 9 = per-iteration trace on stderr.  Both change the PATH to the
+// (default 300), key 3 = no interior point at all (the active-set method cold from z = 0 on every level), key 8 = the working sets carried from the previous tick are ignored, key 9 = per-iteration trace on stderr.  Both change the PATH to the
 // vertex only: the tests use them to check that the result does not.
 void qmo_set_experiment(int key, double value) {
-  if (key == 0) g_expLowerLevelStart = value; else if (key == 3) g_expNoInteriorPoint = value != 0.0; else if (key == 4) g_expNoMinNormStart = value != 0.0; else if (key == 7) g_expGuessOrder = value != 0.0; else if (key == 9) g_expTrace = int(value);
+  if (key == 0) g_expLowerLevelStart = value; else if (key == 3) g_expNoInteriorPoint = value != 0.0; else if (key == 4) g_expNoMinNormStart = value != 0.0; else if (key == 7) g_expGuessOrder = value != 0.0; else if (key == 8) g_expNoWarmStart = value != 0.0; else if (key == 9) g_expTrace = int(value);
 }
 
 // WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],
@@ -227,7 +231,8 @@ int qmo_wbc_batch_mt(const qmgpu_problem* P, int batch, int threads, int variant
     pool.emplace_back([=, &failed]() {
       for (int i = t; i < batch; i += threads) {
         status[i] = wbcUpdate(*P, variant, xDes + size_t(i) * 30, uDes + size_t(i) * 30, rbd + size_t(i) * 55, mode[i], period[i], time[i], inputLast + size_t(i) * 30,
-                              out + size_t(i) * 54, nullptr, eeForce ? eeForce + size_t(i) * 3 : nullptr, diag ? diag + size_t(i) * 8 : nullptr);
+                              out + size_t(i) * 54, nullptr, eeForce ? eeForce + size_t(i) * 3 : nullptr, diag ? diag + size_t(i) * 8 : nullptr,
+                              g_wbcWorkingSet ? g_wbcWorkingSet + size_t(i) * QMGPU_WBC_STATE_WORDS : nullptr);
         failed[t] += status[i] != 0;
       }
     });
@@ -305,7 +310,7 @@ void qmo_wbc_model(const qmgpu_problem* P, const double* xDes, const double* uDe
 
 int qmo_wbc_update(const qmgpu_problem* P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
                    double* inputLast, double* out54) {
-  return wbcUpdate(*P, variant, xDes, uDes, rbd, mode, period, time, inputLast, out54, nullptr, g_wbcEeForce);
+  return wbcUpdate(*P, variant, xDes, uDes, rbd, mode, period, time, inputLast, out54, nullptr, g_wbcEeForce, nullptr, g_wbcWorkingSet);
 }
 
 // generic QP (row-major H n x n, D m x n) for KKT tests

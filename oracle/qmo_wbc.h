@@ -332,9 +332,10 @@ inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting val
 inline int g_expNoMinNormStart = 0;                      // 1: the first level without its minimum-norm start (tests: same torques)
 inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
 inline int g_expGuessOrder = 1;
+inline int g_expNoWarmStart = 0;                         // 1: the working set carried from the previous tick (wbcUpdate: ws) is ignored -- every level cold (tests: same torques)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
-struct QpStats { int ipmIterations = 0, iterations = 0, adds = 0, drops = 0, zeroSteps = 0, innerSteps = 0, eliminated = 0, status = 0; bool minNorm = false; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed
+struct QpStats { int ipmIterations = 0, iterations = 0, adds = 0, drops = 0, zeroSteps = 0, innerSteps = 0, eliminated = 0, status = 0; bool minNorm = false, warmTried = false, warmRefuted = false; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed
 
 // Cholesky that leaves out the directions without curvature (pivot <= floorv): row / column replaced by the identity, the right-hand side entry by zero, so their step is exactly zero.
 // A pivot is a difference, A_jj - sum_k L_jk^2, rounded relative to A_jj: it counts as curvature once it exceeds floorAbs + floorRel (j + 1) A_jj.
@@ -498,7 +499,11 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
 // their bounds in front, so that a dependency shows on a guessed row); a row the guessed step reaches only at its very end is not in its way; and if another row cuts
 // the step short before anything has moved, the guess is refuted and solveLevel lets the interior point go on (at most twice; after that the step is taken as far as
 // it goes and the row that cut it is pinned).  The first full step puts every pinned row on its bound; from there on the method is the textbook one.
-inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut, const std::vector<char>* fixedVars = nullptr, bool* guessRefuted = nullptr) {
+// warmMask (inherited rows only; bit i = row i): the working set the PREVIOUS tick of this robot ended this level with, taken as the guess from z = 0 -- same rules as for
+// the interior point's guess (dependent rows leave first, the first step is only taken in full), and a first step that any row cuts short refutes it, also when the
+// guess was "no row is active": the level then starts over the cold way.
+inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut, const std::vector<char>* fixedVars = nullptr, bool* guessRefuted = nullptr,
+                              const uint64_t* warmMask = nullptr, const Vec* warmZ = nullptr) {
   enum { I = 0, P = 1, V = 2 };
   QpStats st;
   const int n = q.n(), m = q.m(), mOwn = q.mOwn;
@@ -516,6 +521,8 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     const Vec Dz = D * z;
     for (int i = mOwn; i < m; ++i) if (rowOn[i] && (start->lam[i] > 1.0 * start->s[i] || Dz[i] - f[i] > 0.0)) { state[i] = P; guess[i] = 1; }
   }
+  if (warmMask) for (int i = mOwn; i < m && i < 64; ++i) if (rowOn[i] && ((*warmMask >> i) & 1ull)) { state[i] = P; guess[i] = 1; }
+  if (warmMask && warmZ) z = *warmZ;      // (the previous tick's solution, scaled back into the rows by solveLevel)
   int lastReleased = -1, fullSteps = 0, guard = 0;
   for (;; ++st.iterations) {
     if (st.iterations > kAsMaxWorkingSetChanges || ++guard > 4 * kAsMaxWorkingSetChanges) { st.status = 1; break; }      // (guard: every trip of the loop counts, also those that do not change the working set)
@@ -607,7 +614,7 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     if (block >= 0 && fullSteps > 0 && pmax <= 1e-9 * zmax0) block = -1;  // (a refinement correction at rounding size changes no row's side: a row that ends exactly ON its bound -- a violated own row whose violation the level removes -- would otherwise be pinned or not by the last bit)
     // the step that was to bring the guessed rows onto their bounds is cut short by another row: the guess is wrong.  Nothing has moved yet: the caller may let the
     // interior point go on from its iterate and read the working set again (solveLevel; at most twice -- after that the step is taken as far as it goes)
-    if (block >= 0 && offBound && guessRefuted && st.adds == 0 && st.drops == 0) { *guessRefuted = true; st.status = 6; break; }
+    if (block >= 0 && (offBound || warmMask) && guessRefuted && st.adds == 0 && st.drops == 0) { *guessRefuted = true; st.status = 6; break; }
     if (block >= 0) {
       const bool moved = alpha * pmax > 1e-13 * zmax0;       // a step that does not move the point beyond its rounding counts as zero-length
       for (int i = 0; i < n; ++i) z[i] += alpha * p[i];
@@ -693,7 +700,13 @@ inline Mat eliminateImpliedEqualities(LevelQp& q, const std::vector<char>& eq) {
 }
 
 // One level: z (decision variables of the level as the reference counts them), and the rows that are strongly active at the solution (eq, in / out).
-inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
+// warm (in / out, may be null): bit 63 = valid, bits 0..55 = the rows this level ended pinned at the previous tick of the same robot in the same contact mode (wbcUpdate
+// keeps one word per solve).  A valid word is tried first, from z = 0 (activeSetPhase: warmMask); refuted, the level is solved the cold way.  Any path ends at the same vertex.
+// warmZ (in / out, may be null; with warm only): the level's solution z of that tick -- a level's cost leaves directions unseen (its Hessian is (A Z)'(A Z), rank < n: the next level
+// decides them) and the minimiser reached from z = 0 through the seen directions alone is usually OUTSIDE the inherited rows while minimisers inside them exist (which is
+// what the interior point finds); the previous tick's minimiser, a tick later, is still one of those up to the tick's change.  It is scaled back by t <= 1 until every
+// row holds (z = 0 is feasible and the rows are convex), the carried rows are the guess, the first step must go through in full -- else the cold path.
+inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z, uint64_t* warm = nullptr, double* warmZ = nullptr) {
   const int nFull = q.n(), m = q.m();
   eq.resize(m, 0);
   QpStats st;
@@ -702,7 +715,7 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
   const Mat N = eliminateImpliedEqualities(q, eq);
   const bool reduced = N.r > 0;
   if (reduced) st.eliminated = nFull - N.c;
-  if (reduced && N.c == 0) return st;          // the equalities leave nothing to decide: z = 0
+  if (reduced && N.c == 0) { if (warm) *warm = 0; return st; }          // the equalities leave nothing to decide: z = 0
   const LevelWork w = prepareLevel(q);
   IpmPoint pt;
   bool hard = false; for (int i = q.mOwn; i < m; ++i) hard = hard || w.on[i];
@@ -715,6 +728,26 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
   // (Tried and NOT kept: the level's unconstrained minimiser first -- one factorisation from z = 0, done if no row is in its way: 22 % of a trot's ticks.  A direction whose
   //  curvature sits at the exclusion floor of the factorisation is then either solved for or left at ZERO, the full size of its component apart; behind the interior point it is
   //  left at the interior point's iterate, which is next to the minimiser either way.  HierarchicalMpcWbc's closed loop went from 5e-4 to 0.8 in its worst tick.)
+  bool warmTried = false, warmRefuted = false;
+  if (warm && (*warm >> 63) && q.mOwn == 0 && !g_expNoWarmStart) {
+    const uint64_t mask = *warm & ((1ull << 56) - 1ull);
+    warmTried = true;
+    Vec z0(q.n(), 0.0);
+    const bool haveZ = warmZ && ((*warm >> 62) & 1ull) && !reduced;
+    if (haveZ) {
+      for (int j = 0; j < q.n(); ++j) z0[j] = warmZ[j];
+      const Vec Dz = q.D * z0;
+      double t = 1.0;
+      // (rows of the carried set may start beyond their bound -- the first step brings them onto it, as it does the rows an interior point's iterate violates; every
+      //  other row must hold: f >= 0, the ratio is in [0, 1), and t depends continuously on the data)
+      for (int i = 0; i < m; ++i) if (w.on[i] && !((mask >> i) & 1ull) && Dz[i] > q.f[i]) t = std::min(t, q.f[i] / Dz[i]);
+      bool fin = t == t; for (double v : z0) fin = fin && v == v;
+      for (double& v : z0) v = fin ? v * t : 0.0;
+    }
+    st = activeSetPhase(q, w, nullptr, zw, lam, state, nullptr, &warmRefuted, &mask, haveZ ? &z0 : nullptr);
+    solved = !warmRefuted;
+    if (g_expTrace) fprintf(stderr, "  working set of the previous tick %014llx: %s\n", (unsigned long long)mask, solved ? "taken" : "refuted");
+  }
   if (!solved && useIpm) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt);
   // A level with own rows whose bound is zero (the friction rows of the first level: every one of them acts on the contact forces only, 0 <= 0 at z = 0): pinning
   // them all holds those forces at zero.  Tried in that form first -- the variables held, the rows left out: no working set to carry, one factorisation and one solve away
@@ -757,6 +790,8 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
       for (double v : zw) ok = ok && v == v;
     }
     if (ok) { minNorm = solved = true; st = QpStats(); st.minNorm = true; lam.assign(m, 0.0); state.assign(m, 0); }
+    // (Measured in round 6 and NOT kept: the active-set method started FROM this point when it violates limits -- origin shifted, the violated rows start violated -- instead
+    //  of from z = 0: on the eleven slowest ticks of the bench's steady-state leg, robots whose torque limits cannot hold, 58-72 working-set changes instead of 40-46.)
     if (g_expTrace) fprintf(stderr, "  minimum-norm start of the level: %s\n", ok ? "taken" : "rejected");
   }
   if (!solved && q.mOwn > 0) {
@@ -780,7 +815,13 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z) {
       ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt, muTarget, true, ipmIt);
     }
   }
-  st.ipmIterations = ipmIt; st.eliminated = reduced ? nFull - N.c : 0;
+  st.ipmIterations = ipmIt; st.eliminated = reduced ? nFull - N.c : 0; st.warmTried = warmTried; st.warmRefuted = warmRefuted;
+  if (warm) {
+    uint64_t mask = 0;
+    if (st.status == 0 && q.mOwn == 0) { mask = 1ull << 63; for (int i = 0; i < m && i < 56; ++i) if (w.on[i] && !state.empty() && state[i] == 1) mask |= 1ull << i; }
+    if (mask && warmZ && !reduced) { mask |= 1ull << 62; for (int j = 0; j < q.n(); ++j) warmZ[j] = zw[j]; }      // (bit 62: the solution travels with the rows)
+    *warm = mask;
+  }
   if (st.status == 2) zw.assign(q.n(), 0.0);      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
   z = reduced ? N * zw : zw;
   for (int i = 0; i < m; ++i) if (w.on[i]) eq[i] = eq[i] || (state[i] != 0 && lam[i] > 0.0);
@@ -807,7 +848,7 @@ struct HoQp {
   std::vector<int> sel, selNext; // the coordinates of x that ARE the level's decision variables: z = (x - xPrev)[sel] (the kernel bases carry an identity block, kernelFullPivLU); selNext: the next level's
   int qpIters = 0, attempts = 0, polished = 0;   // (diagnostics kept for the tests: attempts is always 0 -- no relaxed re-solve exists any more; polished = the level ended at a verified vertex)
 
-  HoQp(const Task& t, const HoQp* higher, bool canonical = false) : task(t) {
+  HoQp(const Task& t, const HoQp* higher, bool canonical = false, uint64_t* warmMain = nullptr, uint64_t* warmCanon = nullptr, double* warmZ = nullptr, int warmZCap = 0) : task(t) {
     // initVars
     numSlack = task.d.r; hasEq = task.a.r > 0; hasIneq = numSlack > 0;
     if (higher) { Zprev = higher->Z; stackedTasksPrev = higher->stackedTasks; slackPrev = higher->stackedSlack; xPrev = higher->solution(); numPrevSlack = higher->stackedTasks.d.r; numDec = Zprev.c; }
@@ -850,7 +891,7 @@ struct HoQp {
       if (higher) for (int i = 0; i < numPrevSlack; ++i) eqr[numSlack + i] = higher->stackedEq[i];
       if (g_expTrace) fprintf(stderr, "level: numDec %d own %d inherited %d\n", numDec, numSlack, numPrevSlack);
       Vec zr;
-      stats = solveLevel(q, eqr, zr);
+      stats = solveLevel(q, eqr, zr, warmMain, numDec <= warmZCap ? warmZ : nullptr);
       stackedEq = eqr;      // rows ordered as stackedTasks.d = [own; inherited] (Task::operator+)
       if (g_expTrace) fprintf(stderr, " -> status %d eliminated %d ipm %d iterations %d adds %d drops %d zero steps %d inner %d\n", stats.status, stats.eliminated, stats.ipmIterations, stats.iterations, stats.adds, stats.drops, stats.zeroSteps, stats.innerSteps);
       qpIters = stats.status ? -1 : std::min(stats.ipmIterations + stats.iterations, 59);
@@ -885,7 +926,7 @@ struct HoQp {
       std::vector<char> eqc = stackedEq;
       Vec wv;
       if (g_expTrace) fprintf(stderr, "completion: %d free directions\n", ker.c);
-      completionStats = solveLevel(q, eqc, wv);
+      completionStats = solveLevel(q, eqc, wv, warmCanon);
       completed = true;
       if (completionStats.status == 0 || completionStats.status == 1) { const Vec dzv = ker * wv; for (int i = 0; i < numDec; ++i) decSol[i] += dzv[i]; }
     }
@@ -895,7 +936,8 @@ struct HoQp {
 
 // HierarchicalWbc::update (variant 0) / HierarchicalMpcWbc::update (variant 1); returns [x(36); tau(18)]
 inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, const double* uDes, const double* rbd, int mode, double period, double time,
-                     double* inputLast, double out[54], WbcModel* modelOut = nullptr, const double* eeForce = nullptr, int32_t* diag /*[8]: attempts, iterations per level*/ = nullptr) {
+                     double* inputLast, double out[54], WbcModel* modelOut = nullptr, const double* eeForce = nullptr, int32_t* diag /*[8]: attempts, iterations per level*/ = nullptr,
+                     uint64_t* ws /*[QMGPU_WBC_STATE_WORDS] in / out or null: the solver state carried from tick to tick (qmgpu_wbc_args::working_set)*/ = nullptr) {
   WbcModel w;
   std::unique_ptr<PhaseTimer> phase(new PhaseTimer(PH_WBC_MODEL));
   wbcUpdateMeasured(P, rbd, w);
@@ -923,12 +965,27 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
   std::unique_ptr<HoQp> h0, h1, h2;
   const HoQp* last = nullptr;
   bool canonical = false;
+  // The working sets of the previous tick (one word per solve: [1 + 6 pass + 2 level + completion]) are guesses for this one as long as the rows mean the same thing:
+  // same contact mode, controller and task set (word 0); anything else starts cold.  Words 13 / 14: passes of every solve of this tick (a byte each, bit 7 = guess refuted).
+  if (ws) {
+    const uint64_t key = (1ull << 63) | uint64_t(mode & 15) | (uint64_t(variant & 1) << 8) | (uint64_t(variant == 0 && time < 10.0) << 9);
+    if (ws[0] != key) { for (int i = 1; i < QMGPU_WBC_STATE_WORDS; ++i) ws[i] = 0; ws[0] = key; }
+    ws[13] = ws[14] = 0;
+  }
+  auto slot = [&](int pass, int level, int completion) { return ws ? ws + 1 + 6 * pass + 2 * level + completion : nullptr; };
+  auto count = [&](int pass, int level, int completion, const QpStats& s) {
+    if (!ws) return;
+    const uint64_t b = uint64_t(std::min(s.ipmIterations + s.iterations, 127)) | (s.warmRefuted ? 128ull : 0ull);
+    ws[13 + pass] |= b << (8 * (2 * level + completion));
+  };
   for (int pass = 0; pass < 2; ++pass) {
     h2.reset();
-    h0.reset(new HoQp(task0, nullptr, canonical));
-    h1.reset(new HoQp(task1, h0.get(), canonical));
-    if (h1->Z.c > 0) h2.reset(new HoQp(task2, h1.get(), canonical));     // FLY: level 2 has no decision variables left -> skip
+    h0.reset(new HoQp(task0, nullptr, canonical, slot(pass, 0, 0), slot(pass, 0, 1)));
+    // (words 16..33 / 34..41: the solutions of the second and third level of pass 0 travel with their rows -- solveLevel: warmZ)
+    h1.reset(new HoQp(task1, h0.get(), canonical, slot(pass, 1, 0), slot(pass, 1, 1), (ws && pass == 0) ? reinterpret_cast<double*>(ws + 16) : nullptr, 18));
+    if (h1->Z.c > 0) h2.reset(new HoQp(task2, h1.get(), canonical, slot(pass, 2, 0), slot(pass, 2, 1), (ws && pass == 0) ? reinterpret_cast<double*>(ws + 34) : nullptr, 8));     // FLY: level 2 has no decision variables left -> skip
     last = h2 ? h2.get() : h1.get();
+    { const HoQp* lvp[3] = {h0.get(), h1.get(), h2.get()}; for (int l = 0; l < 3; ++l) if (lvp[l]) { count(pass, l, 0, lvp[l]->stats); if (lvp[l]->completed) count(pass, l, 1, lvp[l]->completionStats); } }
     if (canonical || !(last->Z.c > 0 && last->numDec > 0)) break;
     canonical = true;
   }

@@ -11,6 +11,7 @@ NX, NU, NV, NJ, NB, NC = 30, 30, 24, 18, 19, 4
 NTARGET, NRBD, NWBC_DEC, NWBC_OUT = 37, 55, 36, 54
 MAX_EVENTS = 40
 NSTATS = 10
+WBC_STATE_WORDS = 48   # uint64 words per instance of WbcArgs.working_set
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_FILE_NOT_FOUND, ERR_PARSE, ERR_UNSUPPORTED_MODEL = 1, 2, 3, 4
@@ -72,6 +73,7 @@ class WbcArgs(C.Structure):
         ("batch", i32), ("variant", i32),
         ("state_desired", C.c_void_p), ("input_desired", C.c_void_p), ("rbd_measured", C.c_void_p), ("mode", C.c_void_p),
         ("period", C.c_void_p), ("time", C.c_void_p), ("input_last", C.c_void_p), ("out", C.c_void_p), ("out_status", C.c_void_p), ("ee_force", C.c_void_p),
+        ("working_set", C.c_void_p),
     ]
 
 
@@ -96,7 +98,7 @@ SYMBOLS = [
     "qmgpu_strerror", "qmgpu_last_error", "qmgpu_load_problem", "qmgpu_load_gait", "qmgpu_mode_from_string", "qmgpu_tile_gait", "qmgpu_switch_gait", "qmgpu_time_grid_with_events", "qmgpu_warm_start_batch",
     "qmgpu_create", "qmgpu_create_ex", "qmgpu_destroy", "qmgpu_set_stream", "qmgpu_synchronize", "qmgpu_get_input_weight", "qmgpu_mpc_solve_batch",
     "qmgpu_policy_eval_batch", "qmgpu_frontend_batch", "qmgpu_wbc_solve_batch", "qmgpu_cycle_batch", "qmgpu_debug_get_lq", "qmgpu_last_kernel_ms",
-    "qmgpu_set_overlap", "qmgpu_join_wbc", "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_debug_poison", "qmgpu_kernel_ms_mean", "qmgpu_update_settings", "qmgpu_gait_schedule_batch",
+    "qmgpu_set_overlap", "qmgpu_join_wbc", "qmgpu_enable_timing", "qmgpu_enable_debug", "qmgpu_debug_poison", "qmgpu_kernel_ms_mean", "qmgpu_kernel_ms_history", "qmgpu_update_settings", "qmgpu_gait_schedule_batch",
 ]
 
 _lib = None
@@ -154,6 +156,7 @@ def load_library(path=None):
     lib.qmgpu_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(d)]
     lib.qmgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.qmgpu_kernel_ms_mean.argtypes = [C.c_void_p, C.c_int, C.POINTER(d)]
+    lib.qmgpu_kernel_ms_history.argtypes = [C.c_void_p, C.c_int, C.POINTER(d)]
     lib.qmgpu_enable_debug.argtypes = [C.c_void_p, C.c_int]
     lib.qmgpu_debug_poison.argtypes = [C.c_void_p]
     if path is None:

@@ -68,8 +68,12 @@ class GpuWbc : public WbcBase {
     a.batch = 1; a.variant = variant_;
     a.state_desired = dd + kXd; a.input_desired = dd + kUd; a.rbd_measured = dd + kRbd; a.period = dd + kPeriod; a.time = dd + kTime;
     a.mode = reinterpret_cast<int32_t*>(dd + kInts); a.input_last = dd + kIl; a.out = dd + kOut; a.out_status = reinterpret_cast<int32_t*>(dd + kStatus);
+    // the solver state of the previous tick (the rows every level ended on, the point it ended at) stays on the device next to inputLast_: consecutive 1 kHz ticks of one
+    // robot end on the same rows almost always, and a level that starts there needs one factorisation instead of an interior point's six to twelve.  Same torques
+    // whatever the path (tests/test_gpu_wbc.py); carryWorkingSet(false) gives the reference's cold start of every tick.
+    a.working_set = carry_ ? reinterpret_cast<uint64_t*>(dd + kWs) : nullptr;
     check(qmgpu_wbc_solve_batch(h_, &a));
-    hip(hipMemcpyAsync(host + kOut, dd + kOut, (kDoubles - kOut) * sizeof(double), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync D2H");
+    hip(hipMemcpyAsync(host + kOut, dd + kOut, (kWs - kOut) * sizeof(double), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync D2H");
     hip(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     lastStatus_ = reinterpret_cast<int32_t*>(host + kStatus)[0];   // the reference drops qpOASES' return value (HoQp.cpp:143); kept here for diagnostics
     ocs2::vector_t out(54);
@@ -87,10 +91,12 @@ class GpuWbc : public WbcBase {
   qmgpu_settings settingsCopy() { std::lock_guard<std::mutex> lock(mutex_); return P_.settings; }
   dynamic_reconfigure::Server<qm_wbc::WbcWeightConfig>& gainServer() { return *dynamicSrv_; }
   int lastStatus() const { return lastStatus_; }
+  void carryWorkingSet(bool on) { std::lock_guard<std::mutex> lock(mutex_); if (on && !carry_) hip(hipMemset(static_cast<double*>(dev_) + kWs, 0, QMGPU_WBC_STATE_WORDS * sizeof(uint64_t)), "hipMemset"); carry_ = on; }
 
  private:
-  // doubles: xDes[30] uDes[30] rbd[55] period time | mode (int32 in one double slot) | inputLast[30] | out[54] status (int32 in one double slot)
-  static constexpr int kXd = 0, kUd = 30, kRbd = 60, kPeriod = 115, kTime = 116, kInts = 117, kInDoubles = 118, kIl = 118, kOut = 148, kStatus = 202, kDoubles = 203;
+  // doubles: xDes[30] uDes[30] rbd[55] period time | mode (int32 in one double slot) | inputLast[30] | out[54] status (int32 in one double slot) | working-set record (device only)
+  static constexpr int kXd = 0, kUd = 30, kRbd = 60, kPeriod = 115, kTime = 116, kInts = 117, kInDoubles = 118, kIl = 118, kOut = 148, kStatus = 202, kWs = 203,
+                       kDoubles = 203 + QMGPU_WBC_STATE_WORDS;
   static constexpr size_t kBytes = kDoubles * sizeof(double);
   static void check(int st) { if (st != QMGPU_OK) throw std::runtime_error(std::string("[GpuWbc] ") + qmgpu_strerror(st) + ": " + qmgpu_last_error()); }
   static void hip(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string("[GpuWbc] ") + what + ": " + hipGetErrorString(e)); }
@@ -121,6 +127,7 @@ class GpuWbc : public WbcBase {
   void* pinned_ = nullptr;
   hipStream_t stream_ = nullptr;
   int lastStatus_ = 0;
+  bool carry_ = true;
 };
 
 }  // namespace qm

@@ -139,6 +139,12 @@ class GpuSolver:
         abi.check(self.lib, self.lib.qmgpu_kernel_ms_mean(self.handle, int(last_calls), ms))
         return list(ms)
 
+    def kernel_ms_history(self, last_calls):
+        """[last_calls][6] durations (ad, lq, riccati, line search, wbc, whole) of each of the last timed calls, oldest first"""
+        ms = (abi.d * (6 * int(last_calls)))()
+        abi.check(self.lib, self.lib.qmgpu_kernel_ms_history(self.handle, int(last_calls), ms))
+        return np.array(ms[:]).reshape(int(last_calls), 6)
+
     @staticmethod
     def mpc_args(batch, num_nodes, x0, target_times, target_states, sched_num, sched_times, sched_modes, out_t, out_x, out_u, out_mode, out_stats=None,
                  t0=None, time_grid=None, warm_x=None, warm_u=None, line_search=True, ee_contact_ref=None, algorithm=0):
@@ -155,13 +161,15 @@ class GpuSolver:
         return a
 
     @staticmethod
-    def wbc_args(batch, rbd, period, time, input_last, out, out_status=None, state_desired=None, input_desired=None, mode=None, variant=0, ee_force=None):
+    def wbc_args(batch, rbd, period, time, input_last, out, out_status=None, state_desired=None, input_desired=None, mode=None, variant=0, ee_force=None, working_set=None):
+        """working_set: [batch][abi.WBC_STATE_WORDS] int64 device tensor carried from tick to tick like input_last (the working sets each level of the hierarchical QP ended
+        with: the next tick's starting guess), or None -- every tick cold, as the reference's qpOASES call"""
         a = abi.WbcArgs()
         a.batch, a.variant = batch, variant
         for name, val in (("state_desired", state_desired), ("input_desired", input_desired), ("rbd_measured", rbd), ("mode", mode), ("period", period),
-                          ("time", time), ("input_last", input_last), ("out", out), ("out_status", out_status), ("ee_force", ee_force)):
+                          ("time", time), ("input_last", input_last), ("out", out), ("out_status", out_status), ("ee_force", ee_force), ("working_set", working_set)):
             setattr(a, name, _ptr(val))
-        a._keep = (ee_force, state_desired, input_desired, rbd, mode, period, time, input_last, out, out_status)
+        a._keep = (working_set, ee_force, state_desired, input_desired, rbd, mode, period, time, input_last, out, out_status)
         return a
 
     @staticmethod

@@ -152,7 +152,7 @@ template <int NP, int J> struct IpmFactorStep {
 };
 
 struct QpOff { int G, AZ, rhat, DZ, fhat, Kt, wtL, zs, red, fork, S; };
-struct QpResult { int status; int ipmIterations, iterations; bool strong; };   // status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed | 4 more pinned rows than the small system holds
+struct QpResult { int status; int ipmIterations, iterations; bool strong; unsigned long long pinMask; bool warmRefuted; };   // pinMask: the rows pinned at the solution (status 0); status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed | 4 more pinned rows than the small system holds
 
 // A called function, not inlined: the kernel around it sits at 512 VGPRs with scratch, and three inlined instantiations of this body add
 // ~1400 scalar-register spills to it; as a function each instantiation gets its own allocation.  The arrays arrive as offsets into the
@@ -162,8 +162,13 @@ struct QpResult { int status; int ipmIterations, iterations; bool strong; };   /
 // sigma0: starting slacks / multipliers of the interior point in units of sqrt(scale) (<= 0: no interior point -- the level's own rows, and the tests' cold runs); tryHeld (a level with own rows whose bound is
 // zero -- the friction rows of the first level, each acting on the contact forces only): the variables those rows act on are HELD at zero and the rows left out, instead
 // of the rows being pinned: no working set to carry.  status 5 = the cost wants a held variable moved -- the caller solves again with the rows as rows.
+// warm (bit 63 = valid, bits 0..55 = rows; inherited rows only): the working set the previous tick of this robot ended this level with (qmgpu_wbc_args::working_set), taken
+// as the guess under the rules of the interior point's guess; a first step that any row cuts short refutes it and the level starts over the cold way.  warmZ (global memory,
+// with bit 62 of warm; else null): the level's solution of that tick, the starting point -- scaled back by t <= 1 until every row outside the carried set holds (z = 0 is
+// feasible, the rows are convex; the CPU restatement's solveLevel has the reasoning: the minimiser reached from z = 0 through the directions the cost sees is usually outside
+// the rows, the previous tick's is a minimiser inside them up to the tick's change).
 template <int NP, int LDZ_, int LDK_>
-__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, int lane) {
+__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, unsigned long long warm, const double* warmZ, int lane) {
   QM_DYNAMIC_LDS(ldsBase);
   const QpIo io{ldsBase + off.G, ldsBase + off.AZ, ldsBase + off.rhat, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork, ldsBase + off.S};
   enum { ST_I = 0, ST_P = 1, ST_V = 2 };
@@ -334,11 +339,24 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   double muTarget = 1e-8;            // duality measure (x scale) at which the working set is read off the iterate (= kIpmHandOverMu of the CPU restatement)
   int resumed = 0, status = 0, it = 0;
   bool strong = false;
+  bool warmTry = !own && (warm >> 63) != 0ull, warmRefuted = false;
+  unsigned long long pinOut = 0ull;
+  if (warmTry && warmZ != nullptr && ((warm >> 62) & 1ull)) {
+    const double z0 = colOn ? warmZ[colL] : 0.0;
+    QM_WAVE_SYNC();
+    bc[lane] = z0;
+    QM_WAVE_SYNC();
+    const double Dz0 = rowDot();
+    const bool carried = lane < 56 && ((warm >> lane) & 1ull);
+    const double t = allMin((rowOn && !carried && Dz0 > fl) ? fl / Dz0 : 1.0);
+    const double probe = allSum(z0) + t;
+    zc = (probe == probe) ? z0 * t : 0.0;
+  }
   // The interior point hands over; if the step that is to bring its guessed rows onto their bounds is cut short by another row, the guess is wrong -- nothing has moved
   // yet, the interior point goes on from its iterate (target x 1e-2) and the working set is read again, at most twice; after that the step is taken as far as it goes.
 #pragma unroll 1
   for (;;) {
-  if (ipmOn) {
+  if (ipmOn && !warmTry) {
     const int itStart = ipmIt;
     double zcPrev = zc, s1p = s1, l1p = l1, nrdPrev = 0.0, muPrev = 0.0;
     usable = false;
@@ -431,6 +449,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     const double Dz = rowDot();
     if (rowOn && (l1 > s1 || Dz - fl > 0.0)) { state = ST_P; guess = true; }
   }
+  if (warmTry && rowOn && lane < 56 && ((warm >> lane) & 1ull)) { state = ST_P; guess = true; }
   double lam = 0.0;                  // multiplier of this lane's row (pinned rows)
   int lastReleased = -1, fullSteps = 0, changes = 0, guard = 0;
   bool refuted = false;
@@ -448,7 +467,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     if (pinMask != tightMask) {
       // the guessed rows by decreasing multiplier estimate of the interior point, lam |d| (ties: smaller index): of two guessed rows that depend on each other -- the two
       // sides of a friction pyramid at its apex -- the one with the smaller estimate then shows the vanishing pivot and leaves (the CPU restatement has the numbers)
-      const double key = l1 * dn;
+      const double key = warmTry ? 0.0 : l1 * dn;      // (a carried working set has no estimates: index order)
       int rank = 0;
       unsigned long long gm = pinMask & ~tightMask;
 #pragma unroll 1
@@ -608,6 +627,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       double amin = allMin(a);
       if (offBound && amin >= 1.0 - 1e-9) amin = 2.0;       // (a row the guessed step reaches at its very end is not in its way)
       if (fullSteps > 0 && pmax <= 1e-9 * zmax0) amin = 2.0;  // (a refinement correction at rounding size changes no row's side)
+      if (amin < 1.0 && warmTry && changes == 0) { refuted = true; done = true; break; }                                 // the carried working set is refuted (also the empty one): the cold way
       if (amin < 1.0 && offBound && ipmOn && resumed < 2 && changes == 0) { refuted = true; done = true; break; }     // the guess is refuted before anything moved: back to the interior point
       if (amin < 1.0) {
         const int block = qmFirstBit(qmBallot(a == amin));          // ties keep the smallest row index
@@ -668,6 +688,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         if (qmBallot(wants) != 0ull) status = 5;
       }
       strong = rowOn && ((state == ST_V && Df * dn > gradNoise) || (state == ST_P && lam * dn > gradNoise));       // (a violated own row's multiplier is its violation)
+      pinOut = qmBallot(rowOn && state == ST_P);
       QM_TICK(8);
       done = true;
       break;
@@ -676,13 +697,14 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     (void)rebuild;
   }
   if (!refuted) break;
+  if (warmTry) { warmTry = false; warmRefuted = true; zc = 0.0; continue; }     // (the cold way: z = 0, the interior point starts where it always does)
   ++resumed; muTarget *= 1e-2;
   }
   QM_TICK(7);
   QM_TICK_FLUSH(NP == 36 ? 160 : (NP == 20 ? 256 : 288), blockIdx.x == 0 && lane == 0);
   if (status == 2) zc = 0.0;      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
-  return QpResult{status, ipmIt, it, strong};
+  return QpResult{status, ipmIt, it, strong, (status == 0 && !own) ? (pinOut | (1ull << 63)) : 0ull, warmRefuted};
 }
 
 }  // namespace qmk

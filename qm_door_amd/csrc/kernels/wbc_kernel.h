@@ -34,6 +34,7 @@ struct WbcArgs {
   const double* xDes; const double* uDes; const double* rbd; const int* mode; const double* period; const double* time;
   double* inputLast; double* out; int* status;
   const double* eeForce;   // [batch][3] or null: external force on the arm end-effector (force tracking, own formulation)
+  unsigned long long* workingSet;   // [batch][QMGPU_WBC_STATE_WORDS] in / out or null: the working sets of the previous tick (qmgpu_wbc_args::working_set)
 };
 
 constexpr int ND = 36, NVV = 24, MAXR = 22, MAXM = 56;
@@ -741,10 +742,14 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   // (own: the level's own, soft; else inherited, hard).  Rows a higher level left strongly active (eqIn) are equalities here: removed exactly by the change of variables
   // z = N_E w (N_E = kernel of those rows; DESIGN.md section 4.7 has the argument), the QP is solved in w.  Result: z in zs[0 .. nVars);
   // strongOut: this lane's row is strongly active at the solution; returns the solver's status.  AZp and DZ are overwritten when rows are eliminated.
-  auto levelQp = [&](double* AZp, int rRows, double* rhatp, int nVars, bool own, bool rowOnIn, bool eqIn, bool& strongOut, int& passes) -> int {
+  // warmIo (in / out): the word of this solve in the instance's working-set record (0: none / cold); passes gets bit 7 when the carried guess was refuted.
+  // warmZ (global memory or null): where the solution of this solve travels with its rows (bit 62 of the word; not when implied equalities changed the variables).
+  auto levelQp = [&](double* AZp, int rRows, double* rhatp, int nVars, bool own, bool rowOnIn, bool eqIn, bool& strongOut, int& passes, unsigned long long& warmIo, double* warmZ) -> int {
     int nQ = nVars;
     bool rowOn = rowOnIn, reduced = false;
     strongOut = false;
+    const unsigned long long warmIn = warmIo;
+    warmIo = 0ull;
     if (!own) {
       unsigned long long eqMask = qmBallot(rowOn && eqIn);
       if (eqMask != 0ull) {
@@ -833,15 +838,18 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     const double sigma0 = (own || nQ <= 8) ? -1.0 : 0.5;         // (small levels go without the interior point: cold, the active-set method is shorter there in mean and in the tail)
     auto solve = [&](bool tryHeld) {
       QpResult rr;
-      if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);
-      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);
-      else rr = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, lane);
+      const double* wz = reduced ? nullptr : warmZ;
+      if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lane);
+      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lane);
+      else rr = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lane);
       QM_WAVE_SYNC();
       return rr;
     };
     QpResult res = solve(own);                       // own rows: first with the variables of the zero-bound rows held (qp_dev.h) ...
     if (own && res.status != 0) res = solve(false);  // ... and, if the cost wants them moved, with those rows as rows
-    passes = res.ipmIterations + res.iterations;
+    passes = (res.ipmIterations + res.iterations < 127 ? res.ipmIterations + res.iterations : 127) | (res.warmRefuted ? 128 : 0);
+    warmIo = res.pinMask;
+    if (warmIo != 0ull && warmZ != nullptr && !reduced) { warmIo |= 1ull << 62; if (lane < nQ) warmZ[lane] = zs[lane]; }     // (the solution travels with the rows)
     strongOut = rowOn && res.strong;
     if (reduced) {   // z = N_E w
       double zf = 0.0;
@@ -877,6 +885,18 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   // canonical representative taken at every level (pass 1; DESIGN.md section 4.7 has the argument).
   int n = ND;
   bool canonical = false;
+  // The working sets of the previous tick (one word per solve: [1 + 6 pass + 2 level + completion]) are guesses for this one as long as the rows mean the same thing:
+  // same contact mode, controller and task set (word 0); anything else starts cold.  Words 13 / 14: passes of every solve of this tick (a byte each, bit 7 = guess refuted).
+  unsigned long long* wsRec = a.workingSet ? a.workingSet + size_t(inst) * QMGPU_WBC_STATE_WORDS : nullptr;
+  const unsigned long long wsKey = (1ull << 63) | (unsigned long long)(mode & 15) | ((unsigned long long)(a.variant & 1) << 8) | ((a.variant == 0 && time < 10.0) ? (1ull << 9) : 0ull);
+  const bool wsLive = wsRec != nullptr && wsRec[0] == wsKey;
+  unsigned long long wsCount[2] = {0ull, 0ull};
+  auto wsLoad = [&](int pass, int level, int completion) { return wsLive ? wsRec[1 + 6 * pass + 2 * level + completion] : 0ull; };
+  auto wsStore = [&](int pass, int level, int completion, unsigned long long word, int passes) {
+    wsCount[pass] |= (unsigned long long)(passes & 255) << (8 * (2 * level + completion));
+    if (wsRec && lane == 0) wsRec[1 + 6 * pass + 2 * level + completion] = word;
+  };
+  if (wsRec && !wsLive && lane < QMGPU_WBC_STATE_WORDS) wsRec[lane] = lane == 0 ? wsKey : 0ull;     // (the loads above are wave uniform and precede this store in program order)
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
   status = 0; n = ND;
@@ -1039,7 +1059,11 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     // ---- the level's QP (qp_dev.h)
     bool strong = false; int passes = 0;
     const bool hadEq = level > 0 && qmBallot(eqRow && rowNonZero(n)) != 0ull;
-    const int st = levelQp(AZ, r, tzv, n, level == 0, rowNonZero(n), eqRow, strong, passes);
+    unsigned long long wsWord = wsLoad(pass, level, 0);
+    // (words 16..33 / 34..41 of the record: the solutions of the second and third level of pass 0)
+    double* wsZ = (wsRec && pass == 0 && ((level == 1 && n <= 18) || (level == 2 && n <= 8))) ? reinterpret_cast<double*>(wsRec + (level == 1 ? 16 : 34)) : nullptr;
+    const int st = levelQp(AZ, r, tzv, n, level == 0, rowNonZero(n), eqRow, strong, passes, wsWord, wsZ);
+    wsStore(pass, level, 0, wsWord, passes);
     eqRow = eqRow || strong;
     if (st != 0) status |= (1 << level);
 #ifdef QM_RICCATI_TIMING
@@ -1103,7 +1127,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       marginsAtX();
       QM_WAVE_SYNC();
       bool strongC = false; int passesC = 0;
-      const int stc = levelQp(AZc, nOld, rds, n, false, rowNonZero(n), eqRow, strongC, passesC);
+      unsigned long long wsWordC = wsLoad(pass, level, 1);
+      const int stc = levelQp(AZc, nOld, rds, n, false, rowNonZero(n), eqRow, strongC, passesC, wsWordC, nullptr);
+      wsStore(pass, level, 1, wsWordC, passesC);
       if (stc != 0) status |= 8;
       double xc = 0.0;
       if (lane < ND) { xc = xs[lane]; for (int j = 0; j < n; ++j) xc += Z[lane * LDZ + j] * zs[j]; }
@@ -1127,6 +1153,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     a.out[size_t(inst) * 54 + 36 + lane] = s;
   }
   if (lane == 0 && a.status) a.status[inst] = status;
+  if (wsRec && lane == 0) { wsRec[13] = wsCount[0]; wsRec[14] = wsCount[1]; }
   forkCmd[0] = 0.0;      // release the helper wavefronts
   QM_LDS_BARRIER();
   QM_TICK(10);

@@ -177,7 +177,8 @@ static void joinWbc(qmgpu_handle h) {
 
 int qmgpu_set_stream(qmgpu_handle h, void* hip_stream) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
-  return guarded([&]() { DeviceGuard onDevice(h->device); joinWbc(h); h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->ownStream; });
+  // the NEW stream is the one that has to wait for a WBC still pending on the overlap stream: everything enqueued from here on goes there
+  return guarded([&]() { DeviceGuard onDevice(h->device); h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->ownStream; joinWbc(h); });
 }
 
 int qmgpu_synchronize(qmgpu_handle h) {
@@ -189,14 +190,17 @@ int qmgpu_set_overlap(qmgpu_handle h, int enable) {
   if (!h) return setError(QMGPU_ERR_INVALID_ARGUMENT, "null handle");
   return guarded([&]() { DeviceGuard onDevice(h->device);
     joinWbc(h);
-    if (enable && !h->evWbc) {
+    if (enable) {   // (each resource on its own: a call that failed half way is repeated without leaking what it had created)
       // a HIGH-PRIORITY stream: the runtime spreads streams of one priority over a few hardware queues round robin, and two streams that land on the same queue run
-      // their kernels one after the other (measured: the second handle of a process got no overlap at all); priority levels have hardware queues of their own
-      int least = 0, greatest = 0;
-      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIP_CHECK(hipStreamCreateWithPriority(&h->wbcStream, hipStreamNonBlocking, greatest));
-      HIP_CHECK(hipEventCreateWithFlags(&h->evPolicy, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&h->evWbc, hipEventDisableTiming));
+      // their kernels one after the other (measured: the second handle of a process got no overlap at all); priority levels have hardware queues of their own.  On a
+      // device without priority levels (range 0..0) the stream is an ordinary one: the results are the same, the overlap is whatever the runtime's queue assignment gives
+      if (!h->wbcStream) {
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&h->wbcStream, hipStreamNonBlocking, greatest));
+      }
+      if (!h->evPolicy) HIP_CHECK(hipEventCreateWithFlags(&h->evPolicy, hipEventDisableTiming));
+      if (!h->evWbc) HIP_CHECK(hipEventCreateWithFlags(&h->evWbc, hipEventDisableTiming));
     }
     h->overlap = enable != 0;
   });
@@ -325,7 +329,9 @@ static void enqueueWbc(qmgpu_handle h, const qmgpu_wbc_args* w, hipStream_t stre
   if (!w || w->batch < 1) throw std::invalid_argument("bad WBC arguments");
   if (w->batch > h->maxBatch) throw CapacityError("WBC batch exceeds the capacity given to qmgpu_create");
   if (!w->state_desired || !w->input_desired || !w->rbd_measured || !w->mode || !w->period || !w->time || !w->input_last || !w->out) throw std::invalid_argument("missing WBC pointer");
-  WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, w->ee_force};
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "working-set words");
+  WbcArgs wa{h->m.dP, w->batch, w->variant, w->state_desired, w->input_desired, w->rbd_measured, w->mode, w->period, w->time, w->input_last, w->out, w->out_status, w->ee_force,
+             reinterpret_cast<unsigned long long*>(w->working_set)};
   QM_LAUNCH_DYN(wbc_kernel, w->batch, WBC_THREADS, WBC_LDS_BYTES, stream, wa);
   HIP_CHECK(hipGetLastError());
 }
@@ -479,6 +485,15 @@ int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (long c = h->callCount - n; c < h->callCount; ++c) { double m[6]; readTiming(h, c, m); for (int i = 0; i < 6; ++i) acc[i] += m[i]; }
     for (int i = 0; i < 6; ++i) ms6[i] = acc[i] / double(n);
+  });
+}
+
+int qmgpu_kernel_ms_history(qmgpu_handle h, int last_calls, double* ms6_per_call) {
+  if (!h || !ms6_per_call || last_calls < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad argument");
+  return guarded([&]() { if (!h) throw std::invalid_argument("null handle"); DeviceGuard onDevice(h->device);
+    if (!h->timing || h->callCount == 0) throw std::invalid_argument("no timed call recorded (qmgpu_enable_timing)");
+    if (last_calls > h->callCount || last_calls > qmgpu_context::kRing) throw std::invalid_argument("more calls asked for than the event ring holds");
+    for (long c = h->callCount - last_calls, i = 0; c < h->callCount; ++c, ++i) readTiming(h, c, ms6_per_call + 6 * i);
   });
 }
 

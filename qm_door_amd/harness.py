@@ -57,7 +57,8 @@ class MpcBatch:
 
 
 class WbcBatch:
-    def __init__(self, rbd, period, time, input_last, state_desired=None, input_desired=None, mode=None, variant=0):
+    def __init__(self, rbd, period, time, input_last, state_desired=None, input_desired=None, mode=None, variant=0, carry=False):
+        """carry: a working-set record per instance travels from call to call next to input_last (qmgpu_wbc_args::working_set); off: every call cold"""
         B = rbd.shape[0]
         f64 = torch.float64
         self.rbd = dev(rbd, f64); self.period = dev(period, f64); self.time = dev(time, f64); self.il = dev(input_last, f64)
@@ -65,11 +66,15 @@ class WbcBatch:
         self.ud = dev(input_desired, f64) if input_desired is not None else None
         self.mode = dev(mode, torch.int32) if mode is not None else None
         self.out = torch.zeros((B, 54), dtype=f64, device=DEVICE); self.status = torch.zeros(B, dtype=torch.int32, device=DEVICE)
-        self.args = api.GpuSolver.wbc_args(B, self.rbd, self.period, self.time, self.il, self.out, self.status, self.xd, self.ud, self.mode, variant)
+        self.ws = torch.zeros((B, abi.WBC_STATE_WORDS), dtype=torch.int64, device=DEVICE) if carry else None
+        self.args = api.GpuSolver.wbc_args(B, self.rbd, self.period, self.time, self.il, self.out, self.status, self.xd, self.ud, self.mode, variant, working_set=self.ws)
 
     def results(self):
         _sync()
-        return dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), input_last=self.il.cpu().numpy())
+        r = dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), input_last=self.il.cpu().numpy())
+        if self.ws is not None:
+            r["working_set"] = self.ws.cpu().numpy().view(np.uint64)
+        return r
 
 
 def make_solver(interface, max_batch, max_nodes, dtype="f64"):
@@ -190,7 +195,8 @@ class GpuBackend:
     """The loop through the C ABI: front end, warm start, MPC, policy evaluation and WBC are the library's kernels; buffers stay on the device, the plan is
     downloaded once per cycle for the plan-following measurement."""
 
-    def __init__(self, itf, sc, variant=0):
+    def __init__(self, itf, sc, variant=0, carry=False):
+        """carry: the working sets of the hierarchical QP travel from tick to tick next to inputLast_ (qmgpu_wbc_args::working_set)"""
         import torch
         import qm_door_amd.harness as G
         from qm_door_amd import abi
@@ -206,6 +212,7 @@ class GpuBackend:
         self.sn, self.se, self.sm = G.dev(np.full(B, sc.nev, dtype=np.int32), torch.int32), G.dev(np.tile(sc.ev, (B, 1)), f64), G.dev(np.tile(sc.md, (B, 1)), torch.int32)
         self.kind, self.cmd, self.lastee = z(B, dtype=torch.int32), z(B, 7), z(B, 7)
         self.il = z(B, 30)
+        self.ws = z(B, abi.WBC_STATE_WORDS, dtype=torch.int64) if carry else None
         self.xd, self.ud, self.pm = z(B, 30), z(B, 30), z(B, dtype=torch.int32)
         self.out, self.status = z(B, 54), z(B, dtype=torch.int32)
         self.period = G.dev(np.full(B, WBC_PERIOD), f64)
@@ -255,9 +262,10 @@ class GpuBackend:
         o = self._views(self.sets[self.cur], self.N)
         self.sol.policy_eval(B, self.N, o["T"], o["X"], o["U"], o["M"], G.dev(np.full(B, t), t64), self.xd, self.ud, self.pm)
         rb = G.dev(rbd, t64)
-        a = api.GpuSolver.wbc_args(B, rb, self.period, G.dev(np.full(B, time), t64), self.il, self.out, self.status, self.xd, self.ud, self.pm, self.variant)
+        a = api.GpuSolver.wbc_args(B, rb, self.period, G.dev(np.full(B, time), t64), self.il, self.out, self.status, self.xd, self.ud, self.pm, self.variant, working_set=self.ws)
         self.sol.wbc(a)
         self.torch.cuda.synchronize() if G.DEVICE == "cuda" else None
-        return dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), mode=self.pm.cpu().numpy(), input_last=self.il.cpu().numpy())
+        return dict(out=self.out.cpu().numpy(), status=self.status.cpu().numpy(), mode=self.pm.cpu().numpy(), input_last=self.il.cpu().numpy(),
+                    working_set=None if self.ws is None else self.ws.cpu().numpy().view(np.uint64))
 
 

@@ -72,9 +72,12 @@ int runLatency(const char* outPath, int runs, int ticksPerRun) {
   rm.targetTrajectories.timeTrajectory = {0.0}; rm.targetTrajectories.stateTrajectory = {tgt}; rm.targetTrajectories.inputTrajectory = {ocs2::vector_t(30)};
   ctl.qmInterface_->mpcSettings_.timeHorizon_ = 1.0;
   ctl.setupMpc(nh); ctl.setupWbc(nh, task);
+  const bool coldWbc = std::getenv("QM_WBC_COLD") != nullptr;      // every tick cold, as the reference's qpOASES call (default: the working sets travel from tick to tick)
+  if (coldWbc) dynamic_cast<qm::GpuWbc*>(ctl.wbc_.get())->carryWorkingSet(false);
   std::ofstream out(outPath);
   out.precision(6);
-  out << "{\"controller\": \"" << (Ctl::kWbcVariant ? "qm/QMGpuMpcController" : "qm/QMGpuController") << "\", \"wbc_variant\": " << Ctl::kWbcVariant;
+  out << "{\"controller\": \"" << (Ctl::kWbcVariant ? "qm/QMGpuMpcController" : "qm/QMGpuController") << "\", \"wbc_variant\": " << Ctl::kWbcVariant
+      << ", \"wbc_working_set\": \"" << (coldWbc ? "cold every tick" : "carried from tick to tick") << "\"";
   for (int pass = 0; pass < 2; ++pass) {       // pass 0: wall clock only; pass 1: the same loop with HIP-event kernel timing on both handles
     qmgpu_enable_timing(ctl.mpcHandle(), pass); qmgpu_enable_timing(ctl.wbcHandle(), pass);
     ctl.mpc_->reset();

@@ -269,12 +269,21 @@ class Oracle:
             out.update(x_des=pol[:, :30], u_des=pol[:, 30:], policy_mode=pm, out=wout, status=wst, input_last=il)
         return out
 
-    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False):
+    def set_working_set(self, ws):
+        """ws: np.uint64 [B][48] (kept alive by the caller) or None.  The solver state the WBC entry points of this library carry from tick to tick (instance i of a batch
+        call uses block i): the counterpart of qmgpu_wbc_args::working_set.  None: every tick cold."""
+        assert ws is None or (ws.dtype == np.uint64 and ws.flags["C_CONTIGUOUS"] and ws.shape[-1] == 48)
+        self.lib.qmo_set_wbc_working_set.argtypes = [C.c_void_p]
+        self.lib.qmo_set_wbc_working_set(p(ws))
+        self._ws_keep = ws
+
+    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False, no_warm_start=False):
         """experiment knobs of the WBC restatement (process-wide for this library; the defaults are the product's algorithm).  Both change only the PATH to the vertex
         every level ends at: another starting value of the interior point that runs in front of the active-set method, or no interior point at all (the active-set
         method cold from z = 0)."""
         self.lib.qmo_set_experiment.argtypes = [C.c_int, C.c_double]
         self.lib.qmo_set_experiment(0, float(lower_level_start)); self.lib.qmo_set_experiment(3, float(bool(no_interior_point))); self.lib.qmo_set_experiment(9, float(bool(trace)))
+        self.lib.qmo_set_experiment(8, float(bool(no_warm_start)))
 
     def wbc_batch(self, x_des, u_des, rbd, mode, period, time, input_last, variant=0, ee_force=None, threads=None):
         """qmo_wbc_batch_mt: the WBC update of EVERY instance of a batch on `threads` host threads; returns out [B][54], status [B], input_last [B][30] (updated)"""

@@ -86,6 +86,33 @@ def test_closed_loop_256_instances_100_cycles(interface, variant):
 
 
 @pytest.mark.gpu
+def test_closed_loop_with_the_working_sets_carried_from_tick_to_tick(interface):
+    """qmgpu_wbc_args::working_set (include/qmgpu.h): every level of the hierarchical QP starts from the rows and the point the previous tick of the same robot ended with,
+    instead of cold as the reference's qpOASES call (HoQp.cpp:136-149).  The vertex a level ends at does not depend on the path, so (1) the GPU loop that carries its
+    records and the ORACLE loop that carries its own agree on every tick like the cold loops do, and (2) the GPU loop that carries agrees with the GPU loop that does not --
+    64 robots x 40 MPC cycles x 10 ticks across the end of the start-up branch and the start of the trot, HierarchicalWbc.  The pass counts of both (words 13 / 14 of
+    the records) go to gpurun_out/closed_loop_carry.json: what the carry buys per tick."""
+    B, cycles = 64, 40
+    out = {}
+    for name, other in (("gpu_carry_vs_oracle_carry", "oracle"), ("gpu_carry_vs_gpu_cold", "gpu")):
+        sc = CL.Scenario(interface, B, cycles=cycles, t_start=9.8, gait_start=0.25, seed=43)
+        a = CL.GpuBackend(interface, sc, 0, carry=True)
+        b = CL.OracleBackend(S.Oracle(interface.problem, fast=True), sc, 0, carry=True) if other == "oracle" else CL.GpuBackend(interface, sc, 0, carry=False)
+        offenders = []
+        rows = CL.run_lockstep(sc, a, b, ticks=10, offenders=offenders)
+        s = _check(rows, offenders=offenders, ticks=B * cycles * 10)
+        ticks = B * cycles * 10
+        out[name] = dict(summary=s, passes_per_tick=[sum(r["wbc_passes"][i] for r in rows) / ticks for i in range(2)], passes_max=[max(r["wbc_passes_max"][i] for r in rows) for i in range(2)],
+                         guesses_refuted_per_tick=[sum(r["guesses_refuted"][i] for r in rows) / ticks for i in range(2)], working_sets_differ=sum(r["working_sets_differ"] for r in rows))
+        if other == "gpu":
+            assert s["tau_max"] <= 1e-9, s      # same kernels, same inputs, another path to the same vertex
+    path = os.path.join(S.ROOT, "gpurun_out", "closed_loop_carry.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(out, open(path, "w"), indent=1)
+    assert out["gpu_carry_vs_oracle_carry"]["passes_per_tick"][0] < 3.0      # (cold: ~6 interior-point + active-set passes per tick; the second backend of the cold run records none)
+
+
+@pytest.mark.gpu
 def test_closed_loop_static_walk_three_leg_stances(interface):
     """The same loop on the gait whose every phase is a THREE-leg stance (gait.info static_walk: LF_RF_RH, RF_LH_RH, LF_RF_LH, LF_LH_RH, 0.3 s each) -- the contact modes
     whose lowest WBC level is the nearly degenerate LP of DESIGN.md section 5, here with robots in motion, inputLast_ carried and warm-started solves instead of the

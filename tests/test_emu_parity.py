@@ -124,6 +124,44 @@ def test_emu_wbc_on_the_degenerate_stance_tick(emu):
     assert np.abs(out[0, :36] - ref[:36]).max() <= 1e-9 * max(1.0, np.abs(ref[:36]).max())
 
 
+def test_emu_wbc_with_the_working_sets_carried_from_tick_to_tick(emu):
+    """qmgpu_wbc_args::working_set: the rows every level of the hierarchical QP ended on and the point it ended at travel from tick to tick next to inputLast_ and are
+    the next tick's starting guess (the reference cold-starts qpOASES every tick, HoQp.cpp:136-149).  One robot through two MPC cycles x three 1 kHz ticks on the host-
+    emulated kernel and on the CPU restatement, each carrying its own record: same torques on every tick, and the same torques as the cold solve of the same tick -- the
+    vertex does not depend on the path."""
+    import closed_loop as CL
+    itf, orc = emu
+    sc = CL.Scenario(itf, 1, cycles=2, gait_start=0.02, t_start=10.2)
+    a = CL.OracleBackend(orc, sc, 0, carry=True)
+    sol = api.GpuSolver(itf, max_batch=1, max_nodes=4)
+    ws = np.zeros((1, abi.WBC_STATE_WORDS), dtype=np.uint64)
+    rbd = sc.first_measurement()
+    warm_ticks = 0
+    for k in range(sc.cycles):
+        t0 = sc.t_start + k * CL.MPC_PERIOD
+        N, grid = sc.grid(t0)
+        a.observe(rbd, t0)
+        plan = a.mpc(t0, N, grid)
+        for j in range(3):
+            t = t0 + j * CL.WBC_PERIOD
+            if not (k == 0 and j == 0):
+                rbd = CL.measurement(sc, plan, t)
+            w = a.tick(t, rbd, t)
+            xd, ud, rb, md, tm, il = a.last
+            out, st, il_e = np.zeros((1, 54)), np.zeros(1, dtype=np.int32), il.copy()
+            sol.wbc(sol.wbc_args(1, rb, np.full(1, CL.WBC_PERIOD), np.full(1, tm), il_e, out, st, xd, ud, md.astype(np.int32), 0, working_set=ws))
+            assert st[0] == 0 and w["status"][0] == 0
+            assert S.rel_inf(out[:, 36:], w["out"][:, 36:]).max() <= 1e-9 and S.rel_inf(out[:, :36], w["out"][:, :36]).max() <= 1e-9
+            assert ws[0, 0] >> np.uint64(63) == 1 and ws[0, 0] == a.ws[0, 0]                 # both records carry this tick's key (contact mode, controller, task set)
+            assert (ws[0, 3] >> np.uint64(63)) == 1 and (a.ws[0, 3] >> np.uint64(63)) == 1     # the second level's word is valid on both sides
+            if not (k == 0 and j == 0):
+                warm_ticks += 1
+                cold = orc.wbc_update(xd[0], ud[0], rb[0], int(md[0]), CL.WBC_PERIOD, tm, il[0].copy())[1]
+                assert np.abs(out[0] - cold).max() <= 1e-9 * max(1.0, np.abs(cold).max())
+        rbd = CL.measurement(sc, plan, t0 + CL.MPC_PERIOD)
+    assert warm_ticks == 5
+
+
 def test_emu_mixed_modes_and_event_grid(emu):
     """Flight / three-leg / stance nodes (m~ = 14, 17, 18 tile paths of the MFMA kernels) on an event-aligned, non-uniform grid."""
     itf, orc = emu
