@@ -101,7 +101,7 @@ def _digest(*tensors):
     return torch.stack([t.contiguous().view(torch.int64).sum() for t in tensors])
 
 
-def steady_state(itf, sc, steps, warmup, emulate=False, wbc_state="carry"):
+def steady_state(itf, sc, steps, warmup, emulate=False, wbc_state="cold"):
     """config.steady_state: what the controller does between the first tick and shutdown -- the SAME 256 instances in a receding
     horizon: every step shifts the horizon by one MPC period (10 ms, mpcDesiredFrequency task.info:147), resamples the previous solution on the shifted grid
     ON THE DEVICE as the initial guess (qmgpu_warm_start_batch; coldStart false, task.info:143), solves, evaluates the policy between two nodes and runs the
@@ -354,7 +354,7 @@ def main():
     ap.add_argument("--no-steady-state", action="store_true", help="skip config.steady_state (the receding-horizon leg, N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="qmgpu_set_overlap off: every kernel of a step on one stream, one after the other (the kernel times then add up to the step)")
-    ap.add_argument("--wbc-state", choices=["carry", "cold"], default="carry", help="steady-state leg: the WBC's solver state travels from step to step (qmgpu_wbc_args::working_set), or every tick cold")
+    ap.add_argument("--wbc-state", choices=["carry", "cold"], default="cold", help="steady-state leg: every WBC tick cold as the reference's qpOASES call (default), or the WBC's solver state travels from step to step (qmgpu_wbc_args::working_set)")
     ap.add_argument("--force-collective", action="store_true",
                     help="single process: run the N > 1 code path (pack -> RCCL all_gather_into_tensor -> unpack) on a 1-rank nccl group and verify it")
     ap.add_argument("--emulate", action="store_true",
@@ -459,12 +459,18 @@ def main():
         wb1.il = wb.il      # inputLast_ is carried from step to step: one buffer
         wb1.args = _api.GpuSolver.wbc_args(B, wb1.rbd, wb1.period, wb1.time, wb1.il, wb1.out, wb1.status)
         mbs.append(mb1); wbs.append(wb1)
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "pending": None, "gathers": 0}
+
+    # the record of one step, [B][pack_len(N)]: written by ONE launch on the handle's stream (qmgpu_pack_results) into a buffer that exists before the timed region -- until round 5
+    # four strided copies into a fresh 12.5 MB torch.cat allocation per step
+    packs = [torch.zeros((B, sharding.pack_len(N)), dtype=torch.float64, device=G.DEVICE) for _ in range(2)] if collective else []
 
     def gather_of(i):
-        packed = sharding.pack(mbs[i].oX, mbs[i].oU, wbs[i].out, mbs[i].oM)
         if inflight["work"] is not None:
-            inflight["work"].wait()
+            inflight["work"].wait()          # (the collective still in flight reads the other buffer; the stream waits, not the host)
+        packed = packs[state["gathers"] & 1]
+        state["gathers"] += 1
+        sol.pack_results(B, N, mbs[i].oX, mbs[i].oU, wbs[i].out, mbs[i].oM, packed)
         inflight["work"] = dist.all_gather_into_tensor(gathered, packed, async_op=True)
         inflight["buf"] = packed
 
@@ -520,6 +526,7 @@ def main():
     # and its HIP-event interval includes that wait (0.71 instead of 0.37 ms) -- not a property of the kernel.  A short calibration pass of the same cycle on one stream, after
     # the timed region and outside `value`, gives the unobstructed durations; the kernels the overlap does not touch (lq_node, riccati, line search) measure the same in both.
     kernel_ms_serial = kernel_ms
+    calibration_same = None
     if OVERLAP and not args.emulate:
         cal = max(5, min(args.steps, 20))
         sol.set_overlap(False); sol.enable_timing(True)
@@ -528,6 +535,9 @@ def main():
         sync()
         kernel_ms_serial = sol.kernel_ms_mean(cal)
         sol.enable_timing(False); sol.set_overlap(True)
+        # the calibration pass solves the same cycle as the timed steps (same inputs; inputLast_ has been the cycle's own input since the second step): same results, bit for bit
+        rc, wc = mbs[0].results(), wbs[0].results()
+        calibration_same = bool(np.array_equal(rc["X"], res["X"]) and np.array_equal(rc["U"], res["U"]) and np.array_equal(wc["out"], wres["out"]))
     ok = bool(np.isfinite(res["X"]).all() and np.isfinite(wres["out"]).all() and (res["stats"][:, 7] == 0).all() and (wres["status"] == 0).all())
     gather_ok = None
     if collective:   # this rank's block of the gathered tensor is what it solved, bit for bit; every other block is finite and carries that rank's initial states
@@ -568,9 +578,11 @@ def main():
         dom_name = max(flops, key=lambda k: kernel_ms_serial[names.index(k)])   # longest launch (device to itself) among the kernels that carry algorithmic FLOPs
         path_flops = flops["ad_node_kernel"] + flops["lq_node_kernel"] + flops["riccati_kernel"]
         roof_kernel = dom_name
-        kms = kernel_ms[names.index(roof_kernel)]
         tf = lambda fl, ms: (fl / (ms * 1e-3) / 1e12) if ms > 0 else None   # noqa: E731  (the emulation has no clocks)
-        achieved = tf(flops[roof_kernel], kms)
+        # ONE source for the roofline block: the kernel, its duration, achieved / frac, kernel_frac and hbm_gbps all come from the one-stream durations (the calibration pass
+        # when the overlap is on, the timed region itself otherwise); the timed region's own interval of the same kernel is reported next to it
+        achieved = tf(flops[roof_kernel], kernel_ms_serial[names.index(roof_kernel)])
+        achieved_timed = tf(flops[roof_kernel], kernel_ms[names.index(roof_kernel)])
         tag, ctr = profile_counters()
         traffic = ctr.get(roof_kernel, {}).get("bytes")
         src = (f"profiles/{tag}_counters.json (separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-overlap --steps 5`, summarised by tools/make_profile_summaries.py; "
@@ -605,6 +617,7 @@ def main():
                        "gather_matches_local_results": gather_ok},
             "roofline": {"bound": "mfma", "kernel": roof_kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved is not None else None,
+                         "achieved_from_the_timed_regions_interval": achieved_timed, "calibration_pass_reproduces_the_timed_results": calibration_same,
                          "traffic": traffic, "traffic_source": src,
                          "mfma_busy": busy.get(roof_kernel), "hbm_gbps": hbm.get(roof_kernel),
                          "mfma_busy_by_kernel": busy, "hbm_gbps_by_kernel": hbm,
@@ -617,7 +630,7 @@ def main():
                          "kernel_ms_one_stream": dict(zip(names + ["whole_call"], kernel_ms_serial)),
                          "kernel_ms_note": "kernel_ms: HIP events over the TIMED region (with the overlap on, ad_node's interval includes its wait for the CUs the previous step's WBC still holds, and whole_call spans two "
                                            "streams); kernel_ms_one_stream: the same cycle on one stream in a calibration pass after the timed region (outside `value`): what `kernel`, kernel_frac and hbm_gbps are computed "
-                                           "from; `achieved` / `frac` use the timed region's duration of `kernel` (the overlap does not touch riccati / lq_node)",
+                                           "from, `achieved` / `frac` included (achieved_from_the_timed_regions_interval: the same FLOPs over the timed region's own interval of that kernel)",
                          # launches within 5 % of the longest one: since round 3 the three FLOP-carrying kernels take 0.45-0.47 ms each, so which of them is
                          # "the dominant kernel" (the longest; `kernel`, `frac` above) changes from run to run -- their fractions are all in kernel_frac
                          "dominant_within_5pct": [k for k in flops if kernel_ms_serial[names.index(k)] >= 0.95 * kernel_ms_serial[names.index(roof_kernel)]],

@@ -190,7 +190,7 @@ int qmgpu_synchronize(qmgpu_handle h);
  * are complete after qmgpu_synchronize, or on the handle's stream after qmgpu_join_wbc (a device-side wait, no host wait) -- NOT after the caller synchronises its own stream.
  * Which calls join by themselves: qmgpu_cycle_batch (before its policy evaluation), qmgpu_wbc_solve_batch, qmgpu_set_stream (the NEW stream waits), qmgpu_set_overlap,
  * qmgpu_update_settings, qmgpu_debug_poison, qmgpu_synchronize, qmgpu_destroy.  Which do NOT: qmgpu_mpc_solve_batch, qmgpu_policy_eval_batch, qmgpu_frontend_batch,
- * qmgpu_warm_start_batch, qmgpu_gait_schedule_batch, qmgpu_get_input_weight -- they touch nothing the library owns that a pending WBC reads or writes, and run next to it.
+ * qmgpu_warm_start_batch, qmgpu_gait_schedule_batch, qmgpu_get_input_weight, qmgpu_pack_results -- they touch nothing the library owns that a pending WBC reads or writes, and run next to it.
  * The pending WBC still READS the caller's rbd_measured / period / time (and ee_force) of that cycle and reads and writes input_last / working_set: those buffers must not
  * be modified -- by the caller's own kernels or copies on any stream, or through a non-joining call above -- until qmgpu_join_wbc, qmgpu_synchronize, or the next
  * qmgpu_cycle_batch / qmgpu_wbc_solve_batch has been issued on the handle. */
@@ -290,6 +290,12 @@ int qmgpu_wbc_solve_batch(qmgpu_handle h, const qmgpu_wbc_args* args);
 
 /* One control cycle per robot: MPC solve, policy evaluation at t_eval, WBC.  */
 int qmgpu_cycle_batch(qmgpu_handle h, const qmgpu_mpc_args* mpc, const double* t_eval /*[batch]*/, qmgpu_wbc_args* wbc);
+
+/* The solved batch as ONE record per instance, [batch][(N+1)*30 + N*30 + 54 + (N+1)] doubles = X | U | WBC output | contact modes (as doubles: exact): what the ranks of a
+ * sharded batch all-gather (the path's only exchange; the collective itself is issued by the host through RCCL).  All device pointers; enqueued
+ * on the handle's stream.  Does NOT join a WBC pending on the overlap stream (qmgpu_set_overlap): pack the buffers of a cycle whose WBC has been joined -- behind the
+ * next qmgpu_cycle_batch for alternating output buffers, or behind qmgpu_join_wbc. */
+int qmgpu_pack_results(qmgpu_handle h, int batch, int num_nodes, const double* X, const double* U, const double* wbc_out, const int32_t* modes, double* packed);
 
 /* ---- front end of a control cycle: what sits immediately before the MPC call ----------
  * (1) state estimate -> MPC observation: rbdState[55] -> centroidal state x[30] with the yaw unwrapped against the previous

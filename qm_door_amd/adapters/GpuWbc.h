@@ -68,9 +68,10 @@ class GpuWbc : public WbcBase {
     a.batch = 1; a.variant = variant_;
     a.state_desired = dd + kXd; a.input_desired = dd + kUd; a.rbd_measured = dd + kRbd; a.period = dd + kPeriod; a.time = dd + kTime;
     a.mode = reinterpret_cast<int32_t*>(dd + kInts); a.input_last = dd + kIl; a.out = dd + kOut; a.out_status = reinterpret_cast<int32_t*>(dd + kStatus);
-    // the solver state of the previous tick (the rows every level ended on, the point it ended at) stays on the device next to inputLast_: consecutive 1 kHz ticks of one
-    // robot end on the same rows almost always, and a level that starts there needs one factorisation instead of an interior point's six to twelve.  Same torques
-    // whatever the path (tests/test_gpu_wbc.py); carryWorkingSet(false) gives the reference's cold start of every tick.
+    // opt-in (carryWorkingSet(true)): the solver state of the previous tick (the rows every level ended on, the point it ended at) stays on the device next to inputLast_ and
+    // is the next tick's starting guess.  Same torques whatever the path (tests/test_closed_loop.py); measured at this plugin's operating point (profiles/r06*_adapter_latency.json):
+    // the average update gets ~10 % shorter, the slowest one longer (a refuted guess costs its factorisation on top of the cold solve) -- so the default is the
+    // reference's: every tick cold (HoQp.cpp:136-149).
     a.working_set = carry_ ? reinterpret_cast<uint64_t*>(dd + kWs) : nullptr;
     check(qmgpu_wbc_solve_batch(h_, &a));
     hip(hipMemcpyAsync(host + kOut, dd + kOut, (kWs - kOut) * sizeof(double), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync D2H");
@@ -127,7 +128,7 @@ class GpuWbc : public WbcBase {
   void* pinned_ = nullptr;
   hipStream_t stream_ = nullptr;
   int lastStatus_ = 0;
-  bool carry_ = true;
+  bool carry_ = false;
 };
 
 }  // namespace qm

@@ -207,6 +207,10 @@ class GpuSolver:
         abi.check(self.lib, self.lib.qmgpu_policy_eval_batch(self.handle, batch, num_nodes, _ptr(t_grid), _ptr(X), _ptr(U), _ptr(modes), _ptr(t_eval),
                                                             _ptr(x_out), _ptr(u_out), _ptr(mode_out)))
 
+    def pack_results(self, batch, num_nodes, X, U, wbc_out, modes, packed):
+        """X | U | WBC output | modes of every instance into one row of `packed` [batch][sharding.pack_len(N)] on the handle's stream (qmgpu_pack_results): the all-gather record"""
+        abi.check(self.lib, self.lib.qmgpu_pack_results(self.handle, batch, num_nodes, _ptr(X), _ptr(U), _ptr(wbc_out), _ptr(modes), _ptr(packed)))
+
     def warm_start(self, batch, prev_nodes, prev_grid, prev_X, prev_U, new_nodes, new_grid, x0, warm_x, warm_u):
         """Previous solution resampled on the new grid (the initial guess upstream's SqpSolver takes from its PrimalSolution)."""
         abi.check(self.lib, self.lib.qmgpu_warm_start_batch(self.handle, batch, prev_nodes, _ptr(prev_grid), _ptr(prev_X), _ptr(prev_U), new_nodes, _ptr(new_grid),

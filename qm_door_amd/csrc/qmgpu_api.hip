@@ -246,6 +246,23 @@ __global__ void __launch_bounds__(256) lds_poison_kernel(int doubles, double* si
   if (sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) sink[0] = lds[1];   // keeps the stores alive
 }
 
+// X | U | WBC output | contact modes (as doubles: exact) of every instance into one row of `packed`: the record the ranks of a sharded batch all-gather
+// (qm_door_amd/sharding.py: pack_len / unpack), written by one launch instead of four strided copies into a fresh allocation
+__global__ void __launch_bounds__(256) pack_results_kernel(int batch, int N, const double* X, const double* U, const double* wbc, const int32_t* modes, double* packed) {
+  const int inst = blockIdx.x;
+  if (inst >= batch) return;
+  const int nx = (N + 1) * 30, nu = N * 30, len = nx + nu + QMGPU_NWBC_OUT + (N + 1);
+  double* row = packed + size_t(inst) * len;
+  for (int e = threadIdx.x; e < len; e += 256) {
+    double v;
+    if (e < nx) v = X[size_t(inst) * nx + e];
+    else if (e < nx + nu) v = U[size_t(inst) * nu + (e - nx)];
+    else if (e < nx + nu + QMGPU_NWBC_OUT) v = wbc[size_t(inst) * QMGPU_NWBC_OUT + (e - nx - nu)];
+    else v = double(modes[size_t(inst) * (N + 1) + (e - nx - nu - QMGPU_NWBC_OUT)]);
+    row[e] = v;
+  }
+}
+
 #ifdef QM_RICCATI_TIMING
 // profiling build only (tools/riccati_phase_probe.py): the phase clocks of riccati_kernel's workgroup 0, [wavefront][16]
 int qmgpu_debug_riccati_ticks(unsigned long long* out64, int reset) {
@@ -485,6 +502,14 @@ int qmgpu_kernel_ms_mean(qmgpu_handle h, int last_calls, double* ms6) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (long c = h->callCount - n; c < h->callCount; ++c) { double m[6]; readTiming(h, c, m); for (int i = 0; i < 6; ++i) acc[i] += m[i]; }
     for (int i = 0; i < 6; ++i) ms6[i] = acc[i] / double(n);
+  });
+}
+
+int qmgpu_pack_results(qmgpu_handle h, int batch, int num_nodes, const double* X, const double* U, const double* wbc_out, const int32_t* modes, double* packed) {
+  if (!h || !X || !U || !wbc_out || !modes || !packed || batch < 1 || num_nodes < 1) return setError(QMGPU_ERR_INVALID_ARGUMENT, "bad arguments");
+  return guarded([&]() { DeviceGuard onDevice(h->device);
+    QM_LAUNCH(pack_results_kernel, batch, 256, h->stream, batch, num_nodes, X, U, wbc_out, modes, packed);
+    HIP_CHECK(hipGetLastError());
   });
 }
 

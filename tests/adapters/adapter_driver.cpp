@@ -72,8 +72,8 @@ int runLatency(const char* outPath, int runs, int ticksPerRun) {
   rm.targetTrajectories.timeTrajectory = {0.0}; rm.targetTrajectories.stateTrajectory = {tgt}; rm.targetTrajectories.inputTrajectory = {ocs2::vector_t(30)};
   ctl.qmInterface_->mpcSettings_.timeHorizon_ = 1.0;
   ctl.setupMpc(nh); ctl.setupWbc(nh, task);
-  const bool coldWbc = std::getenv("QM_WBC_COLD") != nullptr;      // every tick cold, as the reference's qpOASES call (default: the working sets travel from tick to tick)
-  if (coldWbc) dynamic_cast<qm::GpuWbc*>(ctl.wbc_.get())->carryWorkingSet(false);
+  const bool coldWbc = std::getenv("QM_WBC_CARRY") == nullptr;      // default: every tick cold, as the reference's qpOASES call; QM_WBC_CARRY: the working sets travel from tick to tick
+  dynamic_cast<qm::GpuWbc*>(ctl.wbc_.get())->carryWorkingSet(!coldWbc);
   std::ofstream out(outPath);
   out.precision(6);
   out << "{\"controller\": \"" << (Ctl::kWbcVariant ? "qm/QMGpuMpcController" : "qm/QMGpuController") << "\", \"wbc_variant\": " << Ctl::kWbcVariant

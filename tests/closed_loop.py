@@ -95,7 +95,7 @@ def run_lockstep(sc, a, b, ticks=10, on_cycle=None, offenders=None, tol=1e-6):
         row = dict(cycle=k, N=int(N), x0=float(rel_inf(pa["x0"], pb["x0"]).max()), X=float(rel_inf(pa["X"], pb["X"]).max()), U=float(rel_inf(pa["U"], pb["U"]).max()),
                    modes_equal=bool(np.array_equal(pa["mode"], pb["mode"])), alpha_differs=int((pa["stats"][:, 4] != pb["stats"][:, 4]).sum()),
                    step_type_differs=int((pa["stats"][:, 5] != pb["stats"][:, 5]).sum()), alpha_min=float(pb["stats"][:, 4].min()),
-                   riccati_status=[int((pa["stats"][:, 7] != 0).sum()), int((pb["stats"][:, 7] != 0).sum())], tau=0.0, xacc=0.0, wbc_status=[0, 0], policy_mode_differs=0,
+                   riccati_status=[int((pa["stats"][:, 7] != 0).sum()), int((pb["stats"][:, 7] != 0).sum())], tau=0.0, xacc=0.0, tau_legs=0.0, tau_arm=0.0, wbc_status=[0, 0], policy_mode_differs=0,
                    working_sets_differ=0, wbc_passes=[0, 0], wbc_passes_max=[0, 0], guesses_refuted=[0, 0])
         for j in range(ticks):
             t = t0 + j * WBC_PERIOD
@@ -107,6 +107,9 @@ def run_lockstep(sc, a, b, ticks=10, on_cycle=None, offenders=None, tol=1e-6):
             wa, wb = ws
             row["tau"] = max(row["tau"], float(rel_inf(wa["out"][:, 36:], wb["out"][:, 36:]).max()))
             row["xacc"] = max(row["xacc"], float(rel_inf(wa["out"][:, :36], wb["out"][:, :36]).max()))
+            # per block, each with its own norm: the separated-system plugin commands the LEG torques only (QMController.cpp:428-431)
+            e_legs, e_arm = rel_inf(wa["out"][:, 36:48], wb["out"][:, 36:48]), rel_inf(wa["out"][:, 48:54], wb["out"][:, 48:54])
+            row["tau_legs"] = max(row["tau_legs"], float(e_legs.max())); row["tau_arm"] = max(row["tau_arm"], float(e_arm.max()))
             row["wbc_status"] = [row["wbc_status"][0] + int((wa["status"] != 0).sum()), row["wbc_status"][1] + int((wb["status"] != 0).sum())]
             row["policy_mode_differs"] += int((wa["mode"] != wb["mode"]).sum())
             if wa.get("working_set") is not None and wb.get("working_set") is not None:     # the carried solver state: the rows every solve ended pinned, the same on both sides
@@ -116,11 +119,12 @@ def run_lockstep(sc, a, b, ticks=10, on_cycle=None, offenders=None, tol=1e-6):
                     per, ref_ = passes_of(w_["working_set"])
                     row["wbc_passes"][s_] += int(per.sum()); row["wbc_passes_max"][s_] = max(row["wbc_passes_max"][s_], int(per.max())); row["guesses_refuted"][s_] += int(ref_.sum())
             if offenders is not None:
-                e = rel_inf(wa["out"][:, 36:], wb["out"][:, 36:])
+                e = np.maximum(rel_inf(wa["out"][:, 36:], wb["out"][:, 36:]), np.maximum(e_legs, e_arm))     # (the worst of the 18-wide norm and the two blocks' own)
                 bad = np.nonzero((e > tol) | (wa["status"] != 0) | (wb["status"] != 0))[0]
                 sens = b.sensitivity(bad) if len(bad) and hasattr(b, "sensitivity") else None
                 for n_, i in enumerate(bad):
-                    rec = dict(cycle=k, tick=j, instance=int(i), time=float(t), tau_dev=float(e[i]), status=[int(wa["status"][i]), int(wb["status"][i])], mode=int(wb["mode"][i]))
+                    rec = dict(cycle=k, tick=j, instance=int(i), time=float(t), tau_dev=float(e[i]), tau_legs_dev=float(e_legs[i]), tau_arm_dev=float(e_arm[i]),
+                               tau_legs_abs_dev=float(np.abs(wa["out"][i, 36:48] - wb["out"][i, 36:48]).max()), status=[int(wa["status"][i]), int(wb["status"][i])], mode=int(wb["mode"][i]))
                     for key in ("attempts", "polished", "iterations"):
                         if key in wb:
                             rec[key] = wb[key][i].tolist()

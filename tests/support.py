@@ -452,12 +452,51 @@ def ee_contact_force(oracle, x, contact_knot, stiffness=FT_STIFFNESS):
     return -stiffness * (ee - contact_knot[3:6])
 
 
+def wbc_stress_batch(interface, variant, B=2048):
+    """2048 random (NOT MPC-consistent) instances over every contact mode of gait.info, robots in motion, non-zero inputLast_, 20 % on the start-up branch"""
+    rng = np.random.default_rng(17 + variant)
+    x_nom, m = interface.initial_state, interface.robot_mass
+    modes_all = np.array([15, 9, 6, 0, 10, 5, 13, 7, 14, 11], dtype=np.int32)
+    mode = modes_all[rng.integers(0, len(modes_all), B)]
+    xd = x_nom[None, :] + rng.uniform(-1, 1, (B, 30)) * 0.03
+    xm = x_nom[None, :] + rng.uniform(-1, 1, (B, 30)) * 0.02
+    vm = rng.uniform(-1, 1, (B, 24)) * 0.1
+    u = np.zeros((B, 30))
+    for i in range(B):
+        flags = [(int(mode[i]) >> (3 - c)) & 1 for c in range(4)]
+        for c in range(4):
+            if flags[c]:
+                u[i, 3 * c + 2] = m * 9.81 / max(1, sum(flags))
+    u[:, :12] += rng.uniform(-1, 1, (B, 12)) * 2.0 * (u[:, :12] != 0)
+    u[:, 12:] = rng.uniform(-1, 1, (B, 18)) * 0.1
+    il = u + rng.uniform(-1, 1, (B, 30)) * 0.002
+    t = np.where(rng.uniform(size=B) < 0.2, 5.0, 20.0)
+    rbd = np.zeros((B, 55))
+    rbd[:, 0:3] = xm[:, 9:12]; rbd[:, 3:6] = xm[:, 6:9]; rbd[:, 6:24] = xm[:, 12:30]; rbd[:, 24:48] = vm
+    return dict(xd=xd, u=u, rbd=rbd, mode=mode, t=t, il=il)
+
+
 # ------------------------------------------------------------------------------------------------ whole-batch parity (every instance, not a sample)
 def rel_inf(got, ref):
     """||got - ref||_inf / max(1, ||ref||_inf) per instance (axis 0 = instance)"""
     B = ref.shape[0]
     d = np.abs(got.reshape(B, -1) - ref.reshape(B, -1)).max(axis=1)
     return d / np.maximum(1.0, np.abs(ref.reshape(B, -1)).max(axis=1))
+
+
+WBC_BLOCKS = {"tau_legs": (36, 48), "tau_arm": (48, 54), "accelerations": (0, 24), "contact_forces": (24, 36)}
+
+
+def rel_inf_blocks(got, ref):
+    """rel-inf deviation per instance and per block of the WBC output [B][54] = [ddq (24), F (12); tau (18)].  The blocks are normalised SEPARATELY: the separated-system
+    plugin commands only the leg torques tau[0:12] (qm_controllers/src/QMController.cpp:428-431; the arm runs on position PIDs), and an arm torque of 30 N m in the
+    same norm would hide a leg deviation 30 times smaller."""
+    return {k: rel_inf(got[:, a:b], ref[:, a:b]) for k, (a, b) in WBC_BLOCKS.items()}
+
+
+def block_summary(got, ref):
+    return {k: {"max": float(e.max()), "p99": float(np.percentile(e, 99)), "median": float(np.median(e)), "argmax": int(e.argmax()), "above_1e-6": int((e > 1e-6).sum())}
+            for k, e in rel_inf_blocks(got, ref).items()}
 
 
 def parity_report(name, got, ref, keys=("X", "U"), tau=True, record=True):
@@ -472,6 +511,7 @@ def parity_report(name, got, ref, keys=("X", "U"), tau=True, record=True):
         np.savez(os.path.join(ROOT, "gpurun_out", f"wbc_{name}.npz"), gpu=got["out"], oracle=ref["out"])     # scratch, for offline analysis
         e = rel_inf(got["out"][:, 36:], ref["out"][:, 36:])
         rep["tau"] = {"max": float(e.max()), "p99": float(np.percentile(e, 99)), "median": float(np.median(e)), "argmax": int(e.argmax()), "above_tol": int((e > 1e-6).sum())}
+        rep["wbc_blocks"] = block_summary(got["out"], ref["out"])
         rep["wbc_status_nonzero"] = [int((got["status"] != 0).sum()), int((ref["status"] != 0).sum())]
     rep["modes_equal"] = bool(np.array_equal(got["mode"], ref["mode"]))
     rep["alpha_equal"] = int((got["stats"][:, 4] == ref["stats"][:, 4]).sum())
@@ -502,3 +542,4 @@ def assert_parity(rep, tol=1e-6, tau_tol=1e-6):
     if "tau" in rep:
         assert rep["wbc_status_nonzero"] == [0, 0], rep
         assert rep["tau"]["max"] <= tau_tol, rep
+        assert rep["wbc_blocks"]["tau_legs"]["max"] <= tau_tol and rep["wbc_blocks"]["tau_arm"]["max"] <= tau_tol, rep["wbc_blocks"]

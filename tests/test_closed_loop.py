@@ -14,6 +14,7 @@ import support as S
 
 def _summary(rows):
     return dict(cycles=len(rows), X_max=max(r["X"] for r in rows), U_max=max(r["U"] for r in rows), x0_max=max(r["x0"] for r in rows), tau_max=max(r["tau"] for r in rows),
+                tau_legs_max=max(r["tau_legs"] for r in rows), tau_arm_max=max(r["tau_arm"] for r in rows),
                 xacc_max=max(r["xacc"] for r in rows), alpha_differs=sum(r["alpha_differs"] for r in rows), step_type_differs=sum(r["step_type_differs"] for r in rows),
                 modes_equal=all(r["modes_equal"] for r in rows), policy_mode_differs=sum(r["policy_mode_differs"] for r in rows),
                 riccati_status=[sum(r["riccati_status"][0] for r in rows), sum(r["riccati_status"][1] for r in rows)],
@@ -38,7 +39,7 @@ def _check(rows, tol=1e-6, offenders=None, ticks=None, loose_per=None, loose_max
     assert max(s["X_max"], s["U_max"], s["x0_max"]) <= tol, s
     assert s["wbc_status"] == [0, 0], (s, [o for o in (offenders or []) if o["status"] != [0, 0]][:5])
     if loose_per is None:
-        assert s["tau_max"] <= tol, (s, (offenders or [])[:5])
+        assert s["tau_max"] <= tol and s["tau_legs_max"] <= tol and s["tau_arm_max"] <= tol, (s, (offenders or [])[:5])
     else:
         loose = [o for o in offenders if o["tau_dev"] > tol]
         assert len(loose) <= ticks // loose_per and all(o["tau_dev"] <= loose_max for o in loose), (len(loose), sorted(o["tau_dev"] for o in loose)[-5:])

@@ -76,28 +76,7 @@ def test_cycle_matches_oracle(interface, oracle):
         assert np.abs(w["out"][i][36:] - out[36:]).max() <= 1e-6 * max(1.0, np.abs(out[36:]).max())
 
 
-def stress_batch(interface, variant, B=2048):
-    """2048 random (NOT MPC-consistent) instances over every contact mode of gait.info, robots in motion, non-zero inputLast_, 20 % on the start-up branch"""
-    rng = np.random.default_rng(17 + variant)
-    x_nom, m = interface.initial_state, interface.robot_mass
-    modes_all = np.array([15, 9, 6, 0, 10, 5, 13, 7, 14, 11], dtype=np.int32)
-    mode = modes_all[rng.integers(0, len(modes_all), B)]
-    xd = x_nom[None, :] + rng.uniform(-1, 1, (B, 30)) * 0.03
-    xm = x_nom[None, :] + rng.uniform(-1, 1, (B, 30)) * 0.02
-    vm = rng.uniform(-1, 1, (B, 24)) * 0.1
-    u = np.zeros((B, 30))
-    for i in range(B):
-        flags = [(int(mode[i]) >> (3 - c)) & 1 for c in range(4)]
-        for c in range(4):
-            if flags[c]:
-                u[i, 3 * c + 2] = m * 9.81 / max(1, sum(flags))
-    u[:, :12] += rng.uniform(-1, 1, (B, 12)) * 2.0 * (u[:, :12] != 0)
-    u[:, 12:] = rng.uniform(-1, 1, (B, 18)) * 0.1
-    il = u + rng.uniform(-1, 1, (B, 30)) * 0.002
-    t = np.where(rng.uniform(size=B) < 0.2, 5.0, 20.0)
-    rbd = np.zeros((B, 55))
-    rbd[:, 0:3] = xm[:, 9:12]; rbd[:, 3:6] = xm[:, 6:9]; rbd[:, 6:24] = xm[:, 12:30]; rbd[:, 24:48] = vm
-    return dict(xd=xd, u=u, rbd=rbd, mode=mode, t=t, il=il)
+stress_batch = S.wbc_stress_batch
 
 
 def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=8, seed=5):
@@ -149,17 +128,20 @@ def test_wbc_stress_all_modes_converge(interface, variant):
     ref = orc.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], 0.002, c["t"], c["il"], variant)
     assert (ref["status"] == 0).all()
     assert np.array_equal(r["input_last"], ref["input_last"])
-    err = S.rel_inf(r["out"][:, 36:], ref["out"][:, 36:])
+    blocks = S.rel_inf_blocks(r["out"], ref["out"])
+    err = np.maximum(S.rel_inf(r["out"][:, 36:], ref["out"][:, 36:]), np.maximum(blocks["tau_legs"], blocks["tau_arm"]))     # the 18-wide norm and each block's own: the worst
     errx = S.rel_inf(r["out"][:, :36], ref["out"][:, :36])
     np.savez(os.path.join(S.ROOT, "gpurun_out", f"wbc_stress_v{variant}.npz"), gpu=r["out"], oracle=ref["out"], iterations=ref["iterations"], as_iterations=ref["as_iterations"])   # scratch, for offline analysis
     above = np.nonzero(err > 1e-6)[0]
     sens_in, sens_path = oracle_sensitivity(orc, c, above, variant) if len(above) else (np.zeros(0), np.zeros(0))
     rep = {"instances": B, "tau": {"max": float(err.max()), "p99": float(np.percentile(err, 99)), "p90": float(np.percentile(err, 90)), "median": float(np.median(err))},
            "x": {"max": float(errx.max()), "p99": float(np.percentile(errx, 99)), "median": float(np.median(errx))},
+           "blocks": S.block_summary(r["out"], ref["out"]),
            "count_above_1e-6": int(len(above)), "count_above_1e-9": int((err > 1e-9).sum()), "count_above_1e-12": int((err > 1e-12).sum()),
            "oracle_passes_mean_max_per_level": [[float(ref["iterations"][:, l].mean()), int(ref["iterations"][:, l].max())] for l in range(4)],
            "oracle_active_set_iterations_mean_max_per_level": [[float(ref["as_iterations"][:, l].mean()), int(ref["as_iterations"][:, l].max())] for l in range(4)],
            "above_1e-6": [{"instance": int(i), "mode": int(c["mode"][i]), "time": float(c["t"][i]), "tau_dev": float(err[i]), "x_dev": float(errx[i]),
+                           "tau_legs_dev": float(blocks["tau_legs"][i]), "tau_arm_dev": float(blocks["tau_arm"][i]), "tau_legs_abs_dev_Nm": float(np.abs(r["out"][i, 36:48] - ref["out"][i, 36:48]).max()),
                            "oracle_passes": ref["iterations"][i].tolist(),
                            "oracle_tau_move_under_1e-9_input_perturbation": float(sens_in[k]), "oracle_tau_move_on_another_path_to_the_vertex": float(sens_path[k])}
                           for k, i in enumerate(above)]}
@@ -172,6 +154,7 @@ def test_wbc_stress_all_modes_converge(interface, variant):
     json.dump(allrep, open(path, "w"), indent=1)
     assert np.median(err) <= 1e-12 and np.percentile(err, 99) <= 1e-9, rep["tau"]
     assert len(above) <= B // 200, rep["count_above_1e-6"]
+    assert err.max() <= 0.1, rep["above_1e-6"]            # gross cap, whatever the checker's own sensitivity says (advisor r05): a shared regression in an ill-conditioned class must not pass as "explained"
     for k, i in enumerate(above):
         assert max(sens_in[k], sens_path[k]) >= err[i] / 3, rep["above_1e-6"][k]
 

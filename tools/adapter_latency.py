@@ -25,13 +25,13 @@ def main(runs=200, ticks=10):
            "what_is_timed": "wall clock of mpc_->run(t, x) and wbc_->update(...) through qm_door_amd/adapters (std::chrono::steady_clock around the call, as the reference's RepeatedTimer)"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for variant in (0, 1):
-        for cold in (False, True):     # the adapter's default (working sets carried from tick to tick), then every tick cold (what rounds 1-5 measured)
-            path = os.path.join(ROOT, "gpurun_out", f"adapter_latency_v{variant}{'_cold' if cold else ''}.json")
-            env = dict(os.environ, QM_WBC_COLD="1") if cold else {k: v for k, v in os.environ.items() if k != "QM_WBC_COLD"}
+        for cold in (True, False):     # the adapter's default (every tick cold: what rounds 1-5 measured), then GpuWbc::carryWorkingSet(true)
+            path = os.path.join(ROOT, "gpurun_out", f"adapter_latency_v{variant}{'' if cold else '_carry'}.json")
+            env = {k: v for k, v in os.environ.items() if k != "QM_WBC_CARRY"} if cold else dict(os.environ, QM_WBC_CARRY="1")
             p = subprocess.run([exe, f"{d}/task.info", f"{d}/aliengo_z1.urdf", f"{d}/reference.info", "--latency", path, str(variant), str(runs), str(ticks)], capture_output=True, text=True, timeout=900, env=env)
             if p.returncode != 0:
                 raise SystemExit(p.stderr)
-            out[("qm/QMGpuController" if variant == 0 else "qm/QMGpuMpcController") + (" (WBC cold every tick)" if cold else "")] = json.load(open(path))
+            out[("qm/QMGpuController" if variant == 0 else "qm/QMGpuMpcController") + ("" if cold else " (WBC working sets carried)")] = json.load(open(path))
     # the CPU restatement at the same size: cold-start cycles of one instance, N = 68, three worker threads over the nodes (task.info:78) and one thread
     itf = api.QMInterface()
     orc = S.Oracle(itf.problem, fast=True)
@@ -50,7 +50,7 @@ def main(runs=200, ticks=10):
                                           "note": "own CPU restatement (g++ -O3), not OCS2; cold-start cycle = one SQP iteration + one WBC update"}
     path = os.path.join(ROOT, "gpurun_out", "adapter_latency.json")
     json.dump(out, open(path, "w"), indent=1)
-    for k in ("qm/QMGpuController", "qm/QMGpuController (WBC cold every tick)", "qm/QMGpuMpcController", "qm/QMGpuMpcController (WBC cold every tick)"):
+    for k in ("qm/QMGpuController", "qm/QMGpuController (WBC working sets carried)", "qm/QMGpuMpcController", "qm/QMGpuMpcController (WBC working sets carried)"):
         w = out[k]["wall_clock"]
         print(k, "mpc_run avg %.3f max %.3f ms | wbc_update avg %.3f max %.3f ms | nodes %.1f" % (w["mpc_run"]["avg_ms"], w["mpc_run"]["max_ms"], w["wbc_update"]["avg_ms"], w["wbc_update"]["max_ms"], w["mean_nodes"]))
         print("   kernels:", out[k]["with_kernel_timing"]["kernel_ms_mean"])
