@@ -332,6 +332,7 @@ inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting val
 inline int g_expNoMinNormStart = 0;                      // 1: the first level without its minimum-norm start (tests: same torques)
 inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
 inline int g_expGuessOrder = 1;
+inline int g_expLiteralRegMaxN = 8;                      // levels of at most this many variables keep HoQp's 1e-12 I IN the factorised matrix and the gradient (LevelQp::lit); 0: the limit everywhere, as until round 5
 inline int g_expNoWarmStart = 0;                         // 1: the working set carried from the previous tick (wbcUpdate: ws) is ignored -- every level cold (tests: same torques)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
@@ -368,7 +369,19 @@ struct LevelQp {
   int n() const { return G0.r; } int m() const { return D.r; }
   // gradient of the smooth part.  In residual form when the task is known: AZ'(AZ z + rhat) is rounded relative to the RESIDUAL, G0 z + g relative to |G0| |z| -- two
   // orders of magnitude worse where a weakly seen direction carries a large z (the arm accelerations of HierarchicalMpcWbc, 1e4 rad/s^2 through singular values of 1e-5)
-  Vec costGradient(const Vec& z) const { if (AZ.r > 0) return tmul(AZ, AZ * z + rhat); return G0 * z + g; }
+  // lit: the regulariser is kept LITERALLY -- in the factorised matrix and in the gradient -- instead of in the limit.  Round 6 (tools/hoqp_exact.py): the
+  // 50-digit solution of the reference's own level QPs shows what the limit costs where a level sees a direction only WEAKLY: HierarchicalMpcWbc's last level (the contact-force
+  // task in the six variables the levels above left) sees one combination of arm accelerations through a singular value of ~2e-7, curvature 5e-14 -- under the exclusion floor, so
+  // the direction stayed where it was, while its gradient (2e-6: the task's residual is O(10)) is eight orders above its rounding and the reference's answer, -g / (c + 1e-12) ~ 1e6,
+  // runs into a torque limit: arm torques off by 100 %, leg torques by 1e-5 .. 1e-2 on those ticks.  With 1e-12 on the diagonal the pivot is c + 1e-12, resolved as long as the
+  // level's own rounding, 16 eps n max(K_jj), stays below 1e-12: true for the small, well-scaled last levels (n <= 8, K_jj ~ 1), NOT for the 18-variable level (K_jj ~ 2e3: its
+  // rounding is 1e-10, and a direction it does not see at all would carry the rounding of the gradient divided by 1e-12) -- so the literal form is taken for levels of at most
+  // kLiteralRegMaxN variables whose variables are still the reference's z (no implied-equality change of variables), the limit elsewhere.
+  bool lit = false;
+  bool literal() const { return lit && reg > 0.0; }
+  double floorAbs() const { return literal() ? 0.0 : 10.0 * reg; }
+  Mat hessian() const { Mat K = G0; if (literal()) for (int i = 0; i < K.r; ++i) K(i, i) += reg; return K; }
+  Vec costGradient(const Vec& z) const { Vec gr = AZ.r > 0 ? tmul(AZ, AZ * z + rhat) : G0 * z + g; if (literal()) for (size_t i = 0; i < gr.size(); ++i) gr[i] += reg * z[i]; return gr; }
   // what one rounding of that gradient amounts to, component by component: the residual AZ z + rhat carries eps (|AZ| |z| + |rhat|) -- whatever its own size, it is a
   // difference -- and the product with AZ' passes that on: the largest component of eps |AZ|'(|AZ| |z| + |rhat|).  (The generic form: eps (|G0| |z| + |g|), passed in.)
   double gradientRounding(const Vec& z, double generic) const {
@@ -435,7 +448,8 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
   auto handOver = [&](const Vec& zz, const Vec& ss, const Vec& ll) { pt.z = zz; for (int r = 0; r < mr; ++r) { pt.s[rows[r]] = ss[r]; pt.lam[rows[r]] = ll[r]; } pt.usable = true; };
   int it = itStart;
   for (; it < 40; ++it) {
-    const Vec rd = G * z + q.g + tmul(D, lam);
+    Vec rd = G * z + q.g + tmul(D, lam);
+    if (q.literal()) for (int i = 0; i < n; ++i) rd[i] += q.reg * z[i];
     Vec rp = D * z + s - f;
     const double mu = dot(s, lam) / mr;
     double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
@@ -444,10 +458,10 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
     if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= muTarget * scale) { handOver(z, s, lam); return it; }     // the working set can be read: over to the active-set method, for good
     if (it > itStart && mu > 0.5 * muPrev && mu <= kStagnationMu * scale) { handOver(z, s, lam); return it; }          // stagnation at the rounding floor
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
-    Mat K = G;
+    Mat K = q.hessian();
     for (int r = 0; r < mr; ++r) { const double wr = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
     std::vector<char> excluded;
-    if (!choleskyExcluding(K, 10.0 * q.reg, 16.0 * kEps, excluded)) { handOver(zPrev, sPrev, lamPrev); return it; }
+    if (!choleskyExcluding(K, q.floorAbs(), 16.0 * kEps, excluded)) { handOver(zPrev, sPrev, lamPrev); return it; }
     auto solve = [&](const Vec& rc, Vec& dz, Vec& ds, Vec& dl) {
       Vec t(mr); for (int i = 0; i < mr; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
       dz = -1.0 * (rd + tmul(D, t));
@@ -526,7 +540,7 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
   int lastReleased = -1, fullSteps = 0, guard = 0;
   for (;; ++st.iterations) {
     if (st.iterations > kAsMaxWorkingSetChanges || ++guard > 4 * kAsMaxWorkingSetChanges) { st.status = 1; break; }      // (guard: every trip of the loop counts, also those that do not change the working set)
-    Mat K = q.G0;       // (without HoQp's regulariser: a direction it alone would carry counts as having no curvature, below)
+    Mat K = q.hessian();       // (without HoQp's regulariser: a direction it alone would carry counts as having no curvature, below)
     std::vector<int> pin;      // the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
     for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && !guess[r]) pin.push_back(r);
     { // (the guessed rows by decreasing multiplier estimate of the interior point, lam |d|: of two guessed rows that depend on each other -- the two sides of a friction
@@ -546,7 +560,7 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     // a direction has no curvature when its pivot does not stand clear of the rounding of the matrix being factorised, or of HoQp's regulariser (x10: the reference's
     // 1e-12 I decides the directions whose curvature is comparable with it by a blend of task and minimum norm; here they count as unseen by the task)
     std::vector<char> excluded, dependent;
-    if (!choleskyExcluding(K, 10.0 * q.reg, 16.0 * kEps, excluded, fixedVars)) { st.status = 2; break; }
+    if (!choleskyExcluding(K, q.floorAbs(), 16.0 * kEps, excluded, fixedVars)) { st.status = 2; break; }
     auto forward = [&](Vec b) { for (int i = 0; i < n; ++i) { if (excluded[i]) { b[i] = 0.0; continue; } double t = b[i]; for (int c = 0; c < i; ++c) t -= K(i, c) * b[c]; b[i] = t / K(i, i); } return b; };
     auto backward = [&](Vec b) { for (int i = n - 1; i >= 0; --i) { if (excluded[i]) { b[i] = 0.0; continue; } double t = b[i]; for (int c = i + 1; c < n; ++c) t -= K(c, i) * b[c]; b[i] = t / K(i, i); } return b; };
     Mat Tm(n, k), S(k, k);
@@ -685,7 +699,7 @@ inline Mat eliminateImpliedEqualities(LevelQp& q, const std::vector<char>& eq) {
   Mat DE(int(E.size()), n);
   for (size_t r = 0; r < E.size(); ++r) for (int j = 0; j < n; ++j) DE(int(r), j) = q.D(E[r], j);
   const Mat N = kernelFullPivLU(DE);
-  LevelQp r; r.mOwn = q.mOwn; r.reg = q.reg; r.f = q.f;
+  LevelQp r; r.mOwn = q.mOwn; r.reg = q.reg; r.lit = q.lit; r.f = q.f;
   r.G0 = T(N) * (q.G0 * N); r.g = tmul(N, q.g); r.D = q.D * N;
   if (q.AZ.r > 0) { r.AZ = q.AZ * N; r.rhat = q.rhat; r.G0 = T(r.AZ) * r.AZ; r.g = tmul(r.AZ, r.rhat); }
   // rows that are combinations of the eliminated ones vanish up to rounding in the new variables: they stay tight, and carry no information
@@ -714,6 +728,7 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z, uint64_t* wa
   if (nFull == 0) return st;
   const Mat N = eliminateImpliedEqualities(q, eq);
   const bool reduced = N.r > 0;
+  if (reduced) q.lit = false;      // (in the new variables w the regulariser would be 1e-12 N'N, not 1e-12 I: the limit is taken there)
   if (reduced) st.eliminated = nFull - N.c;
   if (reduced && N.c == 0) { if (warm) *warm = 0; return st; }          // the equalities leave nothing to decide: z = 0
   const LevelWork w = prepareLevel(q);
@@ -884,7 +899,7 @@ struct HoQp {
     Vec sol(nz, 0.0);
     if (numDec > 0) {
       const int mAll = numSlack + numPrevSlack;
-      LevelQp q; q.G0 = zz0; q.g = Vec(cv.begin(), cv.begin() + numDec); if (hasEq) { q.AZ = aZ; q.rhat = task.a * xPrev - task.b; } q.D = Mat(mAll, numDec); q.f = Vec(mAll, 0.0); q.mOwn = numSlack; q.reg = hasEq ? 1e-12 : 0.0;
+      LevelQp q; q.G0 = zz0; q.g = Vec(cv.begin(), cv.begin() + numDec); if (hasEq) { q.AZ = aZ; q.rhat = task.a * xPrev - task.b; } q.D = Mat(mAll, numDec); q.f = Vec(mAll, 0.0); q.mOwn = numSlack; q.reg = hasEq ? 1e-12 : 0.0; q.lit = hasEq && numSlack == 0 && numDec <= g_expLiteralRegMaxN;
       for (int i = 0; i < numSlack; ++i) { for (int j = 0; j < numDec; ++j) q.D(i, j) = Dm(numSlack + numPrevSlack + i, j); q.f[i] = fv[numSlack + numPrevSlack + i]; }
       for (int i = 0; i < numPrevSlack; ++i) { for (int j = 0; j < numDec; ++j) q.D(numSlack + i, j) = Dm(numSlack + i, j); q.f[numSlack + i] = fv[numSlack + i]; }
       std::vector<char> eqr(mAll, 0);

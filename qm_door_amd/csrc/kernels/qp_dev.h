@@ -167,8 +167,11 @@ struct QpResult { int status; int ipmIterations, iterations; bool strong; unsign
 // with bit 62 of warm; else null): the level's solution of that tick, the starting point -- scaled back by t <= 1 until every row outside the carried set holds (z = 0 is
 // feasible, the rows are convex; the CPU restatement's solveLevel has the reasoning: the minimiser reached from z = 0 through the directions the cost sees is usually outside
 // the rows, the previous tick's is a minimiser inside them up to the tick's change).
+// lit: HoQp's 1e-12 I is kept LITERALLY -- on the diagonal of the factorised matrix and in the gradient, no absolute exclusion floor -- instead of in the limit: the small last
+// levels (at most 8 variables, still the reference's own z), where a direction the task sees through a singular value of 1e-7 has a gradient that counts and a curvature below
+// any floor (the CPU restatement's LevelQp::lit has the case and the numbers).
 template <int NP, int LDZ_, int LDK_>
-__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, unsigned long long warm, const double* warmZ, int lane) {
+__device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, unsigned long long warm, const double* warmZ, bool lit, int lane) {
   QM_DYNAMIC_LDS(ldsBase);
   const QpIo io{ldsBase + off.G, ldsBase + off.AZ, ldsBase + off.rhat, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork, ldsBase + off.S};
   enum { ST_I = 0, ST_P = 1, ST_V = 2 };
@@ -214,7 +217,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     for (int j = 0; j < n; ++j) inside = inside && (DZ[rowL * LDZ_ + j] == 0.0 || ((heldMask >> j) & 1ull));
     rowOn = rowOn && !inside;
   }
-  const double floorAbs = 10.0 * QP_REG, floorRel = 16.0 * QP_EPS;
+  const double floorAbs = lit ? 0.0 : 10.0 * QP_REG, floorRel = 16.0 * QP_EPS;
   double zc = 0.0;
   double kc[NP], uc[NP], myInv = 1.0;   // row c of L, row c of L^T
   unsigned long long exMask = 0ull;
@@ -253,7 +256,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       if (absForm) { g0 += fabs(t0) * resL[q]; g1 += fabs(t1) * resL[q + 1]; } else { g0 += t0 * resL[q]; g1 += t1 * resL[q + 1]; }
     }
     if (r & 1) { const double t0 = AZ[(r - 1) * LDZ_ + colL]; g0 += (absForm ? fabs(t0) : t0) * resL[r - 1]; }
-    return colOn ? g0 + g1 : 0.0;
+    return colOn ? (g0 + g1) + ((lit && !absForm) ? QP_REG * bc[colL] : 0.0) : 0.0;
   };
   // K = G + DZ' diag(wt) DZ = L L^T: tiles on the matrix cores, factorisation in registers, rows of L (and 1 / L_cc) to LDS, rows of L^T back
   auto factorise = [&](double wt) {
@@ -278,7 +281,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
 #pragma unroll
     for (int q = 0; q < NP; ++q) QM_KEEP(kc[q]);
 #pragma unroll
-    for (int q = 0; q < NP; ++q) kc[q] = (colOn && q < n) ? kc[q] : ((q == lane) ? 1.0 : 0.0);   // identity padding beyond n
+    for (int q = 0; q < NP; ++q) kc[q] = (colOn && q < n) ? kc[q] + ((lit && q == lane) ? QP_REG : 0.0) : ((q == lane) ? 1.0 : 0.0);   // identity padding beyond n; lit: HoQp's regulariser on the diagonal
     double diag0 = 0.0;
 #pragma unroll
     for (int q = 0; q < NP; ++q) diag0 = (q == lane) ? kc[q] : diag0;

@@ -744,7 +744,8 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   // strongOut: this lane's row is strongly active at the solution; returns the solver's status.  AZp and DZ are overwritten when rows are eliminated.
   // warmIo (in / out): the word of this solve in the instance's working-set record (0: none / cold); passes gets bit 7 when the carried guess was refuted.
   // warmZ (global memory or null): where the solution of this solve travels with its rows (bit 62 of the word; not when implied equalities changed the variables).
-  auto levelQp = [&](double* AZp, int rRows, double* rhatp, int nVars, bool own, bool rowOnIn, bool eqIn, bool& strongOut, int& passes, unsigned long long& warmIo, double* warmZ) -> int {
+  // regular: a level's own solve (HoQp's regulariser applies: kept literally where qp_dev.h's `lit` says), not the canonical representative's.
+  auto levelQp = [&](double* AZp, int rRows, double* rhatp, int nVars, bool own, bool rowOnIn, bool eqIn, bool& strongOut, int& passes, unsigned long long& warmIo, double* warmZ, bool regular) -> int {
     int nQ = nVars;
     bool rowOn = rowOnIn, reduced = false;
     strongOut = false;
@@ -839,9 +840,10 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     auto solve = [&](bool tryHeld) {
       QpResult rr;
       const double* wz = reduced ? nullptr : warmZ;
-      if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lane);
-      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lane);
-      else rr = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lane);
+      const bool lit = regular && !own && !reduced && nQ <= 8;      // (= LevelQp::lit of the CPU restatement)
+      if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lit, lane);
+      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, false, lane);
+      else rr = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, false, lane);
       QM_WAVE_SYNC();
       return rr;
     };
@@ -1062,7 +1064,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     unsigned long long wsWord = wsLoad(pass, level, 0);
     // (words 16..33 / 34..41 of the record: the solutions of the second and third level of pass 0)
     double* wsZ = (wsRec && pass == 0 && ((level == 1 && n <= 18) || (level == 2 && n <= 8))) ? reinterpret_cast<double*>(wsRec + (level == 1 ? 16 : 34)) : nullptr;
-    const int st = levelQp(AZ, r, tzv, n, level == 0, rowNonZero(n), eqRow, strong, passes, wsWord, wsZ);
+    const int st = levelQp(AZ, r, tzv, n, level == 0, rowNonZero(n), eqRow, strong, passes, wsWord, wsZ, true);
     wsStore(pass, level, 0, wsWord, passes);
     eqRow = eqRow || strong;
     if (st != 0) status |= (1 << level);
@@ -1128,7 +1130,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       QM_WAVE_SYNC();
       bool strongC = false; int passesC = 0;
       unsigned long long wsWordC = wsLoad(pass, level, 1);
-      const int stc = levelQp(AZc, nOld, rds, n, false, rowNonZero(n), eqRow, strongC, passesC, wsWordC, nullptr);
+      const int stc = levelQp(AZc, nOld, rds, n, false, rowNonZero(n), eqRow, strongC, passesC, wsWordC, nullptr, false);
       wsStore(pass, level, 1, wsWordC, passesC);
       if (stc != 0) status |= 8;
       double xc = 0.0;

@@ -92,7 +92,7 @@ def test_oracle_against_the_50_digit_solution_of_the_reference_qp(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(EXACT))
-def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, name):
+def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, oracle, name):
     """The kernel on the fixture's ticks against the exact answer -- no oracle in the loop.  The offenders' file is reported, and bounded by the loose figure only: those are
     the ticks on which GPU and oracle disagreed most in a full-size closed loop / stress run, kept to show where BOTH stand against the reference's own problem."""
     import json
@@ -110,8 +110,11 @@ def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, name):
         r = wb.results()
         assert (r["status"] == 0).all()
         out[idx] = r["out"]
-    dev_gpu, dev_orc = exact_deviations(out, d), exact_deviations(d["oracle"], d)
-    rep = {"ticks": n, "what": "rel-inf per block against the 50-digit solution of the reference's literal level QPs (tools/hoqp_exact.py); oracle = the CPU restatement's output stored with the fixture"}
+    orc_out = np.zeros((n, 54))
+    for i in range(n):
+        orc_out[i] = oracle.wbc_update(d["xd"][i], d["ud"][i], d["rbd"][i], int(d["mode"][i]), float(d["period"][i]), float(d["time"][i]), d["il"][i].copy(), variant=int(d["variant"][i]))[1]
+    dev_gpu, dev_orc = exact_deviations(out, d), exact_deviations(orc_out, d)
+    rep = {"ticks": n, "what": "rel-inf per block against the 50-digit solution of the reference's literal level QPs (tools/hoqp_exact.py); oracle = the CPU restatement (checker build) on the same inputs"}
     for variant in (0, 1):
         idx = np.nonzero(d["variant"] == variant)[0]
         if len(idx):
@@ -119,10 +122,10 @@ def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, name):
                 "ticks": int(len(idx)),
                 "gpu_vs_exact": {k: {"median": float(np.median(e[idx])), "max": float(e[idx].max())} for k, e in dev_gpu.items()},
                 "oracle_vs_exact": {k: {"median": float(np.median(e[idx])), "max": float(e[idx].max())} for k, e in dev_orc.items()},
-                "gpu_vs_oracle": {k: {"median": float(np.median(e[idx])), "max": float(e[idx].max())} for k, e in S.rel_inf_blocks(out, d["oracle"]).items()}}
+                "gpu_vs_oracle": {k: {"median": float(np.median(e[idx])), "max": float(e[idx].max())} for k, e in S.rel_inf_blocks(out, orc_out).items()}}
     if name == "hoqp_exact_offenders":
         rep["per_tick"] = [{"source": str(d["source"][i]), "gpu_vs_exact": {k: float(e[i]) for k, e in dev_gpu.items()}, "oracle_vs_exact": {k: float(e[i]) for k, e in dev_orc.items()},
-                            "tau_legs_abs_Nm": [float(np.abs(out[i, 36:48] - d["exact"][i, 36:48]).max()), float(np.abs(d["oracle"][i, 36:48] - d["exact"][i, 36:48]).max())]} for i in range(n)]
+                            "tau_legs_abs_Nm": [float(np.abs(out[i, 36:48] - d["exact"][i, 36:48]).max()), float(np.abs(orc_out[i, 36:48] - d["exact"][i, 36:48]).max())]} for i in range(n)]
     os.makedirs(os.path.join(S.ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rep, open(os.path.join(S.ROOT, "gpurun_out", name + "_gpu.json"), "w"), indent=1)
     if name == "hoqp_exact_ticks":

@@ -95,6 +95,10 @@ def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=8, seed=5):
         rbd[:, :48] *= 1 + eps * rng.uniform(-1, 1, (len(idx), 48))
         worst = np.maximum(worst, S.rel_inf(orc.wbc_batch(*args(xd, rbd))["out"][:, 36:], base))
     path = np.zeros(len(idx))
+    # (the checker against ITSELF compiled differently -- the checker build next to the timing-grade one, other contractions and vector widths: where its two builds part,
+    #  a third implementation cannot be pinned any better; instance 221 of the HierarchicalMpcWbc batch is such a tick: 2.5e-3 between the builds, 1.5e-8 between GPU and the other one)
+    other = S.Oracle(orc.P, fast=not orc.lib.qmo_is_fast_build())
+    path = np.maximum(path, S.rel_inf(other.wbc_batch(*args(c["xd"][idx], c["rbd"][idx]))["out"][:, 36:], base))
     for kw in (dict(lower_level_start=0.15), dict(no_interior_point=True)):
         orc.set_experiment(**kw)
         try:
