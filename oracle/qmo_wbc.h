@@ -327,12 +327,14 @@ constexpr double kMinNormCheap = 1e4;
 constexpr int kIpmMinVariables = 8;
 constexpr double kAsLamTol = 8.0;            // a multiplier counts once it exceeds this many roundings of the gradient it balances
 constexpr int kAsMaxWorkingSetChanges = 100; // nWSR of HoQp.cpp:141
+constexpr int kAsMaxPinned = 28;             // = QP_KMAX of the kernels (qp_dev.h): rows the small system of the pinned set holds
 // Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  inline: one copy whatever the number of translation units; written between batches only.
 inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting value of the interior point = another path to the same vertex (tests: the result must not depend on it)
 inline int g_expNoMinNormStart = 0;                      // 1: the first level without its minimum-norm start (tests: same torques)
 inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
 inline int g_expGuessOrder = 1;
 inline int g_expLiteralRegMaxN = 8;                      // levels of at most this many variables keep HoQp's 1e-12 I IN the factorised matrix and the gradient (LevelQp::lit); 0: the limit everywhere, as until round 5
+inline int g_expCanonicalFirst = 1;                      // HierarchicalMpcWbc takes the canonical representative at every level from the first pass on (0: only when directions are left over at the end, as until round 6)
 inline int g_expNoWarmStart = 0;                         // 1: the working set carried from the previous tick (wbcUpdate: ws) is ignored -- every level cold (tests: same torques)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
@@ -550,6 +552,9 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
       for (int r = 0; r < m; ++r) if (rowOn[r] && state[r] == P && guess[r]) gs.push_back(r);
       if (start && start->usable && g_expGuessOrder) std::stable_sort(gs.begin(), gs.end(), [&](int a, int b) { return start->lam[a] * w.dn[a] > start->lam[b] * w.dn[b]; });
       for (int r : gs) pin.push_back(r);
+      // (the kernels' small system holds kAsMaxPinned rows; of a larger guess -- the interior point of a degenerate level: dozens of zero-margin rows with multiplier above
+      //  slack -- the rows with the smallest estimates stay out, on both sides; the ratio test meets them again if the step crosses them)
+      while (int(pin.size()) > kAsMaxPinned && guess[pin.back()]) { state[pin.back()] = I; guess[pin.back()] = 0; pin.pop_back(); }
     }
     for (int r = 0; r < m; ++r) {
       if (!rowOn[r] || state[r] == I) continue;
@@ -979,7 +984,12 @@ inline int wbcUpdate(const qmgpu_problem& P, int variant, const double* xDes, co
   // Taken in the limit 1e-12 -> 0 (with the regulariser itself those directions carry the rounding of the gradient divided by 1e-12).
   std::unique_ptr<HoQp> h0, h1, h2;
   const HoQp* last = nullptr;
-  bool canonical = false;
+  // HierarchicalMpcWbc gives the arm no task: its last level (contact forces) sees one combination of arm accelerations through a singular value of ~2e-7 -- curvature 5e-14, less
+  // than the regulariser's 1e-12 -- so WHERE the level above left that direction is visible in the answer: the reference's regulariser pulls the last level's z to zero there, i.e.
+  // back to the point the level above returned, which its own regulariser had made the minimum-norm one.  That controller therefore takes the canonical representative at every
+  // level from the first pass on (measured against the 50-digit solution of the reference's QPs, tools/hoqp_exact.py: leg torques median 2.9e-8 -> 1.3e-10, and the answer stops
+  // depending on the path to the vertex: 23 of 512 stress instances above 1e-9 -> 1).  HierarchicalWbc's last level sees everything that is left strongly; it keeps the rule above.
+  bool canonical = g_expCanonicalFirst && variant == 1;
   // The working sets of the previous tick (one word per solve: [1 + 6 pass + 2 level + completion]) are guesses for this one as long as the rows mean the same thing:
   // same contact mode, controller and task set (word 0); anything else starts cold.  Words 13 / 14: passes of every solve of this tick (a byte each, bit 7 = guess refuted).
   if (ws) {

