@@ -2,7 +2,8 @@
 
 wbc_kernel is a 400+-VGPR kernel with called functions; in round 2 a variant of it was computed correctly by one build and wrongly by another of
 the same sources, which the parity tests of a single binary cannot see.  tools/wbc_variants.py builds the library with phase clocks
-(-DQM_RICCATI_TIMING), at -O2, with a low inliner threshold and with round 2's bare wave barrier; every variant runs one MPC + WBC cycle at batch
+(-DQM_RICCATI_TIMING), at -O2, with a low inliner threshold, with LLVM's interprocedural register allocation on and with the LDS carve behind an opaque base (round 2's bare
+wave barrier was one of them until round 5: tools/wbc_variants.py says why it no longer has to agree); every variant runs one MPC + WBC cycle at batch
 256 (twice, the second WBC from the first one's inputLast) and the WBC alone on every contact mode (both controllers, start-up branch), and must
 agree with the product library: modes / status words bit-exact, X, U and the WBC output within 1e-9.
 

@@ -87,6 +87,12 @@ for k in f:
         tr[m.group(1)] = {"fetch_bytes": f[k] * 2048, "write_bytes": w.get(k, 0) * 1024, "bytes": f[k] * 2048 + w.get(k, 0) * 1024}
 json.dump(tr, open(os.path.join(P, f"{tag}_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(G, f"bench_{tag}.json"), os.path.join(P, f"{tag}_bench.json"))
+for src, dst in ((f"bench_{tag}_driver.json", f"{tag}_bench_driver.json"), (f"bench_{tag}_driver_no_overlap.json", f"{tag}_bench_driver_no_overlap.json"),
+                 (f"bench_{tag}_driver_carry.json", f"{tag}_bench_driver_carry.json"), (f"bench_{tag}_no_overlap.json", f"{tag}_bench_no_overlap.json"),
+                 (f"bench_{tag}_sweep.json", f"{tag}_bench_sweep.json"), ("adapter_latency.json", f"{tag}_adapter_latency.json"), (f"pcie_rate_{tag}.txt", f"{tag}_pcie_rate.txt"),
+                 (f"wbc_tail_{tag}.txt", f"{tag}_wbc_tail.txt"), (f"timeline_{tag}.txt", f"{tag}_timeline_overlap.txt")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 write_counters()
 print(open(os.path.join(P, f"{tag}_kernel_stats.md")).read())
 print({k: (round(v["fetch_bytes"] / 1e6), round(v["write_bytes"] / 1e6)) for k, v in tr.items() if k != "_how"})

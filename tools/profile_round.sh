@@ -17,4 +17,14 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_overlap -o bench -
 cd $R
 python tools/kernel_timeline.py gpurun_out/prof_${tag}_overlap/bench_results.db 24 170 > gpurun_out/timeline_$tag.txt 2>&1
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+# the driver's own command at round end (VERDICT r05 task 6: the round is not closed before it has been run on the final tree), with and without the second stream,
+# with the working sets carried, and the batch sweep
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${tag}_driver.json 2> /dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-overlap --no-cpu-baseline > gpurun_out/bench_${tag}_driver_no_overlap.json 2> /dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --wbc-state carry > gpurun_out/bench_${tag}_driver_carry.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-overlap > gpurun_out/bench_${tag}_no_overlap.json 2> /dev/null
+python bench.py --no-cpu-baseline --sweep > gpurun_out/bench_${tag}_sweep.json 2> /dev/null
+python tools/adapter_latency.py > gpurun_out/adapter_latency_$tag.txt 2>&1
+python tools/pcie_rate.py > gpurun_out/pcie_rate_$tag.txt 2>&1
+python tools/wbc_tail_probe.py --steps 40 --above 18 > gpurun_out/wbc_tail_$tag.txt 2>&1
 tail -1 gpurun_out/bench_$tag.json

@@ -28,7 +28,11 @@ VARIANTS = {
     "ticks": (("-DQM_RICCATI_TIMING",), True, "phase clocks (s_memtime + s_waitcnt at every phase boundary): different register allocation and scheduling"),
     "o2": (("-O2",), True, "-O2 instead of -O3: different inlining / unrolling decisions"),
     "noinl": (("-mllvm", "-inline-threshold=40"), True, "inliner threshold 40 (default 225 at -O3): helpers that are inlined in the product become calls"),
-    "bare": (("-DQM_WAVE_SYNC_BARE",), True, "round 2's QM_WAVE_SYNC (bare wave barrier, no fences)"),
+    # (required until round 5, when it was bit-identical.  Round 6: after a semantically neutral edit of qp_dev.h -- the pinned-row count checked after the slots are assigned
+    #  instead of before -- the bare build returns torques 1e-9 .. 7e-5 off on every RF_RH (mode 5) instance of the sweep and on no other, while the product agrees with the CPU
+    #  restatement to 5e-14 on those instances and with the five other variants bit for bit.  Bisected over the round's commits with both builds of each: the bare builtin's memory
+    #  semantics at the hand-off are whatever this LLVM gives it; the product states them -- fence release / barrier / fence acquire -- and does not depend on that.  Kept buildable.)
+    "bare": (("-DQM_WAVE_SYNC_BARE",), False, "round 2's QM_WAVE_SYNC (bare wave barrier, no fences): NOT a build that has to agree since round 6"),
     "ipra": (("-mllvm", "-enable-ipra=1"), True, "interprocedural register allocation on (LLVM's default for AMDGPU; rounds 1-2 shipped this)"),
     "opq_noipra": (("-DQM_WBC_OPAQUE_MASK=511",), True, "whole LDS carve of wbc_kernel behind one opaque address-space-3 base: wrong torques with IPRA on (round 2), correct with it off"),
     "opq": (("-DQM_WBC_OPAQUE_MASK=511", "-mllvm", "-enable-ipra=1"), False, "round 2's failing experiment (REPRODUCER: returns wrong torques): opaque LDS base + IPRA on"),
