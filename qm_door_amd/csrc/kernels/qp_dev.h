@@ -43,6 +43,7 @@ struct QpIo {
   double* red;          // exchange scratch (>= 1024 doubles; the host emulation uses all of it)
   double* fork;         // [1] command word of the fork-join with the three helper wavefronts (wbc_kernel): 0 = leave, NP = K tiles of that size
   double* S;            // [QP_KMAX][QP_SLD] scratch: the small system of the pinned rows
+  double* Tp;           // [QP_KMAX][ldk] scratch: T_P = L^-1 DZ_P', one row per pinned row (slot order)
 };
 
 // K = G + DZ' diag(w) DZ: the upper-triangle 16 x 16 tiles t with t % 4 == wave (wave < 0: all of them) on the matrix cores, written
@@ -151,7 +152,7 @@ template <int NP, int J> struct IpmFactorStep {
   }
 };
 
-struct QpOff { int G, AZ, rhat, DZ, fhat, Kt, wtL, zs, red, fork, S; };
+struct QpOff { int G, AZ, rhat, DZ, fhat, Kt, wtL, zs, red, fork, S, Tp; };
 struct QpResult { int status; int ipmIterations, iterations; bool strong; unsigned long long pinMask; bool warmRefuted; };   // pinMask: the rows pinned at the solution (status 0); status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed | 4 more pinned rows than the small system holds
 
 // A called function, not inlined: the kernel around it sits at 512 VGPRs with scratch, and three inlined instantiations of this body add
@@ -173,7 +174,7 @@ struct QpResult { int status; int ipmIterations, iterations; bool strong; unsign
 template <int NP, int LDZ_, int LDK_>
 __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, unsigned long long warm, const double* warmZ, bool lit, int lane) {
   QM_DYNAMIC_LDS(ldsBase);
-  const QpIo io{ldsBase + off.G, ldsBase + off.AZ, ldsBase + off.rhat, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork, ldsBase + off.S};
+  const QpIo io{ldsBase + off.G, ldsBase + off.AZ, ldsBase + off.rhat, ldsBase + off.DZ, ldsBase + off.fhat, ldsBase + off.Kt, ldsBase + off.wtL, ldsBase + off.zs, ldsBase + off.red, ldsBase + off.fork, ldsBase + off.S, ldsBase + off.Tp};
   enum { ST_I = 0, ST_P = 1, ST_V = 2 };
   const double* G = io.G; const double* DZ = io.DZ; const double* AZ = io.AZ; double* red = io.red;
   double* bc = io.red;              // [0..63] broadcast line (z, multipliers, u, v ...)
@@ -493,53 +494,92 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     // ---- T_P = L^-1 DZ_P' by slot into LDS, S = T_P'T_P
     unsigned long long depMask = 0ull;
     if (k > 0) {
-      // one forward substitution per pinned row, in slot order (rows on their bounds first), through the register-resident factor: t_c lands in lane c and goes to
-      // row `slot` of the LDS square (the K tiles are no longer needed).  (A lane-per-row substitution over L in LDS, fully unrolled, was 630 terms of straight-line
-      // code per instantiation: 74 cycles per term at NP = 36, the function no longer fits the instruction cache.)
+      // Round 6 (tools/wbc_tick_probe.py on the slowest ticks of the bench's steady-state leg: T, S and the small factorisation were 58 % of a 36-variable active-set iteration,
+      // 110 k ticks of 190 k, as one substitution per pinned row through the register-resident factor, S in loops of single LDS round trips and a right-looking factorisation with
+      // three barriers and a read-modify-write chain per step): ALL pinned rows at once, lane s = slot s.
+      // T_P = L^-1 DZ_P': the rows of L and 1 / L_cc come from LDS as wave-uniform (broadcast) reads, the lane's own t from its row of Tp; a finished entry is read back by the
+      // same lane only (LDS is in order within a wavefront).  Directions without curvature: their row of L is the unit vector, their right-hand side entry zero (exMask).
+      QM_WAVE_SYNC();
+      if (lane < NP) io.wtL[lane] = myInv;                       // (the row weights of the K tiles are no longer needed)
+      int* rowOfSlot = reinterpret_cast<int*>(ms);               // [QP_KMAX] ints over the small system's right-hand side (rebuilt by every pass)
+      if (pinned) rowOfSlot[slot] = lane;
+      QM_WAVE_SYNC();
+      const int sa = lane < k ? lane : 0;
+      const int myRow = rowOfSlot[sa];
+      QM_WAVE_SYNC();
       {
+        // four rows of L at a time: the part of their dot products that lies left of the block shares the lane's loads of its own t (one load of t feeds four multiply-adds, four
+        // independent accumulation chains), the 4 x 4 triangle on the diagonal is solved in registers
+        double* Trow = io.Tp + sa * LDK_;
+        const double* drow = DZ + myRow * LDZ_;
+        static_assert(NP % 4 == 0, "blocks of four rows");
 #pragma unroll 1
-        for (int sidx = 0; sidx < k; ++sidx) {
-          const int rowI = qmFirstBit(qmBallot(pinned && slot == sidx));
-          const double d = DZ[rowI * LDZ_ + colL];
-          const double t = forward(colOn ? d : 0.0);
-          QM_WAVE_SYNC();
-          if (lane < NP) io.Kt[sidx * LDK_ + lane] = t;
+        for (int c0 = 0; c0 < NP; c0 += 4) {
+          const double* L0 = io.Kt + c0 * LDK_; const double* L1 = L0 + LDK_; const double* L2 = L1 + LDK_; const double* L3 = L2 + LDK_;
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 1
+          for (int q = 0; q < c0; q += 2) {
+            const double t0 = Trow[q], t1 = Trow[q + 1];
+            const double l00 = L0[q], l01 = L0[q + 1], l10 = L1[q], l11 = L1[q + 1], l20 = L2[q], l21 = L2[q + 1], l30 = L3[q], l31 = L3[q + 1];
+            a0 += l00 * t0; a1 += l10 * t0; a2 += l20 * t0; a3 += l30 * t0;
+            a0 += l01 * t1; a1 += l11 * t1; a2 += l21 * t1; a3 += l31 * t1;
+          }
+          const double l10 = L1[c0], l20 = L2[c0], l21 = L2[c0 + 1], l30 = L3[c0], l31 = L3[c0 + 1], l32 = L3[c0 + 2];
+          const double i0 = io.wtL[c0], i1 = io.wtL[c0 + 1], i2 = io.wtL[c0 + 2], i3 = io.wtL[c0 + 3];
+          const double r0 = drow[c0], r1 = drow[c0 + 1], r2 = drow[c0 + 2], r3 = drow[c0 + 3];
+          const unsigned ex4 = unsigned(exMask >> c0) & 15u;
+          const double d0 = (c0 < n && !(ex4 & 1u)) ? r0 : 0.0, d1 = (c0 + 1 < n && !(ex4 & 2u)) ? r1 : 0.0, d2 = (c0 + 2 < n && !(ex4 & 4u)) ? r2 : 0.0, d3 = (c0 + 3 < n && !(ex4 & 8u)) ? r3 : 0.0;
+          const double t0 = (d0 - a0) * i0;
+          const double t1 = ((d1 - a1) - l10 * t0) * i1;
+          const double t2 = (((d2 - a2) - l20 * t0) - l21 * t1) * i2;
+          const double t3 = ((((d3 - a3) - l30 * t0) - l31 * t1) - l32 * t2) * i3;
+          if (lane < k) { Trow[c0] = t0; Trow[c0 + 1] = t1; Trow[c0 + 2] = t2; Trow[c0 + 3] = t3; }
         }
       }
       QM_WAVE_SYNC();
       QM_TICK(3);
-      {   // S = T_P'T_P: lane a < k its row
-        const int sa = lane < k ? lane : 0;
+      {   // S = T_P T_P': lane a its row; its own t in registers, the other row as broadcast reads
+        double ta[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) ta[c] = io.Tp[sa * LDK_ + c];
 #pragma unroll 1
         for (int sb = 0; sb < k; ++sb) {
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll 1
-          for (int c = 0; c + 1 < NP; c += 2) { a0 += io.Kt[sa * LDK_ + c] * io.Kt[sb * LDK_ + c]; a1 += io.Kt[sa * LDK_ + c + 1] * io.Kt[sb * LDK_ + c + 1]; }
-          if (NP & 1) a0 += io.Kt[sa * LDK_ + NP - 1] * io.Kt[sb * LDK_ + NP - 1];
-          if (lane < k) io.S[lane * QP_SLD + sb] = a0 + a1;
+          const double* Tb = io.Tp + sb * LDK_;
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+          for (int c = 0; c + 3 < NP; c += 4) { a0 += ta[c] * Tb[c]; a1 += ta[c + 1] * Tb[c + 1]; a2 += ta[c + 2] * Tb[c + 2]; a3 += ta[c + 3] * Tb[c + 3]; }
+          if (lane < k) io.S[lane * QP_SLD + sb] = (a0 + a1) + (a2 + a3);
         }
+        static_assert(NP % 4 == 0, "S sums four entries at a time");
       }
       QM_WAVE_SYNC();
-      const int sl = lane < k ? lane : 0;
-      const double sdiag = io.S[sl * QP_SLD + sl];
+      // small Cholesky, left-looking by columns: at step j lane i >= j forms S_ij - sum_{q < j} L_iq L_jq (its own row and row j of the factor, finished columns only), the
+      // pivot is lane j's value; a pivot lost against the row's own diagonal entry marks a dependent row (its row / column of the factor cleared: skipped by the solves).
+      // One barrier per step, no read-modify-write of the trailing matrix.
+      const double sdiag = io.S[sa * QP_SLD + sa];
 #pragma unroll 1
       for (int j = 0; j < k; ++j) {
-        const double d = io.S[j * QP_SLD + j];
-        const double dj0 = io.S[j * QP_SLD + j];
-        (void)dj0;
+        const double* Li = io.S + sa * QP_SLD;
+        const double* Lj = io.S + j * QP_SLD;
+        double a0 = 0.0, a1 = 0.0;
+        int q = 0;
+#pragma unroll 1
+        for (; q + 3 < j; q += 4) {
+          const double x0 = Li[q], x1 = Li[q + 1], x2 = Li[q + 2], x3 = Li[q + 3];
+          const double y0 = Lj[q], y1 = Lj[q + 1], y2 = Lj[q + 2], y3 = Lj[q + 3];
+          a0 += x0 * y0; a1 += x1 * y1; a0 += x2 * y2; a1 += x3 * y3;
+        }
+        for (; q < j; ++q) a0 += Li[q] * Lj[q];
+        const double v = Li[j] - (a0 + a1);
+        const double d = qmReadLane(v, j, red);
         const double sj = qmReadLane(sdiag, j, red);
         const bool dep = !(d > 1e-11 * sj);
         if (dep) depMask |= 1ull << j;
         const double dj = dep ? 1.0 : sqrt(d);
         QM_WAVE_SYNC();
         if (lane == j) io.S[j * QP_SLD + j] = dj;
-        else if (lane > j && lane < k) io.S[lane * QP_SLD + j] = dep ? 0.0 : io.S[lane * QP_SLD + j] / dj;
+        else if (lane > j && lane < k) io.S[lane * QP_SLD + j] = dep ? 0.0 : v / dj;
         if (dep && lane < j) io.S[j * QP_SLD + lane] = 0.0;
-        QM_WAVE_SYNC();
-        if (!dep && lane > j && lane < k) {
-          const double lij = io.S[lane * QP_SLD + j];
-          for (int q = j + 1; q <= lane; ++q) io.S[lane * QP_SLD + q] -= lij * io.S[q * QP_SLD + j];
-        }
         QM_WAVE_SYNC();
       }
     }
@@ -576,40 +616,72 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       QM_WAVE_SYNC();
       double muMine = 0.0;
       if (k > 0) {
-        // right-hand side of the small system: T_P'u + r_P -- lane s < k takes row s of T_P from LDS, the pinned lanes add their residuals
+        // right-hand side of the small system: T_P u + r_P -- lane s < k takes row s of T_P from LDS (u as broadcast reads), the pinned lanes add their residuals
+        double mval;
         {
           const int sl2 = lane < k ? lane : 0;
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll 1
-          for (int c = 0; c + 1 < NP; c += 2) { a0 += io.Kt[sl2 * LDK_ + c] * bc[c]; a1 += io.Kt[sl2 * LDK_ + c + 1] * bc[c + 1]; }
-          if (NP & 1) a0 += io.Kt[sl2 * LDK_ + NP - 1] * bc[NP - 1];
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+          for (int c = 0; c + 3 < NP; c += 4) { a0 += io.Tp[sl2 * LDK_ + c] * bc[c]; a1 += io.Tp[sl2 * LDK_ + c + 1] * bc[c + 1]; a2 += io.Tp[sl2 * LDK_ + c + 2] * bc[c + 2]; a3 += io.Tp[sl2 * LDK_ + c + 3] * bc[c + 3]; }
           QM_WAVE_SYNC();
-          if (lane < k) ms[lane] = a0 + a1;
+          if (lane < k) ms[lane] = (a0 + a1) + (a2 + a3);
           QM_WAVE_SYNC();
           if (pinned) ms[slot] += rRow;
           QM_WAVE_SYNC();
+          mval = lane < k ? ms[lane] : 0.0;
         }
-        // S mu = rhs (lane = row of the small factor)
+        // S mu = rhs through the small factor, the right-hand side in registers (lane = row): the value of step j travels by v_readlane, the lane's own entries of the factor
+        // come from LDS four steps ahead -- no barrier and no LDS round trip on the chain (until round 6: two of each per step, 17 k ticks per pass at 24 pinned rows)
+        {
+          const int sl2 = lane < k ? lane : 0;
+          const double dinv = 1.0 / io.S[sl2 * QP_SLD + sl2];
 #pragma unroll 1
-        for (int j = 0; j < k; ++j) {
-          const double xj = ((depMask >> j) & 1ull) ? 0.0 : ms[j] / io.S[j * QP_SLD + j];
-          QM_WAVE_SYNC();
-          if (lane == j) ms[j] = xj;
-          else if (lane > j && lane < k) ms[lane] -= io.S[lane * QP_SLD + j] * xj;
-          QM_WAVE_SYNC();
-        }
+          for (int j0 = 0; j0 < k; j0 += 4) {
+            double lj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lj[u] = io.S[sl2 * QP_SLD + (j0 + u < k ? j0 + u : 0)];      // L[lane][j] (used for lane > j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + u;
+              if (j < k) {
+                const double xj = ((depMask >> j) & 1ull) ? 0.0 : qmReadLane(mval * dinv, j, red);
+                mval = (lane == j) ? xj : ((lane > j && lane < k) ? mval - lj[u] * xj : mval);
+              }
+            }
+          }
 #pragma unroll 1
-        for (int j = k - 1; j >= 0; --j) {
-          const double xj = ((depMask >> j) & 1ull) ? 0.0 : ms[j] / io.S[j * QP_SLD + j];
+          for (int j0 = k - 1; j0 >= 0; j0 -= 4) {
+            double lj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lj[u] = io.S[(j0 - u >= 0 ? j0 - u : 0) * QP_SLD + sl2];      // L[j][lane] (used for lane < j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 - u;
+              if (j >= 0) {
+                const double xj = ((depMask >> j) & 1ull) ? 0.0 : qmReadLane(mval * dinv, j, red);
+                mval = (lane == j) ? xj : ((lane < j) ? mval - lj[u] * xj : mval);
+              }
+            }
+          }
           QM_WAVE_SYNC();
-          if (lane == j) ms[j] = xj;
-          else if (lane < j) ms[lane] -= io.S[j * QP_SLD + lane] * xj;
+          if (lane < k) ms[lane] = mval;
           QM_WAVE_SYNC();
         }
         muMine = pinned ? ms[slot] : 0.0;
       }
       double vC = uC;
-      for (int sb = 0; sb < k; ++sb) vC -= io.Kt[sb * LDK_ + colL] * ms[sb];
+      {
+        double a0 = 0.0, a1 = 0.0;
+        int sb = 0;
+#pragma unroll 1
+        for (; sb + 3 < k; sb += 4) {
+          const double t0 = io.Tp[sb * LDK_ + colL], t1 = io.Tp[(sb + 1) * LDK_ + colL], t2 = io.Tp[(sb + 2) * LDK_ + colL], t3 = io.Tp[(sb + 3) * LDK_ + colL];
+          const double m0 = ms[sb], m1 = ms[sb + 1], m2 = ms[sb + 2], m3 = ms[sb + 3];
+          a0 += t0 * m0; a1 += t1 * m1; a0 += t2 * m2; a1 += t3 * m3;
+        }
+        for (; sb < k; ++sb) a0 += io.Tp[sb * LDK_ + colL] * ms[sb];
+        vC -= a0 + a1;
+      }
       vC = lane < NP ? vC : 0.0;
       const double pC = backward(vC);
       QM_WAVE_SYNC();

@@ -64,7 +64,8 @@ constexpr int W_VH = W_G + ND * LDK;             // Householder vectors [MAXR][4
 constexpr int W_VEC = W_VH + MAXR * 40;          // vectors: x[36] z[36] g[36] rd[36] rhs[36] dz[36] fhat[56] lam[56] wt[56] tz[56] red[64]
 constexpr int W_BODY2 = W_VEC + 6 * 36 + 4 * 56 + 1024 + 8;   // (red[1024]: wavefront exchange scratch, only the host emulation uses more than 64) body / dof tables of the desired pass (wavefront 1)
 constexpr int W_DOF2 = W_BODY2 + 640;
-constexpr int WBC_LDS_DOUBLES = W_DOF2 + 144;
+constexpr int W_TP = W_DOF2 + 144;               // T_P = L^-1 DZ_P' of the level solver's pinned rows [QP_KMAX][LDK] (round 6; until then over the K square, one row at a time)
+constexpr int WBC_LDS_DOUBLES = W_TP + QP_KMAX * LDK;
 constexpr int WBC_LDS_BYTES = WBC_LDS_DOUBLES * 8;
 constexpr int WBC_THREADS = 256;   // the solving wavefront + three helpers (one per SIMD of the CU)
 // misc block
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
 #elif QM_WBC_EXP == 5
     __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);   // experiment: pure timing -- every helper arrives ~16 k cycles later
 #endif
-    const QpIo hio{G, nullptr, nullptr, DZ, fhat, K, wt, zs, red, forkCmd, nullptr};
+    const QpIo hio{G, nullptr, nullptr, DZ, fhat, K, wt, zs, red, forkCmd, nullptr, nullptr};
 #if defined(QM_WBC_DUMP) && !defined(QMGPU_HOST_EMULATION)
     int dbgIt = 0;
 #endif
@@ -835,7 +836,7 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     QM_WAVE_SYNC();
     forkGemm(true, AZp, LDZ, AZp, LDZ, nQ, nQ, rRows, G, LDK, 0.0);
     QM_WAVE_SYNC();
-    const QpOff io{int(G - lds), int(AZp - lds), int(rhatp - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds), int(Vh - lds)};
+    const QpOff io{int(G - lds), int(AZp - lds), int(rhatp - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds), int(Vh - lds), W_TP};
     const double sigma0 = (own || nQ <= 8) ? -1.0 : 0.5;         // (small levels go without the interior point: cold, the active-set method is shorter there in mean and in the tail)
     auto solve = [&](bool tryHeld) {
       QpResult rr;
