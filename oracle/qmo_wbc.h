@@ -333,7 +333,7 @@ inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting val
 inline int g_expNoMinNormStart = 0;                      // 1: the first level without its minimum-norm start (tests: same torques)
 inline int g_expNoInteriorPoint = 0;                     // 1: the active-set method alone, cold from z = 0 on every level (tests: same vertex)
 inline int g_expGuessOrder = 1;
-inline int g_expLiteralRegMaxN = 8;                      // levels of at most this many variables keep HoQp's 1e-12 I IN the factorised matrix and the gradient (LevelQp::lit); 0: the limit everywhere, as until round 5
+inline int g_expLiteralRegMaxN = 12;                     // levels of at most this many variables keep HoQp's 1e-12 I IN the factorised matrix and the gradient (LevelQp::lit); 0: the limit everywhere, as until round 5
 inline int g_expCanonicalFirst = 1;                      // HierarchicalMpcWbc takes the canonical representative at every level from the first pass on (0: only when directions are left over at the end, as until round 6)
 inline int g_expNoWarmStart = 0;                         // 1: the working set carried from the previous tick (wbcUpdate: ws) is ignored -- every level cold (tests: same torques)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
@@ -376,7 +376,9 @@ struct LevelQp {
   // task in the six variables the levels above left) sees one combination of arm accelerations through a singular value of ~2e-7, curvature 5e-14 -- under the exclusion floor, so
   // the direction stayed where it was, while its gradient (2e-6: the task's residual is O(10)) is eight orders above its rounding and the reference's answer, -g / (c + 1e-12) ~ 1e6,
   // runs into a torque limit: arm torques off by 100 %, leg torques by 1e-5 .. 1e-2 on those ticks.  With 1e-12 on the diagonal the pivot is c + 1e-12, resolved as long as the
-  // level's own rounding, 16 eps n max(K_jj), stays below 1e-12: true for the small, well-scaled last levels (n <= 8, K_jj ~ 1), NOT for the 18-variable level (K_jj ~ 2e3: its
+  // level's own rounding, 16 eps n max(K_jj), stays below 1e-12: true for the small, well-scaled last levels (n <= 12, K_jj ~ 1: the contact-force level of every gait and
+  // controller, 2 .. 12 variables; against the exact solution the start-up branch's went from 6.6e-9 to 6.5e-13, three-leg stances of HierarchicalMpcWbc from 1.2e-7 to 2.5e-11
+  // when the bound went from 8 to 12), NOT for the 18-variable level (K_jj ~ 2e3: its
   // rounding is 1e-10, and a direction it does not see at all would carry the rounding of the gradient divided by 1e-12) -- so the literal form is taken for levels of at most
   // kLiteralRegMaxN variables whose variables are still the reference's z (no implied-equality change of variables), the limit elsewhere.
   bool lit = false;

@@ -169,7 +169,7 @@ struct QpResult { int status; int ipmIterations, iterations; bool strong; unsign
 // feasible, the rows are convex; the CPU restatement's solveLevel has the reasoning: the minimiser reached from z = 0 through the directions the cost sees is usually outside
 // the rows, the previous tick's is a minimiser inside them up to the tick's change).
 // lit: HoQp's 1e-12 I is kept LITERALLY -- on the diagonal of the factorised matrix and in the gradient, no absolute exclusion floor -- instead of in the limit: the small last
-// levels (at most 8 variables, still the reference's own z), where a direction the task sees through a singular value of 1e-7 has a gradient that counts and a curvature below
+// levels (at most 12 variables, still the reference's own z), where a direction the task sees through a singular value of 1e-7 has a gradient that counts and a curvature below
 // any floor (the CPU restatement's LevelQp::lit has the case and the numbers).
 template <int NP, int LDZ_, int LDK_>
 __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, int m0, bool own, bool rowOnIn, double sigma0, bool tryHeld, unsigned long long warm, const double* warmZ, bool lit, int lane) {
@@ -384,7 +384,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         bc[lane] = rowOn ? l1 : 0.0;
         QM_WAVE_SYNC();
         const double dtl = ipmColSum<LDZ_>(io, lane);     // D^T lambda: 56 rows, shared with the helper wavefronts
-        rdz = colOn ? (a0 + a1) + dtl : 0.0;
+        rdz = colOn ? ((a0 + a1) + (lit ? QP_REG * zc : 0.0)) + dtl : 0.0;
       }
       const double mu = allSum(rowOn ? s1 * l1 : 0.0) / nRows;
       const double nrd = allMax(fabs(rdz));

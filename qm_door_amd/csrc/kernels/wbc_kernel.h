@@ -841,9 +841,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     auto solve = [&](bool tryHeld) {
       QpResult rr;
       const double* wz = reduced ? nullptr : warmZ;
-      const bool lit = regular && !own && !reduced && nQ <= 8;      // (= LevelQp::lit of the CPU restatement)
+      const bool lit = regular && !own && !reduced && nQ <= 12;      // (= LevelQp::lit of the CPU restatement: kLiteralRegMaxN)
       if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lit, lane);
-      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, false, lane);
+      else if (nQ <= 20) rr = qpSolve<20, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lit, lane);
       else rr = qpSolve<36, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, false, lane);
       QM_WAVE_SYNC();
       return rr;

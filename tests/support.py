@@ -277,7 +277,7 @@ class Oracle:
         self.lib.qmo_set_wbc_working_set(p(ws))
         self._ws_keep = ws
 
-    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False, no_warm_start=False, literal_reg_max_n=8):
+    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False, no_warm_start=False, literal_reg_max_n=12):
         """experiment knobs of the WBC restatement (process-wide for this library; the defaults are the product's algorithm).  Both change only the PATH to the vertex
         every level ends at: another starting value of the interior point that runs in front of the active-set method, or no interior point at all (the active-set
         method cold from z = 0)."""

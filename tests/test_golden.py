@@ -50,7 +50,7 @@ def test_hip_reproduces_golden(interface):
 
 
 # ------------------------------------------------------------------------------------------------ against the 50-digit solution of the reference's own level QPs
-EXACT = {name: np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")) for name in ("hoqp_exact_ticks", "hoqp_exact_offenders")
+EXACT = {name: np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")) for name in ("hoqp_exact_ticks", "hoqp_exact_offenders", "hoqp_exact_gaits")
          if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))}
 # Stated bounds, rel-inf per block (each block its own norm; legs = what the separated-system plugin commands, QMController.cpp:428-431).
 #   HierarchicalWbc: every block of every tick within 1e-8 (measured: median 3e-10, max 2e-9 -- the size of 1e-12 / curvature, i.e. of taking HoQp's regulariser in the limit).
@@ -80,9 +80,11 @@ def check_against_exact(out, d, who):
     return rep
 
 
-@pytest.mark.skipif("hoqp_exact_ticks" not in EXACT, reason="fixture missing")
-def test_oracle_against_the_50_digit_solution_of_the_reference_qp(oracle):
-    d = EXACT["hoqp_exact_ticks"]
+@pytest.mark.parametrize("name", [n for n in ("hoqp_exact_ticks", "hoqp_exact_gaits") if n in EXACT])
+def test_oracle_against_the_50_digit_solution_of_the_reference_qp(oracle, name):
+    """hoqp_exact_ticks: trot / stance ticks of both controllers; hoqp_exact_gaits: the start-up branch (t < 10 s: the canonical second pass), flying trot (flight phases) and static walk
+    (three-leg stances), both controllers -- measured round 6: every block within 2.6e-7 (legs), 1.1e-6 (arm, HierarchicalMpcWbc three-leg stances)"""
+    d = EXACT[name]
     out = np.zeros((len(d["mode"]), 54))
     for i in range(len(out)):
         st, out[i], _ = oracle.wbc_update(d["xd"][i], d["ud"][i], d["rbd"][i], int(d["mode"][i]), float(d["period"][i]), float(d["time"][i]), d["il"][i].copy(), variant=int(d["variant"][i]))
@@ -128,7 +130,7 @@ def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, oracle
                             "tau_legs_abs_Nm": [float(np.abs(out[i, 36:48] - d["exact"][i, 36:48]).max()), float(np.abs(orc_out[i, 36:48] - d["exact"][i, 36:48]).max())]} for i in range(n)]
     os.makedirs(os.path.join(S.ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rep, open(os.path.join(S.ROOT, "gpurun_out", name + "_gpu.json"), "w"), indent=1)
-    if name == "hoqp_exact_ticks":
+    if name in ("hoqp_exact_ticks", "hoqp_exact_gaits"):
         check_against_exact(out, d, "gpu")
     else:
         # the ticks a full-size closed loop / stress run found hardest: the kernel within 1e-6 of the reference's exact answer on all but three of them (measured round 6: 23 of 26;

@@ -24,7 +24,9 @@ Output per tick: x* (36) and tau = [M_j, -J_j'] x* + h_j (WbcBase::updateCmd, Wb
 the separated-system plugin), arm tau[12:18], accelerations x[0:24], contact forces x[24:36].
 
   python tools/hoqp_exact.py --make-fixture      # CPU: tests/golden/hoqp_exact_ticks.npz = inputs + exact answers of seeded ticks of both controllers
-  python tools/hoqp_exact.py --report            # CPU: oracle vs exact on the fixture, per block  (the GPU side: tests/test_gpu_wbc.py::test_wbc_against_the_50_digit_solution_of_the_reference_qp)
+  python tools/hoqp_exact.py --make-gaits        # CPU: tests/golden/hoqp_exact_gaits.npz = the same for the start-up branch, flying trot and static walk
+  python tools/hoqp_exact.py --make-offenders    # CPU, after a GPU run of the full-size closed loop / stress tests: tests/golden/hoqp_exact_offenders.npz
+  python tools/hoqp_exact.py --report [--noise] [--fixture F]    # CPU: oracle vs exact on the fixture, per block  (the GPU side: tests/test_gpu_wbc.py::test_wbc_against_the_50_digit_solution_of_the_reference_qp)
 """
 import argparse
 import json
@@ -390,16 +392,16 @@ def block_dev(got, ref):
 
 
 # ------------------------------------------------------------------------------------------------ fixture: seeded ticks of both controllers + the slow / ill-conditioned ones
-def closed_loop_ticks(itf, orc, variant, batch, cycles, ticks, seed, pick, t_start=9.9, gait_start=0.15):
+def closed_loop_ticks(itf, orc, variant, batch, cycles, ticks, seed, pick, t_start=9.9, gait_start=0.15, gait="trot", first_cycle=None):
     """WBC inputs of ticks of the oracle's own closed loop (tests/closed_loop.py: plan-following robots in motion, inputLast_ carried): `pick` random (cycle, tick, instance)
     triples after the start-up branch, seeded."""
     import closed_loop as CL
-    sc = CL.Scenario(itf, batch, cycles=cycles, t_start=t_start, gait_start=gait_start, seed=seed)
+    sc = CL.Scenario(itf, batch, cycles=cycles, t_start=t_start, gait_start=gait_start, seed=seed, gait=gait)
     be = CL.OracleBackend(orc, sc, variant)
     rng = np.random.default_rng(seed + 1000)
     wanted = set()
     while len(wanted) < pick:
-        wanted.add((int(rng.integers(cycles // 3, cycles)), int(rng.integers(0, ticks)), int(rng.integers(0, batch))))
+        wanted.add((int(rng.integers(cycles // 3 if first_cycle is None else first_cycle, cycles)), int(rng.integers(0, ticks)), int(rng.integers(0, batch))))
     out = []
     rbd = sc.first_measurement()
     for k in range(cycles):
@@ -416,7 +418,8 @@ def closed_loop_ticks(itf, orc, variant, batch, cycles, ticks, seed, pick, t_sta
             for (kk, jj, i) in wanted:
                 if kk == k and jj == j:
                     out.append(dict(variant=variant, xd=xd[i].copy(), ud=ud[i].copy(), rbd=rb[i].copy(), mode=int(md[i]), period=CL.WBC_PERIOD, time=float(tm), il=il[i].copy(),
-                                    oracle=w["out"][i].copy(), source=f"closed loop seed {seed} cycle {k} tick {j} instance {i}"))
+                                    oracle=w["out"][i].copy(), source=(f"closed loop seed {seed} cycle {k} tick {j} instance {i}" if gait == "trot" and first_cycle is None else
+                                                                       f"closed loop {gait} t_start {t_start} variant {variant} seed {seed} cycle {k} tick {j} instance {i}")))
         rbd = CL.measurement(sc, plan, t0 + CL.MPC_PERIOD)
     return out
 
@@ -491,6 +494,7 @@ def solve_and_save(orc, ticks, path, note):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--make-fixture", action="store_true")
+    ap.add_argument("--make-gaits", action="store_true", help="tests/golden/hoqp_exact_gaits.npz: the start-up branch (t < 10 s), flying trot and static walk, both controllers")
     ap.add_argument("--make-offenders", action="store_true", help="tests/golden/hoqp_exact_offenders.npz from gpurun_out/closed_loop_v1.json and gpurun_out/wbc_stress_v{0,1}.npz of a GPU run")
     ap.add_argument("--report", action="store_true")
     ap.add_argument("--noise", action="store_true", help="with --report: also how far the EXACT solution moves when HoQp's matrices are formed with double-precision product rounding, three seeded draws per tick")
@@ -507,6 +511,11 @@ def main():
         for variant in (0, 1):
             ticks += closed_loop_ticks(itf, orc, variant, batch=16, cycles=36, ticks=10, seed=61 + variant, pick=args.ticks_per_controller)
         solve_and_save(orc, ticks, args.fixture, note)
+    if args.make_gaits:
+        ticks = []
+        for variant, gait, t_start, seed in ((0, "trot", 9.0, 71), (0, "flying_trot", 10.5, 72), (0, "static_walk", 10.5, 73), (1, "flying_trot", 10.5, 74), (1, "static_walk", 10.5, 75)):
+            ticks += closed_loop_ticks(itf, orc, variant, batch=8, cycles=30, ticks=10, seed=seed, pick=16, t_start=t_start, gait_start=0.05, gait=gait, first_cycle=2)
+        solve_and_save(orc, ticks, os.path.join(ROOT, "tests", "golden", "hoqp_exact_gaits.npz"), note)
     if args.make_offenders:
         fast = S.Oracle(itf.problem, fast=True)
         ticks = offender_ticks(itf, fast, os.path.join(ROOT, "gpurun_out", "closed_loop_v1.json"))
