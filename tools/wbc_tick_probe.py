@@ -42,6 +42,18 @@ for i in idx:
     w = wb.results()["working_set"][0]
     cb = np.ascontiguousarray(w[13:15]).view(np.uint8)
     print(f"tick {i}: kernel {ms:.3f} ms, status {int(wb.results()['status'][0])}, passes per solve {[int(v) for v in cb[:12]]}, whole kernel {raw[192:192 + 11].sum():.0f} ticks")
+    WBC = ["S1-S2 inputs, coordinates", "S3 measured pass", "S4 nle, M, Jacobians", "S5 desired pass (join)", "task 0 inequality rows + level-loop re-entry", "assemble level task", "reduced data", "level QP", "x update",
+           "(after the last null space)", "torques", "  reduced data: A Z", "  reduced data: zero + D Z", "  reduced data: A x - b, margins", "  reduced data: zero + (A Z)^T A Z", "  null space: full-pivot LU of A Z",
+           "  null space: kernel vectors (back substitution)", "  null space: Z N, copy"]
+    v = raw[192:192 + len(WBC)]
+    print(f"  kernel sections ({v[:11].sum():.0f} ticks):")
+    for n_, x in zip(WBC, v):
+        print("    %-62s %9.0f  %5.1f %%" % (n_, x, 100 * x / v[:11].sum()))
+    NS = ["entry: row maxima", "step: max reduction, pivot lane", "step: swap, pivot broadcast", "step: elimination", "step: candidates of the chunks", "rank, free columns, zeroing", "kernel vectors (back substitution)"]
+    v = raw[352:352 + len(NS)]
+    print(f"  wbcNullSpace, all calls ({v.sum():.0f} ticks):")
+    for n_, x in zip(NS, v):
+        print("    %-62s %9.0f  %5.1f %%" % (n_, x, 100 * x / max(v.sum(), 1)))
     for base, name in ((160, "NP = 36"), (256, "NP = 20"), (288, "NP = 8")):
         v = raw[base:base + 17]
         if v[:9].sum() > 0:
