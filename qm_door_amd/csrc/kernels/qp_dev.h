@@ -518,11 +518,14 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
           const double* L0 = io.Kt + c0 * LDK_; const double* L1 = L0 + LDK_; const double* L2 = L1 + LDK_; const double* L3 = L2 + LDK_;
           double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 1
-          for (int q = 0; q < c0; q += 2) {
-            const double t0 = Trow[q], t1 = Trow[q + 1];
+          for (int q = 0; q < c0; q += 4) {      // (c0 is a multiple of four: twenty loads in flight in front of sixteen multiply-adds, same order of the sums as two columns per trip)
+            const double t0 = Trow[q], t1 = Trow[q + 1], t2 = Trow[q + 2], t3 = Trow[q + 3];
             const double l00 = L0[q], l01 = L0[q + 1], l10 = L1[q], l11 = L1[q + 1], l20 = L2[q], l21 = L2[q + 1], l30 = L3[q], l31 = L3[q + 1];
+            const double l02 = L0[q + 2], l03 = L0[q + 3], l12 = L1[q + 2], l13 = L1[q + 3], l22 = L2[q + 2], l23 = L2[q + 3], l32 = L3[q + 2], l33 = L3[q + 3];
             a0 += l00 * t0; a1 += l10 * t0; a2 += l20 * t0; a3 += l30 * t0;
             a0 += l01 * t1; a1 += l11 * t1; a2 += l21 * t1; a3 += l31 * t1;
+            a0 += l02 * t2; a1 += l12 * t2; a2 += l22 * t2; a3 += l32 * t2;
+            a0 += l03 * t3; a1 += l13 * t3; a2 += l23 * t3; a3 += l33 * t3;
           }
           const double l10 = L1[c0], l20 = L2[c0], l21 = L2[c0 + 1], l30 = L3[c0], l31 = L3[c0 + 1], l32 = L3[c0 + 2];
           const double i0 = io.wtL[c0], i1 = io.wtL[c0 + 1], i2 = io.wtL[c0 + 2], i3 = io.wtL[c0 + 3];
