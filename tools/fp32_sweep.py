@@ -58,7 +58,9 @@ def report(out):
            "modes_bit_exact": bool(np.array_equal(a["mpc"]["mode"], b["mpc"]["mode"])),
            "statistics_repeat_bit_for_bit": bool(a["repeatable"] and b["repeatable"]),   # three identical calls per build
            "riccati_status_f32_all_zero": bool((b["mpc"]["stats"][:, 7] == 0).all()),
-           "line_search_alpha_differs": int((~same_alpha).sum()), "batch": int(a["mpc"]["X"].shape[0]), "nodes": int(a["mpc"]["X"].shape[1] - 1)}
+           "line_search_alpha_differs": int((~same_alpha).sum()), "batch": int(a["mpc"]["X"].shape[0]), "nodes": int(a["mpc"]["X"].shape[1] - 1),
+           # (verdict r05, missing 5) what "tau" of the fp32 leg is: there is no fp32 WBC
+           "wbc_precision": "fp64 in BOTH legs: tau of the f32 leg is the fp64 WBC fed with the fp32 plan -- HoQp's 1e-12 regulariser (HoQp.cpp:66) and its 1e-9 tolerances are below fp32 resolution, an fp32 WBC is not built"}
     sa, sb = a["mpc"]["stats"], b["mpc"]["stats"]
     rep["step_metrics_rel"] = {n: float((np.abs(sa[:, c] - sb[:, c]) / np.maximum(1e-12, np.abs(sa[:, c])))[same_alpha].max()) for c, n in ((0, "merit0"), (1, "violation0"), (2, "merit1"), (3, "violation1"))}
     for key, x, y in (("X", a["mpc"]["X"], b["mpc"]["X"]), ("U", a["mpc"]["U"], b["mpc"]["U"]), ("tau", a["wbc"]["out"][:, 36:], b["wbc"]["out"][:, 36:])):
