@@ -327,6 +327,7 @@ constexpr double kMinNormCheap = 1e4;
 constexpr int kIpmMinVariables = 8;
 constexpr double kAsLamTol = 8.0;            // a multiplier counts once it exceeds this many roundings of the gradient it balances
 constexpr int kAsMaxWorkingSetChanges = 100; // nWSR of HoQp.cpp:141
+constexpr int kHeldFormMaxIterations = 4;    // the held-variable form of a level with own rows (solveLevel) is given up beyond this many iterations: status 6, the interior point takes over (= QP_HELD_CAP of the kernels)
 constexpr int kAsMaxPinned = 28;             // = QP_KMAX of the kernels (qp_dev.h): rows the small system of the pinned set holds
 // Experiment knobs (qmo_set_experiment; defaults = the product's algorithm).  inline: one copy whatever the number of translation units; written between batches only.
 inline double g_expLowerLevelStart = kLowerLevelStart;   // another starting value of the interior point = another path to the same vertex (tests: the result must not depend on it)
@@ -335,6 +336,7 @@ inline int g_expNoInteriorPoint = 0;                     // 1: the active-set me
 inline int g_expGuessOrder = 1;
 inline int g_expLiteralRegMaxN = 12;                     // levels of at most this many variables keep HoQp's 1e-12 I IN the factorised matrix and the gradient (LevelQp::lit); 0: the limit everywhere, as until round 5
 inline int g_expCanonicalFirst = 1;                      // HierarchicalMpcWbc takes the canonical representative at every level from the first pass on (0: only when directions are left over at the end, as until round 6)
+inline int g_expOwnInteriorPoint = 3;                    // a level with own rows whose held-variable form is rejected (torque limits that cannot hold) runs the interior point, own rows as penalised slacks, in front of its active-set method (0: cold from z = 0, as until round 6: 40-46 changes on diverged robots)
 inline int g_expNoWarmStart = 0;                         // 1: the working set carried from the previous tick (wbcUpdate: ws) is ignored -- every level cold (tests: same torques)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
@@ -430,22 +432,29 @@ inline LevelWork prepareLevel(const LevelQp& q) {
 // Mehrotra predictor-corrector on   min 1/2 z'Gz + g'z  s.t.  D z + s = f, s >= 0   from z = 0, slacks max(sigma, f), multipliers sigma = sigma0 sqrt(scale).  Runs until the working set can
 // plausibly be read off the iterate (duality measure <= 1e-6 scale with residuals to match), until it has converged or stagnates at the rounding floor of its normal
 // equations, or until a step loses all accuracy (the previous iterate is handed over).  Returns the iterations used.
-struct IpmPoint { Vec z, s, lam; bool usable = false; };
+struct IpmPoint { Vec z, s, lam; bool usable = false, ownRows = false; };
 constexpr double kIpmHandOverMu = 1e-8;     // duality measure (x scale) at which the working set is read off the iterate; x 1e-2 for each of the (at most two) resumptions.  (1e-6 saves 7 % of the passes and is NOT
                                             //  taken: a direction at the exclusion floor of the factorisation stays where the interior point left it, and at 1e-6 that is up to 0.7 of the torques away from the minimiser, at 1e-8 5e-4.)
-inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma0, IpmPoint& pt, double muTarget = kIpmHandOverMu, bool resume = false, int itStart = 0) {
+// ownRows (round 6): the level's own rows take part as what they are in the reference's QP -- D z - v <= f with 1/2 v'v in the cost; v = lam at the optimum, so the row reads
+// D z + s - lam = f, its weight in the normal equations is lam / (s + lam) <= 1 and its multiplier IS its violation.
+inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma0, IpmPoint& pt, double muTarget = kIpmHandOverMu, bool resume = false, int itStart = 0, bool ownRows = false) {
   const int n = q.n(), m = q.m();
-  std::vector<int> rows; for (int i = q.mOwn; i < m; ++i) if (w.on[i]) rows.push_back(i);
+  std::vector<int> rows; for (int i = ownRows ? 0 : q.mOwn; i < m; ++i) if (w.on[i]) rows.push_back(i);
   const int mr = int(rows.size());
   const IpmPoint from = pt;
-  pt.z.assign(n, 0.0); pt.s.assign(m, 0.0); pt.lam.assign(m, 0.0); pt.usable = false;
+  pt.z.assign(n, 0.0); pt.s.assign(m, 0.0); pt.lam.assign(m, 0.0); pt.usable = false; pt.ownRows = ownRows;
   if (mr == 0) return 0;
   const Mat& G = q.G0;       // (without HoQp's regulariser, as in the active-set phase: directions it alone would carry are left out of the factorisation)
   Mat D(mr, n); Vec f(mr);
   for (int r = 0; r < mr; ++r) { for (int j = 0; j < n; ++j) D(r, j) = q.D(rows[r], j); f[r] = q.f[rows[r]]; }
   const double scale = w.scale, sigma = sigma0 * std::sqrt(w.scale);
   Vec z(n, 0.0), s(mr), lam(mr, sigma);
-  for (int i = 0; i < mr; ++i) s[i] = std::max(sigma, f[i]);
+  std::vector<char> soft(mr, 0); for (int r = 0; r < mr; ++r) soft[r] = rows[r] < q.mOwn;
+  for (int i = 0; i < mr; ++i) {
+    if (!soft[i]) s[i] = std::max(sigma, f[i]);
+    else if (f[i] >= 0.0) s[i] = f[i] + sigma;             // s - lam = f at z = 0: the row's equation holds from the start
+    else { s[i] = sigma; lam[i] = sigma - f[i]; }
+  }
   if (resume) { z = from.z; for (int r = 0; r < mr; ++r) { s[r] = from.s[rows[r]]; lam[r] = from.lam[rows[r]]; } }     // (the guess its last iterate gave was refuted: on from there)
   Vec zPrev = z, sPrev = s, lamPrev = lam;
   double nrdPrev = 0.0, muPrev = 0.0;
@@ -455,6 +464,7 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
     Vec rd = G * z + q.g + tmul(D, lam);
     if (q.literal()) for (int i = 0; i < n; ++i) rd[i] += q.reg * z[i];
     Vec rp = D * z + s - f;
+    for (int i = 0; i < mr; ++i) if (soft[i]) rp[i] -= lam[i];
     const double mu = dot(s, lam) / mr;
     double nrd = 0, nrp = 0; for (double v : rd) nrd = std::max(nrd, std::fabs(v)); for (double v : rp) nrp = std::max(nrp, std::fabs(v));
     // a late Newton step of a degenerate problem (barrier weights ~1e18) can lose all accuracy: the previous iterate is what the active-set method starts from
@@ -463,16 +473,19 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
     if (it > itStart && mu > 0.5 * muPrev && mu <= kStagnationMu * scale) { handOver(z, s, lam); return it; }          // stagnation at the rounding floor
     zPrev = z; sPrev = s; lamPrev = lam; nrdPrev = nrd; muPrev = mu;
     Mat K = q.hessian();
-    for (int r = 0; r < mr; ++r) { const double wr = lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
+    for (int r = 0; r < mr; ++r) { const double wr = soft[r] ? lam[r] / (s[r] + lam[r]) : lam[r] / s[r]; for (int i = 0; i < n; ++i) { const double wi = wr * D(r, i); if (wi == 0.0) continue; for (int j = 0; j < n; ++j) K(i, j) += wi * D(r, j); } }
     std::vector<char> excluded;
     if (!choleskyExcluding(K, q.floorAbs(), 16.0 * kEps, excluded)) { handOver(zPrev, sPrev, lamPrev); return it; }
     auto solve = [&](const Vec& rc, Vec& dz, Vec& ds, Vec& dl) {
-      Vec t(mr); for (int i = 0; i < mr; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / s[i];
+      Vec t(mr); for (int i = 0; i < mr; ++i) t[i] = (lam[i] * rp[i] - rc[i]) / (soft[i] ? s[i] + lam[i] : s[i]);
       dz = -1.0 * (rd + tmul(D, t));
       cholSolveExcluding(K, excluded, dz);
       const Vec Ddz = D * dz;
       ds.resize(mr); dl.resize(mr);
-      for (int i = 0; i < mr; ++i) { ds[i] = -rp[i] - Ddz[i]; dl[i] = (-rc[i] - lam[i] * ds[i]) / s[i]; }
+      for (int i = 0; i < mr; ++i) {
+        if (soft[i]) { dl[i] = (lam[i] * (Ddz[i] + rp[i]) - rc[i]) / (s[i] + lam[i]); ds[i] = (-rp[i] - Ddz[i]) + dl[i]; }
+        else { ds[i] = -rp[i] - Ddz[i]; dl[i] = (-rc[i] - lam[i] * ds[i]) / s[i]; }
+      }
     };
     auto maxStep = [&](const Vec& ds, const Vec& dl) { double a = 1.0; for (int i = 0; i < mr; ++i) { if (ds[i] < 0) a = std::min(a, -s[i] / ds[i]); if (dl[i] < 0) a = std::min(a, -lam[i] / dl[i]); } return a; };
     Vec rc(mr), dz, ds, dl;
@@ -521,7 +534,7 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
 // the interior point's guess (dependent rows leave first, the first step is only taken in full), and a first step that any row cuts short refutes it, also when the
 // guess was "no row is active": the level then starts over the cold way.
 inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoint* start, Vec& z, Vec& lamOut, std::vector<char>& stateOut, const std::vector<char>* fixedVars = nullptr, bool* guessRefuted = nullptr,
-                              const uint64_t* warmMask = nullptr, const Vec* warmZ = nullptr) {
+                              const uint64_t* warmMask = nullptr, const Vec* warmZ = nullptr, int iterationCap = kAsMaxWorkingSetChanges) {
   enum { I = 0, P = 1, V = 2 };
   QpStats st;
   const int n = q.n(), m = q.m(), mOwn = q.mOwn;
@@ -538,11 +551,14 @@ inline QpStats activeSetPhase(const LevelQp& q, const LevelWork& w, const IpmPoi
     z = start->z;
     const Vec Dz = D * z;
     for (int i = mOwn; i < m; ++i) if (rowOn[i] && (start->lam[i] > 1.0 * start->s[i] || Dz[i] - f[i] > 0.0)) { state[i] = P; guess[i] = 1; }
+    // own rows behind the interior point: on the side of their bound the iterate has them on (no guess: a violated row is a penalty wherever it stands)
+    if (start->ownRows) for (int i = 0; i < mOwn; ++i) if (rowOn[i]) { const double rr = Dz[i] - f[i]; state[i] = rr > tol ? V : (rr >= -tol ? P : I); }
   }
   if (warmMask) for (int i = mOwn; i < m && i < 64; ++i) if (rowOn[i] && ((*warmMask >> i) & 1ull)) { state[i] = P; guess[i] = 1; }
   if (warmMask && warmZ) z = *warmZ;      // (the previous tick's solution, scaled back into the rows by solveLevel)
   int lastReleased = -1, fullSteps = 0, guard = 0;
   for (;; ++st.iterations) {
+    if (st.iterations > iterationCap && iterationCap < kAsMaxWorkingSetChanges) { st.status = 6; break; }      // (the held-variable form given up: solveLevel)
     if (st.iterations > kAsMaxWorkingSetChanges || ++guard > 4 * kAsMaxWorkingSetChanges) { st.status = 1; break; }      // (guard: every trip of the loop counts, also those that do not change the working set)
     Mat K = q.hessian();       // (without HoQp's regulariser: a direction it alone would carry counts as having no curvature, below)
     std::vector<int> pin;      // the pinned rows, those already on their bounds first: a dependency then shows on a row of the guess, never on a row the ratio test pinned
@@ -816,13 +832,19 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z, uint64_t* wa
     //  of from z = 0: on the eleven slowest ticks of the bench's steady-state leg, robots whose torque limits cannot hold, 58-72 working-set changes instead of 40-46.)
     if (g_expTrace) fprintf(stderr, "  minimum-norm start of the level: %s\n", ok ? "taken" : "rejected");
   }
-  if (!solved && q.mOwn > 0) {
+  if (!solved && q.mOwn > 0 && q.mOwn == m && g_expOwnInteriorPoint == 2) {
+    ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt, kIpmHandOverMu, false, 0, true);
+  } else if (!solved && q.mOwn > 0) {
     std::vector<char> fixedVars(q.n(), 0); bool any = false;
     for (int i = 0; i < q.mOwn; ++i) if (w.on[i] && std::fabs(q.f[i]) <= 1e-9 * w.scale) for (int j = 0; j < q.n(); ++j) if (q.D(i, j) != 0.0) { fixedVars[j] = 1; any = true; }
     if (any) {
-      st = activeSetPhase(q, w, nullptr, zw, lam, state, &fixedVars);
+      st = activeSetPhase(q, w, nullptr, zw, lam, state, &fixedVars, nullptr, nullptr, nullptr, g_expOwnInteriorPoint == 3 ? kHeldFormMaxIterations : kAsMaxWorkingSetChanges);
       solved = st.status == 0;
       if (!solved && g_expTrace) fprintf(stderr, "  held-variable form rejected (status %d): the zero-bound rows as rows\n", st.status);
+      // (round 6) rejected means the cost wants the held forces moved: limits are violated wherever the task is met.  From z = 0 the active-set method then changes one row per
+      // iteration -- 40-46 of them on robots whose plan has diverged, the tail of the bench's steady-state leg --; the interior point moves all rows at once and hands over
+      // the side of its bound every row ends on.
+      if (!solved && (g_expOwnInteriorPoint == 1 || g_expOwnInteriorPoint == 3) && q.mOwn == m) ipmIt = interiorPointPhase(q, w, g_expLowerLevelStart, pt, kIpmHandOverMu, false, 0, true);
       if (solved) for (int i = 0; i < q.mOwn; ++i) if (w.on[i] && std::fabs(q.f[i]) <= 1e-9 * w.scale && state[i] == 0) { state[i] = 1; lam[i] = 0.0; }   // (reported as pinned with a vanishing multiplier: what they are)
     }
   }

@@ -27,6 +27,7 @@ constexpr double QP_EPS = 2.220446049250313e-16;
 constexpr double QP_REG = 1e-12;             // HoQp's regulariser (HoQp.cpp:66): a direction it alone would carry counts as having no curvature (x10)
 constexpr double QP_LAM_TOL = 8.0;           // = kAsLamTol of the CPU restatement
 constexpr int QP_MAX_CHANGES = 100;          // nWSR of HoQp.cpp:141
+constexpr int QP_HELD_CAP = 4;               // the held-variable form of the first level is given up beyond this many iterations (status 6; = kHeldFormMaxIterations of the CPU restatement): the interior point takes over
 constexpr int QP_KMAX = 28;                  // pinned rows the small system holds (S: QP_KMAX x (QP_KMAX + 1) doubles of LDS)
 constexpr int QP_SLD = QP_KMAX + 1;
 constexpr double QP_STAGNATION_MU = 1e-10;
@@ -153,7 +154,7 @@ template <int NP, int J> struct IpmFactorStep {
 };
 
 struct QpOff { int G, AZ, rhat, DZ, fhat, Kt, wtL, zs, red, fork, S, Tp; };
-struct QpResult { int status; int ipmIterations, iterations; bool strong; unsigned long long pinMask; bool warmRefuted; };   // pinMask: the rows pinned at the solution (status 0); status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed | 4 more pinned rows than the small system holds
+struct QpResult { int status; int ipmIterations, iterations; bool strong; unsigned long long pinMask; bool warmRefuted; bool heldTried; };   // pinMask: the rows pinned at the solution (status 0); status: 0 ok | 1 working-set changes exhausted | 2 numerical failure | 3 final check failed | 4 more pinned rows than the small system holds | 5 the cost wants held variables moved | 6 held-variable form given up (QP_HELD_CAP); heldTried: variables were held
 
 // A called function, not inlined: the kernel around it sits at 512 VGPRs with scratch, and three inlined instantiations of this body add
 // ~1400 scalar-register spills to it; as a function each instantiation gets its own allocation.  The arrays arrive as offsets into the
@@ -338,8 +339,16 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   bool usable = false;
   double s1 = 1.0, l1 = 0.0;
   const double nRows = allSum(rowOn ? 1.0 : 0.0);
-  const bool ipmOn = sigma0 > 0.0 && !own && nRows > 0.0;
-  if (ipmOn) { const double sigma = sigma0 * sqrt(scale); s1 = rowOn ? fmax(sigma, fl) : 1.0; l1 = rowOn ? sigma : 0.0; }      // (start in units of sqrt(scale): the CPU restatement has the numbers)
+  // (round 6) own rows take part in the interior point when the caller asks for it (sigma0 > 0: the level's held-variable form was rejected -- limits are violated wherever the
+  //  task is met, and from z = 0 the active-set method needed 40-46 changes on the diverged robots of the bench's steady-state leg): as what they are in the reference's QP,
+  //  D z - v <= f with 1/2 v'v in the cost; v = lam at the optimum, the row reads D z + s - lam = f, its weight in the normal equations is lam / (s + lam).
+  const bool ipmOn = sigma0 > 0.0 && nRows > 0.0;
+  if (ipmOn) {
+    const double sigma = sigma0 * sqrt(scale);      // (start in units of sqrt(scale): the CPU restatement has the numbers)
+    if (!own) { s1 = rowOn ? fmax(sigma, fl) : 1.0; l1 = rowOn ? sigma : 0.0; }
+    else if (fl >= 0.0) { s1 = rowOn ? fl + sigma : 1.0; l1 = rowOn ? sigma : 0.0; }      // s - lam = f at z = 0: the row's equation holds from the start
+    else { s1 = rowOn ? sigma : 1.0; l1 = rowOn ? sigma - fl : 0.0; }
+  }
   double muTarget = 1e-8;            // duality measure (x scale) at which the working set is read off the iterate (= kIpmHandOverMu of the CPU restatement)
   int resumed = 0, status = 0, it = 0;
   bool strong = false;
@@ -370,7 +379,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       bc[lane] = zc;
       QM_WAVE_SYNC();
       const double Dz = rowDot();
-      const double rp1 = rowOn ? (Dz + s1 - fl) : 0.0;
+      const double rp1 = rowOn ? (own ? (Dz + s1 - fl) - l1 : (Dz + s1 - fl)) : 0.0;
       double rdz;
       {
         double a0 = gC, a1 = 0.0;
@@ -398,14 +407,15 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       if (nrd <= 1e-4 * scale && nrp <= 1e-9 * scale && mu <= muTarget * scale) { usable = true; break; }               // the working set can be read: over to the active-set method, for good
       if (ipmIt > itStart && mu > 0.5 * muPrev && mu <= QP_STAGNATION_MU * scale) { usable = true; break; }               // stagnation at the rounding floor
       zcPrev = zc; s1p = s1; l1p = l1; nrdPrev = nrd; muPrev = mu;
-      const double w1 = l1 / s1;
+      const double den1 = own ? s1 + l1 : s1;
+      const double w1 = l1 / den1;
       QM_TICK(12);
       factorise(rowOn ? w1 : 0.0);
       double ds1 = 0.0, dl1 = 0.0, dzc = 0.0, alphaAff = 1.0, sigma = 0.0, cw = 1.0;
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
         const double rc1 = pass == 0 ? s1 * l1 : s1 * l1 + cw * ds1 * dl1 - sigma * mu;
-        const double t1 = rowOn ? (l1 * rp1 - rc1) / s1 : 0.0;
+        const double t1 = rowOn ? (l1 * rp1 - rc1) / den1 : 0.0;
         QM_WAVE_SYNC();
         bc[lane] = t1;
         QM_WAVE_SYNC();
@@ -418,7 +428,10 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
         QM_WAVE_SYNC();
         const double Ddz = rowDot();
         QM_TICK(15);
-        if (rowOn) { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
+        if (rowOn) {
+          if (own) { dl1 = (l1 * (Ddz + rp1) - rc1) / den1; ds1 = (-rp1 - Ddz) + dl1; }
+          else { ds1 = -rp1 - Ddz; dl1 = (-rc1 - l1 * ds1) / s1; }
+        }
         double amax = 1.0;
         if (rowOn) { if (ds1 < 0) amax = fmin(amax, -s1 / ds1); if (dl1 < 0) amax = fmin(amax, -l1 / dl1); }
         amax = allMin(amax);
@@ -437,7 +450,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
       }
     }
     QM_TICK(16);
-    if (ipmIt >= 40) usable = true;      // iteration cap: the last iterate is handed over like any other
+    usable = true;                       // every way out of the loop hands an iterate over (the iteration cap too: the last iterate, like any other)
     if (!(allSum(zc) == allSum(zc))) { usable = false; zc = 0.0; }
   }
 
@@ -451,7 +464,8 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
     bc[lane] = zc;
     QM_WAVE_SYNC();
     const double Dz = rowDot();
-    if (rowOn && (l1 > s1 || Dz - fl > 0.0)) { state = ST_P; guess = true; }
+    if (!own) { if (rowOn && (l1 > s1 || Dz - fl > 0.0)) { state = ST_P; guess = true; } }
+    else if (rowOn) { const double rr = Dz - fl; state = rr > tol ? ST_V : (rr >= -tol ? ST_P : ST_I); }      // own rows: on the side of their bound the iterate has them on (no guess: a violated row is a penalty wherever it stands)
   }
   if (warmTry && rowOn && lane < 56 && ((warm >> lane) & 1ull)) { state = ST_P; guess = true; }
   double lam = 0.0;                  // multiplier of this lane's row (pinned rows)
@@ -460,6 +474,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   status = 0; it = 0; strong = false;
 #pragma unroll 1
   for (;; ++it) {
+    if (tryHeld && heldMask != 0ull && it > QP_HELD_CAP) { status = 6; break; }      // (the held-variable form given up: the caller runs the interior point)
     if (it > QP_MAX_CHANGES || ++guard > 4 * QP_MAX_CHANGES) { status = 1; break; }      // (guard: every trip of the loop counts, also those that do not change the working set)
     bool pinned = rowOn && state == ST_P;
     unsigned long long pinMask = qmBallot(pinned);
@@ -788,7 +803,7 @@ __device__ __attribute__((noinline)) QpResult qpSolve(QpOff off, int n, int r, i
   QM_TICK_FLUSH(NP == 36 ? 160 : (NP == 20 ? 256 : 288), blockIdx.x == 0 && lane == 0);
   if (status == 2) zc = 0.0;      // numerical failure: the level is skipped (x stays the higher priorities' solution) and flagged
   if (lane < 36) io.zs[lane] = colOn ? zc : 0.0;
-  return QpResult{status, ipmIt, it, strong, (status == 0 && !own) ? (pinOut | (1ull << 63)) : 0ull, warmRefuted};
+  return QpResult{status, ipmIt, it, strong, (status == 0 && !own) ? (pinOut | (1ull << 63)) : 0ull, warmRefuted, heldMask != 0ull};
 }
 
 }  // namespace qmk

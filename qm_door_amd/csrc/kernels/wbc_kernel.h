@@ -837,9 +837,9 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
     forkGemm(true, AZp, LDZ, AZp, LDZ, nQ, nQ, rRows, G, LDK, 0.0);
     QM_WAVE_SYNC();
     const QpOff io{int(G - lds), int(AZp - lds), int(rhatp - lds), int(DZ - lds), int(fhat - lds), int(K - lds), int(wt - lds), int(zs - lds), int(red - lds), int(forkCmd - lds), int(Vh - lds), W_TP};
-    const double sigma0 = (own || nQ <= 8) ? -1.0 : 0.5;         // (small levels go without the interior point: cold, the active-set method is shorter there in mean and in the tail)
-    auto solve = [&](bool tryHeld) {
+    auto solve = [&](bool tryHeld, bool ownIpm) {
       QpResult rr;
+      const double sigma0 = ownIpm ? 0.5 : ((own || nQ <= 8) ? -1.0 : 0.5);         // (small levels go without the interior point: cold, the active-set method is shorter there in mean and in the tail)
       const double* wz = reduced ? nullptr : warmZ;
       const bool lit = regular && !own && !reduced && nQ <= 12;      // (= LevelQp::lit of the CPU restatement: kLiteralRegMaxN)
       if (nQ <= 8) rr = qpSolve<8, LDZ, LDK>(io, nQ, rRows, m0, own, rowOn, sigma0, tryHeld, warmIn, wz, lit, lane);
@@ -848,8 +848,8 @@ __global__ void __launch_bounds__(WBC_THREADS) QM_ONE_WAVE_PER_SIMD wbc_kernel(W
       QM_WAVE_SYNC();
       return rr;
     };
-    QpResult res = solve(own);                       // own rows: first with the variables of the zero-bound rows held (qp_dev.h) ...
-    if (own && res.status != 0) res = solve(false);  // ... and, if the cost wants them moved, with those rows as rows
+    QpResult res = solve(own, false);                // own rows: first with the variables of the zero-bound rows held (qp_dev.h) ...
+    if (own && res.status != 0) res = solve(false, res.heldTried);  // ... and, if the cost wants them moved (or that form takes more than QP_HELD_CAP iterations), with those rows as rows behind the interior point
     passes = (res.ipmIterations + res.iterations < 127 ? res.ipmIterations + res.iterations : 127) | (res.warmRefuted ? 128 : 0);
     warmIo = res.pinMask;
     if (warmIo != 0ull && warmZ != nullptr && !reduced) { warmIo |= 1ull << 62; if (lane < nQ) warmZ[lane] = zs[lane]; }     // (the solution travels with the rows)

@@ -49,6 +49,7 @@ VARIANTS["x_wave2"] = ((*_OPQ, "-DQM_WBC_EXP=3"), False, "failing combination, d
 VARIANTS["x_drain"] = ((*_OPQ, "-DQM_WBC_EXP=4"), False, "failing combination, s_waitcnt vmcnt(0) lgkmcnt(0) before the fork-join loop: still fails (not memory ordering)")
 VARIANTS["x_sleep"] = ((*_OPQ, "-DQM_WBC_EXP=5"), False, "failing combination, helpers sleep before the fork-join loop: still fails (not timing)")
 # timing experiments (tools/variant_timing.py): the instruction scheduler's strategy for the whole translation unit
+VARIANTS["qptrace"] = (("-DQM_QP_TRACE=0",), False, "device printf of instance 0's level-solver iterations (experiments: tools/wbc_variants.py --build qptrace, then a batch of one through that library)")
 VARIANTS["s_maxilp"] = (("-mllvm", "-amdgpu-sched-strategy=max-ilp"), False, "LLVM's max-ILP scheduling strategy (timing experiment)")
 VARIANTS["s_iterilp"] = (("-mllvm", "-amdgpu-sched-strategy=iterative-ilp"), False, "LLVM's iterative ILP scheduling strategy (timing experiment)")
 VARIANTS["s_maxmem"] = (("-mllvm", "-amdgpu-sched-strategy=max-memory-clause"), False, "LLVM's max-memory-clause scheduling strategy (timing experiment)")
