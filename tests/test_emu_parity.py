@@ -162,6 +162,32 @@ def test_emu_wbc_with_the_working_sets_carried_from_tick_to_tick(emu):
     assert warm_ticks == 5
 
 
+def test_emu_first_level_of_a_diverged_robot_goes_through_the_interior_point(emu):
+    """One of the slowest ticks of round 6's steady-state leg (tests/golden/wbc_slow_ticks.npz, index 1: 40 working-set changes of the 36-variable level from z = 0 until the
+    end of round 6) on the host-emulated kernel: held-variable form given up after QP_HELD_CAP iterations, the interior point with the own rows as penalised slacks,
+    the active-set method behind it -- same torques as the CPU restatement on the same path AND on its cold path, a bounded number of passes."""
+    import os
+    itf, orc = emu
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wbc_slow_ticks.npz"))
+    i = 1
+    sol = api.GpuSolver(itf, max_batch=1, max_nodes=4)
+    out, st = np.zeros((1, 54)), np.zeros(1, dtype=np.int32)
+    ws = np.zeros((1, abi.WBC_STATE_WORDS), dtype=np.uint64)
+    sol.wbc(sol.wbc_args(1, d["rbd"][i][None], np.array([float(d["period"][i])]), np.array([float(d["time"][i])]), d["il"][i][None].copy(), out, st, d["xd"][i][None], d["ud"][i][None],
+                         np.array([int(d["mode"][i])], dtype=np.int32), 0, working_set=ws))
+    a = (d["xd"][i], d["ud"][i], d["rbd"][i], int(d["mode"][i]), float(d["period"][i]), float(d["time"][i]))
+    s_now, now, _ = orc.wbc_update(*a, d["il"][i].copy())
+    try:
+        orc.set_experiment(own_interior_point=0)
+        s_cold, cold, _ = orc.wbc_update(*a, d["il"][i].copy())
+    finally:
+        orc.set_experiment()
+    assert st[0] == 0 and s_now == 0 and s_cold == 0
+    for ref in (now, cold):
+        assert all(v.max() <= 1e-9 for v in S.rel_inf_blocks(out, ref[None]).values())       # measured 2e-15 / 4e-14
+    assert (int(np.ascontiguousarray(ws[0, 13:14]).view(np.uint8)[0]) & 127) <= 12              # measured 8 (interior-point iterations + working-set changes)
+
+
 def test_emu_mixed_modes_and_event_grid(emu):
     """Flight / three-leg / stance nodes (m~ = 14, 17, 18 tile paths of the MFMA kernels) on an event-aligned, non-uniform grid."""
     itf, orc = emu

@@ -139,3 +139,31 @@ def test_hip_against_the_50_digit_solution_of_the_reference_qp(interface, oracle
             assert np.median(e) <= 1e-6 and (e > 1e-5).sum() <= 3 and e.max() <= 0.5, (k, float(np.median(e)), int((e > 1e-5).sum()), float(e.max()))
         for k, e in dev_orc.items():
             assert e.max() <= 1e-5, (k, float(e.max()))
+
+
+def test_first_level_behind_the_interior_point_ends_at_the_cold_vertex(oracle):
+    """tests/golden/wbc_slow_ticks.npz (the ten slowest WBC ticks of round 6's steady-state leg: robots whose torque limits cannot hold): the first level through the interior
+    point with its own rows as penalised slacks (default) against the same level cold from z = 0 (own_interior_point = 0, the algorithm until round 6): same torques,
+    a bounded number of passes instead of up to 46 working-set changes."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wbc_slow_ticks.npz"))
+    n = len(d["mode"])
+
+    def run():
+        outs, passes = [], []
+        for i in range(n):
+            ws = np.zeros((1, 48), dtype=np.uint64)      # (qmgpu.h: QMGPU_WBC_STATE_WORDS)
+            oracle.set_working_set(ws)
+            st, out, _ = oracle.wbc_update(d["xd"][i], d["ud"][i], d["rbd"][i], int(d["mode"][i]), float(d["period"][i]), float(d["time"][i]), d["il"][i].copy())
+            assert st == 0
+            outs.append(out); passes.append(int(np.ascontiguousarray(ws[0, 13:14]).view(np.uint8)[0]) & 127)
+        oracle.set_working_set(None)
+        return np.array(outs), np.array(passes)
+    try:
+        oracle.set_experiment(own_interior_point=0)
+        cold, p_cold = run()
+    finally:
+        oracle.set_experiment()
+    now, p_now = run()
+    dev = S.rel_inf_blocks(now, cold)
+    assert all(v.max() <= 1e-9 for v in dev.values()), {k: float(v.max()) for k, v in dev.items()}        # measured 2.6e-13
+    assert p_cold.max() >= 40 and p_now.max() <= 12, (p_cold, p_now)                                      # measured: up to 46 cold, at most 8 now

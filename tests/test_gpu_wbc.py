@@ -108,6 +108,34 @@ def oracle_sensitivity(orc, c, idx, variant, eps=1e-9, draws=8, seed=5):
     return worst, path
 
 
+def test_first_level_of_diverged_robots_goes_through_the_interior_point(interface, oracle):
+    """tests/golden/wbc_slow_ticks.npz: the ten slowest WBC ticks of round 6's steady-state leg -- robots whose plan has diverged, the first level's minimum-norm point
+    violates 7-16 limits.  Until the end of round 6 three of them took 23-46 working-set changes of a 36-variable level from z = 0 (3.1-3.5 ms, the tail of every
+    256-instance launch they were in).  Now a held-variable form that is rejected, or still running after QP_HELD_CAP iterations, hands the level to the interior point with the
+    own rows as penalised slacks: same vertex (the CPU restatement's cold path is the reference here: own_interior_point = 0), a bounded number of passes."""
+    import os
+    import gpu_harness as G
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wbc_slow_ticks.npz"))
+    n = len(d["mode"])
+    sol = G.make_solver(interface, n, 4)
+    wb = G.WbcBatch(d["rbd"], d["period"].astype(np.float64), d["time"].astype(np.float64), d["il"].copy(), d["xd"], d["ud"], d["mode"].astype(np.int32), 0, carry=True)
+    sol.wbc(wb.args)
+    r = wb.results()
+    assert (r["status"] == 0).all()
+    passes = np.ascontiguousarray(r["working_set"][:, 13:15]).view(np.uint8).astype(int) & 127
+    oracle.set_experiment(own_interior_point=0)      # cold from z = 0, as until round 6
+    try:
+        cold = np.array([oracle.wbc_update(d["xd"][i], d["ud"][i], d["rbd"][i], int(d["mode"][i]), float(d["period"][i]), float(d["time"][i]), d["il"][i].copy())[1] for i in range(n)])
+    finally:
+        oracle.set_experiment()
+    now = np.array([oracle.wbc_update(d["xd"][i], d["ud"][i], d["rbd"][i], int(d["mode"][i]), float(d["period"][i]), float(d["time"][i]), d["il"][i].copy())[1] for i in range(n)])
+    for name, ref in (("the oracle on the same path", now), ("the oracle cold from z = 0", cold)):
+        dev = S.rel_inf_blocks(r["out"], ref)
+        assert all(v.max() <= 1e-9 for v in dev.values()), (name, {k: float(v.max()) for k, v in dev.items()})       # measured 4e-13 / 4e-13
+    assert passes[:, 0].max() <= 12, passes[:, 0]          # first level: interior-point iterations + working-set changes (measured: 1, 8, 8, 5, 6, 6, 5, 6, 5, 8; cold: up to 46)
+    sol.close()
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_wbc_stress_all_modes_converge(interface, variant):
     """2048 random instances over every contact mode of gait.info, robots in motion (NOT MPC-consistent desired states, 20 % on the start-up branch, swing legs during it:

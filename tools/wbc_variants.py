@@ -205,6 +205,17 @@ def cycle_all_modes(lib, B=256, N=40, cycles=2):
         out["wbc_modes_v%d_t%g" % (variant, time)] = w2["out"]
         out["wbc_modes_status_v%d_t%g" % (variant, time)] = w2["status"]
     sol2.close()
+    # the ten slowest ticks of round 6's steady-state leg (robots whose torque limits cannot hold: held-variable form given up, interior point in front of the first level): the
+    # outputs AND the pass counts of every solve -- five of seven builds once lost the interior point's hand-over there (same torques, 24 iterations more)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "wbc_slow_ticks.npz"))
+    ns = len(d["mode"])
+    sol3 = G.make_solver(itf, ns, 4)
+    wb3 = G.WbcBatch(d["rbd"], d["period"].astype(np.float64), d["time"].astype(np.float64), d["il"].copy(), d["xd"], d["ud"], d["mode"].astype(np.int32), 0, carry=True)
+    sol3.wbc(wb3.args)
+    w3 = wb3.results()
+    out["wbc_slow_ticks"] = w3["out"]; out["wbc_slow_ticks_status"] = w3["status"]
+    out["wbc_slow_ticks_passes"] = np.ascontiguousarray(w3["working_set"][:, 13:15]).view(np.uint8).astype(np.int32)
+    sol3.close()
     sol.close()
     return out
 
