@@ -796,7 +796,6 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z, uint64_t* wa
   //   z = (A Z)' y,   (A Z)(A Z)' y = -rhat        (a Cholesky of the size of the TASK: 18 instead of 36)
   // -- contact forces that carry the robot and small accelerations, inside the friction cones and the torque limits in every regular tick.  Taken if it is: every own
   // row strictly satisfied (then no row is active, the point is the level's minimiser AND its canonical representative: wbcUpdate needs no completion here).
-  bool minNorm = false;
   if (q.mOwn > 0 && q.mOwn == m && q.AZ.r > 0 && q.AZ.r <= q.n() && !g_expNoMinNormStart) {
     const int r = q.AZ.r, n = q.n();
     Mat Gd(r, r);
@@ -827,7 +826,7 @@ inline QpStats solveLevel(LevelQp q, std::vector<char>& eq, Vec& z, uint64_t* wa
       for (int i = 0; i < m && ok; ++i) if (w.on[i] && !(Dz[i] - q.f[i] <= 0.0)) ok = false;
       for (double v : zw) ok = ok && v == v;
     }
-    if (ok) { minNorm = solved = true; st = QpStats(); st.minNorm = true; lam.assign(m, 0.0); state.assign(m, 0); }
+    if (ok) { solved = true; st = QpStats(); st.minNorm = true; lam.assign(m, 0.0); state.assign(m, 0); }
     // (Measured in round 6 and NOT kept: the active-set method started FROM this point when it violates limits -- origin shifted, the violated rows start violated -- instead
     //  of from z = 0: on the eleven slowest ticks of the bench's steady-state leg, robots whose torque limits cannot hold, 58-72 working-set changes instead of 40-46.)
     if (g_expTrace) fprintf(stderr, "  minimum-norm start of the level: %s\n", ok ? "taken" : "rejected");
