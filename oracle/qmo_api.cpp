@@ -216,7 +216,7 @@ int qmo_cycle_batch_mt(const qmgpu_problem* P, int batch, int N, int K, int thre
 // (default 300), key 3 = no interior point at all (the active-set method cold from z = 0 on every level), key 8 = the working sets carried from the previous tick are ignored, key 9 = per-iteration trace on stderr.  Both change the PATH to the
 // vertex only: the tests use them to check that the result does not.
 void qmo_set_experiment(int key, double value) {
-  if (key == 0) g_expLowerLevelStart = value; else if (key == 3) g_expNoInteriorPoint = value != 0.0; else if (key == 4) g_expNoMinNormStart = value != 0.0; else if (key == 7) g_expGuessOrder = value != 0.0; else if (key == 8) g_expNoWarmStart = value != 0.0; else if (key == 12) g_expLiteralRegMaxN = int(value); else if (key == 13) g_expCanonicalFirst = int(value); else if (key == 14) g_expOwnInteriorPoint = int(value); else if (key == 9) g_expTrace = int(value);
+  if (key == 0) g_expLowerLevelStart = value; else if (key == 3) g_expNoInteriorPoint = value != 0.0; else if (key == 4) g_expNoMinNormStart = value != 0.0; else if (key == 7) g_expGuessOrder = value != 0.0; else if (key == 8) g_expNoWarmStart = value != 0.0; else if (key == 12) g_expLiteralRegMaxN = int(value); else if (key == 13) g_expCanonicalFirst = int(value); else if (key == 14) g_expOwnInteriorPoint = int(value); else if (key == 15) g_expIpmStartDelta = value; else if (key == 9) g_expTrace = int(value);
 }
 
 // WBC updates of a BATCH of independent instances on `threads` host threads (what qmgpu_wbc_solve_batch computes): xDes / uDes [B][30], rbd [B][55],

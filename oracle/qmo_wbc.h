@@ -337,6 +337,7 @@ inline int g_expGuessOrder = 1;
 inline int g_expLiteralRegMaxN = 12;                     // levels of at most this many variables keep HoQp's 1e-12 I IN the factorised matrix and the gradient (LevelQp::lit); 0: the limit everywhere, as until round 5
 inline int g_expCanonicalFirst = 1;                      // HierarchicalMpcWbc takes the canonical representative at every level from the first pass on (0: only when directions are left over at the end, as until round 6)
 inline int g_expOwnInteriorPoint = 3;                    // a level with own rows whose held-variable form is rejected (torque limits that cannot hold) runs the interior point, own rows as penalised slacks, in front of its active-set method (0: cold from z = 0, as until round 6: 40-46 changes on diverged robots)
+inline double g_expIpmStartDelta = 0.0;                  // experiment, off: inherited rows of the interior point started on their margins (interiorPointPhase has what it did)
 inline int g_expNoWarmStart = 0;                         // 1: the working set carried from the previous tick (wbcUpdate: ws) is ignored -- every level cold (tests: same torques)
 inline int g_expTrace = 0;                               // per-iteration trace on stderr
 
@@ -450,6 +451,15 @@ inline int interiorPointPhase(const LevelQp& q, const LevelWork& w, double sigma
   const double scale = w.scale, sigma = sigma0 * std::sqrt(w.scale);
   Vec z(n, 0.0), s(mr), lam(mr, sigma);
   std::vector<char> soft(mr, 0); for (int r = 0; r < mr; ++r) soft[r] = rows[r] < q.mOwn;
+  if (g_expIpmStartDelta > 0.0 && !ownRows) {
+    // Experiment of round 6, measured and NOT kept (default 0 = off): inherited rows started ON their margins and centred, s = max(f, delta |d|_inf), lam = sigma^2 / s, instead of
+    // s = lam = sigma (1.5e3 next to margins of 0-90: a start 1.4e3 outside every row, from which the diverged robots of the bench's steady-state leg crawl for ten iterations
+    // at step lengths of 1-5 %).  delta = 10: second-level iterations on those robots 13.5 -> 9.3 in the mean, 23 -> 13 at most, regular closed-loop ticks 5.4 -> 5.2, their
+    // ticks on the GPU 0.82 -> 0.66 ms -- but another path to the vertex: ONE tick of the static walk's 76,800 (HierarchicalWbc, where every tick had been within 1e-6) came out
+    // 6e-3 apart between GPU and this restatement, on a tick whose torques move by 5e-3 under 1e-9 input noise on this side alone, and one instance of the 120-step bench leg
+    // took 47 passes.  Parity on every tick is worth more than 0.15 ms on three robots.
+    for (int i = 0; i < mr; ++i) { s[i] = std::max(f[i], g_expIpmStartDelta * w.dn[rows[i]]); lam[i] = sigma * sigma / s[i]; }
+  } else
   for (int i = 0; i < mr; ++i) {
     if (!soft[i]) s[i] = std::max(sigma, f[i]);
     else if (f[i] >= 0.0) s[i] = f[i] + sigma;             // s - lam = f at z = 0: the row's equation holds from the start

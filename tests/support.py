@@ -277,13 +277,13 @@ class Oracle:
         self.lib.qmo_set_wbc_working_set(p(ws))
         self._ws_keep = ws
 
-    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False, no_warm_start=False, literal_reg_max_n=12, own_interior_point=True):
+    def set_experiment(self, lower_level_start=0.5, no_interior_point=False, trace=False, no_warm_start=False, literal_reg_max_n=12, own_interior_point=3, ipm_start_delta=0.0):
         """experiment knobs of the WBC restatement (process-wide for this library; the defaults are the product's algorithm).  Both change only the PATH to the vertex
         every level ends at: another starting value of the interior point that runs in front of the active-set method, or no interior point at all (the active-set
         method cold from z = 0)."""
         self.lib.qmo_set_experiment.argtypes = [C.c_int, C.c_double]
         self.lib.qmo_set_experiment(0, float(lower_level_start)); self.lib.qmo_set_experiment(3, float(bool(no_interior_point))); self.lib.qmo_set_experiment(9, float(bool(trace)))
-        self.lib.qmo_set_experiment(8, float(bool(no_warm_start))); self.lib.qmo_set_experiment(12, float(literal_reg_max_n)); self.lib.qmo_set_experiment(14, float(int(own_interior_point)))
+        self.lib.qmo_set_experiment(8, float(bool(no_warm_start))); self.lib.qmo_set_experiment(12, float(literal_reg_max_n)); self.lib.qmo_set_experiment(14, float(int(own_interior_point))); self.lib.qmo_set_experiment(15, float(ipm_start_delta))
 
     def wbc_batch(self, x_des, u_des, rbd, mode, period, time, input_last, variant=0, ee_force=None, threads=None):
         """qmo_wbc_batch_mt: the WBC update of EVERY instance of a batch on `threads` host threads; returns out [B][54], status [B], input_last [B][30] (updated)"""
