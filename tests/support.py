@@ -476,6 +476,22 @@ def wbc_stress_batch(interface, variant, B=2048):
     return dict(xd=xd, u=u, rbd=rbd, mode=mode, t=t, il=il)
 
 
+def wbc_fast_robots_batch(interface, variant, B=512, velocity=150.0):
+    """The stress batch with the robots MOVING FAST (joint rates of +-15 rad/s, base +-15 m/s; planned forces +-150 N off the weight, desired joint rates +-30 rad/s, joint
+    accelerations +-2500 rad/s^2): the stance feet's -Jdot v asks for accelerations the torque limits cannot deliver, the first level's minimum-norm point is rejected and in
+    40 % of the instances its held-variable form too -- the regime of the diverged robots of the bench's steady-state leg (tests/golden/wbc_slow_ticks.npz), as a batch.
+    Beyond velocity ~ 250 (25 rad/s) a few instances per hundred end with 18 limits violated, every lower level eliminated and one direction of the first level unseen by any row:
+    its value then depends on the path (cold and interior-point path 1e-2 apart, the reference's 1e-12 I would pick the minimum-norm one) -- stated in DESIGN.md section 5, not tested."""
+    b = wbc_stress_batch(interface, variant, B)
+    rng = np.random.default_rng(99 + variant)
+    u = b["u"].copy()
+    u[:, :12] += rng.uniform(-1, 1, (B, 12)) * 150.0 * (u[:, :12] != 0)
+    u[:, 12:] = rng.uniform(-1, 1, (B, 18)) * 30.0
+    rbd = b["rbd"].copy(); rbd[:, 24:48] *= velocity
+    il = u + rng.uniform(-1, 1, (B, 30)) * np.r_[np.zeros(12), np.full(18, 5.0)]
+    return dict(xd=b["xd"], u=u, rbd=rbd, mode=b["mode"], t=b["t"], il=il)
+
+
 # ------------------------------------------------------------------------------------------------ whole-batch parity (every instance, not a sample)
 def rel_inf(got, ref):
     """||got - ref||_inf / max(1, ||ref||_inf) per instance (axis 0 = instance)"""

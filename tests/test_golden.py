@@ -167,3 +167,31 @@ def test_first_level_behind_the_interior_point_ends_at_the_cold_vertex(oracle):
     dev = S.rel_inf_blocks(now, cold)
     assert all(v.max() <= 1e-9 for v in dev.values()), {k: float(v.max()) for k, v in dev.items()}        # measured 2.6e-13
     assert p_cold.max() >= 40 and p_now.max() <= 12, (p_cold, p_now)                                      # measured: up to 46 cold, at most 8 now
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_first_level_paths_agree_on_fast_robots(oracle, interface, variant):
+    """support.wbc_fast_robots_batch (128 instances): robots moving so fast that the first level's limits cannot hold.  The default path (held-variable form for at most four
+    iterations, then the interior point with the own rows as penalised slacks) and the cold path (own_interior_point = 0) end at the same torques; a third of the instances
+    take the new path."""
+    b = S.wbc_fast_robots_batch(interface, variant, 128)
+
+    def run():
+        outs, passes = [], []
+        for i in range(128):
+            ws = np.zeros((1, 48), dtype=np.uint64)
+            oracle.set_working_set(ws)
+            st, out, _ = oracle.wbc_update(b["xd"][i], b["u"][i], b["rbd"][i], int(b["mode"][i]), 0.002, float(b["t"][i]), b["il"][i].copy(), variant=variant)
+            assert st == 0
+            outs.append(out); passes.append(int(np.ascontiguousarray(ws[0, 13:14]).view(np.uint8)[0]) & 127)
+        oracle.set_working_set(None)
+        return np.array(outs), np.array(passes)
+    try:
+        oracle.set_experiment(own_interior_point=0)
+        cold, p_cold = run()
+    finally:
+        oracle.set_experiment()
+    now, p_now = run()
+    dev = S.rel_inf_blocks(now, cold)
+    assert all(v.max() <= 1e-9 for v in dev.values()), {k: float(v.max()) for k, v in dev.items()}        # measured 4e-13 / 7e-13
+    assert (p_now != p_cold).sum() >= 128 // 5, (p_now != p_cold).sum()                                 # the batch exercises the new path (measured: 40 %)

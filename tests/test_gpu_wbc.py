@@ -137,6 +137,44 @@ def test_first_level_of_diverged_robots_goes_through_the_interior_point(interfac
 
 
 @pytest.mark.parametrize("variant", [0, 1])
+def test_wbc_fast_robots_whose_limits_cannot_hold(interface, variant):
+    """support.wbc_fast_robots_batch (512 instances, every contact mode, both controllers): joint rates of +-15 rad/s -- the first level's limits cannot hold, 40 % of the instances
+    go through the interior point with the own rows as penalised slacks.  GPU against the oracle on the same path and against the oracle's cold path (own_interior_point = 0,
+    the algorithm until round 6): status words zero, every block within 1e-9, first-level passes bounded."""
+    import gpu_harness as G
+    B = 512
+    c = S.wbc_fast_robots_batch(interface, variant, B)
+    sol = G.make_solver(interface, B, 4)
+    wb = G.WbcBatch(c["rbd"], np.full(B, 0.002), c["t"], c["il"].copy(), c["xd"], c["u"], c["mode"], variant, carry=True)
+    sol.wbc(wb.args)
+    r = wb.results()
+    assert (r["status"] == 0).all(), np.nonzero(r["status"])[0][:10]
+    passes = np.ascontiguousarray(r["working_set"][:, 13:15]).view(np.uint8).astype(int) & 127
+    orc = S.Oracle(interface.problem, fast=True)
+    w = orc.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], 0.002, c["t"], c["il"], variant=variant)
+    ref, st = w["out"], w["status"]
+    assert (st == 0).all()
+    try:
+        orc.set_experiment(own_interior_point=0)
+        w = orc.wbc_batch(c["xd"], c["u"], c["rbd"], c["mode"], 0.002, c["t"], c["il"], variant=variant)
+        cold, st_c = w["out"], w["status"]
+    finally:
+        orc.set_experiment()
+    assert (st_c == 0).all()
+    rep = {}
+    for name, o in (("same_path", ref), ("cold_path", cold)):
+        dev = S.rel_inf_blocks(r["out"], o)
+        rep[name] = {k: float(v.max()) for k, v in dev.items()}
+        assert all(v.max() <= 1e-9 for v in dev.values()), (name, rep[name])          # measured 6e-12 (HierarchicalWbc) / 2e-12 (HierarchicalMpcWbc) on either path
+    assert passes[:, 0].max() <= 25, passes[:, 0].max()          # (cold: up to 15 on this batch, 46 on the bench's diverged robots)
+    import json, os
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "wbc_fast_robots_v%d.json" % variant), "w") as f:
+        json.dump({"instances": B, "first_level_passes_max": int(passes[:, 0].max()), "first_level_passes_mean": float(passes[:, 0].mean()), "gpu_vs_oracle": rep}, f, indent=1)
+    sol.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
 def test_wbc_stress_all_modes_converge(interface, variant):
     """2048 random instances over every contact mode of gait.info, robots in motion (NOT MPC-consistent desired states, 20 % on the start-up branch, swing legs during it:
     the canonical second pass of the cascade runs): no level is flagged anywhere, and EVERY instance is compared with the (multi-threaded) oracle -- no sampling.  The
