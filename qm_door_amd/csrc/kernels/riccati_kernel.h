@@ -136,25 +136,29 @@ template <int J, int R, int REND> struct RiccatiDppRows {
 };
 template <int NT, int J> struct RiccatiStep {
   static constexpr int DEND = NT < 16 ? NT : 16;    // DPP rows end here
-  static __device__ __forceinline__ void run(real* col, real& inv, real& mine, real& bcP, real& ncP, int c, int& status, real* scr, real* out, int ostr) {
+  static __device__ __forceinline__ void run(real* col, real& inv, real& bcP, real& ncP, int& status, real* scr, real* out, int ostr) {
     if constexpr (J < NT) {
       col[J] *= inv;                                     // row J of [L^T | W] / sqrt(pivot)
-      out[J * ostr] = col[J];                            // final: element (c, J) of L for an H lane, (J, c) of W for a G lane (asynchronous LDS write)
-      mine = c == J ? inv : mine;
+      // final: element (c, J) of L for an H lane, (J, c) of W for a G lane (asynchronous LDS write); lane J's own entry is L_JJ.  (Until round 6 every lane
+      // carried the reciprocal of "its" diagonal entry through the steps for the gains' back-substitution; the compiler kept all the reciprocals and lane masks
+      // alive to the end and selected there -- ~50 instructions behind the last pivot, on the critical wavefront, and spilled masks inside the loop.  The
+      // diagonal is inverted after the factorisation now, while this wavefront has nothing to do: riccatiInvertDiagonal.)
+      *out = col[J];
+      out += ostr;
       const QmGather gj = qmGather(col[J], scr);
       if constexpr (J + 1 < NT) {
         col[J + 1] -= gj.get(J + 1) * col[J];
         const real piv = qmReadLane(col[J + 1], J + 1, scr);
-        const bool ok = piv > REAL_PIVOT_MIN;
-        if (!ok) status = 1;
-        inv = qmRsqrtPos(ok ? piv : 1.0_r);              // started here: its latency hides behind the remaining updates
+        if (!(piv > REAL_PIVOT_MIN)) status = 1;         // beside the chain: a failed pivot (not a positive number) flags the instance, whose step is then discarded (linesearch_kernel) ...
+        inv = qmRsqrtPos(fmax(piv, REAL_PIVOT_MIN));     // ... and the factorisation runs on with the pivot floored: ONE instruction on the chain (fmax drops a NaN) where the exact
+                                                         // select "failed ? 1 : piv" was a compare, two scalar selects and their way back to the vector unit.  Started here: its latency hides behind the remaining updates
       }
       if constexpr (J + 2 < NT) col[J + 2] -= gj.get(J + 2) * col[J];
       if constexpr (J >= 1) RiccatiDppRows<J - 1, J + 2, DEND>::run(col, bcP, ncP, scr);     // the previous step's rows J + 2 .. 15
 #pragma unroll
       for (int r = (J + 3 > 16 ? J + 3 : 16); r < NT; ++r) col[r] -= gj.get(r) * col[J];
       if constexpr (J + 3 < DEND) { bcP = qmReplicateRow0(col[J], scr); ncP = -col[J]; }
-      RiccatiStep<NT, J + 1>::run(col, inv, mine, bcP, ncP, c, status, scr, out, ostr);
+      RiccatiStep<NT, J + 1>::run(col, inv, bcP, ncP, status, scr, out, ostr);
     }
   }
 };
@@ -180,18 +184,17 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
   const unsigned long long tq0 = clock64();
 #endif
   // steps j >= nt meet identity columns (pivot 1, multipliers 0): no branch, one basic block
-  real inv, mine = 1.0_r, bcP = 0.0_r, ncP = 0.0_r;
+  real inv, bcP = 0.0_r, ncP = 0.0_r;
   {
     const real piv = qmReadLane(col[0], 0, scr);
-    const bool ok = piv > REAL_PIVOT_MIN;
-    if (!ok) status = 1;
-    inv = qmRsqrtPos(ok ? piv : 1.0_r);
+    if (!(piv > REAL_PIVOT_MIN)) status = 1;
+    inv = qmRsqrtPos(fmax(piv, REAL_PIVOT_MIN));
   }
   // every lane streams its finished rows out as the elimination goes: H lane c writes row c of L (entries right of the diagonal are
   // elimination residue and never read), G lane c column c of W, the idle lanes a scratch word (row 19 of L)
   real* out = isH ? LL + c * LDS_LL : (isG ? W + c : LL + 19 * LDS_LL);
   const int ostr = isH ? 1 : (isG ? LDS_W : 0);
-  RiccatiStep<NT, 0>::run(col, inv, mine, bcP, ncP, c, status, scr, out, ostr);
+  RiccatiStep<NT, 0>::run(col, inv, bcP, ncP, status, scr, out, ostr);
 #ifdef QM_RICCATI_TIMING
   { real keep_ = col[NT - 1]; QM_KEEP(keep_); col[NT - 1] = keep_; }
   const unsigned long long tq1 = clock64();
@@ -199,29 +202,57 @@ template <int NT> __device__ __forceinline__ void riccatiFactorise(const real* T
 #endif
 #pragma unroll
   for (int r = NT; r < MT; ++r) out[r * ostr] = 0.0_r;   // identity rows / columns beyond the unrolled size; rows of W beyond m~ (the buffer may hold a stage with more inputs)
-  QM_WAVE_SYNC();
-  if (isH) LL[c * LDS_LL + c] = mine;   // the diagonal slot: 1 / L_cc (1 for an identity row), after the row itself (LDS writes of one wavefront complete in order)
 #ifdef QM_RICCATI_TIMING
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   tk[2] += clock64() - tq1;
 #endif
 }
 
+// The factorisation leaves L_qq in the diagonal slots of L; the gains' back-substitution multiplies by 1 / L_qq.  Lane q inverts its own entry -- by the factorising
+// wavefront itself behind the stage's third barrier, where it waits for the others' P6b and has nothing else to do.  A slot that does not hold a positive
+// number (a failed factorisation: flagged, its step is discarded; or a row beyond the unrolled size: zero, never read) is taken as 1, as the factorisation took it.
+__device__ __forceinline__ void riccatiInvertDiagonal(real* LL, int lane) {
+  if (lane < MT) { const real dq = LL[lane * LDS_LL + lane]; LL[lane * LDS_LL + lane] = qmRcpPos(dq > REAL_PIVOT_MIN ? dq : 1.0_r); }
+}
+
 // [K | k] = -L^-T W of one stage by back-substitution, one column of [K | k] per lane (31 lanes of one wavefront), in the axpy order:
 // the dependent chain is one multiply + one multiply-add per row, the other multiply-adds of a step are independent.
+// Rows QLO .. QHI - 1 of L (each up to and including its diagonal slot = 1 / L_qq, the same address in every lane) are requested TOGETHER and the substitution
+// steps of those rows follow: one LDS latency per batch.  (Row by row -- the loop as written until round 6 -- every step waited for its own row: sixteen
+// latencies in a row, two thirds of this wavefront's phase.)
+template <int QLO, int QHI> __device__ __forceinline__ void riccatiGainsRows(real* w, const real* LLp) {
+  if constexpr (QHI > QLO) {
+    constexpr int NB = QHI - QLO, NP = (QHI + 1) / 2;   // pairs of the longest row
+    QmD2 lr[NB][NP];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) if (2 * pr <= QLO + b) lr[b][pr] = *reinterpret_cast<const QmD2*>(LLp + (QLO + b) * LDS_LL + 2 * pr);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) if (2 * pr <= QLO + b) QM_KEEP(lr[b][pr]);
+    }
+#pragma unroll
+    for (int q = QHI - 1; q >= QLO; --q) {
+      const int b = q - QLO;
+      w[q] *= (q & 1) ? lr[b][q >> 1].y : lr[b][q >> 1].x;
+#pragma unroll
+      for (int r = 0; r < q; ++r) w[r] -= ((r & 1) ? lr[b][r >> 1].y : lr[b][r >> 1].x) * w[q];
+    }
+  }
+}
 template <int NTP> __device__ __forceinline__ void riccatiGainsN(const real* Wp, const real* LLp, int ntp, int lane, real* kst) {
   real w[NTP];   // rows >= NTP of W are zero and those rows of L identity: their gains are zero
 #pragma unroll
   for (int r = 0; r < NTP; ++r) w[r] = Wp[r * LDS_W + lane];
-#pragma unroll
-  for (int q = NTP - 1; q >= 0; --q) {
-    real lrow[NTP + 1];   // row q of L up to and including the diagonal slot (= 1 / L_qq), the same address in every lane
-#pragma unroll
-    for (int r = 0; r <= q; r += 2) { const QmD2 v = *reinterpret_cast<const QmD2*>(LLp + q * LDS_LL + r); lrow[r] = v.x; lrow[r + 1] = v.y; }
-    w[q] *= lrow[q];
-#pragma unroll
-    for (int r = 0; r < q; ++r) w[r] -= lrow[r] * w[q];
-  }
+  constexpr int B3 = NTP < 16 ? NTP : 16, B2 = NTP < 13 ? NTP : 13, B1 = NTP < 9 ? NTP : 9, B0 = NTP < 4 ? NTP : 4;   // <= 24 pairs (96 registers) per batch
+  riccatiGainsRows<B3, NTP>(w, LLp);
+  riccatiGainsRows<B2, B3>(w, LLp);
+  riccatiGainsRows<B1, B2>(w, LLp);
+  riccatiGainsRows<B0, B1>(w, LLp);
+  riccatiGainsRows<0, B0>(w, LLp);
   // into the LDS image of the record (immediate-offset ds_write, consecutive lanes consecutive addresses)
   real* gp = kst + (lane < 30 ? OFF_KFB + lane : OFF_kff);
   if (lane < 30) {
@@ -382,6 +413,41 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const bool splitK = nTiles == 3;                 // (wave uniform, per stage)
     const real y2On = splitK ? 1.0_r : 0.0_r;        // consumers of Y rows 16..31 add Y2 times this (Y2 always holds finite numbers)
     real* Y2 = lds + R_Y2;
+    // P6a of one 16 x 16 tile (tm, tn) of [Q~ | q~] + A~^T [S A~ | y] (needs all of Y: behind the stage's first barrier), in accumulator layout
+    auto p6aTile = [&](int tm, int tn) -> QmAcc {
+      const int j = tn * 16 + l16;
+      real qv[4], qq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tm * 16 + h + 4 * r, ic = i < 30 ? i : 0;
+        const int jq = j < 30 ? j : 0;   // diagonal tiles: only the upper triangle of the symmetric Q~ is stored (lq_node_kernel)
+        qv[r] = stg[OFF_QT + (tm == tn && jq < ic ? jq * 30 + ic : ic * 30 + jq)]; qq[r] = stg[OFF_qt + ic];
+      }
+      const int ai = tm * 16 + la < 30 ? tm * 16 + la : 29;   // rows 30,31 of the result are discarded
+      real av[8], bw[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
+        av[ks] = stg[OFF_AT + kc * 30 + ai]; bw[ks] = Y[kk * LDS_Y + j];   // A~^T[i][k] = A~[k][i]
+      }
+#pragma unroll
+      for (int ks = 4; ks < 8; ++ks) bw[ks] = fma(y2On, lds[R_Y2 + (4 * (ks - 4) + h) * LDS_Y + j], bw[ks]);   // rows 16..31 of Y: the other half of the k sum (P1)
+      QmAcc c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        QM_KEEP(qv[r]); QM_KEEP(qq[r]);
+        const int i = tm * 16 + h + 4 * r;
+        const real v = j < 30 ? qv[r] : (j == 30 ? qq[r] : 0.0_r);
+        c[r] = i < 30 ? v : 0.0_r;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qmMfma(c, av[ks], bw[ks], scr);
+      return c;
+    };
+    // The off-diagonal tile (0,1) belongs to wavefront 2, which also forms the gains of the previous stage -- with both it was the longest wavefront of the
+    // factorisation phase once the factorisation had lost its tail (round 6).  In stages with three column tiles (m~ <= 16) wavefront 3 has no part in P2:
+    // it forms that tile THERE and parks it in the free square of the symmetrisation scratch (rows 0..15, columns 16..31); wavefront 2 picks it up behind its gains.
+    const bool early01 = nTiles == 3;
     if (wave < nTiles) {
       QmAcc c0, c1;
       real a0[8], a1[8], bv[8];   // all operands first: the LDS latency is paid once
@@ -475,6 +541,11 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
         for (int r = 0; r < 4; ++r) T[(h + 4 * r) * LDS_Y + jc] = c0[r];
       }
     }
+    if (wave == 3 && early01) {
+      const QmAcc ce = p6aTile(0, 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[R_SYM + (h + 4 * r) * LDS_TS + 16 + l16] = ce[r];
+    }
     QM_TICK(3);
     QM_LDS_BARRIER();
     QM_TICK(4);
@@ -506,31 +577,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       //      antisymmetric part of the rounding error is propagated by the OPEN-loop dynamics (it sees A~^T . A~ but not the cancelling
       //      G^T H^-1 G) and grows ~1.13x per stage.
       const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
-      real qv[4], qq[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = tm * 16 + h + 4 * r, ic = i < 30 ? i : 0;
-        const int jq = j < 30 ? j : 0;   // diagonal tiles: only the upper triangle of the symmetric Q~ is stored (lq_node_kernel)
-        qv[r] = stg[OFF_QT + (tm == tn && jq < ic ? jq * 30 + ic : ic * 30 + jq)]; qq[r] = stg[OFF_qt + ic];
-      }
-      const int ai = tm * 16 + la < 30 ? tm * 16 + la : 29;   // rows 30,31 of the result are discarded
-      real av[8], bw[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int kk = 4 * ks + h, kc = kk < 30 ? kk : 29;      // rows 30,31 of Y are zero
-        av[ks] = stg[OFF_AT + kc * 30 + ai]; bw[ks] = Y[kk * LDS_Y + j];   // A~^T[i][k] = A~[k][i]
-      }
-#pragma unroll
-      for (int ks = 4; ks < 8; ++ks) bw[ks] = fma(y2On, lds[R_Y2 + (4 * (ks - 4) + h) * LDS_Y + j], bw[ks]);   // rows 16..31 of Y: the other half of the k sum (P1)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        QM_KEEP(qv[r]); QM_KEEP(qq[r]);
-        const int i = tm * 16 + h + 4 * r;
-        const real v = j < 30 ? qv[r] : (j == 30 ? qq[r] : 0.0_r);
-        c6[r] = i < 30 ? v : 0.0_r;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) qmMfma(c6, av[ks], bw[ks], scr);
+      if (wave != 2 || !early01) c6 = p6aTile(tm, tn);
       if (wave != 2) {    // diagonal tiles (0,0) and (1,1); column 30 (s') and the rows / columns beyond 29 stay as they are
         real* SYM = lds + R_SYM;
 #pragma unroll
@@ -549,6 +596,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
       if (wave == 2) {
         if (k + 1 < N && lane < 31)
           riccatiGains(lds + R_W + ((k + 1) & 1) * W_DOUBLES, lds + R_LT + ((k + 1) & 1) * LT_DOUBLES, 30 - ncPrev, lane, lds + R_KST + ((k + 1) & 1) * GAIN_DOUBLES);
+        if (early01) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c6[r] = lds[R_SYM + (h + 4 * r) * LDS_TS + 16 + l16];
+        }
       } else if (k + 2 < N) {
         riccatiGainsOut(lds + R_KST + (k & 1) * GAIN_DOUBLES, a.gains + (size_t(inst) * N + k + 2) * GAIN_DOUBLES, wave == 1 ? lane : 64 + lane);
       }
@@ -560,6 +611,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QM_TICK(7);
     // ---- P6b: S' = P6a - W^T W on the tiles' owners, written straight into S (s' = column 30 -> row 30 of S); the owner of the tile
     //      (0,1) also writes its mirror image (1,0)
+    if (wave == 0) riccatiInvertDiagonal(LL, lane);
     if (wave != 0) {
       const int tm = myTile >> 1, tn = myTile & 1, j = tn * 16 + l16;
       real av[5], bw[5];
