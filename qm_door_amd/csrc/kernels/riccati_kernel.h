@@ -405,7 +405,10 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     const real* stg = lds + R_STG + (k & 1) * STG_B;        // this stage (committed during the previous one)
     real* stgNext = lds + R_STG + ((k + 1) & 1) * STG_B;    // buffer of stage k - 1
     const int nt = 30 - ncCur;
-    const int ncLoad = ncI[k > 0 ? k - 1 : 0];
+    // constraint rows of the stage after this one: wanted at the END of this stage.  Requested here through an address the compiler cannot prove uniform, and made
+    // a scalar down there: as a uniform load it was a global_load followed at once by s_waitcnt vmcnt(0) + v_readfirstlane -- a trip to the L2 (~300 cycles) on
+    // every wavefront at the head of every stage (round 6: the "issue" slot of the phase clocks).
+    const int ncLoadV = ncI[(k > 0 ? k - 1 : 0) + qmOpaqueLane(0)];
     const int mtTiles = nt > 16 ? 2 : 1;     // 16-row tiles covering the m~ projected inputs
     const int nTiles = nt > 16 ? 4 : 3;      // 16-column tiles covering [A~ | b~ | . | B~]
     QM_TICK(0);
@@ -636,7 +639,7 @@ template <int NW> __global__ void __launch_bounds__(NW * 64) QM_ONE_WAVE_PER_SIM
     QM_TICK(10);
     QM_LDS_BARRIER();
     QM_TICK(11);
-    ncPrev = ncCur; ncCur = ncLoad;
+    ncPrev = ncCur; ncCur = qmReadLaneInt(qmOpaqueLane(ncLoadV), 0);
   }
   // ---- gains of stage 0 (nobody factorises any more)
   if (wave == 2) { if (lane < 31) riccatiGains(lds + R_W, lds + R_LT, 30 - ncPrev, lane, lds + R_KST); }
