@@ -52,7 +52,7 @@ constexpr int R_Y = R_STG + 2 * STG_B;            // Y [32][LDS_Y]
 constexpr int R_T = R_Y + 32 * LDS_Y;             // T [32][LDS_Y]
 constexpr int R_S = R_T + 32 * LDS_Y;             // S [32][LDS_S]
 constexpr int W_DOUBLES = 20 * LDS_W;             // W [20][LDS_W] of one stage
-constexpr int LT_DOUBLES = 20 * LDS_LL;            // L [20][LDS_LL] row major, strictly lower triangle; the diagonal slot holds 1 / L_cc
+constexpr int LT_DOUBLES = 20 * LDS_LL;            // L [20][LDS_LL] row major, lower triangle; the diagonal slot holds L_cc out of the factorisation and 1 / L_cc from the stage's P6b on (riccatiInvertDiagonal)
 constexpr int R_W = R_S + 32 * LDS_S;              // W of the stage in flight and of the previous one (by stage parity): the gains of stage k + 1 are
 constexpr int R_LT = R_W + 2 * W_DOUBLES;         // formed while stage k factorises, from W / L^T of stage k + 1
 constexpr int R_KST = R_LT + 2 * LT_DOUBLES;        // the gains record [GAIN_DOUBLES] of two stages: formed here by one wavefront, copied to HBM by two others a stage later
@@ -123,7 +123,7 @@ template <int PF, int NTHR> __device__ __forceinline__ unsigned long long jointR
 }
 
 // P3: rows 0..NT-1 of [H | G g] (T, one column per lane: lanes < MT the columns of H, lanes MT..MT+30 those of [G | g]) -> L (row c written by
-// lane c, 1 / L_cc on the diagonal) and W = L^-1 [G | g].  nt <= NT is the number of real pivots; rows / columns nt..NT-1 are identity.
+// lane c, L_cc on the diagonal: inverted later, riccatiInvertDiagonal) and W = L^-1 [G | g].  nt <= NT is the number of real pivots; rows / columns nt..NT-1 are identity.
 // One elimination step, written as a template recursion so that the DPP controls are immediates.  Multipliers L[r][J] = (scaled row J)
 // at lane r: rows J + 1 (on the pivot chain) and J + 2 take them by v_readlane, rows J + 3 .. 15 by DPP row_newbcast from a copy of the
 // row's lanes 0..15 replicated into the four rows of 16 lanes -- ONE v_fmac_f64_dpp per row update instead of two v_readlane, a wait
