@@ -415,3 +415,37 @@ def test_emu_cycle_with_the_overlap_option(emu):
         sol.close()
     assert outs[0][2] == 0 and np.isfinite(outs[0][0]).all() and np.abs(outs[0][1]).max() > 0
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_emu_failed_factorisation_flags_the_instance_and_leaves_the_iterate(emu):
+    """The failure path of riccati_kernel on the CPU tier (tests/test_gpu_edges.py has the GPU twin): input weights negated by a settings update -> the Cholesky of the
+    backward sweep fails, the instance is flagged (stats[7] = 1), X / U stay the oracle's initial guess, and the next solve with the weights restored is the first one again."""
+    itf, orc = emu
+    B, N = 1, 4
+    x0 = S.perturbed_states(itf.initial_state, B, seed=3)
+    tgt = S.nominal_target(orc, itf.initial_state)
+    tt = np.zeros((B, 1)); ts = np.tile(tgt, (B, 1, 1)).copy()
+    nev, ev, md = S.trot_schedule(2.0, phase0=0.03)
+    sol = api.GpuSolver(itf, max_batch=B, max_nodes=N)
+
+    def solve():
+        oT, oX, oU, oM, oS = np.zeros((B, N + 1)), np.zeros((B, N + 1, 30)), np.zeros((B, N, 30)), np.zeros((B, N + 1), dtype=np.int32), np.zeros((B, abi.NSTATS))
+        sol.mpc(sol.mpc_args(B, N, x0, tt, ts, np.full(B, nev, dtype=np.int32), np.tile(ev, (B, 1)).copy(), np.tile(md, (B, 1)).copy(), oT, oX, oU, oM, oS, t0=np.zeros(B)))
+        return oX, oU, oS
+
+    gX, gU, gS = solve()
+    assert gS[0, 7] == 0
+    P2 = type(itf.problem).from_buffer_copy(itf.problem)
+    for k in range(900):
+        P2.settings.R_task[k] = -P2.settings.R_task[k]
+    abi.check(itf.lib, itf.lib.qmgpu_update_settings(sol.handle, C.byref(P2.settings)))
+    try:
+        bX, bU, bS = solve()
+        assert bS[0, 7] == 1 and np.isfinite(bX).all() and np.isfinite(bU).all()
+        ref = S.Oracle(P2).mpc_solve(N, 0.0, x0[0], tt[0], ts[0], nev, ev, md)
+        assert ref["status"] != 0 or ref["stats"][7] != 0
+        assert np.abs(bX[0] - ref["X"]).max() <= 1e-12 * max(1.0, np.abs(ref["X"]).max()) and np.abs(bU[0] - ref["U"]).max() <= 1e-12 * max(1.0, np.abs(ref["U"]).max())
+    finally:
+        abi.check(itf.lib, itf.lib.qmgpu_update_settings(sol.handle, C.byref(itf.problem.settings)))
+    aX, aU, aS = solve()
+    assert np.array_equal(aX, gX) and np.array_equal(aU, gU) and aS[0, 7] == 0

@@ -252,3 +252,37 @@ def test_policy_evaluation_and_warm_start_over_long_grids(interface, oracle):
     sol.warm_start(B, N, dT, dX, dU, Nn, G.dev(gn, f64), G.dev(x0, f64), wx, wu)
     rx, ru = oracle.warm_start_batch(T, X, U, gn, x0)
     assert np.abs(wx.cpu().numpy() - rx).max() <= 1e-12 and np.abs(wu.cpu().numpy() - ru).max() <= 1e-12
+
+
+def test_a_failed_factorisation_flags_the_instance_and_leaves_the_iterate(interface, oracle):
+    """H = R~ + B~' S B~ that is not positive definite -- here: the input weights negated by a settings update -- fails the Cholesky of the backward sweep.  The reference's
+    HPIPM call would return an error and ocs2_sqp would throw; the library flags the instance (stats[7] = 1), leaves its iterate where it was (for a cold start: the initial
+    guess, exactly what the oracle returns) and goes on: riccati_kernel runs its elimination on with the failed pivot floored (round 6: one fmax on the dependent chain instead
+    of a select), so whatever it wrote into its own buffers must neither reach X / U nor survive into the next solve."""
+    import gpu_harness as G
+    from qm_door_amd import abi
+    B, N = 3, 8
+    sol = G.make_solver(interface, B, N)
+    mb, (x0, tt, ts, nev, ev, md) = _batch(G, interface, oracle, B, N, seed=23)
+    sol.mpc(mb.args)
+    good = {k: v.copy() for k, v in mb.results().items()}
+    assert (good["stats"][:, 7] == 0).all()
+    P2 = type(interface.problem).from_buffer_copy(interface.problem)
+    for k in range(900):
+        P2.settings.R_task[k] = -P2.settings.R_task[k]
+    abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(P2.settings)))
+    sol.mpc(mb.args)
+    bad = {k: v.copy() for k, v in mb.results().items()}
+    assert (bad["stats"][:, 7] == 1).all(), bad["stats"][:, 7]
+    assert np.isfinite(bad["X"]).all() and np.isfinite(bad["U"]).all()
+    o2 = S.Oracle(P2)
+    for i in range(B):
+        ref = o2.mpc_solve(N, 0.0, x0[i], tt[i], ts[i], nev, ev, md)
+        assert ref["status"] != 0 or ref["stats"][7] != 0
+        assert np.array_equal(bad["mode"][i], ref["mode"])
+        assert np.abs(bad["X"][i] - ref["X"]).max() <= 1e-12 * max(1.0, np.abs(ref["X"]).max())
+        assert np.abs(bad["U"][i] - ref["U"]).max() <= 1e-12 * max(1.0, np.abs(ref["U"]).max())
+    abi.check(interface.lib, interface.lib.qmgpu_update_settings(sol.handle, C.byref(interface.problem.settings)))
+    sol.mpc(mb.args)
+    again = mb.results()
+    assert np.array_equal(again["X"], good["X"]) and np.array_equal(again["U"], good["U"]) and (again["stats"][:, 7] == 0).all()
